@@ -1,0 +1,150 @@
+/*
+ * ecref.c — CPU ORACLE (test infrastructure, see ecref.h): curve dispatch plus the two
+ * group-independent recodings.
+ *
+ *   Radix16Decomposition::new   primeorder/src/tables/radix16.rs:35-61
+ *   wnaf_form / LimbBuffer      wnaf/src/lib.rs:70-150, wnaf/src/limb_buffer.rs:5-69
+ */
+#include "ecref_internal.h"
+
+__attribute__((constructor)) static void ecref_init_all(void) {
+    ecref_k256_init();
+    ecref_p256_init();
+    ecref_p384_init();
+}
+
+size_t ecref_field_bytes(int curve) {
+    switch (curve) {
+    case ECREF_K256: case ECREF_P256: return 32;
+    case ECREF_P384: return 48;
+    default: return 0;
+    }
+}
+
+/* Radix16Decomposition::<D>::new — radix16.rs:35-61.
+ * Step 1: nibbles of the low (D-1)/2 bytes of the big-endian repr, least significant first.
+ * Step 2: recentre from [0,16) to [-8,8) with a carry into the next digit. */
+int ecref_radix16(const uint8_t *scalar_be, size_t scalar_len, int ndigits, int8_t *digits) {
+    memset(digits, 0, (size_t)ndigits);
+    for (int i = 0; i < (ndigits - 1) / 2; i++) {
+        uint8_t b = scalar_be[scalar_len - 1 - (size_t)i];
+        digits[2 * i] = (int8_t)(b & 0xf);
+        digits[2 * i + 1] = (int8_t)((b >> 4) & 0xf);
+    }
+    for (int i = 0; i < ndigits - 1; i++) {
+        int8_t carry = (int8_t)((digits[i] + 8) >> 4);
+        digits[i] = (int8_t)(digits[i] - (carry << 4));
+        digits[i + 1] = (int8_t)(digits[i + 1] + carry);
+    }
+    return ECREF_OK;
+}
+
+/* LimbBuffer::get — limb_buffer.rs: u64 limb `idx` of the little-endian byte string, bytes
+ * past the end read as zero. */
+static uint64_t le_limb(const uint8_t *buf, size_t nbytes, size_t idx) {
+    uint64_t v = 0;
+    for (size_t j = 0; j < 8; j++) {
+        size_t k = 8 * idx + j;
+        if (k < nbytes) v |= (uint64_t)buf[k] << (8 * j);
+    }
+    return v;
+}
+
+/* wnaf_form — lib.rs:70-150 */
+int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int window,
+                    int8_t *wnaf) {
+    const uint64_t width = 1ULL << window;
+    const uint64_t window_mask = width - 1;
+    size_t pos = 0, cursor = 0;
+    uint64_t carry = 0;
+
+    while (pos < bit_len) {
+        size_t u64_idx = pos / 64, bit_idx = pos % 64;
+        uint64_t cur = le_limb(le_bytes, nbytes, u64_idx);
+        uint64_t next = le_limb(le_bytes, nbytes, u64_idx + 1);
+        uint64_t bit_buf;
+        if (bit_idx + (size_t)window < 64) bit_buf = cur >> bit_idx;
+        else bit_buf = (cur >> bit_idx) | (next << (64 - bit_idx));
+
+        uint64_t window_val = carry + (bit_buf & window_mask);
+        if ((window_val & 1) == 0) {
+            wnaf[cursor++] = 0;
+            pos += 1;
+        } else {
+            int8_t d = (int8_t)window_val;
+            if (window_val < width / 2) {
+                carry = 0;
+            } else {
+                carry = 1;
+                d = (int8_t)(d - (int8_t)width);
+            }
+            wnaf[cursor++] = d;
+            size_t max_pos = bit_len >= carry ? bit_len - (size_t)carry : 0;   /* saturating_sub */
+            size_t skip = (size_t)window < max_pos - pos ? (size_t)window : max_pos - pos;
+            for (size_t s = 1; s < skip; s++) wnaf[cursor++] = 0;
+            pos += skip;
+        }
+    }
+    if (carry != 0) wnaf[cursor++] = (int8_t)carry;
+    return (int)cursor;
+}
+
+#define DISPATCH(curve, call_k, call_p256, call_p384) \
+    switch (curve) {                                  \
+    case ECREF_K256: return call_k;                   \
+    case ECREF_P256: return call_p256;                \
+    case ECREF_P384: return call_p384;                \
+    default: return ECREF_ERR_CURVE;                  \
+    }
+
+int ecref_batch_mul_base(int curve, const uint8_t *s, size_t n, uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_batch_mul_base(s, n, o, oi), ecref_p256_batch_mul_base(s, n, o, oi),
+             ecref_p384_batch_mul_base(s, n, o, oi))
+}
+int ecref_batch_mul(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
+                    uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_batch_mul(s, p, pi, n, 0, o, oi), ecref_p256_batch_mul(s, p, pi, n, 0, o, oi),
+             ecref_p384_batch_mul(s, p, pi, n, 0, o, oi))
+}
+int ecref_batch_mul_vartime(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi,
+                            size_t n, uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_batch_mul(s, p, pi, n, 1, o, oi), ecref_p256_batch_mul(s, p, pi, n, 1, o, oi),
+             ecref_p384_batch_mul(s, p, pi, n, 1, o, oi))
+}
+int ecref_msm(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
+              size_t chunk, int vartime, uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_msm(s, p, pi, n, chunk, vartime, o, oi),
+             ecref_p256_msm(s, p, pi, n, chunk, vartime, o, oi),
+             ecref_p384_msm(s, p, pi, n, chunk, vartime, o, oi))
+}
+int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_t *b,
+                                       const uint8_t *p, int pi, uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi),
+             ecref_p256_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi),
+             ecref_p384_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi))
+}
+int ecref_field_op(int curve, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    DISPATCH(curve, ecref_k256_field_op(op, a, b, out), ecref_p256_field_op(op, a, b, out),
+             ecref_p384_field_op(op, a, b, out))
+}
+int ecref_point_op(int curve, int op, const uint8_t *p, int pi, const uint8_t *q, int qi,
+                   uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_point_op(op, p, pi, q, qi, o, oi), ecref_p256_point_op(op, p, pi, q, qi, o, oi),
+             ecref_p384_point_op(op, p, pi, q, qi, o, oi))
+}
+int ecref_batch_normalize(int curve, const uint8_t *xyz, size_t n, uint8_t *o, uint8_t *oi) {
+    DISPATCH(curve, ecref_k256_batch_normalize(xyz, n, o, oi), ecref_p256_batch_normalize(xyz, n, o, oi),
+             ecref_p384_batch_normalize(xyz, n, o, oi))
+}
+int ecref_validate_points(int curve, const uint8_t *p, const uint8_t *pi, size_t n, size_t *bad) {
+    DISPATCH(curve, ecref_k256_validate_points(p, pi, n, bad), ecref_p256_validate_points(p, pi, n, bad),
+             ecref_p384_validate_points(p, pi, n, bad))
+}
+int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
+    switch (curve) {
+    case ECREF_K256: ecref_k256_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_P256: ecref_p256_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_P384: ecref_p384_scalar_reduce(s, n); return ECREF_OK;
+    default: return ECREF_ERR_CURVE;
+    }
+}

@@ -1,0 +1,324 @@
+/*
+ * ecref_prime.c — CPU ORACLE (test infrastructure, see ecref.h): NIST P-256 and P-384 field
+ * arithmetic restated from the reference, plus two instantiations of the generic primeorder
+ * layer (ecref_prime.inc).
+ *
+ *   p256 field   p256/src/arithmetic/field.rs:59-108, field/field64.rs:7-144
+ *                (Montgomery form over U256, hand-written word reduction exploiting p' = 1)
+ *   p384 field   p384/src/arithmetic/field.rs:36-57 -> primefield/src/monty.rs:316-382 ->
+ *                crypto-bigint 0.7.5 ConstMontyForm (NOT under /root/reference; restated here
+ *                as textbook word-by-word Montgomery multiplication, HAC 14.32/14.36)
+ */
+#include "ecref_internal.h"
+
+/* ======================================================================================
+ * Generic Montgomery helpers (crypto-bigint ConstMontyForm semantics), NL words
+ * ==================================================================================== */
+
+/* add_mod / sub_mod / neg_mod on fully reduced values */
+static void mont_add(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *p, size_t nl) {
+    uint64_t t[8];
+    uint64_t carry = ecref_mp_add(r, a, b, nl);
+    uint64_t borrow = ecref_mp_sub(t, r, p, nl);
+    if (carry || !borrow) memcpy(r, t, 8 * nl);
+}
+static void mont_sub(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *p, size_t nl) {
+    uint64_t t[8];
+    uint64_t borrow = ecref_mp_sub(r, a, b, nl);
+    if (borrow) { ecref_mp_add(t, r, p, nl); memcpy(r, t, 8 * nl); }
+}
+
+/* Word-by-word Montgomery reduction of a 2*nl-word value t: returns t * R^-1 mod p,
+ * m_inv = -p^-1 mod 2^64 (crypto-bigint montgomery_reduction). */
+static void mont_reduce(uint64_t *r, const uint64_t *t_in, const uint64_t *p, uint64_t m_inv, size_t nl) {
+    uint64_t t[17];
+    memcpy(t, t_in, 8 * 2 * nl);
+    t[2 * nl] = 0;
+    for (size_t i = 0; i < nl; i++) {
+        uint64_t u = t[i] * m_inv;
+        u128 c = 0;
+        for (size_t j = 0; j < nl; j++) {
+            c += (u128)u * p[j] + t[i + j];
+            t[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+        for (size_t k = i + nl; c != 0 && k <= 2 * nl; k++) {
+            c += t[k];
+            t[k] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    uint64_t s[8];
+    uint64_t borrow = ecref_mp_sub(s, t + nl, p, nl);
+    if (t[2 * nl] || !borrow) memcpy(r, s, 8 * nl);
+    else memcpy(r, t + nl, 8 * nl);
+}
+
+static uint64_t mont_neg_inv64(uint64_t p0) {      /* -p^-1 mod 2^64 by Newton iteration */
+    uint64_t x = p0;                               /* correct to 3 bits for odd p0 */
+    for (int i = 0; i < 6; i++) x *= 2 - p0 * x;
+    return (uint64_t)0 - x;
+}
+
+/* R^k mod p by repeated doubling: start from 1 and double 64*nl*k times */
+static void mont_pow2_mod(uint64_t *r, const uint64_t *p, size_t nl, size_t doublings) {
+    memset(r, 0, 8 * nl);
+    r[0] = 1;
+    for (size_t i = 0; i < doublings; i++) mont_add(r, r, r, p, nl);
+}
+
+/* ======================================================================================
+ * P-256 field (Montgomery form)
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe256;
+
+static const uint64_t P256_P[4] = {                     /* p256/src/arithmetic/field.rs:35 */
+    0xFFFFFFFFFFFFFFFFULL, 0x00000000FFFFFFFFULL, 0x0000000000000000ULL, 0xFFFFFFFF00000001ULL};
+static const uint64_t P256_N[4] = {                     /* p256/src/lib.rs:60 */
+    0xF3B9CAC2FC632551ULL, 0xBCE6FAADA7179E84ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL};
+static const uint8_t P256_B_BYTES[32] = {               /* p256/src/arithmetic.rs:55-57 */
+    0x5a, 0xc6, 0x35, 0xd8, 0xaa, 0x3a, 0x93, 0xe7, 0xb3, 0xeb, 0xbd, 0x55, 0x76, 0x98, 0x86, 0xbc,
+    0x65, 0x1d, 0x06, 0xb0, 0xcc, 0x53, 0xb0, 0xf6, 0x3b, 0xce, 0x3c, 0x3e, 0x27, 0xd2, 0x60, 0x4b};
+static const uint8_t P256_GX[32] = {                    /* p256/src/arithmetic.rs:67-74 */
+    0x6b, 0x17, 0xd1, 0xf2, 0xe1, 0x2c, 0x42, 0x47, 0xf8, 0xbc, 0xe6, 0xe5, 0x63, 0xa4, 0x40, 0xf2,
+    0x77, 0x03, 0x7d, 0x81, 0x2d, 0xeb, 0x33, 0xa0, 0xf4, 0xa1, 0x39, 0x45, 0xd8, 0x98, 0xc2, 0x96};
+static const uint8_t P256_GY[32] = {
+    0x4f, 0xe3, 0x42, 0xe2, 0xfe, 0x1a, 0x7f, 0x9b, 0x8e, 0xe7, 0xeb, 0x4a, 0x7c, 0x0f, 0x9e, 0x16,
+    0x2b, 0xce, 0x33, 0x57, 0x6b, 0x31, 0x5e, 0xce, 0xcb, 0xb6, 0x40, 0x68, 0x37, 0xbf, 0x51, 0xf5};
+
+static fe256 P256_R, P256_R2, P256_B_MONT;
+static int p256_ready;
+
+/* carrying_mul_add(a, b, addend, carry) = a*b + addend + carry -> (lo, hi) */
+static inline uint64_t cma(uint64_t a, uint64_t b, uint64_t add, uint64_t carry, uint64_t *hi) {
+    u128 t = (u128)a * b + add + carry;
+    *hi = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+/* carrying_add(a, b, carry) -> (sum, carry) */
+static inline uint64_t cadd(uint64_t a, uint64_t b, uint64_t carry, uint64_t *co) {
+    u128 t = (u128)a + b + carry;
+    *co = (uint64_t)(t >> 64);
+    return (uint64_t)t;
+}
+
+/* sub_inner — field64.rs:127-144: (l - r) over five limbs, add p back under the borrow mask */
+static void p256_sub_inner(uint64_t out[4], const uint64_t l[5], const uint64_t r[5]) {
+    uint64_t w[5], borrow = 0;
+    for (int i = 0; i < 5; i++) {
+        u128 d = (u128)l[i] - r[i] - borrow;
+        w[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+    uint64_t mask = (uint64_t)0 - borrow, carry = 0;
+    for (int i = 0; i < 4; i++) out[i] = cadd(w[i], P256_P[i] & mask, carry, &carry);
+}
+
+/* montgomery_reduce — field64.rs:83-123 */
+static fe256 p256_montgomery_reduce(const uint64_t lo[4], const uint64_t hi[4]) {
+    uint64_t a0 = lo[0], a1 = lo[1], a2 = lo[2], a3 = lo[3];
+    uint64_t a4 = hi[0], a5 = hi[1], a6 = hi[2], a7 = hi[3], a8;
+    uint64_t carry, carry2;
+    const uint64_t M1 = P256_P[1], M3 = P256_P[3];
+
+    a1 = cma(a0, M1, a1, a0, &carry);
+    a2 = cadd(a2, 0, carry, &carry);
+    a3 = cma(a0, M3, a3, carry, &carry);
+    a4 = cadd(a4, 0, carry, &carry2);
+
+    a2 = cma(a1, M1, a2, a1, &carry);
+    a3 = cadd(a3, 0, carry, &carry);
+    a4 = cma(a1, M3, a4, carry, &carry);
+    a5 = cadd(a5, carry2, carry, &carry2);
+
+    a3 = cma(a2, M1, a3, a2, &carry);
+    a4 = cadd(a4, 0, carry, &carry);
+    a5 = cma(a2, M3, a5, carry, &carry);
+    a6 = cadd(a6, carry2, carry, &carry2);
+
+    a4 = cma(a3, M1, a4, a3, &carry);
+    a5 = cadd(a5, 0, carry, &carry);
+    a6 = cma(a3, M3, a6, carry, &carry);
+    a7 = cadd(a7, carry2, carry, &a8);
+
+    uint64_t l[5] = {a4, a5, a6, a7, a8};
+    uint64_t r[5] = {P256_P[0], P256_P[1], P256_P[2], P256_P[3], 0};
+    fe256 out;
+    p256_sub_inner(out.w, l, r);
+    return out;
+}
+
+static fe256 p256_fe_mul(const fe256 *a, const fe256 *b) {       /* field.rs:99-102 */
+    uint64_t t[8];
+    ecref_mp_mul(t, a->w, b->w, 4);                               /* U256::widening_mul */
+    return p256_montgomery_reduce(t, t + 4);
+}
+static fe256 p256_fe_sqr(const fe256 *a) { return p256_fe_mul(a, a); }   /* field.rs:105-108 */
+
+static fe256 p256_fe_add(const fe256 *a, const fe256 *b) {       /* field64.rs:7-23 */
+    uint64_t w[5], c = 0;
+    for (int i = 0; i < 4; i++) w[i] = cadd(a->w[i], b->w[i], c, &c);
+    w[4] = c;
+    uint64_t r[5] = {P256_P[0], P256_P[1], P256_P[2], P256_P[3], 0};
+    fe256 out;
+    p256_sub_inner(out.w, w, r);
+    return out;
+}
+static fe256 p256_fe_sub(const fe256 *a, const fe256 *b) {       /* field64.rs:25-34 */
+    uint64_t l[5] = {a->w[0], a->w[1], a->w[2], a->w[3], 0};
+    uint64_t r[5] = {b->w[0], b->w[1], b->w[2], b->w[3], 0};
+    fe256 out;
+    p256_sub_inner(out.w, l, r);
+    return out;
+}
+static fe256 p256_fe_zero(void) { fe256 z = {{0, 0, 0, 0}}; return z; }
+static fe256 p256_fe_neg(const fe256 *a) { fe256 z = p256_fe_zero(); return p256_fe_sub(&z, a); }   /* field.rs:74-76 */
+static fe256 p256_fe_dbl(const fe256 *a) { return p256_fe_add(a, a); }                                /* field.rs:69-71 */
+static int p256_fe_is_zero(const fe256 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void p256_init(void) {
+    if (p256_ready) return;
+    mont_pow2_mod(P256_R.w, P256_P, 4, 256);
+    mont_pow2_mod(P256_R2.w, P256_P, 4, 512);                     /* field.rs:183-185 (R2) */
+    fe256 b;
+    ecref_be_to_words(P256_B_BYTES, 32, b.w);
+    P256_B_MONT = p256_fe_mul(&b, &P256_R2);
+    p256_ready = 1;
+}
+static fe256 p256_fe_one(void) { p256_init(); return P256_R; }
+static fe256 p256_fe_b(void) { p256_init(); return P256_B_MONT; }
+
+/* from_bytes — field.rs (from_uint: range check, then to Montgomery form via * R2) */
+static int p256_fe_from_bytes(fe256 *r, const uint8_t *b) {
+    p256_init();
+    fe256 t;
+    ecref_be_to_words(b, 32, t.w);
+    if (ecref_mp_cmp(t.w, P256_P, 4) >= 0) return 0;
+    *r = p256_fe_mul(&t, &P256_R2);
+    return 1;
+}
+/* to_bytes — to_canonical = montgomery_reduce(a, 0) field64.rs:37-39 */
+static void p256_fe_to_bytes(uint8_t *out, const fe256 *a) {
+    uint64_t z[4] = {0, 0, 0, 0};
+    fe256 c = p256_montgomery_reduce(a->w, z);
+    ecref_words_to_be(c.w, 4, out);
+}
+/* invert — field.rs (crypto-bigint invert on the Montgomery form); unique result, computed
+ * here as a^(p-2) by square-and-multiply. Returns 0 for a == 0. */
+static int p256_fe_invert(fe256 *out, const fe256 *a) {
+    if (p256_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, P256_P, two, 4);
+    fe256 r = p256_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = p256_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p256_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+#define PO_PFX p256
+#define PO_NL 4
+#define PO_FE fe256
+#define PO_F(name) p256_fe_##name
+#define PO_ORDER P256_N
+#define PO_GX P256_GX
+#define PO_GY P256_GY
+#include "ecref_prime.inc"
+
+/* ======================================================================================
+ * P-384 field (generic Montgomery, crypto-bigint ConstMontyForm semantics)
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[6]; } fe384;
+
+static const uint64_t P384_P[6] = {                     /* p384/src/arithmetic/field.rs:34 */
+    0x00000000FFFFFFFFULL, 0xFFFFFFFF00000000ULL, 0xFFFFFFFFFFFFFFFEULL,
+    0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint64_t P384_N[6] = {                     /* p384/src/lib.rs:14 */
+    0xECEC196ACCC52973ULL, 0x581A0DB248B0A77AULL, 0xC7634D81F4372DDFULL,
+    0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint8_t P384_B_BYTES[48] = {               /* p384/src/arithmetic.rs:57-59 */
+    0xb3, 0x31, 0x2f, 0xa7, 0xe2, 0x3e, 0xe7, 0xe4, 0x98, 0x8e, 0x05, 0x6b, 0xe3, 0xf8, 0x2d, 0x19,
+    0x18, 0x1d, 0x9c, 0x6e, 0xfe, 0x81, 0x41, 0x12, 0x03, 0x14, 0x08, 0x8f, 0x50, 0x13, 0x87, 0x5a,
+    0xc6, 0x56, 0x39, 0x8d, 0x8a, 0x2e, 0xd1, 0x9d, 0x2a, 0x85, 0xc8, 0xed, 0xd3, 0xec, 0x2a, 0xef};
+static const uint8_t P384_GX[48] = {                    /* p384/src/arithmetic.rs:71-78 */
+    0xaa, 0x87, 0xca, 0x22, 0xbe, 0x8b, 0x05, 0x37, 0x8e, 0xb1, 0xc7, 0x1e, 0xf3, 0x20, 0xad, 0x74,
+    0x6e, 0x1d, 0x3b, 0x62, 0x8b, 0xa7, 0x9b, 0x98, 0x59, 0xf7, 0x41, 0xe0, 0x82, 0x54, 0x2a, 0x38,
+    0x55, 0x02, 0xf2, 0x5d, 0xbf, 0x55, 0x29, 0x6c, 0x3a, 0x54, 0x5e, 0x38, 0x72, 0x76, 0x0a, 0xb7};
+static const uint8_t P384_GY[48] = {
+    0x36, 0x17, 0xde, 0x4a, 0x96, 0x26, 0x2c, 0x6f, 0x5d, 0x9e, 0x98, 0xbf, 0x92, 0x92, 0xdc, 0x29,
+    0xf8, 0xf4, 0x1d, 0xbd, 0x28, 0x9a, 0x14, 0x7c, 0xe9, 0xda, 0x31, 0x13, 0xb5, 0xf0, 0xb8, 0xc0,
+    0x0a, 0x60, 0xb1, 0xce, 0x1d, 0x7e, 0x81, 0x9d, 0x7a, 0x43, 0x1d, 0x7c, 0x90, 0xea, 0x0e, 0x5f};
+
+static fe384 P384_R, P384_R2, P384_B_MONT;
+static uint64_t P384_MINV;
+static int p384_ready;
+
+static fe384 p384_fe_mul(const fe384 *a, const fe384 *b) {       /* monty.rs:346-350 */
+    uint64_t t[12];
+    fe384 r;
+    ecref_mp_mul(t, a->w, b->w, 6);
+    mont_reduce(r.w, t, P384_P, P384_MINV, 6);
+    return r;
+}
+static fe384 p384_fe_sqr(const fe384 *a) { return p384_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe384 p384_fe_add(const fe384 *a, const fe384 *b) { fe384 r; mont_add(r.w, a->w, b->w, P384_P, 6); return r; }   /* :316-320 */
+static fe384 p384_fe_sub(const fe384 *a, const fe384 *b) { fe384 r; mont_sub(r.w, a->w, b->w, P384_P, 6); return r; }   /* :331-335 */
+static fe384 p384_fe_zero(void) { fe384 z; memset(&z, 0, sizeof z); return z; }
+static fe384 p384_fe_neg(const fe384 *a) { fe384 z = p384_fe_zero(); return p384_fe_sub(&z, a); }                         /* :353-357 */
+static fe384 p384_fe_dbl(const fe384 *a) { return p384_fe_add(a, a); }                                                     /* :323-327 */
+static int p384_fe_is_zero(const fe384 *a) { return ecref_mp_is_zero(a->w, 6); }
+
+static void p384_init(void) {
+    if (p384_ready) return;
+    P384_MINV = mont_neg_inv64(P384_P[0]);
+    mont_pow2_mod(P384_R.w, P384_P, 6, 384);
+    mont_pow2_mod(P384_R2.w, P384_P, 6, 768);
+    fe384 b;
+    ecref_be_to_words(P384_B_BYTES, 48, b.w);
+    P384_B_MONT = p384_fe_mul(&b, &P384_R2);
+    p384_ready = 1;
+}
+static fe384 p384_fe_one(void) { p384_init(); return P384_R; }
+static fe384 p384_fe_b(void) { p384_init(); return P384_B_MONT; }
+
+static int p384_fe_from_bytes(fe384 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    p384_init();
+    fe384 t;
+    ecref_be_to_words(b, 48, t.w);
+    if (ecref_mp_cmp(t.w, P384_P, 6) >= 0) return 0;
+    *r = p384_fe_mul(&t, &P384_R2);
+    return 1;
+}
+static void p384_fe_to_bytes(uint8_t *out, const fe384 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[12];
+    fe384 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 48);
+    mont_reduce(c.w, t, P384_P, P384_MINV, 6);
+    ecref_words_to_be(c.w, 6, out);
+}
+static int p384_fe_invert(fe384 *out, const fe384 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (p384_fe_is_zero(a)) return 0;
+    uint64_t e[6], two[6] = {2, 0, 0, 0, 0, 0};
+    ecref_mp_sub(e, P384_P, two, 6);
+    fe384 r = p384_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = p384_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p384_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+#define PO_PFX p384
+#define PO_NL 6
+#define PO_FE fe384
+#define PO_F(name) p384_fe_##name
+#define PO_ORDER P384_N
+#define PO_GX P384_GX
+#define PO_GY P384_GY
+#include "ecref_prime.inc"

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Extract the reference's known-answer vectors for the scalar-mul hot path into JSON fixtures.
+
+Run in the build container (needs /root/reference); the GPU box only ever reads the JSON.
+
+    python tests/golden/extract_golden.py [/root/reference]
+
+Sources:
+  {k256,p256,p384}/src/test_vectors/group.rs   ADD_TEST_VECTORS (k*G for k = 1..20, affine x,y)
+                                               MUL_TEST_VECTORS ((k, x, y) with k*G = (x, y))
+  {k256,p256,p384}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
+  {k256,p256}/src/test_vectors/field.rs        DBL_TEST_VECTORS (repeated doubling of 1 mod p)
+
+Only the hex constants are taken (public NIST / point-at-infinity.org / FIPS 186-4 data); no
+reference source code is copied.
+"""
+import json
+import os
+import re
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEX = re.compile(r'hex!\(\s*"([0-9A-Fa-f\s]+)"\s*\)')
+
+
+def const_block(text, name):
+    """Text of `pub const NAME ... = &[ ... ];`"""
+    m = re.search(r"pub const %s\b" % name, text)
+    if not m:
+        return None
+    start = text.index("=", m.end())
+    # the const ends at the first "];" at column 0 after start
+    end = re.search(r"^\]\)?;|\}\];", text[start:], re.M)
+    return text[start:start + end.end()]
+
+
+def hexes(block):
+    return [re.sub(r"\s+", "", h).lower() for h in HEX.findall(block)]
+
+
+def group_vectors(curve):
+    text = open(os.path.join(REF, curve, "src/test_vectors/group.rs")).read()
+    add = hexes(const_block(text, "ADD_TEST_VECTORS"))
+    mul = hexes(const_block(text, "MUL_TEST_VECTORS"))
+    assert len(add) % 2 == 0 and len(mul) % 3 == 0
+    return {
+        "add": [{"k": i // 2 + 1, "x": add[i], "y": add[i + 1]} for i in range(0, len(add), 2)],
+        "mul": [{"k": mul[i], "x": mul[i + 1], "y": mul[i + 2]} for i in range(0, len(mul), 3)],
+    }
+
+
+def ecdsa_vectors(curve):
+    text = open(os.path.join(REF, curve, "src/test_vectors/ecdsa.rs")).read()
+    out = []
+    for body in re.findall(r"TestVector\s*\{(.*?)\}", text, re.S):
+        fields = dict(re.findall(r'(\w+):\s*&hex!\(\s*"([0-9A-Fa-f\s]+)"\s*\)', body))
+        if fields:
+            out.append({k: re.sub(r"\s+", "", v).lower() for k, v in fields.items()})
+    return out
+
+
+def field_vectors(curve):
+    path = os.path.join(REF, curve, "src/test_vectors/field.rs")
+    if not os.path.exists(path):
+        return None
+    return hexes(const_block(open(path).read(), "DBL_TEST_VECTORS"))
+
+
+def main():
+    summary = {}
+    for curve in ("k256", "p256", "p384"):
+        data = {
+            "source": "RustCrypto/elliptic-curves %s/src/test_vectors/{group,ecdsa,field}.rs" % curve,
+            "group": group_vectors(curve),
+            "ecdsa": ecdsa_vectors(curve),
+        }
+        dbl = field_vectors(curve)
+        if dbl is not None:
+            data["field_dbl"] = dbl
+        with open(os.path.join(HERE, "%s.json" % curve), "w") as f:
+            json.dump(data, f, indent=1)
+            f.write("\n")
+        summary[curve] = (len(data["group"]["add"]), len(data["group"]["mul"]), len(data["ecdsa"]),
+                          len(dbl) if dbl else 0)
+    for curve, (a, m, e, d) in summary.items():
+        print("%s: %d add, %d mul, %d ecdsa, %d field-dbl vectors" % (curve, a, m, e, d))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle_ecref.so) — test infrastructure only."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_ecref.so")
+
+K256, P256, P384 = 0, 1, 2
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i8p = ctypes.POINTER(ctypes.c_int8)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.ecref_field_bytes.restype = ctypes.c_size_t
+    return _lib
+
+
+def _buf(a):
+    """numpy uint8 array (or None) -> ctypes pointer"""
+    if a is None:
+        return None
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_u8p)
+
+
+def _arr(b, n=None):
+    a = np.frombuffer(bytes(b), dtype=np.uint8).copy() if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, dtype=np.uint8)
+    return a
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__("oracle error %d" % code)
+        self.code = code
+
+
+def _chk(rc):
+    if rc != 0:
+        raise OracleError(rc)
+
+
+def batch_mul_base(curve, scalars):
+    L = FIELD_BYTES[curve]
+    s = _arr(scalars)
+    n = s.size // L
+    out = np.zeros(n * 2 * L, np.uint8)
+    inf = np.zeros(n, np.uint8)
+    _chk(lib().ecref_batch_mul_base(curve, _buf(s), ctypes.c_size_t(n), _buf(out), _buf(inf)))
+    return out, inf
+
+
+def batch_mul(curve, scalars, points_xy, points_inf=None, vartime=False):
+    L = FIELD_BYTES[curve]
+    s, p = _arr(scalars), _arr(points_xy)
+    pi = None if points_inf is None else _arr(points_inf)
+    n = s.size // L
+    out = np.zeros(n * 2 * L, np.uint8)
+    inf = np.zeros(n, np.uint8)
+    fn = lib().ecref_batch_mul_vartime if vartime else lib().ecref_batch_mul
+    _chk(fn(curve, _buf(s), _buf(p), _buf(pi), ctypes.c_size_t(n), _buf(out), _buf(inf)))
+    return out, inf
+
+
+def msm(curve, scalars, points_xy, points_inf=None, chunk=0, vartime=False):
+    L = FIELD_BYTES[curve]
+    s, p = _arr(scalars), _arr(points_xy)
+    pi = None if points_inf is None else _arr(points_inf)
+    n = s.size // L
+    out = np.zeros(2 * L, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    _chk(lib().ecref_msm(curve, _buf(s), _buf(p), _buf(pi), ctypes.c_size_t(n), ctypes.c_size_t(chunk),
+                         int(vartime), _buf(out), _buf(inf)))
+    return out, int(inf[0])
+
+
+def mul_base_and_mul_add_vartime(curve, a, b, p_xy, p_inf=0):
+    L = FIELD_BYTES[curve]
+    out = np.zeros(2 * L, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    _chk(lib().ecref_mul_base_and_mul_add_vartime(curve, _buf(_arr(a)), _buf(_arr(b)), _buf(_arr(p_xy)), int(p_inf),
+                                                  _buf(out), _buf(inf)))
+    return out, int(inf[0])
+
+
+def field_op(curve, op, a, b=None):
+    L = FIELD_BYTES[curve]
+    out = np.zeros(L, np.uint8)
+    _chk(lib().ecref_field_op(curve, op, _buf(_arr(a)), None if b is None else _buf(_arr(b)), _buf(out)))
+    return bytes(out)
+
+
+def point_op(curve, op, p_xy, p_inf=0, q_xy=None, q_inf=0):
+    L = FIELD_BYTES[curve]
+    out = np.zeros(2 * L, np.uint8)
+    inf = np.zeros(1, np.uint8)
+    _chk(lib().ecref_point_op(curve, op, _buf(_arr(p_xy)), int(p_inf), None if q_xy is None else _buf(_arr(q_xy)),
+                              int(q_inf), _buf(out), _buf(inf)))
+    return bytes(out), int(inf[0])
+
+
+def batch_normalize(curve, xyz):
+    L = FIELD_BYTES[curve]
+    a = _arr(xyz)
+    n = a.size // (3 * L)
+    out = np.zeros(n * 2 * L, np.uint8)
+    inf = np.zeros(n, np.uint8)
+    _chk(lib().ecref_batch_normalize(curve, _buf(a), ctypes.c_size_t(n), _buf(out), _buf(inf)))
+    return out, inf
+
+
+def radix16(scalar_be, ndigits):
+    s = _arr(scalar_be)
+    d = np.zeros(ndigits, np.int8)
+    _chk(lib().ecref_radix16(_buf(s), ctypes.c_size_t(s.size), ndigits, d.ctypes.data_as(_i8p)))
+    return d
+
+
+def wnaf_form(le_bytes, bit_len, window=5):
+    s = _arr(le_bytes)
+    d = np.zeros(bit_len + 1, np.int8)
+    n = lib().ecref_wnaf_form(_buf(s), ctypes.c_size_t(s.size), ctypes.c_size_t(bit_len), window,
+                              d.ctypes.data_as(_i8p))
+    return d[:n]
+
+
+def k256_glv_decompose(k_be):
+    r1 = np.zeros(32, np.uint8)
+    r2 = np.zeros(32, np.uint8)
+    _chk(lib().ecref_k256_glv_decompose(_buf(_arr(k_be)), _buf(r1), _buf(r2)))
+    return bytes(r1), bytes(r2)
+
+
+def validate_points(curve, points_xy, points_inf=None):
+    L = FIELD_BYTES[curve]
+    p = _arr(points_xy)
+    pi = None if points_inf is None else _arr(points_inf)
+    bad = ctypes.c_size_t(0)
+    rc = lib().ecref_validate_points(curve, _buf(p), _buf(pi), ctypes.c_size_t(p.size // (2 * L)), ctypes.byref(bad))
+    return rc, bad.value
+
+
+def scalar_reduce(curve, scalars):
+    """Scalar::reduce(bytes) of the reference's proptest generators, applied to a uint8 array."""
+    L = FIELD_BYTES[curve]
+    s = _arr(scalars).copy()
+    _chk(lib().ecref_scalar_reduce(curve, _buf(s), ctypes.c_size_t(s.size // L)))
+    return s

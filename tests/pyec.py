@@ -1,0 +1,127 @@
+"""Independent big-integer affine model of the three curves (test infrastructure).
+
+Deliberately shares nothing with oracle/ (C restatement of the reference) or with the HIP
+kernels: textbook affine chord-and-tangent arithmetic on Python ints.  Used as a second opinion
+for cases where the reference holds no known-answer vector (variable base, MSM, GLV).
+Curve constants: SURVEY.md Appendix A (reference file:line cited there).
+"""
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Curve:
+    name: str
+    cid: int
+    L: int
+    p: int
+    n: int
+    a: int
+    b: int
+    gx: int
+    gy: int
+
+
+K256 = Curve(
+    "k256", 0, 32,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFC2F,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    0, 7,
+    0x79BE667EF9DCBBAC55A06295CE870B07029BFCDB2DCE28D959F2815B16F81798,
+    0x483ADA7726A3C4655DA4FBFC0E1108A8FD17B448A68554199C47D08FFB10D4B8,
+)
+P256 = Curve(
+    "p256", 1, 32,
+    0xFFFFFFFF00000001000000000000000000000000FFFFFFFFFFFFFFFFFFFFFFFF,
+    0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551,
+    -3, 0x5AC635D8AA3A93E7B3EBBD55769886BC651D06B0CC53B0F63BCE3C3E27D2604B,
+    0x6B17D1F2E12C4247F8BCE6E563A440F277037D812DEB33A0F4A13945D898C296,
+    0x4FE342E2FE1A7F9B8EE7EB4A7C0F9E162BCE33576B315ECECBB6406837BF51F5,
+)
+P384 = Curve(
+    "p384", 2, 48,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFFFF0000000000000000FFFFFFFF,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7634D81F4372DDF581A0DB248B0A77AECEC196ACCC52973,
+    -3, 0xB3312FA7E23EE7E4988E056BE3F82D19181D9C6EFE8141120314088F5013875AC656398D8A2ED19D2A85C8EDD3EC2AEF,
+    0xAA87CA22BE8B05378EB1C71EF320AD746E1D3B628BA79B9859F741E082542A385502F25DBF55296C3A545E3872760AB7,
+    0x3617DE4A96262C6F5D9E98BF9292DC29F8F41DBD289A147CE9DA3113B5F0B8C00A60B1CE1D7E819D7A431D7C90EA0E5F,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384}
+
+# secp256k1 endomorphism constants (k256/src/arithmetic/mul.rs:4-5, projective.rs:31-37)
+K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+K256_BETA = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+
+INF = None  # point at infinity
+
+
+def on_curve(c, P):
+    if P is INF:
+        return True
+    x, y = P
+    return 0 <= x < c.p and 0 <= y < c.p and (y * y - (x * x * x + c.a * x + c.b)) % c.p == 0
+
+
+def neg(c, P):
+    if P is INF:
+        return INF
+    return (P[0], (-P[1]) % c.p)
+
+
+def add(c, P, Q):
+    if P is INF:
+        return Q
+    if Q is INF:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % c.p == 0:
+            return INF
+        lam = (3 * x1 * x1 + c.a) * pow(2 * y1, -1, c.p) % c.p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, c.p) % c.p
+    x3 = (lam * lam - x1 - x2) % c.p
+    return (x3, (lam * (x1 - x3) - y1) % c.p)
+
+
+def mul(c, k, P):
+    k %= c.n
+    R = INF
+    Q = P
+    while k:
+        if k & 1:
+            R = add(c, R, Q)
+        Q = add(c, Q, Q)
+        k >>= 1
+    return R
+
+
+def G(c):
+    return (c.gx, c.gy)
+
+
+def msm(c, ks, Ps):
+    R = INF
+    for k, P in zip(ks, Ps):
+        R = add(c, R, mul(c, k, P))
+    return R
+
+
+# ---- wire-format helpers (big-endian fixed width, identity = zeros + flag) ----
+
+def enc_scalar(c, k):
+    return int(k).to_bytes(c.L, "big")
+
+
+def enc_point(c, P):
+    """-> (xy bytes, inf flag)"""
+    if P is INF:
+        return bytes(2 * c.L), 1
+    return P[0].to_bytes(c.L, "big") + P[1].to_bytes(c.L, "big"), 0
+
+
+def dec_point(c, xy, inf):
+    if inf:
+        assert xy == bytes(2 * c.L), "identity must be encoded as zeros"
+        return INF
+    return (int.from_bytes(xy[: c.L], "big"), int.from_bytes(xy[c.L:], "big"))

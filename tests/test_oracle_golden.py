@@ -1,0 +1,283 @@
+"""Pins the CPU oracle (oracle/, a C restatement of the reference's algorithms) against every
+golden vector the reference holds for the scalar-mul path, and against an independent big-int
+model.  CPU only.  (reference tests cited per case.)"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import pyec
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CURVES = ["k256", "p256", "p384"]
+
+
+def load(curve):
+    with open(os.path.join(GOLDEN, curve + ".json")) as f:
+        return json.load(f)
+
+
+def xy(c, v):
+    return bytes.fromhex(v["x"]) + bytes.fromhex(v["y"])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_add_vectors_repeated_addition(oracle, curve):
+    """primeorder/src/dev.rs:20-55 / k256 projective.rs:977-1010: G + G + ... through add,
+    mixed add, and double."""
+    c = pyec.CURVES[curve]
+    vec = load(curve)["group"]["add"]
+    g_xy, _ = pyec.enc_point(c, pyec.G(c))
+    assert xy(c, vec[0]) == g_xy
+    for op in (0, 1):  # full add, mixed add
+        cur = g_xy
+        for v in vec[1:]:
+            cur, inf = oracle.point_op(c.cid, op, cur, 0, g_xy, 0)
+            assert inf == 0 and cur == xy(c, v)
+    # doubling: 2G, 4G, 8G, 16G are vectors 2, 4, 8, 16
+    cur = g_xy
+    for k in (2, 4, 8, 16):
+        cur, inf = oracle.point_op(c.cid, 2, cur, 0)
+        assert cur == xy(c, vec[k - 1])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_mul_vectors_all_drivers(oracle, curve):
+    """k256 projective.rs:1040-1087 / primeorder dev.rs:100-150: G * k for ADD (k=1..20) and MUL
+    vectors, through mul (const-time LUT path), mul_vartime (wNAF), mul_by_generator (table)."""
+    c = pyec.CURVES[curve]
+    g = load(curve)["group"]
+    ks = [pyec.enc_scalar(c, v["k"]) for v in g["add"]] + [bytes.fromhex(v["k"]) for v in g["mul"]]
+    want = b"".join(xy(c, v) for v in g["add"] + g["mul"])
+    n = len(ks)
+    scal = b"".join(ks)
+    gxy = pyec.enc_point(c, pyec.G(c))[0] * n
+    for out, inf in (oracle.batch_mul_base(c.cid, scal), oracle.batch_mul(c.cid, scal, gxy),
+                     oracle.batch_mul(c.cid, scal, gxy, vartime=True)):
+        assert bytes(out) == want
+        assert not inf.any()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ecdsa_vectors_fixed_base_and_verify(oracle, curve):
+    """{p256,p384,k256}/src/test_vectors/ecdsa.rs: d*G == Q, x(k*G) mod n == r (signing path,
+    mul_by_generator) and x(u1*G + u2*Q) mod n == r (verification path,
+    mul_by_generator_and_mul_add_vartime)."""
+    c = pyec.CURVES[curve]
+    for v in load(curve)["ecdsa"]:
+        d, k = bytes.fromhex(v["d"]), bytes.fromhex(v["k"])
+        out, inf = oracle.batch_mul_base(c.cid, d + k)
+        q = bytes(out[: 2 * c.L])
+        assert q == bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"])
+        rx = int.from_bytes(bytes(out[2 * c.L: 3 * c.L]), "big")
+        r, s = int(v["r"], 16), int(v["s"], 16)
+        assert rx % c.n == r
+        z = int(v["m"], 16)  # prehash, same width as the field for these vectors
+        w = pow(s, -1, c.n)
+        u1, u2 = z * w % c.n, r * w % c.n
+        pt, pinf = oracle.mul_base_and_mul_add_vartime(c.cid, pyec.enc_scalar(c, u1), pyec.enc_scalar(c, u2), q)
+        assert pinf == 0 and int.from_bytes(bytes(pt[: c.L]), "big") % c.n == r
+
+
+@pytest.mark.parametrize("curve", ["k256", "p256"])
+def test_field_doubling_vectors(oracle, curve):
+    """k256 field.rs tests / p256 field.rs:219-245: repeated doubling of 1."""
+    c = pyec.CURVES[curve]
+    vec = load(curve)["field_dbl"]
+    cur = (1).to_bytes(c.L, "big")
+    for want in vec:
+        assert cur.hex() == want
+        cur = oracle.field_op(c.cid, 0, cur, cur)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_field_ops_vs_bigint(oracle, curve):
+    """k256 field.rs:586-597 style differential against integers mod p."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xF1E1D + c.cid)
+    edge = [0, 1, 2, c.p - 1, c.p - 2, (c.p - 1) // 2, 2 ** (8 * c.L - 1) % c.p, 0xFFFFFFFF, 2 ** 64 - 1]
+    vals = edge + [rng.randrange(c.p) for _ in range(200)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        A, B = a.to_bytes(c.L, "big"), b.to_bytes(c.L, "big")
+        assert int.from_bytes(oracle.field_op(c.cid, 0, A, B), "big") == (a + b) % c.p
+        assert int.from_bytes(oracle.field_op(c.cid, 1, A, B), "big") == (a - b) % c.p
+        assert int.from_bytes(oracle.field_op(c.cid, 2, A, B), "big") == (a * b) % c.p
+        assert int.from_bytes(oracle.field_op(c.cid, 3, A), "big") == (a * a) % c.p
+        assert int.from_bytes(oracle.field_op(c.cid, 5, A), "big") == (-a) % c.p
+        inv = int.from_bytes(oracle.field_op(c.cid, 4, A), "big")
+        assert inv == (pow(a, -1, c.p) if a else 0)
+    # non-canonical input is rejected (from_bytes range check)
+    with pytest.raises(oracle.OracleError):
+        oracle.field_op(c.cid, 0, c.p.to_bytes(c.L, "big"), (0).to_bytes(c.L, "big"))
+
+
+def test_radix16_properties(oracle):
+    """primeorder/src/tables/radix16.rs:109-172: digit range, reconstruction, zero, padding."""
+    rng = random.Random(16)
+    for L, D in ((32, 65), (48, 97), (32, 33)):
+        nbytes = (D - 1) // 2
+        cases = [0, 1, 7, 8, 15, 16, 2 ** (8 * nbytes) - 1, int("88" * nbytes, 16), int("7f" * nbytes, 16)]
+        cases += [rng.getrandbits(8 * nbytes) for _ in range(300)]
+        for k in cases:
+            d = oracle.radix16(k.to_bytes(L, "big"), D)
+            assert len(d) == D
+            assert all(-8 <= x < 8 for x in d[:-1]) and 0 <= d[-1] <= 1
+            assert sum(int(x) << (4 * i) for i, x in enumerate(d)) == k
+        assert not oracle.radix16((0).to_bytes(L, "big"), D).any()
+
+
+def test_wnaf_form_properties(oracle):
+    """wnaf/src/lib.rs:70-150 semantics: odd digits, |d| <= 2^(w-1)-1, w-1 zeros after a non-zero
+    digit, exact reconstruction (including the trailing carry digit)."""
+    rng = random.Random(5)
+    for nbytes, bit_len in ((32, 256), (16, 128), (48, 384)):
+        cases = [0, 1, 2 ** bit_len - 1, 2 ** (bit_len - 1), int("f0" * nbytes, 16)]
+        cases += [rng.getrandbits(bit_len) for _ in range(300)]
+        for k in cases:
+            d = oracle.wnaf_form(k.to_bytes(nbytes, "little"), bit_len, 5)
+            assert len(d) <= bit_len + 1
+            assert sum(int(x) << i for i, x in enumerate(d)) == k
+            for i, x in enumerate(d):
+                if x != 0:
+                    assert x % 2 != 0 and abs(int(x)) <= 15
+                    assert not d[i + 1: i + 5].any()
+
+
+def test_k256_glv_decompose(oracle):
+    """k256 mul/glv.rs:149-156 + proof :43-146: r1 + r2*lambda == k (mod n), |r_i| < 2^128 after
+    sign folding.  Also cross-checks the rounding against exact rational arithmetic."""
+    c = pyec.K256
+    rng = random.Random(0x61)
+    g1 = 0x3086D221A7D46BCDE86C90E49284EB153DAA8A1471E8CA7FE893209A45DBB031
+    g2 = 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
+    mb1 = 0xE4437ED6010E88286F547FA90ABFE4C3
+    mb2 = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE8A280AC50774346DD765CDA83DB1562C
+    cases = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, pyec.K256_LAMBDA, 2 ** 255 % c.n]
+    cases += [rng.randrange(c.n) for _ in range(500)]
+    for k in cases:
+        r1b, r2b = oracle.k256_glv_decompose(k.to_bytes(32, "big"))
+        r1, r2 = int.from_bytes(r1b, "big"), int.from_bytes(r2b, "big")
+        c1 = ((k * g1 + (1 << 383)) >> 384) * mb1 % c.n
+        c2 = ((k * g2 + (1 << 383)) >> 384) * mb2 % c.n
+        e2 = (c1 + c2) % c.n
+        e1 = (k - e2 * pyec.K256_LAMBDA) % c.n
+        assert (r1, r2) == (e1, e2)
+        assert (r1 + r2 * pyec.K256_LAMBDA) % c.n == k
+        assert min(r1, c.n - r1) < 2 ** 128 and min(r2, c.n - r2) < 2 ** 128
+    with pytest.raises(oracle.OracleError):
+        oracle.k256_glv_decompose(c.n.to_bytes(32, "big"))
+
+
+def _rand_points(c, rng, n):
+    pts = []
+    for _ in range(n):
+        pts.append(pyec.mul(c, rng.randrange(1, c.n), pyec.G(c)))
+    return pts
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_variable_base_vs_bigint(oracle, curve):
+    """No reference KAT exists for P != G (SURVEY.md §8c 'Gaps'): differential of both variable-base
+    drivers against the independent affine model, including the edge scalars/points of §8d."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xBA5E + c.cid)
+    pts = _rand_points(c, rng, 6)
+    G = pyec.G(c)
+    edge_k = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128]
+    if curve == "k256":
+        edge_k.append(pyec.K256_LAMBDA)
+    pairs = [(k, P) for k in edge_k for P in (G, pyec.neg(c, G), pts[0])]
+    pairs += [(rng.randrange(c.n), P) for P in pts for _ in range(3)]
+    pairs += [(rng.randrange(c.n), pyec.INF), (0, pyec.INF)]
+    scal = b"".join(pyec.enc_scalar(c, k) for k, _ in pairs)
+    enc = [pyec.enc_point(c, P) for _, P in pairs]
+    pxy = b"".join(e[0] for e in enc)
+    pinf = np.array([e[1] for e in enc], np.uint8)
+    for vt in (False, True):
+        out, inf = oracle.batch_mul(c.cid, scal, pxy, pinf, vartime=vt)
+        for i, (k, P) in enumerate(pairs):
+            got = pyec.dec_point(c, bytes(out[2 * c.L * i: 2 * c.L * (i + 1)]), inf[i])
+            assert got == pyec.mul(c, k, P), (curve, vt, i)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_lincomb_vs_bigint_and_identities(oracle, curve):
+    """k256/tests/projective.rs:75-140, p256/tests/projective.rs:83-148: lincomb == sum of
+    products, lincomb_vartime == lincomb, chunking does not matter; n == 0 gives the identity."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0x11CC + c.cid)
+    pts = _rand_points(c, rng, 9) + [pyec.INF, pyec.G(c), pyec.neg(c, pyec.G(c))]
+    ks = [rng.randrange(c.n) for _ in pts]
+    ks[3] = 0
+    ks[-1] = ks[-2]  # k*G + k*(-G) cancels
+    pts.append(pts[0]); ks.append(c.n - ks[0])  # P0 term cancels too
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    enc = [pyec.enc_point(c, P) for P in pts]
+    pxy = b"".join(e[0] for e in enc)
+    pinf = np.array([e[1] for e in enc], np.uint8)
+    want = pyec.msm(c, ks, pts)
+    for vt in (False, True):
+        for chunk in (0, 1, 3, 5):
+            out, inf = oracle.msm(c.cid, scal, pxy, pinf, chunk=chunk, vartime=vt)
+            assert pyec.dec_point(c, bytes(out), inf) == want
+    out, inf = oracle.msm(c.cid, b"", b"", None)
+    assert inf == 1 and not out.any()
+    # three-term proptest shape
+    for _ in range(5):
+        sub = rng.sample(range(9), 3)
+        s3 = b"".join(pyec.enc_scalar(c, ks[i]) for i in sub)
+        p3 = b"".join(enc[i][0] for i in sub)
+        out, inf = oracle.msm(c.cid, s3, p3)
+        assert pyec.dec_point(c, bytes(out), inf) == pyec.msm(c, [ks[i] for i in sub], [pts[i] for i in sub])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_mul_by_generator_matches_variable_base(oracle, curve):
+    """p256/src/arithmetic/tables.rs:64-80, k256/tests/projective.rs mul_by_generator == G * s,
+    scalars drawn like the reference generators (32/48 random bytes -> Scalar::reduce)."""
+    c = pyec.CURVES[curve]
+    rng = np.random.default_rng(0xEC000000 + c.cid)
+    n = 64
+    raw = rng.integers(0, 256, n * c.L, dtype=np.uint8)
+    raw[: c.L] = 0xFF  # forces the reduction branch
+    scal = oracle.scalar_reduce(c.cid, raw)
+    for i in range(n):
+        k = int.from_bytes(bytes(raw[c.L * i: c.L * (i + 1)]), "big")
+        assert int.from_bytes(bytes(scal[c.L * i: c.L * (i + 1)]), "big") == (k - c.n if k >= c.n else k)
+    gxy = pyec.enc_point(c, pyec.G(c))[0] * n
+    a, ai = oracle.batch_mul_base(c.cid, scal)
+    b, bi = oracle.batch_mul(c.cid, scal, gxy)
+    assert bytes(a) == bytes(b) and bytes(ai) == bytes(bi)
+    k0 = int.from_bytes(bytes(scal[: c.L]), "big")
+    assert pyec.dec_point(c, bytes(a[: 2 * c.L]), ai[0]) == pyec.mul(c, k0, pyec.G(c))
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_batch_normalize_and_validation(oracle, curve):
+    """k256/tests/projective.rs batch_normalize == to_affine; identity handling; decode errors."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xB0 + c.cid)
+    pts = _rand_points(c, rng, 5)
+    xyz = b""
+    want = []
+    for i, P in enumerate(pts + [pyec.INF]):
+        z = rng.randrange(1, c.p)
+        if P is pyec.INF:
+            xyz += (0).to_bytes(c.L, "big") + (1).to_bytes(c.L, "big") + (0).to_bytes(c.L, "big")
+        else:
+            xyz += (P[0] * z % c.p).to_bytes(c.L, "big") + (P[1] * z % c.p).to_bytes(c.L, "big") + z.to_bytes(c.L, "big")
+        want.append(P)
+    out, inf = oracle.batch_normalize(c.cid, xyz)
+    for i, P in enumerate(want):
+        assert pyec.dec_point(c, bytes(out[2 * c.L * i: 2 * c.L * (i + 1)]), inf[i]) == P
+    good = pyec.enc_point(c, pts[0])[0]
+    bad = good[:-1] + bytes([good[-1] ^ 1])
+    rc, idx = oracle.validate_points(c.cid, good + bad + good)
+    assert rc == -3 and idx == 1
+    assert oracle.validate_points(c.cid, good + good)[0] == 0
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.batch_mul_base(c.cid, c.n.to_bytes(c.L, "big"))
+    assert e.value.code == -2
