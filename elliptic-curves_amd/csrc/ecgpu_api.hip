@@ -1,0 +1,587 @@
+// ecgpu_api.hip — the C ABI of include/ecgpu.h on top of the gfx950 kernels.
+// No torch, no CPU compute path: every entry point either runs HIP kernels or returns an error.
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "../../include/ecgpu.h"
+#include "ecgpu_launch.h"
+#include "ecgpu_recode.h"
+
+using namespace ecgpu;
+
+namespace {
+
+constexpr int BLOCK = 256;
+enum : int { ST_BAD_SCALAR = 1, ST_BAD_POINT = 2 };
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct Table {
+    uint32_t* d = nullptr;
+    int w = 0, nwin = 0;
+};
+
+}  // namespace
+
+struct ecgpu_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    int* d_status = nullptr;
+    int* h_status = nullptr;
+    Table table[3];
+    int want_w[3] = {16, 16, 16};
+    int msm_c = 0;   // 0 = choose from n
+    DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
+    hipEvent_t ev[6] = {};
+    std::map<std::string, double> timing;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                      \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return e_ == hipErrorOutOfMemory ? ECGPU_ERR_OOM : ECGPU_ERR_HIP;                   \
+        }                                                                                       \
+    } while (0)
+
+int ensure(ecgpu_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return ECGPU_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ECGPU_OK;
+}
+
+template <class F>
+int dispatch(int curve, F&& f) {
+    switch (curve) {
+    case ECGPU_K256: return f(K256Params{});
+    case ECGPU_P256: return f(P256Params{});
+    case ECGPU_P384: return f(P384Params{});
+    default: return ECGPU_ERR_CURVE;
+    }
+}
+
+inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int reset_status(ecgpu_ctx* ctx) {
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+    return ECGPU_OK;
+}
+
+// reads the status word back (synchronises the stream) and maps it to an error code
+int finish(ecgpu_ctx* ctx) {
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int st = *ctx->h_status;
+    if (st & ST_BAD_SCALAR) { ctx->err = "scalar not in [0, n)"; return ECGPU_ERR_SCALAR_RANGE; }
+    if (st & ST_BAD_POINT) { ctx->err = "point coordinate >= p or not on curve"; return ECGPU_ERR_POINT; }
+    return ECGPU_OK;
+}
+
+void record(ecgpu_ctx* ctx, int i) { (void)hipEventRecord(ctx->ev[i], ctx->stream); }
+
+void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*, std::pair<int, int>>> spans) {
+    ctx->timing.clear();
+    for (auto& s : spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev[s.second.first], ctx->ev[s.second.second]) == hipSuccess)
+            ctx->timing[s.first] = ms;
+    }
+}
+
+// ---- basepoint table ---------------------------------------------------------------------------------
+
+template <class C>
+int ensure_table(ecgpu_ctx* ctx) {
+    constexpr int N = C::N;
+    Table& t = ctx->table[C::ID];
+    int w = ctx->want_w[C::ID];
+    if (t.d && t.w == w) return ECGPU_OK;
+    if (t.d) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(t.d));
+        t.d = nullptr;
+    }
+    const int bits = 32 * N;
+    const int nwin = signed_window_count(bits, w);
+    const size_t half = (size_t)1 << (w - 1);
+    const size_t entries = half * nwin;
+    int rc;
+    if ((rc = ensure(ctx, ctx->bases, (size_t)nwin * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, entries * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->prefix, entries * N * 4)) != ECGPU_OK) return rc;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.d), entries * 2 * N * 4));
+    launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, w, nwin);
+    launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, w, nwin);
+    launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, entries, nullptr, nullptr,
+                        t.d);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    t.w = w;
+    t.nwin = nwin;
+    return ECGPU_OK;
+}
+
+// launches the normalisation of n projective points in ctx->proj to wire-format output
+template <class C>
+int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
+    int rc;
+    if ((rc = ensure(ctx, ctx->prefix, n * C::N * 4)) != ECGPU_OK) return rc;
+    launch_normalize<C>(ctx->stream, false, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, n, (uint8_t*)d_out_xy,
+                        (uint8_t*)d_out_inf, nullptr);
+    return ECGPU_OK;
+}
+
+// ---- device-pointer implementations --------------------------------------------------------------------
+
+template <class C>
+int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf) {
+    constexpr int N = C::N;
+    int rc;
+    if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+    if (n == 0) return ECGPU_OK;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    const Table& t = ctx->table[C::ID];
+    record(ctx, 0);
+    launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_scalars, n, (const uint32_t*)t.d, t.w, t.nwin, (uint32_t*)ctx->proj.p,
+                         ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+int mul_var_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, const void* d_points_inf, size_t n,
+                void* d_out_xy, void* d_out_inf) {
+    constexpr int N = C::N;
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    size_t tstride = var_base_slots<C>(n);
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
+                       (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+int normalize_dev(ecgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_out_xy, void* d_out_inf) {
+    constexpr int N = C::N;
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_load_proj<C>(ctx->stream, (const uint8_t*)d_xyz, n, (uint32_t*)ctx->proj.p, ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf) {
+    constexpr int N = C::N;
+    int rc;
+    if ((rc = ensure(ctx, ctx->proj, 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_point_sum<C>(ctx->stream, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, (uint32_t*)ctx->proj.p, ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy,
+            void* d_out_inf) {
+    constexpr int N = C::N;
+    int rc;
+    if ((rc = ensure(ctx, ctx->proj, 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    MsmPlan plan = msm_plan<C>(n, ctx->msm_c);
+    if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_msm<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
+                  ctx->msm_ws.p, (uint32_t*)ctx->proj.p, ctx->d_status, ctx->ev[3], ctx->ev[4]);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
+                         {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
+    return rc;
+}
+
+// ---- host-pointer plumbing ---------------------------------------------------------------------------------
+
+int upload(ecgpu_ctx* ctx, DevBuf& b, const void* host, size_t bytes) {
+    int rc = ensure(ctx, b, bytes ? bytes : 16);
+    if (rc != ECGPU_OK) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ECGPU_OK;
+}
+int download(ecgpu_ctx* ctx, void* host, const DevBuf& b, size_t bytes) {
+    if (bytes && host) {
+        HIP_TRY(ctx, hipMemcpyAsync(host, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ECGPU_OK;
+}
+
+bool check_ctx(ecgpu_ctx* ctx) {
+    if (!ctx) return false;
+    return hipSetDevice(ctx->device) == hipSuccess;
+}
+
+}  // namespace
+
+// ================================================================================================================
+// C ABI
+// ================================================================================================================
+
+extern "C" {
+
+const char* ecgpu_version(void) { return "ecgpu 0.1 (gfx950)"; }
+
+size_t ecgpu_field_bytes(int curve) {
+    switch (curve) {
+    case ECGPU_K256: case ECGPU_P256: return 32;
+    case ECGPU_P384: return 48;
+    default: return 0;
+    }
+}
+
+int ecgpu_init(ecgpu_ctx** out, int device) {
+    if (!out) return ECGPU_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ECGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ECGPU_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ECGPU_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        std::fprintf(stderr, "ecgpu: device %d is %s; this library is built for gfx950 only\n", device, prop.gcnArchName);
+        return ECGPU_ERR_NO_DEVICE;
+    }
+    ecgpu_ctx* ctx = new (std::nothrow) ecgpu_ctx();
+    if (!ctx) return ECGPU_ERR_OOM;
+    ctx->device = device;
+    bool ok = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->stream = ctx->own_stream;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(int)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(int)) == hipSuccess;
+    for (auto& e : ctx->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) {
+        ecgpu_destroy(ctx);
+        return ECGPU_ERR_HIP;
+    }
+    *out = ctx;
+    return ECGPU_OK;
+}
+
+void ecgpu_destroy(ecgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3,
+                      &ctx->out0, &ctx->out1, &ctx->msm_ws})
+        if (b->p) (void)hipFree(b->p);
+    for (auto& t : ctx->table)
+        if (t.d) (void)hipFree(t.d);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* ecgpu_last_error(const ecgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
+    if (!ctx) return ECGPU_ERR_ARG;
+    ctx->stream = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own_stream;
+    return ECGPU_OK;
+}
+
+int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
+    if (!ctx || curve < 0 || curve > 2) return ECGPU_ERR_CURVE;
+    if (window_bits < 4 || window_bits > 16) return ECGPU_ERR_ARG;
+    ctx->want_w[curve] = window_bits;
+    return ECGPU_OK;
+}
+
+int ecgpu_last_timing(const ecgpu_ctx* ctx, const char* name, double* ms) {
+    if (!ctx || !name || !ms) return ECGPU_ERR_ARG;
+    auto it = ctx->timing.find(name);
+    if (it == ctx->timing.end()) return ECGPU_ERR_ARG;
+    *ms = it->second;
+    return ECGPU_OK;
+}
+
+// ---- device-pointer entry points ----
+
+int ecgpu_batch_mul_base_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, size_t n, void* d_out_xy,
+                             void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) { return mul_base_dev<decltype(c)>(ctx, d_scalars, n, d_out_xy, d_out_inf); });
+}
+
+int ecgpu_batch_mul_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy,
+                        const void* d_points_inf, size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_points_xy || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_points_xy) ||
+              !aligned16(d_out_xy)))
+        return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
+        return mul_var_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_msm_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
+                  size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
+        return msm_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_batch_normalize_dev(ecgpu_ctx* ctx, int curve, const void* d_points_xyz, size_t n, void* d_out_xy,
+                              void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_points_xyz || !d_out_xy || !aligned16(d_points_xyz) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) { return normalize_dev<decltype(c)>(ctx, d_points_xyz, n, d_out_xy, d_out_inf); });
+}
+
+int ecgpu_point_sum_dev(ecgpu_ctx* ctx, int curve, const void* d_points_xy, const void* d_points_inf, size_t n,
+                        void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy) || (n && (!d_points_xy || !aligned16(d_points_xy)))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
+        return point_sum_dev<decltype(c)>(ctx, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* d_a, const void* d_b,
+                                         const void* d_points_xy, const void* d_points_inf, size_t n, void* d_out_xy,
+                                         void* d_out_inf) {
+    // aG + bP per element = two-term lincomb (mul_backend.rs:29-40).  Evaluated as a*G (table kernel) and
+    // b*P (variable-base kernel) into projective scratch halves, then one complete addition per element.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_a || !d_b || !d_points_xy || !d_out_xy || !aligned16(d_a) || !aligned16(d_b) ||
+              !aligned16(d_points_xy) || !aligned16(d_out_xy)))
+        return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
+        using C = decltype(c);
+        constexpr int N = C::N;
+        int rc;
+        if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+        if (n == 0) return (int)ECGPU_OK;
+        size_t tstride = var_base_slots<C>(n);
+        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * N * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * N * 4)) != ECGPU_OK) return rc;
+        if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+        const Table& t = ctx->table[C::ID];
+        uint32_t* pa = (uint32_t*)ctx->proj.p;
+        uint32_t* pb = pa + n * 3 * N;
+        record(ctx, 0);
+        launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_a, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
+        launch_var_base<C>(ctx->stream, (const uint8_t*)d_b, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
+                           (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
+        launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+        record(ctx, 1);
+        if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+        record(ctx, 2);
+        rc = finish(ctx);
+        collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+        return rc;
+    });
+}
+
+// ---- host-pointer entry points ----
+
+int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy,
+                         uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!scalars || !out_xy)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_base_dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy,
+                    const uint8_t* points_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_dev(ctx, curve, ctx->in0.p, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
+                                  ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf,
+              size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (!out_xy || (n && (!scalars || !points_xy))) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_msm_dev(ctx, curve, ctx->in0.p, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
+                            ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, 1);
+}
+
+int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a_scalars, const uint8_t* b_scalars,
+                                     const uint8_t* points_xy, const uint8_t* points_inf, size_t n, uint8_t* out_xy,
+                                     uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, a_scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, b_scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_base_and_mul_add_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in1.p,
+                                                   points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p, ctx->out1.p)) !=
+        ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, size_t n, uint8_t* out_xy,
+                          uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!points_xyz || !out_xy)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, points_xyz, n * 3 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_normalize_dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const uint8_t* points_inf, size_t n,
+                    uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (!out_xy || (n && !points_xy)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_point_sum_dev(ctx, curve, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
+                                  ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, 1);
+}
+
+int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!scalars || !r1 || !r2)) return ECGPU_ERR_ARG;
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->in1, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    launch_k256_glv(ctx->stream, (const uint8_t*)ctx->in0.p, n, (uint8_t*)ctx->out0.p, (uint8_t*)ctx->in1.p, ctx->d_status);
+    if ((rc = finish(ctx)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, r1, ctx->out0, n * 32)) != ECGPU_OK) return rc;
+    return download(ctx, r2, ctx->in1, n * 32);
+}
+
+int ecgpu_valu_probe(ecgpu_ctx* ctx, int which, double* ops_per_sec) {
+    if (!check_ctx(ctx) || !ops_per_sec) return ECGPU_ERR_ARG;
+    const int blocks = 256 * 8, iters = 2048;
+    int rc;
+    if ((rc = ensure(ctx, ctx->out0, (size_t)blocks * BLOCK * 4)) != ECGPU_OK) return rc;
+    auto launch = [&](int it) { launch_valu_probe(ctx->stream, which, (uint32_t*)ctx->out0.p, blocks, it); };
+    launch(16);  // warm-up
+    record(ctx, 0);
+    launch(iters);
+    record(ctx, 1);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    double ops = (double)blocks * BLOCK * (double)iters * 64.0;
+    *ops_per_sec = ops / (ms * 1e-3);
+    return ECGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// ecgpu_inst_base.hip — instantiates the "base" kernel group for -DECGPU_CURVE=<K256Params|P256Params|P384Params>.
+#include "ecgpu_kernels.h"
+#include "ecgpu_launch.h"
+
+namespace ecgpu {
+
+using CurveT = ECGPU_CURVE;
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK); }
+
+template <> void launch_window_bases<CurveT>(hipStream_t s, uint32_t* bases, int w, int nwin) {
+    hipLaunchKernelGGL(k_window_bases<CurveT>, dim3(1), dim3(64), 0, s, bases, w, nwin);
+}
+template <> void launch_table_entries<CurveT>(hipStream_t s, const uint32_t* bases, uint32_t* entries, int w, int nwin) {
+    size_t total = ((size_t)1 << (w - 1)) * nwin;
+    hipLaunchKernelGGL(k_table_entries<CurveT>, dim3(grid_for(total)), dim3(BLOCK), 0, s, bases, entries, w, nwin);
+}
+// One inversion per thread, amortised over K = ceil(n / 32768) <= 64 points (Montgomery's trick).
+template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
+                                          uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
+    if (n == 0) return;
+    size_t k = (n + 32767) / 32768;
+    if (k > 64) k = 64;
+    size_t nthreads = (n + k - 1) / k;
+    if (out_internal)
+        hipLaunchKernelGGL((k_normalize<CurveT, true>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                           out_xy, out_inf, out_limbs);
+    else
+        hipLaunchKernelGGL((k_normalize<CurveT, false>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                           out_xy, out_inf, out_limbs);
+}
+template <> void launch_fixed_base<CurveT>(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
+                                           int nwin, uint32_t* proj_out, int* status) {
+    hipLaunchKernelGGL(k_fixed_base<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, scalars, n, table, w, nwin, proj_out, status);
+}
+template <> void launch_load_proj<CurveT>(hipStream_t s, const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status) {
+    hipLaunchKernelGGL(k_load_proj<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xyz, n, proj_out, status);
+}
+template <> void launch_point_sum<CurveT>(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
+                                          int* status) {
+    hipLaunchKernelGGL(k_point_sum<CurveT>, dim3(1), dim3(BLOCK), 0, s, xy, inf, n, proj_out, status);
+}
+template <> void launch_proj_add_pairs<CurveT>(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n) {
+    hipLaunchKernelGGL(k_proj_add_pairs<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, pa, pb, n);
+}
+
+}  // namespace ecgpu

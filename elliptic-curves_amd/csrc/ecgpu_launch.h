@@ -1,0 +1,50 @@
+// ecgpu_launch.h — host-side launch wrappers, one explicit instantiation per curve.
+// The kernels are large fully-inlined bodies; each (kernel group x curve) is its own translation
+// unit (ecgpu_inst_*.hip compiled with -DECGPU_CURVE=...) so the build parallelises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ecgpu_field.h"
+
+namespace ecgpu {
+
+struct MsmPlan {
+    int c = 0, nwin = 0, seg = 0;
+    size_t nb = 0;     // buckets per window = 2^(c-1)
+    size_t nseg = 0;   // segments per window
+    size_t off_points = 0, off_rank = 0, off_sorted = 0, off_count = 0, off_offset = 0, off_buckets = 0,
+           off_segs = 0, off_wins = 0;
+    size_t workspace_bytes = 0;
+};
+
+// ---- group "base": table construction, fixed-base kernel, normalisation, small helpers ----
+template <class C> void launch_window_bases(hipStream_t s, uint32_t* bases, int w, int nwin);
+template <class C> void launch_table_entries(hipStream_t s, const uint32_t* bases, uint32_t* entries, int w, int nwin);
+template <class C> void launch_normalize(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
+                                         uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs);
+template <class C> void launch_fixed_base(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
+                                          int nwin, uint32_t* proj_out, int* status);
+template <class C> void launch_load_proj(hipStream_t s, const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status);
+template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
+                                         int* status);
+template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n);
+
+// ---- group "var": variable-base kernel ----
+template <class C> size_t var_base_slots(size_t n);     // table slots (threads) the launch will use
+template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf,
+                                        size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
+
+// ---- group "msm": Pippenger pipeline ----
+template <class C> MsmPlan msm_plan(size_t n, int force_c);
+template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,
+                                   const uint8_t* inf, size_t n, void* workspace, uint32_t* out, int* status,
+                                   hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
+
+// ---- curve-independent ----
+void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status);
+void launch_valu_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
+
+}  // namespace ecgpu

@@ -1,0 +1,204 @@
+// ecgpu_recode.h — scalar recodings used by the kernels (host+device, see ecgpu_field.h).
+//
+//  * signed fixed windows of W bits, digits in (-2^(W-1), 2^(W-1)], least significant first —
+//    for W = 4 this is the digit set of `Radix16Decomposition::new`
+//    (primeorder/src/tables/radix16.rs:35-61) up to the tie-break at |d| = 8 (the reference
+//    emits -8 and carries, we emit +8 ... see signed_radix16_msb for the bit-exact variant);
+//  * `signed_radix16_msb`: the reference's exact radix-16 digits [-8, 7] obtained in O(1) per
+//    digit from k' = k + 0x88..8 (adding 8 to every nibble performs the reference's
+//    recentring carry chain `carry = (d+8)>>4` in one multi-limb addition), so the kernel can
+//    walk the digits most-significant-first without storing them;
+//  * k256 GLV split `decompose_scalar` (k256/src/arithmetic/mul/glv.rs:149-156,
+//    scalar/wide64.rs:64-119) on 32-bit limbs.
+#pragma once
+
+#include "ecgpu_field.h"
+
+namespace ecgpu {
+
+// bits [pos, pos+w) of a little-endian limb array of NL limbs (w <= 16), zero past the end
+template <int NL>
+ECGPU_HD uint32_t get_bits(const uint32_t* k, int pos, int w) {
+    int limb = pos >> 5, sh = pos & 31;
+    if (limb >= NL) return 0;
+    uint32_t lo = k[limb] >> sh;
+    if (sh + w > 32 && limb + 1 < NL) lo |= k[limb + 1] << (32 - sh);
+    return lo & ((1u << w) - 1);
+}
+
+// One step of the least-significant-first signed window recoding.
+// in: raw window value (w bits) and carry (0/1); out: digit in (-2^(w-1), 2^(w-1)], new carry.
+ECGPU_HD int signed_window_step(uint32_t raw, int w, uint32_t* carry) {
+    uint32_t v = raw + *carry;
+    uint32_t half = 1u << (w - 1);
+    if (v > half) {
+        *carry = 1;
+        return (int)v - (int)(1u << w);
+    }
+    *carry = 0;
+    return (int)v;
+}
+
+// Number of signed windows needed for a `bits`-bit scalar: the top window only absorbs what is
+// left plus the carry.
+ECGPU_HD int signed_window_count(int bits, int w) { return bits / w + 1; }
+
+// k' = k + 0x8888...8 over NL limbs (+1 limb for the carry). digit(i) = nibble_i(k') - 8 for
+// i < 8*NL, and nibble (0/1) for i = 8*NL: exactly Radix16Decomposition::new's output.
+template <int NL>
+struct Radix16Msb {
+    uint32_t kp[NL + 1];
+    ECGPU_HD void init(const uint32_t* k) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            c += (uint64_t)k[i] + 0x88888888u;
+            kp[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        kp[NL] = (uint32_t)c;
+    }
+    ECGPU_HD int digit(int i) const {
+        uint32_t nib = (kp[i >> 3] >> ((i & 7) * 4)) & 0xF;
+        return (i < 8 * NL) ? (int)nib - 8 : (int)nib;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// secp256k1 scalar arithmetic mod n on 8x32 limbs + GLV decomposition
+// ---------------------------------------------------------------------------------------------
+
+struct K256Scalar {
+    using C = K256Params;
+    // 2^256 - n  (129 bits)                      k256 scalar/wide64.rs:11 NEG_MODULUS
+    ECGPU_CONST uint32_t NEG_N[5] = {0x2FC9BEBFu, 0x402DA173u, 0x50B75FC4u, 0x45512319u, 1u};
+    // (n - 1) / 2                                 k256 scalar.rs FRAC_MODULUS_2
+    ECGPU_CONST uint32_t HALF_N[8] = {0x681B20A0u, 0xDFE92F46u, 0x57A4501Du, 0x5D576E73u,
+                                      0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x7FFFFFFFu};
+    // GLV constants, little-endian limbs           k256 mul/glv.rs:10-37
+    ECGPU_CONST uint32_t MINUS_LAMBDA[8] = {0xB51283CFu, 0xE0CFC810u, 0x8EC739C2u, 0xA880B9FCu,
+                                            0x77ED9BA4u, 0x5AD9E3FDu, 0x3FA3CF1Fu, 0xAC9C52B3u};
+    ECGPU_CONST uint32_t MINUS_B1[8] = {0x0ABFE4C3u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u,
+                                        0, 0, 0, 0};
+    ECGPU_CONST uint32_t MINUS_B2[8] = {0x3DB1562Cu, 0xD765CDA8u, 0x0774346Du, 0x8A280AC5u,
+                                        0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    ECGPU_CONST uint32_t G1[8] = {0x45DBB031u, 0xE893209Au, 0x71E8CA7Fu, 0x3DAA8A14u,
+                                  0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+    ECGPU_CONST uint32_t G2[8] = {0x8AC47F71u, 0x1571B4AEu, 0x9DF506C6u, 0x221208ACu,
+                                  0x0ABFE4C4u, 0x6F547FA9u, 0x010E8828u, 0xE4437ED6u};
+
+    // r = a + b mod n (inputs < n)                 k256 scalar.rs:106-108
+    static ECGPU_HD void add(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+        uint32_t t[8], d[8];
+        uint32_t carry = mp_add<8>(t, a, b);
+        uint32_t borrow = mp_sub<8>(d, t, C::ORDER);
+        bool use_d = carry || !borrow;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = use_d ? d[i] : t[i];
+    }
+    static ECGPU_HD void neg(uint32_t* r, const uint32_t* a) {           // scalar.rs:100-102
+        uint32_t d[8];
+        bool z = mp_is_zero<8>(a);
+        mp_sub<8>(d, C::ORDER, a);
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = z ? 0u : d[i];
+    }
+    static ECGPU_HD bool is_high(const uint32_t* a) {                    // scalar.rs:419-423
+        uint32_t t[8];
+        return mp_sub<8>(t, HALF_N, a) != 0;  // HALF_N < a
+    }
+
+    // acc[0..na+5) = x[0..na) * NEG_N, helper for the folding reduction
+    template <int NA>
+    static ECGPU_HD void mul_neg_n(uint32_t* out, const uint32_t* x) {
+#pragma unroll
+        for (int i = 0; i < NA + 5; i++) out[i] = 0;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                uint64_t t = (uint64_t)x[i] * NEG_N[j] + out[i + j] + carry;
+                out[i + j] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+            out[i + 5] = carry;
+        }
+    }
+
+    // 512-bit l -> l mod n by folding the high part with 2^256 = NEG_N (mod n) three times and one
+    // conditional subtraction                      k256 scalar/wide64.rs:121-212
+    static ECGPU_HD void reduce_wide(uint32_t* r, const uint32_t* l) {
+        // fold 1: m = l[0..8) + l[8..16) * NEG_N        (< 2^386, 13 limbs)
+        uint32_t m[13], prod[13];
+        mul_neg_n<8>(prod, l + 8);
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 13; i++) {
+                c += (uint64_t)prod[i] + (i < 8 ? l[i] : 0u);
+                m[i] = (uint32_t)c;
+                c >>= 32;
+            }
+        }
+        // fold 2: p = m[0..8) + m[8..13) * NEG_N        (< 2^259, 10 limbs used)
+        uint32_t p[10], prod2[10];
+        mul_neg_n<5>(prod2, m + 8);
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                c += (uint64_t)prod2[i] + (i < 8 ? m[i] : 0u);
+                p[i] = (uint32_t)c;
+                c >>= 32;
+            }
+        }
+        // fold 3: t = p[0..8) + p[8] * NEG_N            (p[9] == 0, p[8] <= 4)
+        uint32_t t[9];
+        {
+            uint64_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                c += (uint64_t)p[i] + (i < 5 ? (uint64_t)p[8] * NEG_N[i] : 0u);
+                t[i] = (uint32_t)c;
+                c >>= 32;
+            }
+            t[8] = (uint32_t)c;
+        }
+        uint32_t d[8];
+        uint32_t borrow = mp_sub<8>(d, t, C::ORDER);
+        bool use_d = t[8] || !borrow;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = use_d ? d[i] : t[i];
+    }
+
+    static ECGPU_HD void mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {  // scalar.rs:120-122
+        uint32_t l[16];
+        mp_mul<8>(l, a, b);
+        reduce_wide(r, l);
+    }
+
+    // round(a*b / 2^384)                            wide64.rs:64-119 with shift = 384
+    static ECGPU_HD void mul_shift_384(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+        uint32_t l[16];
+        mp_mul<8>(l, a, b);
+        uint32_t res[8] = {l[12], l[13], l[14], l[15], 0, 0, 0, 0};
+        uint32_t round_bit = l[11] >> 31;
+        uint32_t one[8] = {round_bit, 0, 0, 0, 0, 0, 0, 0};
+        add(r, res, one);
+    }
+
+    // k -> (r1, r2), r1 + r2*lambda = k mod n         mul/glv.rs:149-156
+    static ECGPU_HD void decompose(uint32_t* r1, uint32_t* r2, const uint32_t* k) {
+        uint32_t t[8], c1[8], c2[8];
+        mul_shift_384(t, k, G1);
+        mul(c1, t, MINUS_B1);
+        mul_shift_384(t, k, G2);
+        mul(c2, t, MINUS_B2);
+        add(r2, c1, c2);
+        mul(t, r2, MINUS_LAMBDA);
+        add(r1, k, t);
+    }
+};
+
+}  // namespace ecgpu

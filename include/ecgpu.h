@@ -1,0 +1,172 @@
+/*
+ * ecgpu.h — C ABI of libecgpu.so, the MI355X (gfx950) batch scalar-multiplication / MSM engine
+ * that drops in behind RustCrypto/elliptic-curves' scalar-mul surface for k256, p256 and p384.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * root).  The reference's own API works on one element at a time; the GPU entry points are the
+ * batch forms of the same operations, plus `lincomb`, which is already a batch.  INTEGRATION.md
+ * shows the Rust `extern "C"` block and the `MulBackend` / `LinearCombination` adapter a
+ * maintainer would add on the reference side.
+ *
+ * Wire format (identical for host- and device-pointer entry points)
+ *   scalars   n * L bytes, big-endian, canonical (< group order n) — `Scalar::to_repr`
+ *             (k256/src/arithmetic/scalar.rs:310-316, primefield/src/monty.rs:498-500);
+ *             L = 32 (k256, p256) or 48 (p384) = `FieldBytesSize`.
+ *   points    n * 2L bytes, big-endian affine x || y — `AffinePoint::{x,y}`
+ *             (primeorder/src/affine.rs:106-112) + optional n-byte identity flags
+ *             (`AffinePoint::infinity`, k256/src/arithmetic/affine.rs:45-49); NULL flags = none.
+ *             The identity is encoded as x = y = 0 with flag 1 on output.
+ *   projective inputs (batch_normalize only): n * 3L bytes X || Y || Z, canonical big-endian.
+ *
+ * Ownership: the caller owns every buffer passed in; the library keeps no pointer after return.
+ * Device memory, streams and the precomputed basepoint tables belong to the context
+ * (the analogue of the reference's `static BASEPOINT_TABLE: LazyLock<..>`,
+ * k256/src/arithmetic/tables.rs:18, primeorder/src/tables/basepoint.rs:29-31).
+ *
+ * Errors: every function returns ECGPU_OK (0) or a negative code; nothing aborts or throws across
+ * the ABI.  Decoding failures mirror the reference's `CtOption`/`Error` results; the arithmetic
+ * itself is total (complete formulas).  There is NO CPU fallback: without a usable gfx950 device
+ * ecgpu_init fails with ECGPU_ERR_NO_DEVICE.
+ *
+ * Threading: a context may be used from one thread at a time (calls serialise on its stream);
+ * create one context per thread / per GPU for concurrency.
+ */
+#ifndef ECGPU_H
+#define ECGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ecgpu_ctx ecgpu_ctx;
+
+enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2 };
+
+enum {
+    ECGPU_OK = 0,
+    ECGPU_ERR_CURVE = -1,        /* unknown curve id */
+    ECGPU_ERR_SCALAR_RANGE = -2, /* a scalar >= n          (Scalar::from_repr -> None) */
+    ECGPU_ERR_POINT = -3,        /* coordinate >= p or not on curve (AffinePoint::from_coordinates
+                                    -> None, primeorder/src/affine.rs:100-109) */
+    ECGPU_ERR_NO_DEVICE = -4,    /* no gfx950 device / HIP runtime unusable */
+    ECGPU_ERR_HIP = -5,          /* a HIP call failed; see ecgpu_last_error */
+    ECGPU_ERR_OOM = -6,          /* device or host allocation failed */
+    ECGPU_ERR_ARG = -7           /* NULL / inconsistent argument */
+};
+
+/* ---- context -------------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device` (as numbered by the HIP runtime in this process).
+ * Basepoint tables are built lazily on first use per curve and kept on the device. */
+int ecgpu_init(ecgpu_ctx **ctx, int device);
+void ecgpu_destroy(ecgpu_ctx *ctx);
+
+/* Human-readable text of the last error on this context (valid until the next call). */
+const char *ecgpu_last_error(const ecgpu_ctx *ctx);
+
+/* Field-byte length L of a curve (32 / 48), 0 for a bad id. */
+size_t ecgpu_field_bytes(int curve);
+
+/* Use an externally owned HIP stream (e.g. torch's current stream) for all later work on this
+ * context; NULL restores the context's own stream.  `stream` is a hipStream_t. */
+int ecgpu_set_stream(ecgpu_ctx *ctx, void *stream);
+
+/* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..16, default 16).
+ * The table is rebuilt on next use. A tuning knob, like the reference's WINDOW_SIZE constants
+ * (k256/src/arithmetic/tables.rs:12, p384/src/arithmetic/tables.rs:8). */
+int ecgpu_set_base_window(ecgpu_ctx *ctx, int curve, int window_bits);
+
+/* ---- host-pointer entry points (copy in, compute on the GPU, copy out) ------------------------ */
+
+/* out[i] = k[i] * G.
+ * Batch form of `ProjectivePoint::mul_by_generator` (k256/src/arithmetic/mul.rs:180-203) and
+ * `MulBackend::mul_by_generator` (primeorder/src/mul_backend.rs:15-17,
+ * p256/src/arithmetic/tables.rs:33-43), followed by `to_affine`. */
+int ecgpu_batch_mul_base(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, size_t n,
+                         uint8_t *out_xy, uint8_t *out_inf);
+
+/* out[i] = k[i] * P[i].
+ * Batch form of `impl Mul<Scalar> for ProjectivePoint` (k256/src/arithmetic/mul.rs:249-274,
+ * primeorder/src/projective.rs:847-886) / `MulVartime` (:888-921), followed by `to_affine`. */
+int ecgpu_batch_mul(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy,
+                    const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+
+/* out = sum_i k[i] * P[i].
+ * `LinearCombination<[(ProjectivePoint, Scalar)]>::{lincomb, lincomb_vartime}`
+ * (k256/src/arithmetic/mul.rs:84-109, primeorder/src/projective.rs:480-511); n == 0 gives the
+ * identity. out_xy holds 2L bytes, out_inf one byte. */
+int ecgpu_msm(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy,
+              const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+
+/* out[i] = a[i] * G + b[i] * P[i].
+ * Batch form of `MulByGeneratorVartime::mul_by_generator_and_mul_add_vartime`
+ * (primeorder/src/mul_backend.rs:29-40, k256/src/arithmetic/mul.rs:303-310) — the ECDSA/Schnorr
+ * verification shape. */
+int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx *ctx, int curve, const uint8_t *a_scalars,
+                                     const uint8_t *b_scalars, const uint8_t *points_xy,
+                                     const uint8_t *points_inf, size_t n, uint8_t *out_xy,
+                                     uint8_t *out_inf);
+
+/* Projective -> affine for n points.
+ * `BatchNormalize::batch_normalize` (k256/src/arithmetic/projective.rs:367-391,
+ * primeorder/src/projective.rs:452-478). */
+int ecgpu_batch_normalize(ecgpu_ctx *ctx, int curve, const uint8_t *points_xyz, size_t n,
+                          uint8_t *out_xy, uint8_t *out_inf);
+
+/* ---- device-pointer entry points ------------------------------------------------------------- *
+ * Same semantics, all buffers already resident in this context's device memory (e.g. torch CUDA
+ * tensors' data_ptr()).  Work is enqueued on the context stream; the call returns after the
+ * status word has been read back (one small D2H copy + stream sync), so errors are reported
+ * synchronously exactly like the host-pointer forms. */
+
+int ecgpu_batch_mul_base_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, size_t n,
+                             void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_mul_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,
+                        const void *d_points_inf, size_t n, void *d_out_xy, void *d_out_inf);
+int ecgpu_msm_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,
+                  const void *d_points_inf, size_t n, void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx *ctx, int curve, const void *d_a_scalars,
+                                         const void *d_b_scalars, const void *d_points_xy,
+                                         const void *d_points_inf, size_t n, void *d_out_xy,
+                                         void *d_out_inf);
+int ecgpu_batch_normalize_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xyz, size_t n,
+                              void *d_out_xy, void *d_out_inf);
+
+/* Sum of n affine points (out = P[0] + ... + P[n-1]) — the combine step of a sharded MSM:
+ * each GPU's partial `lincomb` result is all-gathered and added here.
+ * Uses the same `Add` as `impl Sum for ProjectivePoint` (k256 projective.rs, primeorder
+ * projective.rs `Sum` impls). */
+int ecgpu_point_sum(ecgpu_ctx *ctx, int curve, const uint8_t *points_xy, const uint8_t *points_inf,
+                    size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
+                        const void *d_points_inf, size_t n, void *d_out_xy, void *d_out_inf);
+
+/* ---- introspection / measurement ---------------------------------------------------------------- */
+
+/* k256 GLV split on the device: k -> (r1, r2) with r1 + r2*lambda = k (mod n), canonical scalars
+ * before sign folding — `glv::decompose_scalar` (k256/src/arithmetic/mul/glv.rs:149-156).
+ * Host buffers of n*32 bytes each. */
+int ecgpu_k256_glv_decompose(ecgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *r1,
+                             uint8_t *r2);
+
+/* Integer-VALU roof probe: runs a dependency-free v_mad_u64_u32 stream on every CU and returns
+ * the measured 32x32->64 multiply-add rate in operations per second (SURVEY.md §8d "peak to
+ * divide by").  `which` selects the instruction: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32,
+ * 3 v_add_u32, 4 v_lshl_add_u64, 5 v_mad_u32_u24, 6 v_fma_f64, 7 v_addc_co_u32 chain. */
+int ecgpu_valu_probe(ecgpu_ctx *ctx, int which, double *ops_per_sec);
+
+/* Milliseconds the device spent in the kernels of the last *_dev / host call on this context,
+ * measured with HIP events on the context stream; `name` selects a stage:
+ *   "total", "main" (the scalar-mul / bucket kernels), "normalize", "recode", "sort", "reduce". */
+int ecgpu_last_timing(const ecgpu_ctx *ctx, const char *name, double *ms);
+
+/* Library version string. */
+const char *ecgpu_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGPU_H */

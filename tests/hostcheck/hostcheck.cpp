@@ -1,0 +1,458 @@
+// hostcheck.cpp — TEST INFRASTRUCTURE.  Compiles the exact __host__ __device__ arithmetic the gfx950
+// kernels use (csrc/ecgpu_field.h, ecgpu_point.h, ecgpu_recode.h) with g++ so that it can be checked
+// against the oracle on a machine without a GPU.  The driver loops below mirror the kernels' control
+// flow (k_fixed_base, k_var_base, k_normalize, the Pippenger pipeline) on one CPU thread.  Nothing here
+// is linked into libecgpu.so.
+#include <cstring>
+#include <vector>
+
+#include "../../elliptic-curves_amd/csrc/ecgpu_point.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_recode.h"
+
+using namespace ecgpu;
+
+namespace {
+
+template <class C>
+bool load_affine(Affine<C>* a, const uint8_t* xy, int inf) {
+    using F = Field<C>;
+    if (inf) return false;
+    bool ok1, ok2;
+    a->x = F::from_bytes(xy, &ok1);
+    a->y = F::from_bytes(xy + 4 * C::N, &ok2);
+    return true;
+}
+
+template <class C>
+void store_affine(const Proj<C>& p, uint8_t* xy, uint8_t* inf) {
+    using F = Field<C>;
+    if (F::is_zero(p.z)) {
+        std::memset(xy, 0, 8 * C::N);
+        if (inf) *inf = 1;
+        return;
+    }
+    auto zi = F::inv(p.z);
+    F::to_bytes(xy, F::mul(p.x, zi));
+    F::to_bytes(xy + 4 * C::N, F::mul(p.y, zi));
+    if (inf) *inf = 0;
+}
+
+template <class C>
+int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    using F = Field<C>;
+    bool ok;
+    auto x = F::from_bytes(a, &ok);
+    if (!ok) return -3;
+    Fe<C::N> y = F::zero();
+    if (b) { y = F::from_bytes(b, &ok); if (!ok) return -3; }
+    Fe<C::N> r;
+    switch (op) {
+    case 0: r = F::add(x, y); break;
+    case 1: r = F::sub(x, y); break;
+    case 2: r = F::mul(x, y); break;
+    case 3: r = F::sqr(x); break;
+    case 4: r = F::inv(x); break;
+    case 5: r = F::neg(x); break;
+    case 6: r = F::mul_small(x, 21); break;
+    case 7: r = F::dbl(x); break;
+    default: return -1;
+    }
+    F::to_bytes(out, r);
+    return 0;
+}
+
+// chains of operations keep values in their lazy (weakly reduced) internal form between steps
+template <class C>
+int field_chain(const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
+    using F = Field<C>;
+    bool ok;
+    auto x = F::from_bytes(a, &ok), y = F::from_bytes(b, &ok);
+    for (int i = 0; i < steps; i++) {
+        auto t = F::mul(x, y);
+        auto u = F::sub(F::add(t, x), F::dbl(y));
+        x = F::sqr(u);
+        y = F::neg(F::add(t, F::mul_small(y, 21)));
+    }
+    F::to_bytes(out, F::add(x, y));
+    return 0;
+}
+
+template <class C>
+int point_op(int op, const uint8_t* pxy, int pinf, const uint8_t* qxy, int qinf, uint8_t* out, uint8_t* oinf) {
+    using G = Group<C>;
+    auto b = G::curve_b();
+    Affine<C> pa, qa;
+    Proj<C> p = G::identity(), r;
+    if (load_affine<C>(&pa, pxy, pinf)) p = G::from_affine(pa);
+    bool qfinite = false;
+    if (op == 0 || op == 1) qfinite = load_affine<C>(&qa, qxy, qinf);
+    switch (op) {
+    case 0: r = G::add(p, qfinite ? G::from_affine(qa) : G::identity(), b); break;
+    case 1: r = qfinite ? G::add_mixed(p, qa, b) : p; break;
+    case 2: r = G::dbl(p, b); break;
+    case 3: r = G::neg(p); break;
+    default: return -1;
+    }
+    store_affine<C>(r, out, oinf);
+    return 0;
+}
+
+template <class C>
+int on_curve(const uint8_t* xy) {
+    using G = Group<C>;
+    using F = Field<C>;
+    bool ok1, ok2;
+    Affine<C> a;
+    a.x = F::from_bytes(xy, &ok1);
+    a.y = F::from_bytes(xy + 4 * C::N, &ok2);
+    return ok1 && ok2 && G::on_curve(a, G::curve_b());
+}
+
+// ---- mirrors of the kernels' control flow ----------------------------------------------------------
+
+template <class C>
+struct BaseTable {
+    int w = 0, nwin = 0;
+    std::vector<Affine<C>> e;   // [nwin][2^(w-1)]
+};
+
+// k_window_bases + k_table_entries + k_normalize<.., true>
+template <class C>
+void build_table(BaseTable<C>& t, int w) {
+    using G = Group<C>;
+    using F = Field<C>;
+    auto b = G::curve_b();
+    t.w = w;
+    t.nwin = signed_window_count(32 * C::N, w);
+    size_t half = (size_t)1 << (w - 1);
+    t.e.resize(half * t.nwin);
+    Affine<C> g;
+    for (int i = 0; i < C::N; i++) { g.x.v[i] = C::GX[i]; g.y.v[i] = C::GY[i]; }
+    g.x = F::from_canonical(g.x);
+    g.y = F::from_canonical(g.y);
+    Proj<C> base = G::from_affine(g);
+    for (int j = 0; j < t.nwin; j++) {
+        // running multiples instead of per-entry double-and-add: same group elements, cheaper on one core
+        Proj<C> cur = base;
+        for (size_t e = 0; e < half; e++) {
+            auto zi = F::inv(cur.z);
+            t.e[j * half + e].x = F::mul(cur.x, zi);
+            t.e[j * half + e].y = F::mul(cur.y, zi);
+            cur = G::add(cur, base, b);
+        }
+        for (int s = 0; s < w; s++) base = G::dbl(base, b);
+    }
+}
+
+// k_table_entries' per-entry rule, for spot checks
+template <class C>
+Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e) {
+    using G = Group<C>;
+    auto b = G::curve_b();
+    Proj<C> acc = base;
+    int top = 31 - __builtin_clz(e);
+    for (int bit = top - 1; bit >= 0; bit--) {
+        acc = G::dbl(acc, b);
+        if ((e >> bit) & 1) acc = G::add(acc, base, b);
+    }
+    return acc;
+}
+
+// k_fixed_base
+template <class C>
+Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k) {
+    using G = Group<C>;
+    using F = Field<C>;
+    auto b = G::curve_b();
+    Proj<C> acc = G::identity();
+    uint32_t carry = 0;
+    size_t half = (size_t)1 << (t.w - 1);
+    for (int j = 0; j < t.nwin; j++) {
+        int d = signed_window_step(get_bits<C::N>(k, j * t.w, t.w), t.w, &carry);
+        if (d != 0) {
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            Affine<C> q = t.e[j * half + (mag - 1)];
+            if (d < 0) q.y = F::neg(q.y);
+            acc = G::add_mixed(acc, q, b);
+        }
+    }
+    return acc;
+}
+
+// k_var_base
+template <class C>
+Proj<C> var_base_one(const Affine<C>& a, const uint32_t* k) {
+    using G = Group<C>;
+    auto b = G::curve_b();
+    Proj<C> tab[8];
+    Proj<C> m = G::from_affine(a);
+    for (int e = 0; e < 8; e++) {
+        tab[e] = m;
+        if (e < 7) m = G::add_mixed(m, a, b);
+    }
+    Radix16Msb<C::N> digits;
+    digits.init(k);
+    Proj<C> acc = G::identity();
+    for (int di = 8 * C::N; di >= 0; di--) {
+        if (di != 8 * C::N) for (int s = 0; s < 4; s++) acc = G::dbl(acc, b);
+        int d = digits.digit(di);
+        if (d != 0) {
+            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+            Proj<C> q = tab[mag - 1];
+            if (d < 0) q = G::neg(q);
+            acc = G::add(acc, q, b);
+        }
+    }
+    return acc;
+}
+
+// k_normalize<.., false> with `nthreads` strided lanes
+template <class C>
+void normalize(const std::vector<Proj<C>>& proj, size_t nthreads, uint8_t* out_xy, uint8_t* out_inf) {
+    using F = Field<C>;
+    constexpr int N = C::N;
+    size_t n = proj.size();
+    std::vector<Fe<N>> prefix(n);
+    for (size_t t = 0; t < nthreads; t++) {
+        Fe<N> acc = F::one();
+        for (size_t j = t; j < n; j += nthreads) {
+            prefix[j] = acc;
+            if (!F::is_zero(proj[j].z)) acc = F::mul(acc, proj[j].z);
+        }
+        Fe<N> inv = F::inv(acc);
+        if (n <= t) continue;
+        size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
+        for (size_t j = last;; j -= nthreads) {
+            const Proj<C>& p = proj[j];
+            if (F::is_zero(p.z)) {
+                std::memset(out_xy + j * 8 * N, 0, 8 * N);
+                out_inf[j] = 1;
+            } else {
+                Fe<N> zinv = F::mul(prefix[j], inv);
+                inv = F::mul(inv, p.z);
+                F::to_bytes(out_xy + j * 8 * N, F::mul(p.x, zinv));
+                F::to_bytes(out_xy + j * 8 * N + 4 * N, F::mul(p.y, zinv));
+                out_inf[j] = 0;
+            }
+            if (j < nthreads) break;
+        }
+    }
+}
+
+template <class C>
+bool load_scalar(uint32_t* k, const uint8_t* be) {
+    load_be<C::N>(k, be);
+    return !mp_geq<C::N>(k, C::ORDER);
+}
+
+template <class C>
+int batch_mul_base(int w, const uint8_t* scalars, size_t n, size_t nthreads, uint8_t* out_xy, uint8_t* out_inf) {
+    static BaseTable<C> table;
+    if (table.w != w) build_table<C>(table, w);
+    std::vector<Proj<C>> proj(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[C::N];
+        if (!load_scalar<C>(k, scalars + i * 4 * C::N)) return -2;
+        proj[i] = fixed_base_one<C>(table, k);
+    }
+    normalize<C>(proj, nthreads ? nthreads : 1, out_xy, out_inf);
+    return 0;
+}
+
+template <class C>
+int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, size_t nthreads,
+              uint8_t* out_xy, uint8_t* out_inf) {
+    using G = Group<C>;
+    std::vector<Proj<C>> proj(n);
+    auto b = G::curve_b();
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[C::N];
+        if (!load_scalar<C>(k, scalars + i * 4 * C::N)) return -2;
+        Affine<C> a;
+        if (!load_affine<C>(&a, pxy + i * 8 * C::N, pinf ? pinf[i] : 0)) { proj[i] = G::identity(); continue; }
+        if (!G::on_curve(a, b)) return -3;
+        proj[i] = var_base_one<C>(a, k);
+    }
+    normalize<C>(proj, nthreads ? nthreads : 1, out_xy, out_inf);
+    return 0;
+}
+
+// the Pippenger pipeline of ecgpu_msm.h: prepare/scan/scatter/accumulate/reduce/combine, sequentially
+template <class C>
+int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy,
+        uint8_t* out_inf) {
+    using G = Group<C>;
+    using F = Field<C>;
+    constexpr int N = C::N;
+    auto b = G::curve_b();
+    int nwin = signed_window_count(32 * N, c);
+    size_t nb = (size_t)1 << (c - 1);
+    int seg = nb < 32 ? (int)nb : 32;
+    size_t nseg = nb / seg;
+    std::vector<Affine<C>> pts(n);
+    std::vector<uint32_t> ranks((size_t)nwin * n), sorted((size_t)nwin * n), counts((size_t)nwin * nb, 0),
+        offsets((size_t)nwin * nb);
+    std::vector<uint8_t> finite(n, 0);
+    std::vector<std::vector<uint32_t>> ks(n, std::vector<uint32_t>(N));
+    for (size_t i = 0; i < n; i++) {                                    // prepare
+        if (!load_scalar<C>(ks[i].data(), scalars + i * 4 * N)) return -2;
+        if (!load_affine<C>(&pts[i], pxy + i * 8 * N, pinf ? pinf[i] : 0)) continue;
+        if (!G::on_curve(pts[i], b)) return -3;
+        finite[i] = 1;
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            int d = signed_window_step(get_bits<N>(ks[i].data(), w * c, c), c, &carry);
+            if (d != 0) {
+                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                ranks[(size_t)w * n + i] = counts[(size_t)w * nb + (mag - 1)]++;
+            }
+        }
+    }
+    for (int w = 0; w < nwin; w++) {                                    // scan
+        uint32_t run = 0;
+        for (size_t j = 0; j < nb; j++) { offsets[w * nb + j] = run; run += counts[w * nb + j]; }
+    }
+    for (size_t i = 0; i < n; i++) {                                    // scatter
+        if (!finite[i]) continue;
+        uint32_t carry = 0;
+        for (int w = 0; w < nwin; w++) {
+            int d = signed_window_step(get_bits<N>(ks[i].data(), w * c, c), c, &carry);
+            if (d != 0) {
+                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                uint32_t pos = offsets[(size_t)w * nb + (mag - 1)] + ranks[(size_t)w * n + i];
+                sorted[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
+    }
+    std::vector<Proj<C>> buckets((size_t)nwin * nb);
+    for (size_t gid = 0; gid < (size_t)nwin * nb; gid++) {              // accumulate
+        size_t w = gid / nb;
+        const uint32_t* run = sorted.data() + w * n + offsets[gid];
+        Proj<C> acc = G::identity();
+        for (uint32_t t = 0; t < counts[gid]; t++) {
+            Affine<C> q = pts[run[t] & 0x7FFFFFFFu];
+            if (run[t] >> 31) q.y = F::neg(q.y);
+            acc = G::add_mixed(acc, q, b);
+        }
+        buckets[gid] = acc;
+    }
+    std::vector<Proj<C>> wins(nwin);
+    for (int w = 0; w < nwin; w++) {                                    // reduce
+        Proj<C> wsum = G::identity();
+        for (size_t s = 0; s < nseg; s++) {
+            Proj<C> running = G::identity(), local = G::identity();
+            size_t base = s * seg;
+            for (int j = seg - 1; j >= 0; j--) {
+                running = G::add(running, buckets[(size_t)w * nb + base + j], b);
+                local = G::add(local, running, b);
+            }
+            if (base) {
+                Proj<C> acc = G::identity();
+                uint32_t k = (uint32_t)base;
+                int top = 31 - __builtin_clz(k);
+                for (int bit = top; bit >= 0; bit--) {
+                    acc = G::dbl(acc, b);
+                    if ((k >> bit) & 1) acc = G::add(acc, running, b);
+                }
+                local = G::add(local, acc, b);
+            }
+            wsum = G::add(wsum, local, b);
+        }
+        wins[w] = wsum;
+    }
+    Proj<C> acc = wins[nwin - 1];                                       // combine
+    for (int w = nwin - 2; w >= 0; w--) {
+        for (int s = 0; s < c; s++) acc = G::dbl(acc, b);
+        acc = G::add(acc, wins[w], b);
+    }
+    store_affine<C>(acc, out_xy, out_inf);
+    return 0;
+}
+
+template <class C>
+int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
+    // e * 2^(w*j) * G via k_window_bases' doubling chain + k_table_entries' rule
+    using G = Group<C>;
+    using F = Field<C>;
+    auto b = G::curve_b();
+    Affine<C> g;
+    for (int i = 0; i < C::N; i++) { g.x.v[i] = C::GX[i]; g.y.v[i] = C::GY[i]; }
+    g.x = F::from_canonical(g.x);
+    g.y = F::from_canonical(g.y);
+    Proj<C> base = G::from_affine(g);
+    for (int s = 0; s < w * j; s++) base = G::dbl(base, b);
+    uint8_t inf;
+    store_affine<C>(table_entry_rule<C>(base, e), out_xy, &inf);
+    return inf;
+}
+
+#define DISPATCH(curve, expr_k, expr_p256, expr_p384) \
+    switch (curve) { case 0: return expr_k; case 1: return expr_p256; case 2: return expr_p384; default: return -1; }
+
+}  // namespace
+
+extern "C" {
+
+int hc_field_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    DISPATCH(curve, field_op<K256Params>(op, a, b, out), field_op<P256Params>(op, a, b, out),
+             field_op<P384Params>(op, a, b, out))
+}
+int hc_field_chain(int curve, const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
+    DISPATCH(curve, field_chain<K256Params>(a, b, steps, out), field_chain<P256Params>(a, b, steps, out),
+             field_chain<P384Params>(a, b, steps, out))
+}
+int hc_point_op(int curve, int op, const uint8_t* p, int pi, const uint8_t* q, int qi, uint8_t* out, uint8_t* oi) {
+    DISPATCH(curve, point_op<K256Params>(op, p, pi, q, qi, out, oi), point_op<P256Params>(op, p, pi, q, qi, out, oi),
+             point_op<P384Params>(op, p, pi, q, qi, out, oi))
+}
+int hc_on_curve(int curve, const uint8_t* xy) {
+    DISPATCH(curve, on_curve<K256Params>(xy), on_curve<P256Params>(xy), on_curve<P384Params>(xy))
+}
+int hc_batch_mul_base(int curve, int w, const uint8_t* s, size_t n, size_t nthreads, uint8_t* o, uint8_t* oi) {
+    DISPATCH(curve, batch_mul_base<K256Params>(w, s, n, nthreads, o, oi), batch_mul_base<P256Params>(w, s, n, nthreads, o, oi),
+             batch_mul_base<P384Params>(w, s, n, nthreads, o, oi))
+}
+int hc_batch_mul(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, size_t nthreads, uint8_t* o,
+                 uint8_t* oi) {
+    DISPATCH(curve, batch_mul<K256Params>(s, p, pi, n, nthreads, o, oi), batch_mul<P256Params>(s, p, pi, n, nthreads, o, oi),
+             batch_mul<P384Params>(s, p, pi, n, nthreads, o, oi))
+}
+int hc_msm(int curve, int c, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o, uint8_t* oi) {
+    DISPATCH(curve, msm<K256Params>(c, s, p, pi, n, o, oi), msm<P256Params>(c, s, p, pi, n, o, oi),
+             msm<P384Params>(c, s, p, pi, n, o, oi))
+}
+int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {
+    DISPATCH(curve, table_rule_check<K256Params>(w, j, e, out_xy), table_rule_check<P256Params>(w, j, e, out_xy),
+             table_rule_check<P384Params>(w, j, e, out_xy))
+}
+// Radix16Msb digits of a big-endian scalar (nl limbs), ndigits = 8*nl + 1, least significant first
+int hc_radix16(const uint8_t* be, int nl, int8_t* digits) {
+    if (nl == 8) {
+        uint32_t k[8]; load_be<8>(k, be);
+        Radix16Msb<8> r; r.init(k);
+        for (int i = 0; i <= 64; i++) digits[i] = (int8_t)r.digit(i);
+    } else if (nl == 12) {
+        uint32_t k[12]; load_be<12>(k, be);
+        Radix16Msb<12> r; r.init(k);
+        for (int i = 0; i <= 96; i++) digits[i] = (int8_t)r.digit(i);
+    } else return -1;
+    return 0;
+}
+// signed w-bit window digits of a 256-bit big-endian scalar, returns nwin
+int hc_signed_windows(const uint8_t* be, int w, int* digits) {
+    uint32_t k[8]; load_be<8>(k, be);
+    int nwin = signed_window_count(256, w);
+    uint32_t carry = 0;
+    for (int j = 0; j < nwin; j++) digits[j] = signed_window_step(get_bits<8>(k, j * w, w), w, &carry);
+    return carry ? -1 : nwin;
+}
+int hc_k256_glv(const uint8_t* k_be, uint8_t* r1_be, uint8_t* r2_be) {
+    uint32_t k[8], r1[8], r2[8];
+    load_be<8>(k, k_be);
+    K256Scalar::decompose(r1, r2, k);
+    store_be<8>(r1_be, r1);
+    store_be<8>(r2_be, r2);
+    return (K256Scalar::is_high(r1) ? 1 : 0) | (K256Scalar::is_high(r2) ? 2 : 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""ctypes loader for tests/hostcheck/libhostcheck.so (the kernels' arithmetic compiled for the CPU).
+Test infrastructure only; see hostcheck.cpp."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+LIB = os.path.join(HERE, "hostcheck", "libhostcheck.so")
+CSRC = os.path.join(os.path.dirname(HERE), "elliptic-curves_amd", "csrc")
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_lib = None
+
+
+def build():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_point.h", "ecgpu_recode.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+        return
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(LIB)
+    return _lib
+
+
+def _a(b):
+    if b is None:
+        return None
+    if isinstance(b, np.ndarray):
+        return np.ascontiguousarray(b, dtype=np.uint8)
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+L = {0: 32, 1: 32, 2: 48}
+
+
+def field_op(curve, op, a, b=None):
+    out = np.zeros(L[curve], np.uint8)
+    A, B = _a(a), _a(b)
+    rc = lib().hc_field_op(curve, op, _p(A), _p(B), _p(out))
+    assert rc == 0, rc
+    return bytes(out)
+
+
+def field_chain(curve, a, b, steps):
+    out = np.zeros(L[curve], np.uint8)
+    A, B = _a(a), _a(b)
+    assert lib().hc_field_chain(curve, _p(A), _p(B), steps, _p(out)) == 0
+    return bytes(out)
+
+
+def point_op(curve, op, p_xy, p_inf=0, q_xy=None, q_inf=0):
+    out = np.zeros(2 * L[curve], np.uint8)
+    inf = np.zeros(1, np.uint8)
+    P, Q = _a(p_xy), _a(q_xy)
+    assert lib().hc_point_op(curve, op, _p(P), int(p_inf), _p(Q), int(q_inf), _p(out), _p(inf)) == 0
+    return bytes(out), int(inf[0])
+
+
+def on_curve(curve, xy):
+    X = _a(xy)
+    return bool(lib().hc_on_curve(curve, _p(X)))
+
+
+def batch_mul_base(curve, w, scalars, nthreads=1):
+    s = _a(scalars)
+    n = s.size // L[curve]
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    inf = np.zeros(max(n, 1), np.uint8)
+    rc = lib().hc_batch_mul_base(curve, w, _p(s), ctypes.c_size_t(n), ctypes.c_size_t(nthreads), _p(out), _p(inf))
+    return rc, out, inf[:n]
+
+
+def batch_mul(curve, scalars, pxy, pinf=None, nthreads=1):
+    s, p, pi = _a(scalars), _a(pxy), _a(pinf)
+    n = s.size // L[curve]
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    inf = np.zeros(max(n, 1), np.uint8)
+    rc = lib().hc_batch_mul(curve, _p(s), _p(p), _p(pi), ctypes.c_size_t(n), ctypes.c_size_t(nthreads), _p(out), _p(inf))
+    return rc, out, inf[:n]
+
+
+def msm(curve, c, scalars, pxy, pinf=None):
+    s, p, pi = _a(scalars), _a(pxy), _a(pinf)
+    n = s.size // L[curve]
+    out = np.zeros(2 * L[curve], np.uint8)
+    inf = np.zeros(1, np.uint8)
+    rc = lib().hc_msm(curve, c, _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
+    return rc, bytes(out), int(inf[0])
+
+
+def table_rule(curve, w, j, e):
+    out = np.zeros(2 * L[curve], np.uint8)
+    inf = lib().hc_table_rule(curve, w, j, ctypes.c_uint32(e), _p(out))
+    return bytes(out), inf
+
+
+def radix16(be, nl):
+    d = np.zeros(8 * nl + 1, np.int8)
+    B = _a(be)
+    assert lib().hc_radix16(_p(B), nl, d.ctypes.data_as(ctypes.POINTER(ctypes.c_int8))) == 0
+    return d
+
+
+def signed_windows(be, w):
+    d = np.zeros(80, np.int32)
+    B = _a(be)
+    n = lib().hc_signed_windows(_p(B), w, d.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return d[:n] if n > 0 else None
+
+
+def k256_glv(k_be):
+    r1 = np.zeros(32, np.uint8)
+    r2 = np.zeros(32, np.uint8)
+    K = _a(k_be)
+    flags = lib().hc_k256_glv(_p(K), _p(r1), _p(r2))
+    return bytes(r1), bytes(r2), flags

@@ -1,0 +1,201 @@
+"""CPU checks of the device arithmetic: the __host__ __device__ field / point / recoding code the HIP
+kernels run, compiled with g++ (tests/hostcheck) and compared with the oracle and the big-int model.
+These do not replace the -m gpu parity tests; they pin the arithmetic the kernels are built from."""
+import random
+
+import numpy as np
+import pytest
+
+import check_header_constants
+import hostcheck_lib as hc
+import pyec
+
+CURVES = ["k256", "p256", "p384"]
+
+
+def test_header_constants():
+    assert check_header_constants.check() == []
+
+
+def _edge_values(c):
+    return [0, 1, 2, 3, c.p - 1, c.p - 2, (c.p - 1) // 2, (c.p + 1) // 2, 2 ** 32 - 1, 2 ** 32, 2 ** 64 - 1,
+            2 ** (8 * c.L - 1) % c.p, (2 ** (8 * c.L) - 1) % c.p, 0x1000003D1 % c.p, c.p - 0x1000003D1,
+            int("ff" * c.L, 16) % c.p, int("80" + "00" * (c.L - 1), 16) % c.p]
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_field_ops_vs_oracle_and_bigint(oracle, curve):
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xF00 + c.cid)
+    vals = _edge_values(c) + [rng.randrange(c.p) for _ in range(400)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 1) % len(vals)]
+        A, B = a.to_bytes(c.L, "big"), b.to_bytes(c.L, "big")
+        for op, want in ((0, (a + b) % c.p), (1, (a - b) % c.p), (2, a * b % c.p)):
+            got = hc.field_op(c.cid, op, A, B)
+            assert int.from_bytes(got, "big") == want, (curve, op, hex(a), hex(b))
+            assert got == oracle.field_op(c.cid, op, A, B)
+        assert int.from_bytes(hc.field_op(c.cid, 3, A), "big") == a * a % c.p
+        assert int.from_bytes(hc.field_op(c.cid, 5, A), "big") == (-a) % c.p
+        assert int.from_bytes(hc.field_op(c.cid, 6, A), "big") == 21 * a % c.p
+        assert int.from_bytes(hc.field_op(c.cid, 7, A), "big") == 2 * a % c.p
+    for a in _edge_values(c)[:8] + [rng.randrange(c.p) for _ in range(12)]:
+        inv = int.from_bytes(hc.field_op(c.cid, 4, a.to_bytes(c.L, "big")), "big")
+        assert inv == (pow(a, -1, c.p) if a else 0)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_field_lazy_chain(curve):
+    """Long mixed chains: exercises the weakly-reduced k256 residues and every carry/fold path."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xC4A1 + c.cid)
+    starts = [(0, 0), (c.p - 1, c.p - 1), (1, c.p - 1), (c.p - 1, 1)] + [(rng.randrange(c.p), rng.randrange(c.p)) for _ in range(40)]
+    for a, b in starts:
+        x, y = a, b
+        for _ in range(25):
+            t = x * y % c.p
+            u = (t + x - 2 * y) % c.p
+            x, y = u * u % c.p, (-(t + 21 * y)) % c.p
+        got = hc.field_chain(c.cid, a.to_bytes(c.L, "big"), b.to_bytes(c.L, "big"), 25)
+        assert int.from_bytes(got, "big") == (x + y) % c.p
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_point_ops_complete_formulas(oracle, curve):
+    """Group law on every edge the complete formulas must absorb: P+P, P+(-P), P+O, O+P, O+O, 2O."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0x9017 + c.cid)
+    G = pyec.G(c)
+    pts = [G, pyec.neg(c, G), pyec.mul(c, 2, G), pyec.INF] + [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(6)]
+    for P in pts:
+        pe, pi = pyec.enc_point(c, P)
+        got, inf = hc.point_op(c.cid, 2, pe, pi)
+        assert pyec.dec_point(c, got, inf) == pyec.add(c, P, P)
+        got, inf = hc.point_op(c.cid, 3, pe, pi)
+        assert pyec.dec_point(c, got, inf) == pyec.neg(c, P)
+        for Q in pts:
+            qe, qi = pyec.enc_point(c, Q)
+            want = pyec.add(c, P, Q)
+            for op in (0, 1):
+                got, inf = hc.point_op(c.cid, op, pe, pi, qe, qi)
+                assert pyec.dec_point(c, got, inf) == want, (curve, op)
+            assert (got, inf) == oracle.point_op(c.cid, 0, pe, pi, qe, qi)
+    assert hc.on_curve(c.cid, pyec.enc_point(c, G)[0])
+    bad = bytearray(pyec.enc_point(c, G)[0]); bad[-1] ^= 1
+    assert not hc.on_curve(c.cid, bytes(bad))
+    assert not hc.on_curve(c.cid, c.p.to_bytes(c.L, "big") + (0).to_bytes(c.L, "big"))
+
+
+def test_radix16_msb_equals_reference_digits(oracle):
+    """Radix16Msb (k + 0x88..8 trick) must reproduce Radix16Decomposition::new digit for digit."""
+    rng = random.Random(0x16)
+    for nl, L in ((8, 32), (12, 48)):
+        cases = [0, 1, 7, 8, 9, 15, 16, 2 ** (8 * L) - 1, int("88" * L, 16), int("77" * L, 16), int("78" * L, 16)]
+        cases += [rng.getrandbits(8 * L) for _ in range(500)]
+        for k in cases:
+            be = k.to_bytes(L, "big")
+            assert list(hc.radix16(be, nl)) == list(oracle.radix16(be, 2 * L + 1))
+
+
+def test_signed_windows_reconstruct():
+    rng = random.Random(0x51)
+    n = pyec.K256.n
+    for w in (4, 5, 8, 11, 12, 13, 16):
+        cases = [0, 1, n - 1, 2 ** 255, 2 ** 256 - 1, int("80" * 32, 16), int("7f" * 32, 16)] + [rng.getrandbits(256) for _ in range(300)]
+        for k in cases:
+            d = hc.signed_windows(k.to_bytes(32, "big"), w)
+            assert d is not None and len(d) == 256 // w + 1
+            assert all(-(1 << (w - 1)) < int(x) <= (1 << (w - 1)) for x in d)
+            assert sum(int(x) << (w * j) for j, x in enumerate(d)) == k
+
+
+def test_k256_glv_equals_reference(oracle):
+    c = pyec.K256
+    rng = random.Random(0x61F)
+    cases = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 2 ** 128, pyec.K256_LAMBDA] + [rng.randrange(c.n) for _ in range(1000)]
+    for k in cases:
+        kb = k.to_bytes(32, "big")
+        r1, r2, flags = hc.k256_glv(kb)
+        assert (r1, r2) == oracle.k256_glv_decompose(kb)
+        a, b = int.from_bytes(r1, "big"), int.from_bytes(r2, "big")
+        assert flags == (1 if a > c.n // 2 else 0) | (2 if b > c.n // 2 else 0)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_table_entry_rule(curve):
+    c = pyec.CURVES[curve]
+    for w, j, e in ((4, 0, 1), (4, 3, 8), (8, 2, 77), (16, 1, 32768), (16, 0, 12345), (12, 5, 2048)):
+        got, inf = hc.table_rule(c.cid, w, j, e)
+        assert pyec.dec_point(c, got, inf) == pyec.mul(c, e << (w * j), pyec.G(c))
+
+
+def _scalars(c, rng, n, edge=True):
+    ks = []
+    if edge:
+        ks = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, 2 ** (8 * c.L - 1) % c.n, int("80" * c.L, 16) % c.n]
+    ks += [rng.randrange(c.n) for _ in range(n - len(ks))]
+    return ks
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("w", [4, 8, 13])
+def test_fixed_base_algorithm(oracle, curve, w):
+    """k_fixed_base's algorithm (signed w-bit comb over the affine table + strided batch normalise)
+    against the oracle's mul_by_generator."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xFB + c.cid + w)
+    ks = _scalars(c, rng, 40 if w < 13 else 24)
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    for nthreads in (1, 7):
+        rc, out, inf = hc.batch_mul_base(c.cid, w, scal, nthreads)
+        assert rc == 0
+        want, winf = oracle.batch_mul_base(c.cid, scal)
+        assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    assert hc.batch_mul_base(c.cid, w, c.n.to_bytes(c.L, "big"))[0] == -2
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_var_base_algorithm(oracle, curve):
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xAB + c.cid)
+    G = pyec.G(c)
+    pts = [G, pyec.neg(c, G), pyec.INF] + [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(5)]
+    ks = _scalars(c, rng, 16)
+    pairs = [(k, P) for k in ks[:9] for P in pts[:4]] + [(k, pts[3 + i % 5]) for i, k in enumerate(ks)]
+    scal = b"".join(pyec.enc_scalar(c, k) for k, _ in pairs)
+    enc = [pyec.enc_point(c, P) for _, P in pairs]
+    pxy = b"".join(e[0] for e in enc)
+    pinf = np.array([e[1] for e in enc], np.uint8)
+    rc, out, inf = hc.batch_mul(c.cid, scal, pxy, pinf, nthreads=5)
+    assert rc == 0
+    want, winf = oracle.batch_mul(c.cid, scal, pxy, pinf)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    bad = bytearray(pxy); bad[2 * c.L - 1] ^= 1
+    assert hc.batch_mul(c.cid, scal, bytes(bad), pinf)[0] == -3
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("cbits", [4, 7, 10])
+def test_pippenger_algorithm(oracle, curve, cbits):
+    c = pyec.CURVES[curve]
+    rng = random.Random(0x9199 + c.cid + cbits)
+    G = pyec.G(c)
+    base_pts = [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(12)]
+    n = 60
+    pts = [base_pts[rng.randrange(12)] for _ in range(n)]
+    ks = _scalars(c, rng, n)
+    pts[5] = pyec.INF
+    pts[7] = pyec.neg(c, pts[6]); ks[7] = ks[6]           # cancelling pair
+    pts[9] = pts[8]                                          # duplicate point, different scalars
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    enc = [pyec.enc_point(c, P) for P in pts]
+    pxy = b"".join(e[0] for e in enc)
+    pinf = np.array([e[1] for e in enc], np.uint8)
+    rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, pinf)
+    assert rc == 0
+    want, winf = oracle.msm(c.cid, scal, pxy, pinf)
+    assert out == bytes(want) and inf == winf
+    assert pyec.dec_point(c, out, inf) == pyec.msm(c, ks, pts)
+    # all-zero scalars and the empty sum give the identity
+    rc, out, inf = hc.msm(c.cid, cbits, bytes(c.L * 4), pxy[: 8 * c.L], None)
+    assert rc == 0 and inf == 1 and out == bytes(2 * c.L)
