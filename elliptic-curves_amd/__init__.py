@@ -1,0 +1,223 @@
+"""ecgpu — Python (ctypes) binding of libecgpu.so, the MI355X batch scalar-multiplication / MSM engine.
+
+This is plumbing around the C ABI of include/ecgpu.h (bench.py, the tests and torch-based callers use
+it); the product is the shared library.  The directory name contains a hyphen, so import it with
+
+    import importlib; ecgpu = importlib.import_module("elliptic-curves_amd")
+
+There is no CPU fallback: `Engine()` raises `EcgpuError` when the HIP extension is missing or no
+gfx950 device is usable.
+
+Operation names follow the reference's trait surface (RustCrypto/elliptic-curves):
+    mul_by_generator          ProjectivePoint::mul_by_generator / MulBackend::mul_by_generator
+    mul                       impl Mul<Scalar> for ProjectivePoint
+    lincomb                   LinearCombination::lincomb
+    mul_by_generator_and_mul_add   MulByGeneratorVartime::mul_by_generator_and_mul_add_vartime
+    batch_normalize           BatchNormalize::batch_normalize
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libecgpu.so")
+
+K256, P256, P384 = 0, 1, 2
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48}
+
+OK = 0
+ERR_CURVE, ERR_SCALAR_RANGE, ERR_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_ARG = -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/ecgpu.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "ecgpu_init", "ecgpu_destroy", "ecgpu_last_error", "ecgpu_field_bytes", "ecgpu_set_stream",
+    "ecgpu_set_base_window", "ecgpu_set_msm_window", "ecgpu_batch_mul_base", "ecgpu_batch_mul", "ecgpu_msm",
+    "ecgpu_batch_mul_base_and_mul_add", "ecgpu_batch_normalize", "ecgpu_batch_mul_base_dev",
+    "ecgpu_batch_mul_dev", "ecgpu_msm_dev", "ecgpu_batch_mul_base_and_mul_add_dev", "ecgpu_batch_normalize_dev",
+    "ecgpu_point_sum", "ecgpu_point_sum_dev", "ecgpu_k256_glv_decompose", "ecgpu_valu_probe",
+    "ecgpu_last_timing", "ecgpu_version",
+]
+
+
+class EcgpuError(RuntimeError):
+    def __init__(self, code, msg=""):
+        super().__init__("ecgpu error %d%s" % (code, (": " + msg) if msg else ""))
+        self.code = code
+
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_lib = None
+
+
+def load_library():
+    """Loads libecgpu.so (built in-tree by `make -C elliptic-curves_amd` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EcgpuError(ERR_NO_DEVICE, "HIP extension %s is missing; run __graft_entry__.build()" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ecgpu_last_error.restype = ctypes.c_char_p
+    lib.ecgpu_version.restype = ctypes.c_char_p
+    lib.ecgpu_field_bytes.restype = ctypes.c_size_t
+    _lib = lib
+    return lib
+
+
+def _host(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return np.ascontiguousarray(a, dtype=np.uint8)
+    return np.frombuffer(bytes(a), dtype=np.uint8).copy()
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def _dp(t):
+    """device pointer of a torch tensor / int / None"""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return ctypes.c_void_p(t)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One context = one GPU, one stream, device-resident basepoint tables."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.ecgpu_init(ctypes.byref(self._ctx), int(device))
+        if rc != OK:
+            self._ctx = None
+            raise EcgpuError(rc, "ecgpu_init failed (no gfx950 device?)")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.ecgpu_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise EcgpuError(rc, (self._lib.ecgpu_last_error(self._ctx) or b"").decode())
+
+    # ---- configuration ----
+    def set_stream(self, stream_ptr):
+        self._chk(self._lib.ecgpu_set_stream(self._ctx, ctypes.c_void_p(stream_ptr or 0)))
+
+    def set_base_window(self, curve, bits):
+        self._chk(self._lib.ecgpu_set_base_window(self._ctx, curve, bits))
+
+    def set_msm_window(self, bits):
+        self._chk(self._lib.ecgpu_set_msm_window(self._ctx, bits))
+
+    def last_timing(self, name="total"):
+        ms = ctypes.c_double(0)
+        rc = self._lib.ecgpu_last_timing(self._ctx, name.encode(), ctypes.byref(ms))
+        return ms.value if rc == OK else None
+
+    def valu_probe(self, which=0):
+        v = ctypes.c_double(0)
+        self._chk(self._lib.ecgpu_valu_probe(self._ctx, which, ctypes.byref(v)))
+        return v.value
+
+    # ---- host-buffer operations (numpy uint8 / bytes in, numpy out) ----
+    def mul_by_generator(self, curve, scalars):
+        L = FIELD_BYTES[curve]
+        s = _host(scalars)
+        n = s.size // L
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_mul_base(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def mul(self, curve, scalars, points_xy, points_inf=None):
+        L = FIELD_BYTES[curve]
+        s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
+        n = s.size // L
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_mul(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def lincomb(self, curve, scalars, points_xy, points_inf=None):
+        L = FIELD_BYTES[curve]
+        s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
+        n = s.size // L
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_msm(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
+    def mul_by_generator_and_mul_add(self, curve, a_scalars, b_scalars, points_xy, points_inf=None):
+        L = FIELD_BYTES[curve]
+        a, b, p, pi = _host(a_scalars), _host(b_scalars), _host(points_xy), _host(points_inf)
+        n = a.size // L
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_mul_base_and_mul_add(self._ctx, curve, _hp(a), _hp(b), _hp(p), _hp(pi),
+                                                             ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def batch_normalize(self, curve, points_xyz):
+        L = FIELD_BYTES[curve]
+        x = _host(points_xyz)
+        n = x.size // (3 * L)
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_normalize(self._ctx, curve, _hp(x), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def point_sum(self, curve, points_xy, points_inf=None):
+        L = FIELD_BYTES[curve]
+        p, pi = _host(points_xy), _host(points_inf)
+        n = p.size // (2 * L)
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_point_sum(self._ctx, curve, _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
+    def k256_glv_decompose(self, scalars):
+        s = _host(scalars)
+        n = s.size // 32
+        r1 = np.zeros(n * 32, np.uint8)
+        r2 = np.zeros(n * 32, np.uint8)
+        self._chk(self._lib.ecgpu_k256_glv_decompose(self._ctx, _hp(s), ctypes.c_size_t(n), _hp(r1), _hp(r2)))
+        return r1, r2
+
+    # ---- device-resident operations (torch uint8 CUDA tensors or raw device pointers) ----
+    def mul_by_generator_dev(self, curve, d_scalars, n, d_out_xy, d_out_inf=None):
+        self._chk(self._lib.ecgpu_batch_mul_base_dev(self._ctx, curve, _dp(d_scalars), ctypes.c_size_t(n), _dp(d_out_xy),
+                                                     _dp(d_out_inf)))
+
+    def mul_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf=None):
+        self._chk(self._lib.ecgpu_batch_mul_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
+                                                ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
+    def lincomb_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
+        self._chk(self._lib.ecgpu_msm_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
+                                          ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
+    def point_sum_dev(self, curve, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
+        self._chk(self._lib.ecgpu_point_sum_dev(self._ctx, curve, _dp(d_points_xy), _dp(d_points_inf), ctypes.c_size_t(n),
+                                                _dp(d_out_xy), _dp(d_out_inf)))
+
+
+def version():
+    return load_library().ecgpu_version().decode()
+
+
+from .sharded import lincomb_sharded, shard_range  # noqa: E402,F401

@@ -350,6 +350,13 @@ int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
     return ECGPU_OK;
 }
 
+int ecgpu_set_msm_window(ecgpu_ctx* ctx, int window_bits) {
+    if (!ctx) return ECGPU_ERR_ARG;
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return ECGPU_ERR_ARG;
+    ctx->msm_c = window_bits;
+    return ECGPU_OK;
+}
+
 int ecgpu_last_timing(const ecgpu_ctx* ctx, const char* name, double* ms) {
     if (!ctx || !name || !ms) return ECGPU_ERR_ARG;
     auto it = ctx->timing.find(name);

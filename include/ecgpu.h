@@ -79,6 +79,9 @@ int ecgpu_set_stream(ecgpu_ctx *ctx, void *stream);
  * (k256/src/arithmetic/tables.rs:12, p384/src/arithmetic/tables.rs:8). */
 int ecgpu_set_base_window(ecgpu_ctx *ctx, int curve, int window_bits);
 
+/* Pippenger window width c for later ecgpu_msm* calls (4..16), 0 = choose from n (default). */
+int ecgpu_set_msm_window(ecgpu_ctx *ctx, int window_bits);
+
 /* ---- host-pointer entry points (copy in, compute on the GPU, copy out) ------------------------ */
 
 /* out[i] = k[i] * G.

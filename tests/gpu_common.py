@@ -1,0 +1,48 @@
+"""Shared helpers of the -m gpu parity tests."""
+import importlib
+import json
+import os
+
+import numpy as np
+
+import oracle_lib
+import pyec
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CURVES = ["k256", "p256", "p384"]
+
+
+def load_golden(curve):
+    with open(os.path.join(GOLDEN, curve + ".json")) as f:
+        return json.load(f)
+
+
+def ecgpu_module():
+    return importlib.import_module("elliptic-curves_amd")
+
+
+def rand_scalars(curve_id, n, seed):
+    """n*L random bytes mapped through Scalar::reduce, like the reference's proptest generators."""
+    L = oracle_lib.FIELD_BYTES[curve_id]
+    rng = np.random.default_rng(seed)
+    return oracle_lib.scalar_reduce(curve_id, rng.integers(0, 256, n * L, dtype=np.uint8))
+
+
+def edge_scalars(c):
+    ks = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, 2 ** (8 * c.L - 1) % c.n, int("80" * c.L, 16) % c.n,
+          int("7f" * c.L, 16) % c.n, 0xFFFF, 0x10000, 0x8000]
+    if c.name == "k256":
+        ks.append(pyec.K256_LAMBDA)
+    return ks
+
+
+def scalars_to_int_sum(scalars, L, n_mod):
+    """sum of n big-endian L-byte integers mod n_mod, via 32-bit limb column sums (cheap for 2^24 terms)."""
+    a = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, L // 4, 4)
+    words = (a[:, :, 0].astype(np.uint64) << 24) | (a[:, :, 1].astype(np.uint64) << 16) | (a[:, :, 2].astype(np.uint64) << 8) | a[:, :, 3].astype(np.uint64)
+    total = 0
+    ncol = L // 4
+    for j in range(ncol):
+        col = int(words[:, j].sum(dtype=np.uint64)) if words.shape[0] < (1 << 31) else sum(int(x) for x in words[:, j])
+        total += col << (32 * (ncol - 1 - j))
+    return total % n_mod

@@ -1,0 +1,322 @@
+"""-m gpu parity tests: the HIP path, called through the C ABI (ctypes -> libecgpu.so), compared
+bit-for-bit with (1) the reference's golden vectors in tests/golden/, (2) the oracle on the same
+seeded inputs, and (3) at BASELINE sizes, size-independent group identities."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import pyec
+from gpu_common import CURVES, ecgpu_module, edge_scalars, load_golden, rand_scalars, scalars_to_int_sum
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    ecgpu = ecgpu_module()
+    e = ecgpu.Engine(0)          # raises without the HIP extension / a gfx950 device: no fallback
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _oracle_built():
+    oracle_lib.build()
+
+
+def xy(v):
+    return bytes.fromhex(v["x"]) + bytes.fromhex(v["y"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# golden vectors of the reference
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_golden_group_vectors(eng, curve):
+    """{k256,p256,p384}/src/test_vectors/group.rs through mul_by_generator, mul and lincomb(1 term)."""
+    c = pyec.CURVES[curve]
+    g = load_golden(curve)["group"]
+    ks = [pyec.enc_scalar(c, v["k"]) for v in g["add"]] + [bytes.fromhex(v["k"]) for v in g["mul"]]
+    want = b"".join(xy(v) for v in g["add"] + g["mul"])
+    scal = b"".join(ks)
+    n = len(ks)
+    gxy = pyec.enc_point(c, pyec.G(c))[0]
+    out, inf = eng.mul_by_generator(c.cid, scal)
+    assert bytes(out) == want and not inf.any()
+    out, inf = eng.mul(c.cid, scal, gxy * n)
+    assert bytes(out) == want and not inf.any()
+    for i in (0, 1, 19, 20, n - 1):
+        o, f = eng.lincomb(c.cid, ks[i], gxy)
+        assert bytes(o) == want[2 * c.L * i: 2 * c.L * (i + 1)] and f == 0
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_golden_add_vectors_via_point_sum(eng, curve):
+    """ADD_TEST_VECTORS: k*G as a sum of k copies of G (complete addition incl. the doubling case)."""
+    c = pyec.CURVES[curve]
+    g = load_golden(curve)["group"]["add"]
+    gxy = pyec.enc_point(c, pyec.G(c))[0]
+    for v in g:
+        o, f = eng.point_sum(c.cid, gxy * v["k"])
+        assert bytes(o) == xy(v) and f == 0
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_golden_ecdsa_vectors(eng, curve):
+    """{p256,p384,k256}/src/test_vectors/ecdsa.rs: d*G == Q and x(k*G) == r via the fixed-base kernel;
+    x(u1*G + u2*Q) == r via mul_by_generator_and_mul_add (verification shape) and via a 2-term lincomb."""
+    c = pyec.CURVES[curve]
+    vec = load_golden(curve)["ecdsa"]
+    scal = b"".join(bytes.fromhex(v["d"]) + bytes.fromhex(v["k"]) for v in vec)
+    out, inf = eng.mul_by_generator(c.cid, scal)
+    a_s, b_s, qs = b"", b"", b""
+    for i, v in enumerate(vec):
+        q = bytes(out[4 * c.L * i: 4 * c.L * i + 2 * c.L])
+        assert q == bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"])
+        rx = int.from_bytes(bytes(out[4 * c.L * i + 2 * c.L: 4 * c.L * i + 3 * c.L]), "big")
+        r, s, z = int(v["r"], 16), int(v["s"], 16), int(v["m"], 16)
+        assert rx % c.n == r
+        w = pow(s, -1, c.n)
+        a_s += pyec.enc_scalar(c, z * w % c.n)
+        b_s += pyec.enc_scalar(c, r * w % c.n)
+        qs += q
+    res, rinf = eng.mul_by_generator_and_mul_add(c.cid, a_s, b_s, qs)
+    gxy = pyec.enc_point(c, pyec.G(c))[0]
+    for i, v in enumerate(vec):
+        assert rinf[i] == 0
+        assert int.from_bytes(bytes(res[2 * c.L * i: 2 * c.L * i + c.L]), "big") % c.n == int(v["r"], 16)
+        o, f = eng.lincomb(c.cid, a_s[c.L * i: c.L * (i + 1)] + b_s[c.L * i: c.L * (i + 1)],
+                           gxy + qs[2 * c.L * i: 2 * c.L * (i + 1)])
+        assert bytes(o) == bytes(res[2 * c.L * i: 2 * c.L * (i + 1)]) and f == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# oracle parity on seeded inputs
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("window", [16, 13, 4])
+def test_fixed_base_vs_oracle(eng, curve, window):
+    c = pyec.CURVES[curve]
+    eng.set_base_window(c.cid, window)
+    n = 3000 if window == 16 else 700
+    scal = rand_scalars(c.cid, n, 0xEC000002 + c.cid)
+    edge = b"".join(pyec.enc_scalar(c, k) for k in edge_scalars(c))
+    scal = np.concatenate([np.frombuffer(edge, np.uint8), scal])
+    out, inf = eng.mul_by_generator(c.cid, scal)
+    want, winf = oracle_lib.batch_mul_base(c.cid, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
+    eng.set_base_window(c.cid, 16)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_variable_base_vs_oracle(eng, curve):
+    c = pyec.CURVES[curve]
+    n = 600
+    pts_s = rand_scalars(c.cid, n, 0xEC000013 + c.cid)
+    pts, _ = oracle_lib.batch_mul_base(c.cid, pts_s)
+    pts = pts.copy()
+    scal = rand_scalars(c.cid, n, 0xEC000003 + c.cid).copy()
+    inf = np.zeros(n, np.uint8)
+    G = pyec.G(c)
+    ek = edge_scalars(c)
+    slot = 0
+    for k in ek:                      # edge scalars x {G, -G, identity}
+        for P in (G, pyec.neg(c, G), pyec.INF):
+            e, f = pyec.enc_point(c, P)
+            scal[slot * c.L: (slot + 1) * c.L] = np.frombuffer(pyec.enc_scalar(c, k), np.uint8)
+            pts[slot * 2 * c.L: (slot + 1) * 2 * c.L] = np.frombuffer(e, np.uint8)
+            inf[slot] = f
+            slot += 1
+    pts[(slot) * 2 * c.L: (slot + 1) * 2 * c.L] = pts[(slot + 1) * 2 * c.L: (slot + 2) * 2 * c.L]   # duplicate point
+    out, oinf = eng.mul(c.cid, scal, pts, inf)
+    want, winf = oracle_lib.batch_mul(c.cid, scal, pts, inf)
+    assert bytes(out) == bytes(want) and bytes(oinf) == bytes(winf)
+    want2, winf2 = oracle_lib.batch_mul(c.cid, scal[: 40 * c.L], pts[: 80 * c.L], inf[:40], vartime=True)
+    assert bytes(out[: 80 * c.L]) == bytes(want2)
+    # NULL flags path
+    out3, _ = eng.mul(c.cid, scal[slot * c.L:], pts[slot * 2 * c.L:], None)
+    assert bytes(out3) == bytes(want[slot * 2 * c.L:])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 257, 4000])
+def test_msm_vs_oracle(eng, curve, n):
+    c = pyec.CURVES[curve]
+    if n == 0:
+        o, f = eng.lincomb(c.cid, b"", b"")
+        assert f == 1 and not o.any()
+        return
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xEC000014 + c.cid + n))
+    pts = pts.copy()
+    scal = rand_scalars(c.cid, n, 0xEC000004 + c.cid + n).copy()
+    inf = np.zeros(n, np.uint8)
+    if n >= 17:
+        ek = edge_scalars(c)
+        for i, k in enumerate(ek[:10]):
+            scal[i * c.L: (i + 1) * c.L] = np.frombuffer(pyec.enc_scalar(c, k), np.uint8)
+        inf[11] = 1; pts[11 * 2 * c.L: 12 * 2 * c.L] = 0                                   # identity term
+        pts[13 * 2 * c.L: 14 * 2 * c.L] = pts[12 * 2 * c.L: 13 * 2 * c.L]                    # duplicate points
+        neg = pyec.neg(c, pyec.dec_point(c, bytes(pts[14 * 2 * c.L: 15 * 2 * c.L]), 0))     # P_15 = -P_14, same scalar
+        pts[15 * 2 * c.L: 16 * 2 * c.L] = np.frombuffer(pyec.enc_point(c, neg)[0], np.uint8)
+        scal[15 * c.L: 16 * c.L] = scal[14 * c.L: 15 * c.L]
+    want, winf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=True)
+    for cbits in ((0,) if n < 257 else (0, 4, 9, 16)):
+        eng.set_msm_window(cbits)
+        o, f = eng.lincomb(c.cid, scal, pts, inf)
+        assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits)
+    eng.set_msm_window(0)
+    if n == 17:
+        want_ct, wf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=False)
+        assert bytes(want_ct) == bytes(want) and wf == winf
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_msm_cancels_to_identity(eng, curve):
+    c = pyec.CURVES[curve]
+    n = 64
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 77))
+    scal = rand_scalars(c.cid, n, 78)
+    neg_scal = b"".join(pyec.enc_scalar(c, (c.n - int.from_bytes(bytes(scal[i * c.L: (i + 1) * c.L]), "big")) % c.n) for i in range(n))
+    o, f = eng.lincomb(c.cid, np.concatenate([scal, np.frombuffer(neg_scal, np.uint8)]), np.concatenate([pts, pts]))
+    assert f == 1 and not o.any()
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_batch_normalize_and_point_sum_vs_oracle(eng, curve):
+    c = pyec.CURVES[curve]
+    rng = np.random.default_rng(5 + c.cid)
+    n = 300
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xB0))
+    xyz = bytearray()
+    for i in range(n):
+        z = int.from_bytes(rng.bytes(c.L), "big") % c.p or 1
+        if i % 50 == 7:
+            xyz += (0).to_bytes(c.L, "big") + (1).to_bytes(c.L, "big") + (0).to_bytes(c.L, "big")
+            continue
+        x = int.from_bytes(bytes(pts[2 * c.L * i: 2 * c.L * i + c.L]), "big")
+        y = int.from_bytes(bytes(pts[2 * c.L * i + c.L: 2 * c.L * (i + 1)]), "big")
+        xyz += (x * z % c.p).to_bytes(c.L, "big") + (y * z % c.p).to_bytes(c.L, "big") + z.to_bytes(c.L, "big")
+    out, inf = eng.batch_normalize(c.cid, bytes(xyz))
+    want, winf = oracle_lib.batch_normalize(c.cid, bytes(xyz))
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf) and inf[7] == 1
+    ones = np.tile(np.array([0] * (c.L - 1) + [1], np.uint8), n)
+    o, f = eng.point_sum(c.cid, pts)
+    w, wf = oracle_lib.msm(c.cid, ones, pts)
+    assert bytes(o) == bytes(w) and f == wf
+    o, f = eng.point_sum(c.cid, b"")
+    assert f == 1
+
+
+def test_k256_glv_decompose_vs_oracle(eng):
+    c = pyec.K256
+    ks = edge_scalars(c)
+    scal = np.concatenate([np.frombuffer(b"".join(pyec.enc_scalar(c, k) for k in ks), np.uint8), rand_scalars(0, 5000, 0x61)])
+    r1, r2 = eng.k256_glv_decompose(scal)
+    for i in range(scal.size // 32):
+        w1, w2 = oracle_lib.k256_glv_decompose(bytes(scal[32 * i: 32 * i + 32]))
+        assert bytes(r1[32 * i: 32 * i + 32]) == w1 and bytes(r2[32 * i: 32 * i + 32]) == w2
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_error_behaviour(eng, curve):
+    """Decoding errors mirror the reference: scalar >= n and off-curve / out-of-range points are refused."""
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES[curve]
+    good_k = pyec.enc_scalar(c, 5)
+    gxy = pyec.enc_point(c, pyec.G(c))[0]
+    for bad_k in (c.n, c.n + 1, 2 ** (8 * c.L) - 1):
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.mul_by_generator(c.cid, good_k + bad_k.to_bytes(c.L, "big"))
+        assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.lincomb(c.cid, good_k + bad_k.to_bytes(c.L, "big"), gxy * 2)
+        assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+    off = bytearray(gxy); off[-1] ^= 1
+    big = c.p.to_bytes(c.L, "big") + gxy[c.L:]
+    for bad_p in (bytes(off), big):
+        for fn in (eng.mul, eng.lincomb):
+            with pytest.raises(ecgpu.EcgpuError) as e:
+                fn(c.cid, good_k * 2, gxy + bad_p)
+            assert e.value.code == ecgpu.ERR_POINT
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.mul_by_generator(7, good_k)
+    assert e.value.code == ecgpu.ERR_CURVE
+    out, inf = eng.mul_by_generator(c.cid, b"")          # empty batch
+    assert out.size == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent identities
+# ---------------------------------------------------------------------------------------------------
+
+def test_full_size_fixed_base_k256(eng):
+    """config 2: 2^20 random k256 scalars.  (a) a strided sample is compared with the oracle bit for
+    bit; (b) checksum of checksums: sum_i (k_i G) == (sum_i k_i) G with the left side summed on the GPU
+    over ALL 2^20 outputs."""
+    c = pyec.K256
+    n = 1 << 20
+    scal = rand_scalars(0, n, 0xEC000002)
+    out, inf = eng.mul_by_generator(0, scal)
+    assert not inf.any()
+    idx = np.arange(0, n, 4099)
+    sample = np.concatenate([scal[32 * i: 32 * i + 32] for i in idx])
+    want, _ = oracle_lib.batch_mul_base(0, sample)
+    got = np.concatenate([out[64 * i: 64 * i + 64] for i in idx])
+    assert bytes(got) == bytes(want)
+    total = scalars_to_int_sum(scal, 32, c.n)
+    o, f = eng.point_sum(0, out)
+    w, wf = oracle_lib.batch_mul_base(0, pyec.enc_scalar(c, total))
+    assert bytes(o) == bytes(w) and f == int(wf[0])
+
+
+def test_full_size_variable_base_p256_sample(eng):
+    """config 3 shape (p256 ECDH), 2^16 pairs here (the 2^20 run is bench.py --workload var_p256):
+    linearity  k*(s*G) == (k*s)*G  for every element, checked through the fixed-base kernel, plus an
+    oracle sample."""
+    c = pyec.P256
+    n = 1 << 16
+    s = rand_scalars(1, n, 0xEC000023)
+    k = rand_scalars(1, n, 0xEC000003)
+    pts, _ = eng.mul_by_generator(1, s)
+    out, inf = eng.mul(1, k, pts)
+    ks = b"".join(pyec.enc_scalar(c, int.from_bytes(bytes(k[32 * i: 32 * i + 32]), "big") * int.from_bytes(bytes(s[32 * i: 32 * i + 32]), "big") % c.n)
+                  for i in range(n))
+    want, winf = eng.mul_by_generator(1, ks)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    wo, _ = oracle_lib.batch_mul(1, k[: 32 * 64], pts[: 64 * 64])
+    assert bytes(out[: 64 * 64]) == bytes(wo)
+
+
+def test_full_size_msm_k256_properties(eng):
+    """config 4 shape at 2^20 terms (2^24 is exercised by bench.py --workload msm_k256 --check):
+    (a) all points = G: MSM == (sum k_i) G;  (b) distinct points P_i = s_i G: MSM == (sum k_i s_i) G;
+    (c) split linearity MSM(all) == MSM(first half) + MSM(second half);  (d) permutation invariance."""
+    c = pyec.K256
+    n = 1 << 20
+    k = rand_scalars(0, n, 0xEC000004)
+    gxy = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+    o, f = eng.lincomb(0, k, np.tile(gxy, n))
+    w, wf = oracle_lib.batch_mul_base(0, pyec.enc_scalar(c, scalars_to_int_sum(k, 32, c.n)))
+    assert bytes(o) == bytes(w) and f == int(wf[0])
+    s = rand_scalars(0, n, 0xEC000024)
+    pts, _ = eng.mul_by_generator(0, s)
+    full, ff = eng.lincomb(0, k, pts)
+    acc = 0
+    kb, sb = bytes(k), bytes(s)
+    for i in range(n):
+        acc += int.from_bytes(kb[32 * i: 32 * i + 32], "big") * int.from_bytes(sb[32 * i: 32 * i + 32], "big")
+    w, wf = oracle_lib.batch_mul_base(0, pyec.enc_scalar(c, acc % c.n))
+    assert bytes(full) == bytes(w) and ff == int(wf[0])
+    h = n // 2
+    a, af = eng.lincomb(0, k[: 32 * h], pts[: 64 * h])
+    b, bf = eng.lincomb(0, k[32 * h:], pts[64 * h:])
+    sm, sf = eng.point_sum(0, np.concatenate([a, b]), np.array([af, bf], np.uint8))
+    assert bytes(sm) == bytes(full) and sf == ff
+    perm = np.random.default_rng(9).permutation(n)
+    kp = k.reshape(n, 32)[perm].reshape(-1)
+    pp = pts.reshape(n, 64)[perm].reshape(-1)
+    p2, pf = eng.lincomb(0, kp, pp)
+    assert bytes(p2) == bytes(full) and pf == ff

@@ -1,0 +1,68 @@
+"""world_size-2 gloo test of the sharded-MSM host logic (elliptic-curves_amd/sharded.py).  The local
+compute is injected: here the oracle stands in for the GPU so that the slice / all-gather / combine
+logic is covered on CPU; on the GPU box the same function runs with Engine methods."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import importlib, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_lib, pyec
+ecgpu = importlib.import_module("elliptic-curves_amd")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=int(sys.argv[2]))
+curve = int(sys.argv[3]); n = int(sys.argv[4])
+L = oracle_lib.FIELD_BYTES[curve]
+rng = np.random.default_rng(1234)
+scal = oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8))
+pts, _ = oracle_lib.batch_mul_base(curve, oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8)))
+inf = np.zeros(n, np.uint8)
+if n > 3:
+    inf[2] = 1; pts[2 * 2 * L: 3 * 2 * L] = 0
+local = lambda s, p, pi: oracle_lib.msm(curve, s, p, pi)
+def psum(p, f):
+    # sum of the partial points = lincomb with all scalars 1
+    ones = np.tile(np.array([0] * (L - 1) + [1], np.uint8), f.size)
+    return oracle_lib.msm(curve, ones, p, f)
+xy, i = ecgpu.lincomb_sharded(L, local, psum, scal, pts, inf, dist=dist, device="cpu")
+want, wi = oracle_lib.msm(curve, scal, pts, inf)
+assert bytes(xy) == bytes(want) and i == wi, "rank %s mismatch" % sys.argv[1]
+lo, hi = ecgpu.shard_range(n, dist.get_rank(), dist.get_world_size())
+print("rank", dist.get_rank(), "ok", lo, hi)
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions():
+    ecgpu = importlib.import_module("elliptic-curves_amd")
+    for n in (0, 1, 2, 7, 8, 9, 1 << 20, (1 << 24) + 5):
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            sizes = []
+            for r in range(world):
+                lo, hi = ecgpu.shard_range(n, r, world)
+                assert lo == prev and hi >= lo
+                prev = hi
+                sizes.append(hi - lo)
+            assert prev == n and max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("curve,n", [(0, 37), (1, 20), (0, 1)])
+def test_lincomb_sharded_world2_gloo(oracle, tmp_path, curve, n):
+    port = 29500 + (os.getpid() + curve * 7 + n) % 2000
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(curve), str(n)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok " in o
