@@ -1,0 +1,236 @@
+// ecgpu.hpp — host-side mirror (C++17, header-only) of the reference's scalar-multiplication surface,
+// written above the C ABI of include/ecgpu.h.
+//
+// The reference is Rust; no Rust toolchain exists in this image, so the host side that a Rust user
+// would see is mirrored here in C++ with the same names, argument meaning and error behaviour:
+//
+//   Scalar::from_repr                      k256/src/arithmetic/scalar.rs:310-316 (rejects >= n)
+//   AffinePoint::{IDENTITY, from_coordinates, x, y}   primeorder/src/affine.rs:45-49,100-112
+//   ProjectivePoint::{IDENTITY, to_affine, mul_by_generator, operator*, lincomb}
+//                                          primeorder/src/projective.rs:60-86,133-137,480-511
+//                                          k256/src/arithmetic/mul.rs:84-109,180-203,249-256
+//   MulBackend<C>::{mul_by_generator, mul_by_generator_vartime, mul_by_generator_and_mul_add_vartime}
+//                                          primeorder/src/mul_backend.rs:11-40
+//   BatchNormalize::batch_normalize        primeorder/src/projective.rs:452-478
+//   Sum for ProjectivePoint                primeorder/src/projective.rs (impl Sum)
+//
+// plus the batch forms that are the reason for a GPU backend (`batch_mul_by_generator`, `batch_mul`).
+// A `ProjectivePoint` here stores the normalised (affine) coordinates: projective triples are
+// algorithm-dependent and only canonical affine bytes cross the ABI.
+// Single-element calls launch a batch of one on the GPU — correct, but the batch forms are the point.
+// There is no CPU fallback: `Engine` throws `Error` when the device or the library is unusable.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ecgpu.h"
+
+namespace ecgpu_host {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error("ecgpu error " + std::to_string(c) + ": " + what), code(c) {}
+};
+
+// One context per process/thread, the analogue of `static BASEPOINT_TABLE: LazyLock<..>`.
+class Engine {
+  public:
+    explicit Engine(int device = 0) {
+        int rc = ecgpu_init(&ctx_, device);
+        if (rc != ECGPU_OK) throw Error(rc, "ecgpu_init failed (no gfx950 device?)");
+    }
+    ~Engine() { ecgpu_destroy(ctx_); }
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+    ecgpu_ctx* ctx() const { return ctx_; }
+    void check(int rc) const {
+        if (rc != ECGPU_OK) throw Error(rc, ecgpu_last_error(ctx_));
+    }
+    static Engine& global() {
+        static thread_local Engine e(0);
+        return e;
+    }
+
+  private:
+    ecgpu_ctx* ctx_ = nullptr;
+};
+
+template <int CURVE, size_t L>
+struct Curve {
+    static constexpr int ID = CURVE;
+    static constexpr size_t FieldBytesSize = L;
+    using FieldBytes = std::array<uint8_t, L>;
+
+    // ---- Scalar ------------------------------------------------------------------------------------
+    struct Scalar {
+        FieldBytes repr{};   // canonical big-endian, < n (checked by the device on use)
+        static Scalar from_repr(const FieldBytes& b) { return Scalar{b}; }
+        static Scalar from_u64(uint64_t v) {
+            Scalar s;
+            for (int i = 0; i < 8; i++) s.repr[L - 1 - i] = (uint8_t)(v >> (8 * i));
+            return s;
+        }
+        const FieldBytes& to_repr() const { return repr; }
+    };
+
+    // ---- AffinePoint -------------------------------------------------------------------------------
+    struct AffinePoint {
+        FieldBytes x_{}, y_{};
+        uint8_t infinity = 1;
+        static AffinePoint IDENTITY() { return AffinePoint{}; }
+        static AffinePoint from_coordinates(const FieldBytes& x, const FieldBytes& y) {
+            AffinePoint p;
+            p.x_ = x; p.y_ = y; p.infinity = 0;
+            return p;   // on-curve / range validation happens on the device (ECGPU_ERR_POINT)
+        }
+        const FieldBytes& x() const { return x_; }
+        const FieldBytes& y() const { return y_; }
+        bool is_identity() const { return infinity != 0; }
+        bool operator==(const AffinePoint& o) const {
+            return infinity == o.infinity && (infinity || (x_ == o.x_ && y_ == o.y_));
+        }
+        bool operator!=(const AffinePoint& o) const { return !(*this == o); }
+    };
+
+    // ---- ProjectivePoint ---------------------------------------------------------------------------
+    struct ProjectivePoint {
+        AffinePoint a;
+        static ProjectivePoint IDENTITY() { return ProjectivePoint{}; }
+        static ProjectivePoint from(const AffinePoint& p) { return ProjectivePoint{p}; }
+        AffinePoint to_affine() const { return a; }
+        bool is_identity() const { return a.is_identity(); }
+        bool operator==(const ProjectivePoint& o) const { return a == o.a; }
+        bool operator!=(const ProjectivePoint& o) const { return !(a == o.a); }
+
+        // Group::mul_by_generator
+        static ProjectivePoint mul_by_generator(const Scalar& k) { return batch_mul_by_generator({k})[0]; }
+        static ProjectivePoint mul_by_generator_vartime(const Scalar& k) { return mul_by_generator(k); }
+        // impl Mul<Scalar> / MulVartime
+        ProjectivePoint operator*(const Scalar& k) const { return batch_mul({*this}, {k})[0]; }
+        ProjectivePoint mul_vartime(const Scalar& k) const { return *this * k; }
+        // impl Add via Sum of two
+        ProjectivePoint operator+(const ProjectivePoint& o) const { return sum({*this, o}); }
+
+        // LinearCombination<[(ProjectivePoint, Scalar)]>::lincomb / lincomb_vartime
+        static ProjectivePoint lincomb(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms) {
+            std::vector<uint8_t> s, p, f;
+            pack(terms, s, p, f);
+            AffinePoint out;
+            Engine& e = Engine::global();
+            uint8_t xy[2 * L];
+            e.check(ecgpu_msm(e.ctx(), ID, s.data(), p.data(), f.data(), terms.size(), xy, &out.infinity));
+            std::memcpy(out.x_.data(), xy, L);
+            std::memcpy(out.y_.data(), xy + L, L);
+            return ProjectivePoint{out};
+        }
+        static ProjectivePoint lincomb_vartime(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms) {
+            return lincomb(terms);
+        }
+        // MulByGeneratorVartime::mul_by_generator_and_mul_add_vartime: a*G + b*P
+        static ProjectivePoint mul_by_generator_and_mul_add_vartime(const Scalar& a, const Scalar& b,
+                                                                    const ProjectivePoint& p) {
+            Engine& e = Engine::global();
+            AffinePoint out;
+            uint8_t pxy[2 * L], xy[2 * L];
+            std::memcpy(pxy, p.a.x_.data(), L);
+            std::memcpy(pxy + L, p.a.y_.data(), L);
+            e.check(ecgpu_batch_mul_base_and_mul_add(e.ctx(), ID, a.repr.data(), b.repr.data(), pxy, &p.a.infinity, 1, xy,
+                                                     &out.infinity));
+            std::memcpy(out.x_.data(), xy, L);
+            std::memcpy(out.y_.data(), xy + L, L);
+            return ProjectivePoint{out};
+        }
+        // impl Sum for ProjectivePoint
+        static ProjectivePoint sum(const std::vector<ProjectivePoint>& pts) {
+            std::vector<uint8_t> p(pts.size() * 2 * L), f(pts.size());
+            for (size_t i = 0; i < pts.size(); i++) {
+                std::memcpy(&p[i * 2 * L], pts[i].a.x_.data(), L);
+                std::memcpy(&p[i * 2 * L + L], pts[i].a.y_.data(), L);
+                f[i] = pts[i].a.infinity;
+                if (f[i]) std::memset(&p[i * 2 * L], 0, 2 * L);
+            }
+            Engine& e = Engine::global();
+            AffinePoint out;
+            uint8_t xy[2 * L];
+            e.check(ecgpu_point_sum(e.ctx(), ID, p.data(), f.data(), pts.size(), xy, &out.infinity));
+            std::memcpy(out.x_.data(), xy, L);
+            std::memcpy(out.y_.data(), xy + L, L);
+            return ProjectivePoint{out};
+        }
+    };
+
+    static ProjectivePoint GENERATOR() { return ProjectivePoint::mul_by_generator(Scalar::from_u64(1)); }
+
+    // ---- batch forms (new API; what the GPU is for) --------------------------------------------------
+    static std::vector<ProjectivePoint> batch_mul_by_generator(const std::vector<Scalar>& ks) {
+        size_t n = ks.size();
+        std::vector<uint8_t> s(n * L), xy(n * 2 * L), inf(n);
+        for (size_t i = 0; i < n; i++) std::memcpy(&s[i * L], ks[i].repr.data(), L);
+        Engine& e = Engine::global();
+        e.check(ecgpu_batch_mul_base(e.ctx(), ID, s.data(), n, xy.data(), inf.data()));
+        return unpack(xy, inf);
+    }
+    static std::vector<ProjectivePoint> batch_mul(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks) {
+        size_t n = ks.size();
+        if (ps.size() != n) throw Error(ECGPU_ERR_ARG, "batch_mul: length mismatch");
+        std::vector<uint8_t> s(n * L), p(n * 2 * L), f(n), xy(n * 2 * L), inf(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&s[i * L], ks[i].repr.data(), L);
+            std::memcpy(&p[i * 2 * L], ps[i].a.x_.data(), L);
+            std::memcpy(&p[i * 2 * L + L], ps[i].a.y_.data(), L);
+            f[i] = ps[i].a.infinity;
+            if (f[i]) std::memset(&p[i * 2 * L], 0, 2 * L);
+        }
+        Engine& e = Engine::global();
+        e.check(ecgpu_batch_mul(e.ctx(), ID, s.data(), p.data(), f.data(), n, xy.data(), inf.data()));
+        return unpack(xy, inf);
+    }
+
+    // ---- MulBackend<C> plug-in (primeorder/src/mul_backend.rs:11-40) ----------------------------------
+    struct GpuBackend {
+        static ProjectivePoint mul_by_generator(const Scalar& k) { return ProjectivePoint::mul_by_generator(k); }
+        static ProjectivePoint mul_by_generator_vartime(const Scalar& k) { return ProjectivePoint::mul_by_generator(k); }
+        static ProjectivePoint mul_by_generator_and_mul_add_vartime(const Scalar& a, const Scalar& b,
+                                                                    const ProjectivePoint& p) {
+            return ProjectivePoint::mul_by_generator_and_mul_add_vartime(a, b, p);
+        }
+    };
+
+  private:
+    static void pack(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms, std::vector<uint8_t>& s,
+                     std::vector<uint8_t>& p, std::vector<uint8_t>& f) {
+        size_t n = terms.size();
+        s.assign(n * L + 1, 0); p.assign(n * 2 * L + 1, 0); f.assign(n + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&s[i * L], terms[i].second.repr.data(), L);
+            f[i] = terms[i].first.a.infinity;
+            if (!f[i]) {
+                std::memcpy(&p[i * 2 * L], terms[i].first.a.x_.data(), L);
+                std::memcpy(&p[i * 2 * L + L], terms[i].first.a.y_.data(), L);
+            }
+        }
+    }
+    static std::vector<ProjectivePoint> unpack(const std::vector<uint8_t>& xy, const std::vector<uint8_t>& inf) {
+        std::vector<ProjectivePoint> out(inf.size());
+        for (size_t i = 0; i < inf.size(); i++) {
+            out[i].a.infinity = inf[i];
+            if (!inf[i]) {
+                std::memcpy(out[i].a.x_.data(), &xy[i * 2 * L], L);
+                std::memcpy(out[i].a.y_.data(), &xy[i * 2 * L + L], L);
+            }
+        }
+        return out;
+    }
+};
+
+using k256 = Curve<ECGPU_K256, 32>;
+using p256 = Curve<ECGPU_P256, 32>;
+using p384 = Curve<ECGPU_P384, 48>;
+
+}  // namespace ecgpu_host

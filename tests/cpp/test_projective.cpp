@@ -1,0 +1,135 @@
+// test_projective.cpp — the reference's projective-point property tests, re-stated against the C++ host
+// mirror (elliptic-curves_amd/host/ecgpu.hpp) so that they read like the originals:
+//   k256/tests/projective.rs:75-140, p256/tests/projective.rs:83-148, p256/src/arithmetic/tables.rs:64-80
+// Every operation below runs on the GPU through the C ABI.  Needs a gfx950 device (run by the -m gpu tests).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../elliptic-curves_amd/host/ecgpu.hpp"
+
+using namespace ecgpu_host;
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t next_u64() {  // SplitMix64
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static const uint8_t N_K256[32] = {0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xfe,
+                                   0xba,0xae,0xdc,0xe6,0xaf,0x48,0xa0,0x3b,0xbf,0xd2,0x5e,0x8c,0xd0,0x36,0x41,0x41};
+static const uint8_t N_P256[32] = {0xff,0xff,0xff,0xff,0x00,0x00,0x00,0x00,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,
+                                   0xbc,0xe6,0xfa,0xad,0xa7,0x17,0x9e,0x84,0xf3,0xb9,0xca,0xc2,0xfc,0x63,0x25,0x51};
+static const uint8_t N_P384[48] = {0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,
+                                   0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xff,0xc7,0x63,0x4d,0x81,0xf4,0x37,0x2d,0xdf,
+                                   0x58,0x1a,0x0d,0xb2,0x48,0xb0,0xa7,0x7a,0xec,0xec,0x19,0x6a,0xcc,0xc5,0x29,0x73};
+
+// Scalar::reduce(bytes): one conditional subtraction of n (k256/tests/projective.rs:27-31)
+template <class C>
+typename C::Scalar random_scalar(const uint8_t* n_be) {
+    constexpr size_t L = C::FieldBytesSize;
+    typename C::FieldBytes b;
+    for (size_t i = 0; i < L; i += 8) {
+        uint64_t v = next_u64();
+        std::memcpy(&b[i], &v, 8);
+    }
+    if (std::memcmp(b.data(), n_be, L) >= 0) {
+        int borrow = 0;
+        for (int i = (int)L - 1; i >= 0; i--) {
+            int d = (int)b[i] - (int)n_be[i] - borrow;
+            borrow = d < 0;
+            b[i] = (uint8_t)(d + (borrow << 8));
+        }
+    }
+    return C::Scalar::from_repr(b);
+}
+
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            return 1;                                                            \
+        }                                                                        \
+    } while (0)
+
+template <class C>
+int run(const char* name, const uint8_t* n_be, int cases) {
+    using Scalar = typename C::Scalar;
+    using P = typename C::ProjectivePoint;
+    const P G = C::GENERATOR();
+    CHECK(!G.is_identity());
+
+    for (int it = 0; it < cases; it++) {
+        // fn projective() -> GENERATOR * scalar   (k256/tests/projective.rs:21-25)
+        Scalar s1 = random_scalar<C>(n_be), s2 = random_scalar<C>(n_be), s3 = random_scalar<C>(n_be);
+        auto pts = C::batch_mul_by_generator({random_scalar<C>(n_be), random_scalar<C>(n_be), random_scalar<C>(n_be)});
+        P p1 = pts[0], p2 = pts[1], p3 = pts[2];
+
+        // lincomb == p1*s1 + p2*s2 + p3*s3, and lincomb_vartime agrees
+        P reference = (p1 * s1) + (p2 * s2) + (p3 * s3);
+        P test = P::lincomb({{p1, s1}, {p2, s2}, {p3, s3}});
+        CHECK(reference == test);
+        CHECK(P::lincomb_vartime({{p1, s1}, {p2, s2}, {p3, s3}}) == reference);
+
+        // mul_by_generator == GENERATOR * s, and the vartime variant
+        CHECK(P::mul_by_generator(s1) == G * s1);
+        CHECK(P::mul_by_generator_vartime(s2) == G * s2);
+
+        // mul_vartime == p * s
+        CHECK(p1.mul_vartime(s3) == p1 * s3);
+
+        // mul_by_generator_and_mul_add_vartime(a, b, P) == G*a + P*b
+        CHECK(P::mul_by_generator_and_mul_add_vartime(s1, s2, p3) == (G * s1) + (p3 * s2));
+        CHECK(C::GpuBackend::mul_by_generator(s3) == G * s3);
+    }
+
+    // identities and edge scalars
+    Scalar zero = Scalar::from_u64(0), one = Scalar::from_u64(1), two = Scalar::from_u64(2);
+    CHECK((G * zero).is_identity());
+    CHECK(G * one == G);
+    CHECK(G * two == G + G);
+    CHECK((P::IDENTITY() * two).is_identity());
+    CHECK(P::mul_by_generator(zero).is_identity());
+    CHECK(P::lincomb({}).is_identity());
+    CHECK(P::lincomb({{P::IDENTITY(), two}, {G, one}}) == G);
+    CHECK((G + P::IDENTITY()) == G);
+
+    // decoding errors: scalar >= n is refused (Scalar::from_repr -> None in the reference)
+    typename C::FieldBytes nb;
+    std::memcpy(nb.data(), n_be, C::FieldBytesSize);
+    bool threw = false;
+    try {
+        (void)P::mul_by_generator(Scalar::from_repr(nb));
+    } catch (const Error& e) {
+        threw = e.code == ECGPU_ERR_SCALAR_RANGE;
+    }
+    CHECK(threw);
+    // a point that is not on the curve is refused (AffinePoint::from_coordinates -> None)
+    auto bad = G.to_affine();
+    bad.y_[C::FieldBytesSize - 1] ^= 1;
+    threw = false;
+    try {
+        (void)(P::from(bad) * two);
+    } catch (const Error& e) {
+        threw = e.code == ECGPU_ERR_POINT;
+    }
+    CHECK(threw);
+    std::printf("%s: %d proptest cases + edge cases ok\n", name, cases);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    int cases = argc > 1 ? std::atoi(argv[1]) : 8;
+    try {
+        if (run<k256>("k256", N_K256, cases)) return 1;
+        if (run<p256>("p256", N_P256, cases)) return 1;
+        if (run<p384>("p384", N_P384, cases)) return 1;
+    } catch (const Error& e) {
+        std::fprintf(stderr, "unexpected %s\n", e.what());
+        return 2;
+    }
+    std::printf("all ok\n");
+    return 0;
+}
