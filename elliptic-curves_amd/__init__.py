@@ -66,6 +66,12 @@ def load_library():
     return lib
 
 
+def _field_bytes(curve):
+    if curve not in FIELD_BYTES:
+        raise EcgpuError(ERR_CURVE, "unknown curve id %r" % (curve,))
+    return FIELD_BYTES[curve]
+
+
 def _host(a):
     if a is None:
         return None
@@ -136,7 +142,7 @@ class Engine:
 
     # ---- host-buffer operations (numpy uint8 / bytes in, numpy out) ----
     def mul_by_generator(self, curve, scalars):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         s = _host(scalars)
         n = s.size // L
         out = np.zeros(n * 2 * L, np.uint8)
@@ -145,7 +151,7 @@ class Engine:
         return out, inf
 
     def mul(self, curve, scalars, points_xy, points_inf=None):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
         n = s.size // L
         out = np.zeros(n * 2 * L, np.uint8)
@@ -154,7 +160,7 @@ class Engine:
         return out, inf
 
     def lincomb(self, curve, scalars, points_xy, points_inf=None):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
         n = s.size // L
         out = np.zeros(2 * L, np.uint8)
@@ -163,7 +169,7 @@ class Engine:
         return out, int(inf[0])
 
     def mul_by_generator_and_mul_add(self, curve, a_scalars, b_scalars, points_xy, points_inf=None):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         a, b, p, pi = _host(a_scalars), _host(b_scalars), _host(points_xy), _host(points_inf)
         n = a.size // L
         out = np.zeros(n * 2 * L, np.uint8)
@@ -173,7 +179,7 @@ class Engine:
         return out, inf
 
     def batch_normalize(self, curve, points_xyz):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         x = _host(points_xyz)
         n = x.size // (3 * L)
         out = np.zeros(n * 2 * L, np.uint8)
@@ -182,7 +188,7 @@ class Engine:
         return out, inf
 
     def point_sum(self, curve, points_xy, points_inf=None):
-        L = FIELD_BYTES[curve]
+        L = _field_bytes(curve)
         p, pi = _host(points_xy), _host(points_inf)
         n = p.size // (2 * L)
         out = np.zeros(2 * L, np.uint8)

@@ -577,7 +577,12 @@ int ecgpu_valu_probe(ecgpu_ctx* ctx, int which, double* ops_per_sec) {
     const int blocks = 256 * 8, iters = 2048;
     int rc;
     if ((rc = ensure(ctx, ctx->out0, (size_t)blocks * BLOCK * 4)) != ECGPU_OK) return rc;
-    auto launch = [&](int it) { launch_valu_probe(ctx->stream, which, (uint32_t*)ctx->out0.p, blocks, it); };
+    // which >= 100: exact inline-asm instruction probes (which - 100 selects the instruction, see ecgpu_misc.hip);
+    // the result is then wave64-instructions per second x 64 (i.e. lane-operations per second).
+    auto launch = [&](int it) {
+        if (which >= 100) launch_isa_probe(ctx->stream, which - 100, (uint32_t*)ctx->out0.p, blocks, it);
+        else launch_valu_probe(ctx->stream, which, (uint32_t*)ctx->out0.p, blocks, it);
+    };
     launch(16);  // warm-up
     record(ctx, 0);
     launch(iters);

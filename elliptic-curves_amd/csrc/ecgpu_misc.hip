@@ -61,6 +61,107 @@ __global__ void __launch_bounds__(BLOCK) k_valu_probe(uint32_t* out, int iters, 
 }
 
 
+
+// ---- exact per-instruction issue-rate probes (inline asm, 8 independent chains x 8 per loop trip) ----
+// Reported as wave-instructions per second over the whole chip; divide (CUs x 4 SIMDs x clock) by it to get
+// cycles per wave64 instruction per SIMD.
+#define ISA_BODY8(STMT) STMT(0) STMT(1) STMT(2) STMT(3) STMT(4) STMT(5) STMT(6) STMT(7)
+template <int WHICH>
+__global__ void __launch_bounds__(BLOCK) k_isa_probe(uint32_t* out, int iters, uint32_t seed) {
+    uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;
+    uint64_t a[8];
+    uint32_t x[8];
+    double f[8];
+    uint32_t m = seed | 1u, m2 = (seed * 2654435761u) | 3u;
+    double fm = 1.0000001, fc = 1e-9;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = ((uint64_t)(t + i) << 32) | (seed + i); x[i] = t * 7 + i; f[i] = (double)(t + i) * 1e-3; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int rep = 0; rep < 8; rep++) {
+            if constexpr (WHICH == 0) {
+#define S(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[i]) : "v"(m), "v"(m2) : "vcc");
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 1) {
+#define S(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 2) {
+#define S(i) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(x[i]), "+v"(x[(i + 4) & 7]) : "v"(m), "v"(m2) : "vcc");
+                S(0) S(1) S(2) S(3)
+#undef S
+            } else if constexpr (WHICH == 3) {
+#define S(i) asm volatile("v_mov_b32 %0, %1" : "=v"(x[i]) : "v"(x[(i + 1) & 7]));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 4) {
+#define S(i) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a[i]) : "v"(a[(i + 1) & 7]));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 5) {
+#define S(i) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 6) {
+#define S(i) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 7) {
+#define S(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 8) {
+#define S(i) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x[i]) : "v"(m), "v"(m2));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 9) {
+#define S(i) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 10) {
+#define S(i) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(m), "v"(m2));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 11) {
+#define S(i) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(a[i]));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 12) {
+#define S(i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fm), "v"(fc));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 13) {
+#define S(i) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else if constexpr (WHICH == 14) {
+#define S(i) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(m));
+                ISA_BODY8(S)
+#undef S
+            } else {
+#define S(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(m) : );
+                ISA_BODY8(S)
+#undef S
+            }
+        }
+    }
+    uint64_t acc = 0;
+    double facc = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { acc ^= a[i] + x[i]; facc += f[i]; }
+    if (acc == 0x1234567 || facc == 1.2345) out[t] = (uint32_t)acc;
+}
+
+void launch_isa_probe(hipStream_t s, int which, uint32_t* o, int blocks, int it) {
+    switch (which) {
+#define C(n) case n: hipLaunchKernelGGL(k_isa_probe<n>, dim3(blocks), dim3(BLOCK), 0, s, o, it, 12345u); break;
+    C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14)
+#undef C
+    default: hipLaunchKernelGGL(k_isa_probe<15>, dim3(blocks), dim3(BLOCK), 0, s, o, it, 12345u); break;
+    }
+}
+
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status) {
     hipLaunchKernelGGL(k_k256_glv, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, scalars, n, r1, r2, status);
 }

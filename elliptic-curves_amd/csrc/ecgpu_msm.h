@@ -81,11 +81,8 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     uint32_t carry = 0;
 #pragma unroll 1
     for (int w = 0; w < nwin; w++) {
-        int d = signed_window_step(get_bits<N>(k, w * c, c), c, &carry);
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            ranks[(size_t)w * n + i] = atomicAdd(&counts[(size_t)w * nb + (mag - 1)], 1u);
-        }
+        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i);
+        if (d.nonzero) ranks[(size_t)w * n + i] = atomicAdd(&counts[(size_t)w * nb + d.bucket], 1u);
     }
 }
 
@@ -129,11 +126,10 @@ k_msm_scatter(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     uint32_t carry = 0;
 #pragma unroll 1
     for (int w = 0; w < nwin; w++) {
-        int d = signed_window_step(get_bits<N>(k, w * c, c), c, &carry);
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            uint32_t pos = offsets[(size_t)w * nb + (mag - 1)] + ranks[(size_t)w * n + i];
-            sorted[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i);
+        if (d.nonzero) {
+            uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * n + i];
+            sorted[(size_t)w * n + pos] = (uint32_t)i | (d.neg << 31);
         }
     }
 }
@@ -195,10 +191,13 @@ __device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const
     return acc;
 }
 
-// segs[w][s] = sum_{j < seg} (s*seg + j + 1) * buckets[w][s*seg + j]
+// segs[w][s] = sum_{j < seg} weight(s*seg + j) * buckets[w][s*seg + j],  weight(b) = (b >> shift_w) + 1 with
+// shift_w = 0 except for the last window (sub-buckets, see msm_digit).  Running-sum trick: walking the
+// segment downwards, `running` is added to `local` once per unit drop of the weight, and the weight of the
+// lowest bucket multiplies the whole segment sum at the end.
 template <class C>
 __global__ void __launch_bounds__(64)
-k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin,
+k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin, int top_shift,
                       uint32_t* __restrict__ segs) {
     using G = Group<C>;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,13 +206,15 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
     Fe<C::N> b = G::curve_b();
     Proj<C> running = G::identity(), local = G::identity();
     size_t base = s * seg;
+    const int sh = (int)w == nwin - 1 ? top_shift : 0;
 #pragma unroll 1
     for (int j = seg - 1; j >= 0; j--) {
         Proj<C> bk = load_proj<C>(buckets, w * nb + base + j);
         running = G::add(running, bk, b);
-        local = G::add(local, running, b);
+        if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
     }
-    if (base) local = G::add(local, small_mul<C>(running, (uint32_t)base, b), b);
+    uint32_t wmin = (uint32_t)(base >> sh) + 1;
+    local = G::add(local, wmin == 1 ? running : small_mul<C>(running, wmin, b), b);
     store_proj<C>(segs, gid, local);
 }
 
@@ -285,7 +286,7 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, segs);
+                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(32 * C::N, p.c), segs);
     hipLaunchKernelGGL(k_msm_reduce_windows<C>, dim3(p.nwin), dim3(BLOCK), 0, stream, (const uint32_t*)segs, p.nseg, wins);
     hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
 }

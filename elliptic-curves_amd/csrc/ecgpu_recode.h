@@ -43,6 +43,47 @@ ECGPU_HD int signed_window_step(uint32_t raw, int w, uint32_t* carry) {
 // left plus the carry.
 ECGPU_HD int signed_window_count(int bits, int w) { return bits / w + 1; }
 
+// ---- Pippenger bucket keys -----------------------------------------------------------------------
+// A `bits`-bit scalar is cut into nwin = bits/c + 1 windows.  Windows 0..nwin-2 carry signed c-bit
+// digits d in (-2^(c-1), 2^(c-1)], bucket = |d| - 1, weight = bucket + 1.  The last window holds the
+// remaining r = bits % c bits plus the carry as an UNSIGNED digit in [0, 2^r].  It has only 2^r distinct
+// values, so without care all n terms of that window would pile into 2^r buckets (for 256-bit scalars
+// and c = 16: half of all terms into ONE bucket).  Its terms are therefore spread over all 2^(c-1)
+// buckets with the low `shift = c-1-r` bits of the term index as a sub-bucket:
+//     bucket = ((d - 1) << shift) | (index mod 2^shift),   weight(bucket) = (bucket >> shift) + 1.
+ECGPU_HD int msm_top_shift(int bits, int c) { return c - 1 - bits % c; }
+
+struct MsmDigit {
+    uint32_t bucket;
+    uint32_t neg;      // 1: subtract the point
+    bool nonzero;
+};
+
+template <int NL>
+ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t* carry, uint32_t term_index) {
+    MsmDigit r;
+    r.bucket = 0; r.neg = 0; r.nonzero = false;
+    if (w < nwin - 1) {
+        int d = signed_window_step(get_bits<NL>(k, w * c, c), c, carry);
+        if (d != 0) {
+            r.nonzero = true;
+            r.neg = d < 0;
+            r.bucket = (uint32_t)(d < 0 ? -d : d) - 1;
+        }
+    } else {
+        const int bits = 32 * NL;
+        const int rem = bits % c;
+        const int shift = c - 1 - rem;
+        uint32_t d = (rem ? get_bits<NL>(k, w * c, rem) : 0u) + *carry;
+        *carry = 0;
+        if (d != 0) {
+            r.nonzero = true;
+            r.bucket = ((d - 1) << shift) | (term_index & ((1u << shift) - 1));
+        }
+    }
+    return r;
+}
+
 // k' = k + 0x8888...8 over NL limbs (+1 limb for the carry). digit(i) = nibble_i(k') - 8 for
 // i < 8*NL, and nibble (0/1) for i = 8*NL: exactly Radix16Decomposition::new's output.
 template <int NL>

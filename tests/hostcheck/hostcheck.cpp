@@ -301,11 +301,8 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         finite[i] = 1;
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
-            int d = signed_window_step(get_bits<N>(ks[i].data(), w * c, c), c, &carry);
-            if (d != 0) {
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                ranks[(size_t)w * n + i] = counts[(size_t)w * nb + (mag - 1)]++;
-            }
+            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i);
+            if (d.nonzero) ranks[(size_t)w * n + i] = counts[(size_t)w * nb + d.bucket]++;
         }
     }
     for (int w = 0; w < nwin; w++) {                                    // scan
@@ -316,11 +313,10 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         if (!finite[i]) continue;
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
-            int d = signed_window_step(get_bits<N>(ks[i].data(), w * c, c), c, &carry);
-            if (d != 0) {
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                uint32_t pos = offsets[(size_t)w * nb + (mag - 1)] + ranks[(size_t)w * n + i];
-                sorted[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
+            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i);
+            if (d.nonzero) {
+                uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * n + i];
+                sorted[(size_t)w * n + pos] = (uint32_t)i | (d.neg << 31);
             }
         }
     }
@@ -342,13 +338,14 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         for (size_t s = 0; s < nseg; s++) {
             Proj<C> running = G::identity(), local = G::identity();
             size_t base = s * seg;
+            const int sh = w == nwin - 1 ? msm_top_shift(32 * N, c) : 0;
             for (int j = seg - 1; j >= 0; j--) {
                 running = G::add(running, buckets[(size_t)w * nb + base + j], b);
-                local = G::add(local, running, b);
+                if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
             }
-            if (base) {
+            {
                 Proj<C> acc = G::identity();
-                uint32_t k = (uint32_t)base;
+                uint32_t k = (uint32_t)(base >> sh) + 1;
                 int top = 31 - __builtin_clz(k);
                 for (int bit = top; bit >= 0; bit--) {
                     acc = G::dbl(acc, b);

@@ -175,7 +175,7 @@ def test_var_base_algorithm(oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("cbits", [4, 7, 10])
+@pytest.mark.parametrize("cbits", [4, 7, 10, 13, 16])
 def test_pippenger_algorithm(oracle, curve, cbits):
     c = pyec.CURVES[curve]
     rng = random.Random(0x9199 + c.cid + cbits)
