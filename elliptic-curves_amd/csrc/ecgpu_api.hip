@@ -115,7 +115,8 @@ void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*,
 
 template <class C>
 int ensure_table(ecgpu_ctx* ctx) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     Table& t = ctx->table[C::ID];
     int w = ctx->want_w[C::ID];
     if (t.d && t.w == w) return ECGPU_OK;
@@ -129,9 +130,9 @@ int ensure_table(ecgpu_ctx* ctx) {
     const size_t half = (size_t)1 << (w - 1);
     const size_t entries = half * nwin;
     int rc;
-    if ((rc = ensure(ctx, ctx->bases, (size_t)nwin * 3 * N * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->proj, entries * 3 * N * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->prefix, entries * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->bases, (size_t)nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, entries * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->prefix, entries * NS * 4)) != ECGPU_OK) return rc;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.d), entries * 2 * N * 4));
     launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, w, nwin);
     launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, w, nwin);
@@ -148,7 +149,7 @@ int ensure_table(ecgpu_ctx* ctx) {
 template <class C>
 int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
     int rc;
-    if ((rc = ensure(ctx, ctx->prefix, n * C::N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->prefix, n * Field<C>::NS * 4)) != ECGPU_OK) return rc;
     launch_normalize<C>(ctx->stream, false, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, n, (uint8_t*)d_out_xy,
                         (uint8_t*)d_out_inf, nullptr);
     return ECGPU_OK;
@@ -158,11 +159,12 @@ int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
 
 template <class C>
 int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     int rc;
     if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
     if (n == 0) return ECGPU_OK;
-    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     const Table& t = ctx->table[C::ID];
     record(ctx, 0);
@@ -179,12 +181,13 @@ int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy
 template <class C>
 int mul_var_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, const void* d_points_inf, size_t n,
                 void* d_out_xy, void* d_out_inf) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     if (n == 0) return ECGPU_OK;
     int rc;
     size_t tstride = var_base_slots<C>(n);
-    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * C::NL * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
@@ -199,10 +202,11 @@ int mul_var_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, 
 
 template <class C>
 int normalize_dev(ecgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_out_xy, void* d_out_inf) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     if (n == 0) return ECGPU_OK;
     int rc;
-    if ((rc = ensure(ctx, ctx->proj, n * 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_load_proj<C>(ctx->stream, (const uint8_t*)d_xyz, n, (uint32_t*)ctx->proj.p, ctx->d_status);
@@ -216,9 +220,10 @@ int normalize_dev(ecgpu_ctx* ctx, const void* d_xyz, size_t n, void* d_out_xy, v
 
 template <class C>
 int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy, void* d_out_inf) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     int rc;
-    if ((rc = ensure(ctx, ctx->proj, 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_point_sum<C>(ctx->stream, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, (uint32_t*)ctx->proj.p, ctx->d_status);
@@ -233,9 +238,10 @@ int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n,
 template <class C>
 int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy,
             void* d_out_inf) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
     int rc;
-    if ((rc = ensure(ctx, ctx->proj, 3 * N * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     MsmPlan plan = msm_plan<C>(n, ctx->msm_c);
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
@@ -422,17 +428,18 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
         return ECGPU_ERR_ARG;
     return dispatch(curve, [&](auto c) {
         using C = decltype(c);
-        constexpr int N = C::N;
+        constexpr int N = C::N, NS = Field<C>::NS;
+    (void)N;
         int rc;
         if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
         if (n == 0) return (int)ECGPU_OK;
         size_t tstride = var_base_slots<C>(n);
-        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * N * 4)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * N * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * C::NL * 4)) != ECGPU_OK) return rc;
         if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
         const Table& t = ctx->table[C::ID];
         uint32_t* pa = (uint32_t*)ctx->proj.p;
-        uint32_t* pb = pa + n * 3 * N;
+        uint32_t* pb = pa + n * 3 * NS;
         record(ctx, 0);
         launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_a, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
         launch_var_base<C>(ctx->stream, (const uint8_t*)d_b, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,

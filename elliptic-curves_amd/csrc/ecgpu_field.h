@@ -1,322 +1,63 @@
 // ecgpu_field.h — prime-field arithmetic for the MI355X scalar-mul engine.
 //
-// Every function is `__host__ __device__` so that the very same code the gfx950 kernels run can
-// be compiled with g++ and unit-checked on a CPU against the oracle (tests/hostcheck/); the
-// product library only ever instantiates it inside HIP kernels.
+// Every function is `__host__ __device__`: the very same code the gfx950 kernels run is compiled with
+// g++ and checked on a CPU against the oracle (tests/hostcheck/).
 //
-// Representation (one thread = one field element held in VGPRs, 32-bit limbs, little-endian):
-//   k256  8 limbs, plain residues kept "weakly reduced" in [0, 2^256) and folded with
-//         2^256 = 0x1000003D1 (mod p).  The reference's 64-bit build uses 5x52 lazy limbs
-//         (k256/src/arithmetic/field/field_5x52.rs:240-401) and its 32-bit build 10x26
-//         (field_10x26.rs:308-620); only canonical bytes are compared, so the GPU is free to
-//         pick the layout that suits v_mad_u64_u32.
-//   p256  8 limbs, Montgomery form R = 2^256, fully reduced — p256/src/arithmetic/field.rs:99-108,
-//         field/field64.rs:83-123 (p' = 1 word-by-word reduction; same trick holds for 32-bit
-//         words, field/field32.rs:110-208).
-//   p384  12 limbs, Montgomery form R = 2^384, fully reduced — p384/src/arithmetic/field.rs:52-57
-//         -> primefield/src/monty.rs:316-368 -> crypto-bigint ConstMontyForm (p' = 1 for 32-bit
-//         words as well because p = -1 mod 2^32).
+// Why unsaturated limbs.  Measured on MI355X (profiles/r01/isa_issue_rates.txt): v_mad_u64_u32
+// (32x32+64 -> 64) issues in 4 cycles per wave64 — the same as a 64-bit add (v_lshl_add_u64) or any
+// other VOP3 instruction — and plain 32-bit VOP2 ops (v_add_u32, v_and_b32, v_mov_b32) in 2.  The
+// first version of this file used 8 saturated 32-bit limbs; its multiplication spent 74 MADs but 300
+// further instructions on zero-extensions and 64-bit carry adds, and every field addition was a carry
+// chain.  With limbs of 29 (k256) / 28 (p256) bits the 64-bit column accumulators cannot overflow, so a
+// product is nothing but multiply-adds, and additions/subtractions are independent 32-bit ops per limb
+// with no carries at all ("lazy" reduction — the same idea as the reference's own 5x52 / 10x26 fields,
+// k256/src/arithmetic/field/field_5x52.rs:203-236, field_10x26.rs:258-290).
+//
+// Representations (C::REPR):
+//   REPR_U29_K256  k256: 9 limbs x 29 bits, plain residues, value < M * 2^261; products are folded with
+//                  2^261 = 256 * 2^29 + 31264 (mod p)
+//   REPR_U28_MONT  p256: 10 limbs x 28 bits, Montgomery form R = 2^280 (p = -1 mod 2^28, so p' = 1 as in
+//                  p256/src/arithmetic/field/field64.rs:59), value < M * 2p
+//   REPR_SAT_MONT  p384: 12 saturated 32-bit limbs, Montgomery form, fully reduced after every operation
+//                  (p384/src/arithmetic/field.rs:52-57 -> crypto-bigint ConstMontyForm)
+//
+// Lazy reduction needs bounds.  Elements carry their bounds in the type: Mag<C, L, V> has limbs
+// <= L * LB ("limb magnitude") and value <= V * (value unit) ("value magnitude"); add/sub/neg grow the
+// magnitudes, mul/sqr require L_a * L_b <= MAXPROD and return magnitude (1, 1), norm() resets the limb
+// magnitude.  Every precondition is a static_assert, i.e. the bound analysis of tools/field_model.py is
+// re-checked by the compiler at each call site — the compile-time twin of the reference's debug-build
+// magnitude checker (k256/src/arithmetic/field/field_impl.rs:17-22).
 #pragma once
 
-#include <stdint.h>
-
-#if defined(__HIPCC__)
-#include <hip/hip_runtime.h>
-#define ECGPU_HD __host__ __device__ __forceinline__
-#define ECGPU_CONST static constexpr
-#else
-#define ECGPU_HD inline
-#define ECGPU_CONST static constexpr
-#endif
+#include "ecgpu_field_consts.h"
+#include "ecgpu_params.h"
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2 };
-
-template <int N>
-struct Fe {
-    uint32_t v[N];
+template <class C, int L, int V>
+struct Mag {
+    Fe<C::NL> e;
 };
-
-// ---------------------------------------------------------------------------------------------
-// small multi-limb helpers
-// ---------------------------------------------------------------------------------------------
-
-template <int N>
-ECGPU_HD uint32_t mp_add(uint32_t* r, const uint32_t* a, const uint32_t* b) {
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (uint64_t)a[i] + b[i];
-        r[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    return (uint32_t)c;
-}
-
-template <int N>
-ECGPU_HD uint32_t mp_sub(uint32_t* r, const uint32_t* a, const uint32_t* b) {
-    int64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        c += (int64_t)a[i] - (int64_t)b[i];
-        r[i] = (uint32_t)c;
-        c >>= 32;  // arithmetic shift: 0 or -1
-    }
-    return (uint32_t)(c & 1);
-}
-
-// returns 1 if a >= b
-template <int N>
-ECGPU_HD bool mp_geq(const uint32_t* a, const uint32_t* b) {
-    uint32_t t[N];
-    return mp_sub<N>(t, a, b) == 0;
-}
-
-template <int N>
-ECGPU_HD bool mp_is_zero(const uint32_t* a) {
-    uint32_t z = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) z |= a[i];
-    return z == 0;
-}
-
-// r[0..2N) = a * b, operand scanning; one v_mad_u64_u32 per limb pair
-template <int N>
-ECGPU_HD void mp_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) r[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint32_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < N; j++) {
-            uint64_t t = (uint64_t)a[i] * b[j] + r[i + j] + carry;
-            r[i + j] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
-        }
-        r[i + N] = carry;
-    }
-}
-
-// r[0..2N) = a^2: off-diagonal products once, doubled, plus the diagonal
-template <int N>
-ECGPU_HD void mp_sqr(uint32_t* r, const uint32_t* a) {
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) r[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-        uint32_t carry = 0;
-#pragma unroll
-        for (int j = i + 1; j < N; j++) {
-            uint64_t t = (uint64_t)a[i] * a[j] + r[i + j] + carry;
-            r[i + j] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
-        }
-        r[i + N] = carry;
-    }
-    // double
-    uint32_t top = 0;
-#pragma unroll
-    for (int i = 1; i < 2 * N; i++) {
-        uint32_t w = r[i];
-        r[i] = (w << 1) | top;
-        top = w >> 31;
-    }
-    // add squares on the diagonal
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t sq = (uint64_t)a[i] * a[i];
-        c += (uint64_t)r[2 * i] + (uint32_t)sq;
-        r[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)r[2 * i + 1] + (uint32_t)(sq >> 32);
-        r[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
-    }
-}
-
-ECGPU_HD uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-
-// big-endian bytes (4-byte aligned) -> little-endian limbs
-template <int N>
-ECGPU_HD void load_be(uint32_t* limbs, const uint8_t* bytes) {
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(bytes);
-#pragma unroll
-    for (int i = 0; i < N; i++) limbs[i] = bswap32(w[N - 1 - i]);
-}
-template <int N>
-ECGPU_HD void store_be(uint8_t* bytes, const uint32_t* limbs) {
-    uint32_t* w = reinterpret_cast<uint32_t*>(bytes);
-#pragma unroll
-    for (int i = 0; i < N; i++) w[N - 1 - i] = bswap32(limbs[i]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// curve parameter packs (constants: SURVEY.md Appendix A, reference lines cited there)
-// ---------------------------------------------------------------------------------------------
-
-struct K256Params {
-    ECGPU_CONST int ID = CURVE_K256;
-    ECGPU_CONST int N = 8;            // 32-bit limbs per field element / scalar
-    ECGPU_CONST bool A_IS_ZERO = true;
-    ECGPU_CONST bool MONTGOMERY = false;
-    // p = 2^256 - 0x1000003D1                      k256/src/arithmetic/field.rs:41-42
-    ECGPU_CONST uint32_t P[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
-                                 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    // group order n                                k256/src/lib.rs:71
-    ECGPU_CONST uint32_t ORDER[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
-                                     0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    // generator, canonical little-endian limbs     k256/src/arithmetic/affine.rs:65-79
-    ECGPU_CONST uint32_t GX[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
-                                  0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
-    ECGPU_CONST uint32_t GY[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
-                                  0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
-    ECGPU_CONST uint32_t B_SMALL = 7;  // y^2 = x^3 + 7   k256/src/arithmetic.rs
-};
-
-struct P256Params {
-    ECGPU_CONST int ID = CURVE_P256;
-    ECGPU_CONST int N = 8;
-    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p256/src/arithmetic.rs:44
-    ECGPU_CONST bool MONTGOMERY = true;
-    // p = 2^256 - 2^224 + 2^192 + 2^96 - 1         p256/src/arithmetic/field.rs:35
-    ECGPU_CONST uint32_t P[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u,
-                                 0x00000000u, 0x00000000u, 0x00000001u, 0xFFFFFFFFu};
-    // n                                            p256/src/lib.rs:60
-    ECGPU_CONST uint32_t ORDER[8] = {0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu,
-                                     0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu};
-    // R^2 mod p, R = 2^256                         p256/src/arithmetic/field.rs:183-185
-    ECGPU_CONST uint32_t R2[8] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFBu,
-                                  0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFDu, 0x00000004u};
-    // R mod p = 2^256 - p
-    ECGPU_CONST uint32_t ONE[8] = {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu,
-                                   0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x00000000u};
-    // curve b, canonical                           p256/src/arithmetic.rs:55-57
-    ECGPU_CONST uint32_t B[8] = {0x27D2604Bu, 0x3BCE3C3Eu, 0xCC53B0F6u, 0x651D06B0u,
-                                 0x769886BCu, 0xB3EBBD55u, 0xAA3A93E7u, 0x5AC635D8u};
-    // generator, canonical                         p256/src/arithmetic.rs:67-74
-    ECGPU_CONST uint32_t GX[8] = {0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u,
-                                  0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u};
-    ECGPU_CONST uint32_t GY[8] = {0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u,
-                                  0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u};
-};
-
-struct P384Params {
-    ECGPU_CONST int ID = CURVE_P384;
-    ECGPU_CONST int N = 12;
-    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p384/src/arithmetic.rs:44
-    ECGPU_CONST bool MONTGOMERY = true;
-    // p = 2^384 - 2^128 - 2^96 + 2^32 - 1          p384/src/arithmetic/field.rs:34
-    ECGPU_CONST uint32_t P[12] = {0xFFFFFFFFu, 0x00000000u, 0x00000000u, 0xFFFFFFFFu,
-                                  0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
-                                  0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    // n                                            p384/src/lib.rs:14
-    ECGPU_CONST uint32_t ORDER[12] = {0xCCC52973u, 0xECEC196Au, 0x48B0A77Au, 0x581A0DB2u,
-                                      0xF4372DDFu, 0xC7634D81u, 0xFFFFFFFFu, 0xFFFFFFFFu,
-                                      0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    // R^2 mod p, R = 2^384: (2^128 + 2^96 - 2^32 + 1)^2
-    ECGPU_CONST uint32_t R2[12] = {0x00000001u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,
-                                   0x00000000u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,
-                                   0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
-    // R mod p = 2^128 + 2^96 - 2^32 + 1
-    ECGPU_CONST uint32_t ONE[12] = {0x00000001u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u,
-                                    0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u,
-                                    0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};
-    // curve b, canonical                           p384/src/arithmetic.rs:57-59
-    ECGPU_CONST uint32_t B[12] = {0xD3EC2AEFu, 0x2A85C8EDu, 0x8A2ED19Du, 0xC656398Du,
-                                  0x5013875Au, 0x0314088Fu, 0xFE814112u, 0x181D9C6Eu,
-                                  0xE3F82D19u, 0x988E056Bu, 0xE23EE7E4u, 0xB3312FA7u};
-    // generator, canonical                         p384/src/arithmetic.rs:71-78
-    ECGPU_CONST uint32_t GX[12] = {0x72760AB7u, 0x3A545E38u, 0xBF55296Cu, 0x5502F25Du,
-                                   0x82542A38u, 0x59F741E0u, 0x8BA79B98u, 0x6E1D3B62u,
-                                   0xF320AD74u, 0x8EB1C71Eu, 0xBE8B0537u, 0xAA87CA22u};
-    ECGPU_CONST uint32_t GY[12] = {0x90EA0E5Fu, 0x7A431D7Cu, 0x1D7E819Du, 0x0A60B1CEu,
-                                   0xB5F0B8C0u, 0xE9DA3113u, 0x289A147Cu, 0xF8F41DBDu,
-                                   0x9292DC29u, 0x5D9E98BFu, 0x96262C6Fu, 0x3617DE4Au};
-};
-
-// ---------------------------------------------------------------------------------------------
-// Field<C>
-// ---------------------------------------------------------------------------------------------
 
 template <class C>
 struct Field {
-    ECGPU_CONST int N = C::N;
-    using E = Fe<C::N>;
+    ECGPU_CONST int N = C::N;     // canonical 32-bit words
+    ECGPU_CONST int NL = C::NL;   // limbs in registers
+    ECGPU_CONST int NS = (C::NL + 3) / 4 * 4;   // words of the raw (lazy) storage form, 16-byte multiple
+    ECGPU_CONST int REPR = C::REPR;
+    using E = Fe<C::NL>;
+    using M1 = Mag<C, 1, 1>;
 
-    static ECGPU_HD E zero() {
-        E r;
-#pragma unroll
-        for (int i = 0; i < N; i++) r.v[i] = 0;
-        return r;
-    }
-    static ECGPU_HD E one() {
-        E r = zero();
-        if constexpr (C::MONTGOMERY) {
-#pragma unroll
-            for (int i = 0; i < N; i++) r.v[i] = C::ONE[i];
-        } else {
-            r.v[0] = 1;
-        }
-        return r;
-    }
+    // largest allowed sum of limb-magnitude products in one column accumulation, largest limb magnitude
+    ECGPU_CONST int MAXPROD = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? 24 : 1);
+    ECGPU_CONST int MAXMAG = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? 15 : 1);
+    ECGPU_CONST bool LAZY = REPR != REPR_SAT_MONT;
 
-    // ---- k256: fold bits >= 2^256 with 2^256 = 2^32 + 977 (mod p) ----------------------------
-    // value = lo[0..8) + top * 2^256, top < 2^34  ->  weakly reduced 8 limbs
-    static ECGPU_HD void k256_fold_top(uint32_t* r, uint64_t top) {
-        uint64_t c = (uint64_t)r[0] + (top & 0xFFFFFFFFu) * 977u;
-        r[0] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)r[1] + (top & 0xFFFFFFFFu) + (top >> 32) * 977u;
-        r[1] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)r[2] + (top >> 32);
-        r[2] = (uint32_t)c;
-        c >>= 32;
-#pragma unroll
-        for (int i = 3; i < 8; i++) {
-            c += r[i];
-            r[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        if (c) {  // wrapped past 2^256 once more: the low part is tiny, one more fold cannot wrap
-            uint64_t d = (uint64_t)r[0] + 977u;
-            r[0] = (uint32_t)d;
-            d >>= 32;
-            d += (uint64_t)r[1] + 1u;
-            r[1] = (uint32_t)d;
-            d >>= 32;
-#pragma unroll
-            for (int i = 2; i < 8; i++) {
-                d += r[i];
-                r[i] = (uint32_t)d;
-                d >>= 32;
-            }
-        }
-    }
-
-    // 512-bit t -> weakly reduced 256-bit
-    static ECGPU_HD E k256_reduce_wide(const uint32_t* t) {
-        E r;
-        // r = lo + hi*977 + (hi << 32)
-        uint64_t c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            c += (uint64_t)t[8 + i] * 977u + t[i];
-            if (i > 0) c += t[8 + i - 1];
-            r.v[i] = (uint32_t)c;
-            c >>= 32;
-        }
-        uint64_t top = c + t[15];
-        k256_fold_top(r.v, top);
-        return r;
-    }
-
-    // ---- Montgomery reduction for p' = 1 (u = t[i]) ------------------------------------------
-    static ECGPU_HD E mont_reduce_wide(uint32_t* t) {
-        uint32_t top = 0;  // carry waiting to enter limb i+N of the next round
+    // =============================================================================================
+    // saturated Montgomery (p384)
+    // =============================================================================================
+    static ECGPU_HD E sat_reduce_wide(uint32_t* t) {   // word-by-word, p' = 1 (p = -1 mod 2^32)
+        uint32_t top = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) {
             uint32_t u = t[i];
@@ -339,145 +80,580 @@ struct Field {
         for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : t[N + i];
         return r;
     }
-
-    static ECGPU_HD E mul(const E& a, const E& b) {
+    static ECGPU_HD E sat_mul(const E& a, const E& b) {
         uint32_t t[2 * N];
         mp_mul<N>(t, a.v, b.v);
-        if constexpr (C::MONTGOMERY) return mont_reduce_wide(t);
-        else return k256_reduce_wide(t);
+        return sat_reduce_wide(t);
     }
-    static ECGPU_HD E sqr(const E& a) {
+    static ECGPU_HD E sat_sqr(const E& a) {
         uint32_t t[2 * N];
         mp_sqr<N>(t, a.v);
-        if constexpr (C::MONTGOMERY) return mont_reduce_wide(t);
-        else return k256_reduce_wide(t);
+        return sat_reduce_wide(t);
     }
-
-    static ECGPU_HD E add(const E& a, const E& b) {
+    static ECGPU_HD E sat_add(const E& a, const E& b) {
         E r;
         uint32_t c = mp_add<N>(r.v, a.v, b.v);
-        if constexpr (C::MONTGOMERY) {
-            uint32_t d[N];
-            uint32_t borrow = mp_sub<N>(d, r.v, C::P);
-            bool use_d = c || !borrow;
+        uint32_t d[N];
+        uint32_t borrow = mp_sub<N>(d, r.v, C::P);
+        bool use_d = c || !borrow;
 #pragma unroll
-            for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : r.v[i];
-        } else {
-            if (c) k256_fold_top(r.v, 1);
-        }
+        for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : r.v[i];
         return r;
     }
-    static ECGPU_HD E sub(const E& a, const E& b) {
+    static ECGPU_HD E sat_sub(const E& a, const E& b) {
         E r;
         uint32_t borrow = mp_sub<N>(r.v, a.v, b.v);
-        if constexpr (C::MONTGOMERY) {
-            if (borrow) mp_add<N>(r.v, r.v, C::P);
-        } else {
-            // wrapped result is a - b + 2^256 = a - b + 0x1000003D1 (mod p): take the excess off
-            if (borrow) {
-                int64_t c = (int64_t)r.v[0] - 977;
-                r.v[0] = (uint32_t)c;
-                c >>= 32;
-                c += (int64_t)r.v[1] - 1;
-                r.v[1] = (uint32_t)c;
-                c >>= 32;
+        if (borrow) mp_add<N>(r.v, r.v, C::P);
+        return r;
+    }
+
+    // =============================================================================================
+    // k256, 9 x 29  (model: tools/field_model.py k256_*)
+    // =============================================================================================
+    using KC = consts::K256U;
+    ECGPU_CONST uint32_t KMASK = (1u << 29) - 1;
+
+    // fold a 64-bit column of weight 2^(261 + 29 j) into columns j, j+1, j+2 through its 32-bit halves:
+    // 2^261 = F1*2^29 + F0 and 2^(261+32) = G2*2^58 + G1*2^29 (mod p)
+    static ECGPU_HD void k_fold(uint64_t* lo, int j, uint64_t col) {
+        uint32_t cl = (uint32_t)col, ch = (uint32_t)(col >> 32);
+        lo[j] += (uint64_t)cl * KC::F0;
+        lo[j + 1] += (uint64_t)cl * KC::F1;
+        lo[j + 1] += (uint64_t)ch * KC::G1;
+        lo[j + 2] += (uint64_t)ch * KC::G2;
+    }
+    // 17 product columns -> 9 limbs of magnitude 1
+    static ECGPU_HD E k_reduce(uint64_t* c) {
+        uint64_t lo[11];
 #pragma unroll
-                for (int i = 2; i < 8; i++) {
-                    c += r.v[i];
-                    r.v[i] = (uint32_t)c;
-                    c >>= 32;
-                }
-                if (c) {  // went below zero again (a - b + 2^256 < 0x1000003D1): add p back
-                    mp_add<N>(r.v, r.v, C::P);
-                }
+        for (int k = 0; k < 9; k++) lo[k] = c[k];
+        lo[9] = 0;
+        lo[10] = 0;
+#pragma unroll
+        for (int k = 9; k < 17; k++) k_fold(lo, k - 9, c[k]);
+        {
+            uint64_t c9 = lo[9], c10 = lo[10];
+            k_fold(lo, 0, c9);
+            k_fold(lo, 1, c10);
+        }
+        E r;
+        uint64_t v = lo[0];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            r.v[k] = (uint32_t)v & KMASK;
+            v = lo[k + 1] + (v >> 29);
+        }
+        r.v[8] = (uint32_t)v & KMASK;
+        uint64_t top = v >> 29;                       // weight 2^261, < 2^36
+        uint32_t tl = (uint32_t)top, th = (uint32_t)(top >> 32);
+        uint64_t t0 = (uint64_t)tl * KC::F0 + r.v[0];
+        uint64_t t1 = (uint64_t)tl * KC::F1 + r.v[1];
+        t1 += (uint64_t)th * KC::G1;
+        uint64_t t2 = (uint64_t)th * KC::G2 + r.v[2];
+        r.v[0] = (uint32_t)t0 & KMASK;
+        t1 += t0 >> 29;
+        r.v[1] = (uint32_t)t1 & KMASK;
+        t2 += t1 >> 29;
+        r.v[2] = (uint32_t)t2 & KMASK;
+        r.v[3] += (uint32_t)(t2 >> 29);               // slack absorbed by LB
+        return r;
+    }
+    static ECGPU_HD void k_columns(uint64_t* c, const uint32_t* a, const uint32_t* b, bool accumulate) {
+        if (!accumulate) {
+#pragma unroll
+            for (int k = 0; k < 17; k++) c[k] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a[i] * b[j];
+        }
+    }
+    static ECGPU_HD void k_columns_sqr(uint64_t* c, const uint32_t* a) {
+        uint32_t a2[9];
+#pragma unroll
+        for (int k = 0; k < 17; k++) c[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++) a2[j] = a[j] << 1;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            c[2 * i] += (uint64_t)a[i] * a[i];
+#pragma unroll
+            for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a[i] * a2[j];
+        }
+    }
+    // carry-propagate a lazy element (limbs < 2^32) and fold the top: magnitude 1
+    static ECGPU_HD E k_norm(const E& a) {
+        E r;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint32_t v = a.v[k] + carry;
+            r.v[k] = v & KMASK;
+            carry = v >> 29;
+        }
+        r.v[0] += carry * KC::F0;
+        r.v[1] += carry * KC::F1;
+        return r;
+    }
+    // a * k for a small constant, normalised
+    static ECGPU_HD E k_mul_small(const E& a, uint32_t k) {
+        E r;
+        uint64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            t += (uint64_t)a.v[i] * k;
+            r.v[i] = (uint32_t)t & KMASK;
+            t >>= 29;
+        }
+        uint32_t top = (uint32_t)t;                    // < 2^32 / 2^29 * k
+        uint64_t t0 = (uint64_t)top * KC::F0 + r.v[0];
+        uint64_t t1 = (uint64_t)top * KC::F1 + r.v[1] + (t0 >> 29);
+        r.v[0] = (uint32_t)t0 & KMASK;
+        r.v[1] = (uint32_t)t1 & KMASK;
+        r.v[2] += (uint32_t)(t1 >> 29);
+        return r;
+    }
+    // exact canonical value in [0, p) as 8 little-endian 32-bit words
+    static ECGPU_HD void k_to_words(uint32_t* w, const E& a) {
+        E r = k_norm(k_norm(a));                      // limbs < 2^29 + tiny, value < 2^261 + tiny
+        // fold everything at or above 2^256 with 2^256 = 2^32 + 977 = 8 * 2^29 + 977, twice, exactly
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t v = r.v[k] + carry;
+                r.v[k] = v & KMASK;
+                carry = v >> 29;
             }
+            uint32_t v8 = r.v[8] + carry;
+            uint32_t e = v8 >> 24;
+            r.v[8] = v8 & 0xFFFFFFu;
+            r.v[0] += e * 977u;
+            r.v[1] += e * 8u;
+        }
+        {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t v = r.v[k] + carry;
+                r.v[k] = v & KMASK;
+                carry = v >> 29;
+            }
+            r.v[8] += carry;                           // value < 2^256 + 2^40: r.v[8] <= 2^24
+        }
+        // r >= p  <=>  r + (2^256 - p) >= 2^256, with 2^256 - p = 2^32 + 977
+        E s = r;
+        s.v[0] += 977u;
+        s.v[1] += 8u;
+        {
+            uint32_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t v = s.v[k] + carry;
+                s.v[k] = v & KMASK;
+                carry = v >> 29;
+            }
+            s.v[8] += carry;
+        }
+        bool ge = (s.v[8] >> 24) != 0;
+        s.v[8] &= 0xFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 9; k++) r.v[k] = ge ? s.v[k] : r.v[k];
+        // 9 x 29 -> 8 x 32
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int bit = 32 * i, l = bit / 29, sh = bit % 29;
+            uint64_t x = (uint64_t)r.v[l] >> sh;
+            x |= (uint64_t)r.v[l + 1] << (29 - sh);
+            if (l + 2 < 9) x |= (uint64_t)r.v[l + 2] << (58 - sh);
+            w[i] = (uint32_t)x;
+        }
+    }
+    template <int NLIMB, int BITS>
+    static ECGPU_HD E words_to_limbs(const uint32_t* w) {   // N words -> NLIMB limbs of BITS bits
+        E r;
+#pragma unroll
+        for (int l = 0; l < NLIMB; l++) {
+            int bit = BITS * l, i = bit / 32, sh = bit % 32;
+            uint64_t x = i < N ? (uint64_t)w[i] >> sh : 0;
+            if (i + 1 < N) x |= (uint64_t)w[i + 1] << (32 - sh);
+            r.v[l] = (uint32_t)x & ((1u << BITS) - 1);
         }
         return r;
     }
-    static ECGPU_HD E neg(const E& a) { return sub(zero(), a); }
-    static ECGPU_HD E dbl(const E& a) { return add(a, a); }
 
-    // a * k for a small constant k (k < 2^16)
-    static ECGPU_HD E mul_small(const E& a, uint32_t k) {
-        if constexpr (C::MONTGOMERY) {
-            // not on the hot path for a = -3 curves; plain double-and-add
-            E r = zero(), base = a;
-            for (; k; k >>= 1) {
-                if (k & 1) r = add(r, base);
-                base = dbl(base);
-            }
-            return r;
-        } else {
-            E r;
-            uint64_t c = 0;
+    // =============================================================================================
+    // p256, 10 x 28 Montgomery  (model: tools/field_model.py p256_*)
+    // =============================================================================================
+    using PC = consts::P256U;
+    ECGPU_CONST uint32_t PMASK = (1u << 28) - 1;
+
+    // 19 product columns (in c[0..18], c[19], c[20] zero) -> Montgomery-reduced 10 limbs, value < 2p
+    static ECGPU_HD E p_reduce(uint64_t* c) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                c += (uint64_t)a.v[i] * k;
-                r.v[i] = (uint32_t)c;
-                c >>= 32;
+        for (int i = 0; i < 10; i++) {
+            uint32_t u = (uint32_t)c[i] & PMASK;
+            // (c[i] + u * p0) >> 28 = (c[i] >> 28) + u since p0 = 2^28 - 1: merged into the p1 term
+            c[i + 1] += (c[i] >> 28);
+            c[i + 1] += (uint64_t)u * (PC::P[1] + 1u);
+#pragma unroll
+            for (int j = 2; j < 10; j++) {
+                if (PC::P[j] != 0) c[i + j] += (uint64_t)u * PC::P[j];
             }
-            k256_fold_top(r.v, c);
+        }
+        E r;
+        uint64_t v = c[10];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            r.v[k] = (uint32_t)v & PMASK;
+            v = c[11 + k] + (v >> 28);
+        }
+        r.v[9] = (uint32_t)v;
+        return r;
+    }
+    static ECGPU_HD void p_columns(uint64_t* c, const uint32_t* a, const uint32_t* b, bool accumulate) {
+        if (!accumulate) {
+#pragma unroll
+            for (int k = 0; k < 21; k++) c[k] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+#pragma unroll
+            for (int j = 0; j < 10; j++) c[i + j] += (uint64_t)a[i] * b[j];
+        }
+    }
+    static ECGPU_HD void p_columns_sqr(uint64_t* c, const uint32_t* a) {
+        uint32_t a2[10];
+#pragma unroll
+        for (int k = 0; k < 21; k++) c[k] = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) a2[j] = a[j] << 1;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            c[2 * i] += (uint64_t)a[i] * a[i];
+#pragma unroll
+            for (int j = i + 1; j < 10; j++) c[i + j] += (uint64_t)a[i] * a2[j];
+        }
+    }
+    static ECGPU_HD E p_norm(const E& a) {             // carry propagation only; the value is unchanged
+        E r;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint32_t v = a.v[k] + carry;
+            r.v[k] = v & PMASK;
+            carry = v >> 28;
+        }
+        r.v[9] = a.v[9] + carry;
+        return r;
+    }
+    // value in [0, 2p) with strict 28-bit limbs -> [0, p)
+    static ECGPU_HD E p_cond_sub(const E& a) {
+        E d;
+        int32_t borrow = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int32_t t = (int32_t)a.v[k] - (int32_t)PC::P[k] + borrow;
+            d.v[k] = (uint32_t)t & PMASK;
+            borrow = t >> 28;                          // 0 or -1
+        }
+        int32_t t9 = (int32_t)a.v[9] - (int32_t)PC::P[9] + borrow;
+        d.v[9] = (uint32_t)t9;
+        bool lt = t9 < 0;
+        E r;
+#pragma unroll
+        for (int k = 0; k < 10; k++) r.v[k] = lt ? a.v[k] : d.v[k];
+        return r;
+    }
+    static ECGPU_HD void p_limbs_to_words(uint32_t* w, const E& r) {   // strict limbs, value < 2^256
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int bit = 32 * i, l = bit / 28, sh = bit % 28;
+            uint64_t x = (uint64_t)r.v[l] >> sh;
+            x |= (uint64_t)r.v[l + 1] << (28 - sh);
+            if (l + 2 < 10) x |= (uint64_t)r.v[l + 2] << (56 - sh);
+            w[i] = (uint32_t)x;
+        }
+    }
+    static ECGPU_HD E p_const(const uint32_t* limbs) {
+        E r;
+#pragma unroll
+        for (int k = 0; k < 10; k++) r.v[k] = limbs[k];
+        return r;
+    }
+    static ECGPU_HD E p_mont_mul(const E& a, const E& b) {
+        uint64_t c[21];
+        p_columns(c, a.v, b.v, false);
+        return p_reduce(c);
+    }
+
+    // =============================================================================================
+    // the typed interface
+    // =============================================================================================
+    // Host-only debug build (-DECGPU_BOUNDS_CHECK, tests/hostcheck): verifies at run time that every element
+    // really obeys the magnitudes its type declares — the run-time twin of the static_asserts, mirroring the
+    // reference's debug-build magnitude checker (k256/src/arithmetic/field/field_impl.rs:17-22).
+    template <int L, int V>
+    static ECGPU_HD void check_mag(const E& e) {
+#if defined(ECGPU_BOUNDS_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (REPR == REPR_U29_K256) {
+            for (int i = 0; i < NL; i++)
+                if ((uint64_t)e.v[i] > (uint64_t)L * KC::LB) { __builtin_trap(); }
+        } else if constexpr (REPR == REPR_U28_MONT) {
+            for (int i = 0; i < NL - 1; i++)
+                if ((uint64_t)e.v[i] > (uint64_t)L * PC::LB) { __builtin_trap(); }
+            if ((uint64_t)e.v[NL - 1] > (uint64_t)V * PC::TOP1 + 16) { __builtin_trap(); }
+        }
+#else
+        (void)e;
+#endif
+    }
+    template <int L, int V>
+    static ECGPU_HD Mag<C, L, V> wrap(const E& e) {
+        check_mag<L, V>(e);
+        Mag<C, L, V> r;
+        r.e = e;
+        return r;
+    }
+    static ECGPU_HD M1 zero() {
+        M1 r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.e.v[i] = 0;
+        return r;
+    }
+    static ECGPU_HD M1 one() {
+        M1 r = zero();
+        if constexpr (REPR == REPR_SAT_MONT) {
+#pragma unroll
+            for (int i = 0; i < N; i++) r.e.v[i] = C::ONE[i];
+        } else if constexpr (REPR == REPR_U28_MONT) {
+            r.e = p_const(PC::ONE);
+        } else {
+            r.e.v[0] = 1;
+        }
+        return r;
+    }
+
+    template <int LA, int VA, int LB, int VB>
+    static ECGPU_HD auto add(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
+        if constexpr (!LAZY) {
+            return wrap<1, 1>(sat_add(a.e, b.e));
+        } else {
+            static_assert(LA + LB <= MAXMAG, "limb magnitude overflow in add: normalise an operand first");
+            Mag<C, LA + LB, VA + VB> r;
+#pragma unroll
+            for (int i = 0; i < NL; i++) r.e.v[i] = a.e.v[i] + b.e.v[i];
+            check_mag<LA + LB, VA + VB>(r.e);
             return r;
         }
     }
+    template <int LA, int VA>
+    static ECGPU_HD auto dbl(const Mag<C, LA, VA>& a) { return add(a, a); }
 
-    // canonical (fully reduced, non-Montgomery) limbs
-    static ECGPU_HD E to_canonical(const E& a) {
-        if constexpr (C::MONTGOMERY) {
+    // flag ? a : b, typed with the larger of the two magnitudes
+    template <int LA, int VA, int LB, int VB>
+    static ECGPU_HD auto sel(bool flag, const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
+        Mag<C, (LA > LB ? LA : LB), (VA > VB ? VA : VB)> r;
+#pragma unroll
+        for (int i = 0; i < NL; i++) r.e.v[i] = flag ? a.e.v[i] : b.e.v[i];
+        return r;
+    }
+
+    // -b as (multiple of p) - b, limb-wise
+    template <int LB, int VB>
+    static ECGPU_HD auto neg(const Mag<C, LB, VB>& b) {
+        if constexpr (!LAZY) {
+            E z;
+#pragma unroll
+            for (int i = 0; i < NL; i++) z.v[i] = 0;
+            return wrap<1, 1>(sat_sub(z, b.e));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            constexpr int m = LB > VB ? LB : VB;
+            static_assert(m <= KC::ZMAX, "no subtraction constant for this magnitude: normalise first");
+            Mag<C, m + 1, m + 1> r;
+            check_mag<LB, VB>(b.e);
+#pragma unroll
+            for (int i = 0; i < NL; i++) r.e.v[i] = KC::Z[m][i] - b.e.v[i];
+            check_mag<m + 1, m + 1>(r.e);
+            return r;
+        } else {
+            static_assert(LB <= PC::LMAX && VB <= PC::VMAX, "no subtraction constant for this magnitude");
+            Mag<C, LB + 1, VB + 1> r;
+            check_mag<LB, VB>(b.e);
+#pragma unroll
+            for (int i = 0; i < NL; i++) r.e.v[i] = PC::Z[LB][VB][i] - b.e.v[i];
+            check_mag<LB + 1, VB + 1>(r.e);
+            return r;
+        }
+    }
+    template <int LA, int VA, int LB, int VB>
+    static ECGPU_HD auto sub(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
+        if constexpr (!LAZY) return wrap<1, 1>(sat_sub(a.e, b.e));
+        else return add(a, neg(b));
+    }
+
+    template <int LA, int VA, int LB, int VB>
+    static ECGPU_HD M1 mul(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            return wrap<1, 1>(sat_mul(a.e, b.e));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            static_assert(LA * LB <= MAXPROD, "k256 mul: limb magnitude product too large");
+            uint64_t c[17];
+            k_columns(c, a.e.v, b.e.v, false);
+            return wrap<1, 1>(k_reduce(c));
+        } else {
+            static_assert(LA * LB <= MAXPROD, "p256 mul: limb magnitude product too large");
+            static_assert((long)VA * VB <= (1L << 20), "p256 mul: value magnitude product too large");
+            uint64_t c[21];
+            p_columns(c, a.e.v, b.e.v, false);
+            return wrap<1, 1>(p_reduce(c));
+        }
+    }
+    template <int LA, int VA>
+    static ECGPU_HD M1 sqr(const Mag<C, LA, VA>& a) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            return wrap<1, 1>(sat_sqr(a.e));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            static_assert(LA * LA <= MAXPROD, "k256 sqr: limb magnitude too large");
+            uint64_t c[17];
+            k_columns_sqr(c, a.e.v);
+            return wrap<1, 1>(k_reduce(c));
+        } else {
+            static_assert(LA * LA <= MAXPROD, "p256 sqr: limb magnitude too large");
+            uint64_t c[21];
+            p_columns_sqr(c, a.e.v);
+            return wrap<1, 1>(p_reduce(c));
+        }
+    }
+    // a*b + c*d with ONE reduction (the two products share their column accumulators)
+    template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
+    static ECGPU_HD M1 mul2(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b, const Mag<C, LC, VC>& c,
+                            const Mag<C, LD, VD>& d) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            return wrap<1, 1>(sat_add(sat_mul(a.e, b.e), sat_mul(c.e, d.e)));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            static_assert(LA * LB + LC * LD <= MAXPROD, "k256 mul2: limb magnitude products too large");
+            uint64_t col[17];
+            k_columns(col, a.e.v, b.e.v, false);
+            k_columns(col, c.e.v, d.e.v, true);
+            return wrap<1, 1>(k_reduce(col));
+        } else {
+            static_assert(LA * LB + LC * LD <= MAXPROD, "p256 mul2: limb magnitude products too large");
+            static_assert((long)VA * VB + (long)VC * VD <= (1L << 20), "p256 mul2: value magnitudes too large");
+            uint64_t col[21];
+            p_columns(col, a.e.v, b.e.v, false);
+            p_columns(col, c.e.v, d.e.v, true);
+            return wrap<1, 1>(p_reduce(col));
+        }
+    }
+    // limb magnitude back to 1 (k256: value magnitude too; p256: the value is untouched)
+    template <int LA, int VA>
+    static ECGPU_HD auto norm(const Mag<C, LA, VA>& a) {
+        if constexpr (REPR == REPR_SAT_MONT) return a;
+        else if constexpr (REPR == REPR_U29_K256) return wrap<1, 1>(k_norm(a.e));
+        else return wrap<1, VA>(p_norm(a.e));
+    }
+    // a * K for a small compile-time constant, result magnitude (1, 1); k256 only (b3 = 21 and friends)
+    template <uint32_t K, int LA, int VA>
+    static ECGPU_HD M1 mul_small(const Mag<C, LA, VA>& a) {
+        static_assert(REPR == REPR_U29_K256, "mul_small is only provided for k256");
+        static_assert(K < (1u << 12), "constant too large");
+        return wrap<1, 1>(k_mul_small(a.e, K));
+    }
+
+    // ---- canonical words / bytes -----------------------------------------------------------------
+    // canonical value (< p, checked by the caller) as N little-endian words -> internal form
+    static ECGPU_HD M1 from_canonical(const uint32_t* w) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            E a, r2;
+#pragma unroll
+            for (int i = 0; i < N; i++) { a.v[i] = w[i]; r2.v[i] = C::R2[i]; }
+            return wrap<1, 1>(sat_mul(a, r2));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            return wrap<1, 1>(words_to_limbs<9, 29>(w));
+        } else {
+            E a = words_to_limbs<10, 28>(w);
+            return wrap<1, 1>(p_mont_mul(a, p_const(PC::R2)));
+        }
+    }
+    template <int LA, int VA>
+    static ECGPU_HD void to_canonical(uint32_t* w, const Mag<C, LA, VA>& a) {
+        if constexpr (REPR == REPR_SAT_MONT) {
             uint32_t t[2 * N];
 #pragma unroll
-            for (int i = 0; i < N; i++) { t[i] = a.v[i]; t[N + i] = 0; }
-            return mont_reduce_wide(t);
-        } else {
-            E r = a;
-            uint32_t d[N];
-            if (mp_sub<N>(d, a.v, C::P) == 0) {
+            for (int i = 0; i < N; i++) { t[i] = a.e.v[i]; t[N + i] = 0; }
+            E r = sat_reduce_wide(t);
 #pragma unroll
-                for (int i = 0; i < N; i++) r.v[i] = d[i];
-            }
+            for (int i = 0; i < N; i++) w[i] = r.v[i];
+        } else if constexpr (REPR == REPR_U29_K256) {
+            k_to_words(w, a.e);
+        } else {
+            static_assert(LA <= MAXPROD, "normalise before to_canonical");
+            E onep;                                       // plain 1: a * 1 * R^-1 leaves the Montgomery domain
+#pragma unroll
+            for (int k = 0; k < 10; k++) onep.v[k] = k == 0 ? 1u : 0u;
+            E r = p_cond_sub(p_mont_mul(a.e, onep));
+            p_limbs_to_words(w, r);
+        }
+    }
+    // internal-domain value fully reduced to [0, p), N words ("packed" storage form: table entries, MSM points)
+    template <int LA, int VA>
+    static ECGPU_HD void pack(uint32_t* w, const Mag<C, LA, VA>& a) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+#pragma unroll
+            for (int i = 0; i < N; i++) w[i] = a.e.v[i];
+        } else if constexpr (REPR == REPR_U29_K256) {
+            k_to_words(w, a.e);
+        } else {
+            static_assert(LA <= MAXPROD, "normalise before pack");
+            E r = p_cond_sub(p_mont_mul(a.e, p_const(PC::ONE)));   // a * R * R^-1 = a, now < 2p with strict limbs
+            p_limbs_to_words(w, r);
+        }
+    }
+    static ECGPU_HD M1 unpack(const uint32_t* w) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            M1 r;
+#pragma unroll
+            for (int i = 0; i < N; i++) r.e.v[i] = w[i];
             return r;
-        }
-    }
-    // canonical limbs (must be < p) -> internal form
-    static ECGPU_HD E from_canonical(const E& a) {
-        if constexpr (C::MONTGOMERY) {
-            E r2;
-#pragma unroll
-            for (int i = 0; i < N; i++) r2.v[i] = C::R2[i];
-            return mul(a, r2);
+        } else if constexpr (REPR == REPR_U29_K256) {
+            return wrap<1, 1>(words_to_limbs<9, 29>(w));
         } else {
-            return a;
+            return wrap<1, 1>(words_to_limbs<10, 28>(w));
         }
     }
-    static ECGPU_HD bool is_zero(const E& a) {
-        if constexpr (C::MONTGOMERY) {
-            return mp_is_zero<N>(a.v);
-        } else {
-            uint32_t x = 0, y = 0;
-#pragma unroll
-            for (int i = 0; i < N; i++) { x |= a.v[i]; y |= a.v[i] ^ C::P[i]; }
-            return x == 0 || y == 0;
-        }
+
+    template <int LA, int VA>
+    static ECGPU_HD bool is_zero(const Mag<C, LA, VA>& a) {
+        uint32_t w[N];
+        pack(w, a);
+        return mp_is_zero<N>(w);
     }
-    static ECGPU_HD bool eq(const E& a, const E& b) { return is_zero(sub(a, b)); }
+    template <int LA, int VA, int LB, int VB>
+    static ECGPU_HD bool eq(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
+        return is_zero(norm(sub(a, b)));
+    }
 
     // big-endian canonical bytes <-> internal; `ok` false if the encoded value is >= p
-    static ECGPU_HD E from_bytes(const uint8_t* be, bool* ok) {
-        E c;
-        load_be<N>(c.v, be);
-        *ok = !mp_geq<N>(c.v, C::P);
-        return from_canonical(c);
+    static ECGPU_HD M1 from_bytes(const uint8_t* be, bool* ok) {
+        uint32_t w[N];
+        load_be<N>(w, be);
+        *ok = !mp_geq<N>(w, C::P);
+        return from_canonical(w);
     }
-    static ECGPU_HD void to_bytes(uint8_t* be, const E& a) {
-        E c = to_canonical(a);
-        store_be<N>(be, c.v);
+    template <int LA, int VA>
+    static ECGPU_HD void to_bytes(uint8_t* be, const Mag<C, LA, VA>& a) {
+        uint32_t w[N];
+        to_canonical(w, a);
+        store_be<N>(be, w);
     }
 
-    // a^(p-2) by a fixed 4-bit window over the constant exponent; a == 0 -> 0.
-    // (The reference inverts with crypto-bigint's safegcd — k256 field.rs:178-184,
-    // primefield monty.rs:373-375; the inverse is unique so any method agrees.)
-    static ECGPU_HD E inv(const E& a) {
-        E tab[16];
+    // a^(p-2), fixed 4-bit window over the constant exponent; a == 0 -> 0.  (The reference inverts with
+    // crypto-bigint's safegcd — k256 field.rs:178-184, primefield monty.rs:373-375; the inverse is unique.)
+    static ECGPU_HD M1 inv(const M1& a) {
+        M1 tab[16];
         tab[0] = one();
         tab[1] = a;
 #pragma unroll 1
@@ -485,12 +661,12 @@ struct Field {
         uint32_t e[N];
 #pragma unroll
         for (int i = 0; i < N; i++) e[i] = C::P[i];
-        e[0] -= 2;  // p is odd and p[0] >= 2 for all three curves
-        E r = one();
+        e[0] -= 2;   // p is odd and its low word is >= 2 for all three curves
+        M1 r = one();
 #pragma unroll 1
         for (int i = 8 * N - 1; i >= 0; i--) {
             uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 0xF;
-            r = sqr(r); r = sqr(r); r = sqr(r); r = sqr(r);
+            r = sqr(sqr(sqr(sqr(r))));
             if (nib) r = mul(r, tab[nib]);
         }
         return r;

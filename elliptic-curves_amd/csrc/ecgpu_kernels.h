@@ -1,14 +1,17 @@
 // ecgpu_kernels.h — gfx950 kernels of the batch scalar-mul engine (HIP only).
 //
 // Data layout in HBM
-//   scalars / points in, affine points out : the wire format of include/ecgpu.h (big-endian
-//       records of L resp. 2L bytes).  One lane owns one record; a wave touches 64 consecutive
-//       records = one contiguous 2 KiB / 4 KiB span, loaded and stored as 16-byte vectors and
-//       byte-swapped in registers.
-//   projective scratch  [n][3][N] u32, internal field form (weak residues / Montgomery)
-//   basepoint table     [nwin][2^(W-1)][2][N] u32 affine, internal form: entry (j, e) = e*2^(Wj)*G
-//   variable-base table [8][3][N][T] u32: multiples 1..8 of each thread's point, thread-minor so
-//       that a wave's accesses to one limb are contiguous.
+//   scalars / points in, affine points out : the wire format of include/ecgpu.h (big-endian records of L
+//       resp. 2L bytes).  One lane owns one record; a wave touches 64 consecutive records = one contiguous
+//       2 KiB / 4 KiB span, loaded and stored as 16-byte vectors and byte-swapped in registers.
+//   "raw" field element      NS = ceil(NL/4)*4 u32 (12 for k256 9x29, 12 for p256 10x28, 12 for p384): the
+//       in-register limbs as they are (lazy form), padded so that records stay 16-byte vectors
+//   "packed" field element   N u32 (8 / 8 / 12): the internal-domain value fully reduced to [0, p)
+//   projective scratch       [n][3] raw elements
+//   basepoint table          [nwin][2^(W-1)][2] packed elements, affine: entry (j, e) = e * 2^(W j) * G
+//                            (64 B per entry for the 256-bit curves: 35.6 MB at W = 16)
+//   variable-base table      [8][3][NL][T] u32: multiples 1..8 of each lane's point, lane-minor so that a
+//                            wave's accesses to one limb are contiguous
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -24,55 +27,97 @@ constexpr int BLOCK = 256;
 
 // ---- 16-byte vector access helpers ---------------------------------------------------------------
 
-template <int N>
-__device__ __forceinline__ void load_limbs_vec(uint32_t* dst, const uint32_t* src) {
+template <int NW>
+__device__ __forceinline__ void load_words_vec(uint32_t* dst, const uint32_t* src) {
     const uint4* s = reinterpret_cast<const uint4*>(src);
 #pragma unroll
-    for (int i = 0; i < N / 4; i++) {
+    for (int i = 0; i < NW / 4; i++) {
         uint4 v = s[i];
         dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
     }
 }
-template <int N>
-__device__ __forceinline__ void store_limbs_vec(uint32_t* dst, const uint32_t* src) {
+template <int NW>
+__device__ __forceinline__ void store_words_vec(uint32_t* dst, const uint32_t* src) {
     uint4* d = reinterpret_cast<uint4*>(dst);
 #pragma unroll
-    for (int i = 0; i < N / 4; i++) d[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+    for (int i = 0; i < NW / 4; i++) d[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
 }
-// big-endian record of N words -> little-endian limbs
-template <int N>
-__device__ __forceinline__ void load_be_vec(uint32_t* limbs, const uint8_t* bytes) {
-    uint32_t w[N];
-    load_limbs_vec<N>(w, reinterpret_cast<const uint32_t*>(bytes));
+// big-endian record of NW words -> little-endian words
+template <int NW>
+__device__ __forceinline__ void load_be_vec(uint32_t* words, const uint8_t* bytes) {
+    uint32_t w[NW];
+    load_words_vec<NW>(w, reinterpret_cast<const uint32_t*>(bytes));
 #pragma unroll
-    for (int i = 0; i < N; i++) limbs[i] = bswap32(w[N - 1 - i]);
+    for (int i = 0; i < NW; i++) words[i] = bswap32(w[NW - 1 - i]);
 }
-template <int N>
-__device__ __forceinline__ void store_be_vec(uint8_t* bytes, const uint32_t* limbs) {
-    uint32_t w[N];
+template <int NW>
+__device__ __forceinline__ void store_be_vec(uint8_t* bytes, const uint32_t* words) {
+    uint32_t w[NW];
 #pragma unroll
-    for (int i = 0; i < N; i++) w[N - 1 - i] = bswap32(limbs[i]);
-    store_limbs_vec<N>(reinterpret_cast<uint32_t*>(bytes), w);
+    for (int i = 0; i < NW; i++) w[NW - 1 - i] = bswap32(words[i]);
+    store_words_vec<NW>(reinterpret_cast<uint32_t*>(bytes), w);
 }
 
+// raw element <-> registers
+template <class C>
+__device__ __forceinline__ void store_raw(uint32_t* dst, const Fe<C::NL>& e) {
+    constexpr int NS = Field<C>::NS;
+    uint32_t w[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) w[i] = i < C::NL ? e.v[i] : 0u;
+    store_words_vec<NS>(dst, w);
+}
+template <class C>
+__device__ __forceinline__ Fe<C::NL> load_raw(const uint32_t* src) {
+    constexpr int NS = Field<C>::NS;
+    uint32_t w[NS];
+    load_words_vec<NS>(w, src);
+    Fe<C::NL> e;
+#pragma unroll
+    for (int i = 0; i < C::NL; i++) e.v[i] = w[i];
+    return e;
+}
 template <class C>
 __device__ __forceinline__ void store_proj(uint32_t* base, size_t idx, const Proj<C>& p) {
-    uint32_t* d = base + idx * (3 * C::N);
-    store_limbs_vec<C::N>(d, p.x.v);
-    store_limbs_vec<C::N>(d + C::N, p.y.v);
-    store_limbs_vec<C::N>(d + 2 * C::N, p.z.v);
+    constexpr int NS = Field<C>::NS;
+    uint32_t* d = base + idx * (3 * NS);
+    store_raw<C>(d, p.x);
+    store_raw<C>(d + NS, p.y);
+    store_raw<C>(d + 2 * NS, p.z);
 }
 template <class C>
 __device__ __forceinline__ Proj<C> load_proj(const uint32_t* base, size_t idx) {
+    constexpr int NS = Field<C>::NS;
     Proj<C> p;
-    const uint32_t* s = base + idx * (3 * C::N);
-    load_limbs_vec<C::N>(p.x.v, s);
-    load_limbs_vec<C::N>(p.y.v, s + C::N);
-    load_limbs_vec<C::N>(p.z.v, s + 2 * C::N);
+    const uint32_t* s = base + idx * (3 * NS);
+    p.x = load_raw<C>(s);
+    p.y = load_raw<C>(s + NS);
+    p.z = load_raw<C>(s + 2 * NS);
     return p;
 }
+// packed affine point (2 x N words) <-> registers
+template <class C>
+__device__ __forceinline__ Affine<C> load_packed_affine(const uint32_t* src) {
+    using F = Field<C>;
+    uint32_t w[C::N];
+    Affine<C> a;
+    load_words_vec<C::N>(w, src);
+    a.x = F::unpack(w).e;
+    load_words_vec<C::N>(w, src + C::N);
+    a.y = F::unpack(w).e;
+    return a;
+}
+template <class C>
+__device__ __forceinline__ void store_packed_affine(uint32_t* dst, const Fe<C::NL>& x, const Fe<C::NL>& y) {
+    using F = Field<C>;
+    uint32_t w[C::N];
+    F::pack(w, Group<C>::m(x));
+    store_words_vec<C::N>(dst, w);
+    F::pack(w, Group<C>::m(y));
+    store_words_vec<C::N>(dst + C::N, w);
+}
 
-// scalar record -> limbs, flags out-of-range scalars (Scalar::from_repr, k256 scalar.rs:310-316)
+// scalar record -> 32-bit words, flags out-of-range scalars (Scalar::from_repr, k256 scalar.rs:310-316)
 template <class C>
 __device__ __forceinline__ void load_scalar(uint32_t* k, const uint8_t* scalars, size_t i, int* status) {
     load_be_vec<C::N>(k, scalars + i * (4 * C::N));
@@ -83,15 +128,15 @@ __device__ __forceinline__ void load_scalar(uint32_t* k, const uint8_t* scalars,
 // and off-curve points (AffinePoint::from_coordinates, primeorder/src/affine.rs:100-109).
 template <class C>
 __device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, const uint8_t* inf, size_t i,
-                                            const Fe<C::N>& b, int* status) {
+                                            const Fe<C::NL>& b, int* status) {
     using F = Field<C>;
     if (inf != nullptr && inf[i]) return false;
-    Fe<C::N> cx, cy;
-    load_be_vec<C::N>(cx.v, xy + i * (8 * C::N));
-    load_be_vec<C::N>(cy.v, xy + i * (8 * C::N) + 4 * C::N);
-    bool ok = !mp_geq<C::N>(cx.v, C::P) && !mp_geq<C::N>(cy.v, C::P);
-    a->x = F::from_canonical(cx);
-    a->y = F::from_canonical(cy);
+    uint32_t cx[C::N], cy[C::N];
+    load_be_vec<C::N>(cx, xy + i * (8 * C::N));
+    load_be_vec<C::N>(cy, xy + i * (8 * C::N) + 4 * C::N);
+    bool ok = !mp_geq<C::N>(cx, C::P) && !mp_geq<C::N>(cy, C::P);
+    a->x = F::from_canonical(cx).e;
+    a->y = F::from_canonical(cy).e;
     ok = ok && Group<C>::on_curve(*a, b);
     if (!ok) atomicOr(status, ST_BAD_POINT);
     return true;
@@ -100,19 +145,18 @@ __device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, con
 // ---- basepoint table construction -------------------------------------------------------------------
 // Replaces the lazily built `BasepointTable` (primeorder/src/tables/basepoint.rs:41-76, k256
 // tables.rs:11-18: 33/49 LUTs of 8 projective multiples) by one signed-window comb table of affine
-// entries sized for HBM/L2 instead of a CPU L1.
+// entries sized for HBM / Infinity Cache instead of a CPU L1.
 
-// bases[j] = 2^(W*j) * G, j < nwin (one thread; nwin*W doublings)
+// bases[j] = 2^(W*j) * G, j < nwin (one lane; nwin*W doublings)
 template <class C>
 __global__ void k_window_bases(uint32_t* bases, int w, int nwin) {
     using G = Group<C>;
+    using F = Field<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Affine<C> g;
-#pragma unroll
-    for (int i = 0; i < C::N; i++) { g.x.v[i] = C::GX[i]; g.y.v[i] = C::GY[i]; }
-    g.x = Field<C>::from_canonical(g.x);
-    g.y = Field<C>::from_canonical(g.y);
-    Fe<C::N> b = G::curve_b();
+    g.x = F::from_canonical(C::GX).e;
+    g.y = F::from_canonical(C::GY).e;
+    Fe<C::NL> b = G::curve_b();
     Proj<C> p = G::from_affine(g);
     for (int j = 0; j < nwin; j++) {
         store_proj<C>(bases, j, p);
@@ -129,7 +173,7 @@ __global__ void __launch_bounds__(BLOCK) k_table_entries(const uint32_t* bases, 
     if (tid >= half * nwin) return;
     int j = (int)(tid >> (w - 1));
     uint32_t e = (uint32_t)(tid & (half - 1)) + 1;
-    Fe<C::N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Proj<C> base = load_proj<C>(bases, j);
     Proj<C> acc = base;
     int top = 31 - __clz(e);
@@ -142,51 +186,50 @@ __global__ void __launch_bounds__(BLOCK) k_table_entries(const uint32_t* bases, 
 
 // ---- normalisation: (X:Y:Z) -> (X/Z, Y/Z) with Montgomery's trick --------------------------------
 // `BatchNormalize::batch_normalize` (k256 projective.rs:367-391 + field.rs:244-265; primeorder
-// projective.rs:452-478).  Thread t owns points t, t+T, t+2T, ... so that a wave always touches
-// consecutive records; one field inversion per thread amortised over its K = n/T points.
-// OUT_INTERNAL = false: big-endian canonical x||y records + identity flags (wire format)
-// OUT_INTERNAL = true : [n][2][N] internal-form limbs (table entries; identities not expected)
-template <class C, bool OUT_INTERNAL>
+// projective.rs:452-478).  Lane t owns points t, t+T, t+2T, ... so that a wave always touches
+// consecutive records; one field inversion per lane amortised over its K = n/T points.
+// OUT_PACKED = false: big-endian canonical x||y records + identity flags (wire format)
+// OUT_PACKED = true : [n][2] packed elements (table entries; identities not expected)
+template <class C, bool OUT_PACKED>
 __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint32_t* prefix, size_t n, size_t nthreads,
-                            uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
+                                                     uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_packed) {
     using F = Field<C>;
-    constexpr int N = C::N;
+    using G = Group<C>;
+    constexpr int N = C::N, NS = F::NS;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
-    Fe<N> acc = F::one();
+    typename F::M1 acc = F::one();
     for (size_t j = t; j < n; j += nthreads) {
-        Fe<N> z;
-        load_limbs_vec<N>(z.v, proj + j * (3 * N) + 2 * N);
-        store_limbs_vec<N>(prefix + j * N, acc.v);
-        if (!F::is_zero(z)) acc = F::mul(acc, z);
+        Fe<C::NL> z = load_raw<C>(proj + j * (3 * NS) + 2 * NS);
+        store_raw<C>(prefix + j * NS, acc.e);
+        if (!F::is_zero(G::m(z))) acc = F::mul(acc, G::m(z));
     }
-    Fe<N> inv = F::inv(acc);
-    // walk back: last owned index first
+    typename F::M1 inv = F::inv(acc);
     if (n <= t) return;
     size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
     for (size_t j = last;; j -= nthreads) {
         Proj<C> p = load_proj<C>(proj, j);
-        if (F::is_zero(p.z)) {
-            if constexpr (!OUT_INTERNAL) {
+        if (F::is_zero(G::m(p.z))) {
+            if constexpr (!OUT_PACKED) {
                 uint32_t zero[2 * N];
 #pragma unroll
                 for (int i = 0; i < 2 * N; i++) zero[i] = 0;
-                store_limbs_vec<2 * N>(reinterpret_cast<uint32_t*>(out_xy + j * (8 * N)), zero);
+                store_words_vec<2 * N>(reinterpret_cast<uint32_t*>(out_xy + j * (8 * N)), zero);
                 if (out_inf) out_inf[j] = 1;
             }
         } else {
-            Fe<N> pre;
-            load_limbs_vec<N>(pre.v, prefix + j * N);
-            Fe<N> zinv = F::mul(pre, inv);
-            inv = F::mul(inv, p.z);
-            Fe<N> x = F::mul(p.x, zinv), y = F::mul(p.y, zinv);
-            if constexpr (OUT_INTERNAL) {
-                store_limbs_vec<N>(out_limbs + j * (2 * N), x.v);
-                store_limbs_vec<N>(out_limbs + j * (2 * N) + N, y.v);
+            typename F::M1 pre = G::m(load_raw<C>(prefix + j * NS));
+            typename F::M1 zinv = F::mul(pre, inv);
+            inv = F::mul(inv, G::m(p.z));
+            typename F::M1 x = F::mul(G::m(p.x), zinv), y = F::mul(G::m(p.y), zinv);
+            if constexpr (OUT_PACKED) {
+                store_packed_affine<C>(out_packed + j * (2 * N), x.e, y.e);
             } else {
-                Fe<N> cx = F::to_canonical(x), cy = F::to_canonical(y);
-                store_be_vec<N>(out_xy + j * (8 * N), cx.v);
-                store_be_vec<N>(out_xy + j * (8 * N) + 4 * N, cy.v);
+                uint32_t w[N];
+                F::to_canonical(w, x);
+                store_be_vec<N>(out_xy + j * (8 * N), w);
+                F::to_canonical(w, y);
+                store_be_vec<N>(out_xy + j * (8 * N) + 4 * N, w);
                 if (out_inf) out_inf[j] = 0;
             }
         }
@@ -198,19 +241,19 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
 // Drop-in for `mul_by_generator` (k256 mul.rs:180-197; primeorder basepoint.rs:82-99).  The reference
 // walks 65 signed nibbles over a 33x8 projective table with full additions; here each lane walks
 // nwin = bits/W + 1 signed W-bit windows over the affine table with complete *mixed* additions
-// (RCB Alg 8 / Alg 5), so there are no doublings and no exceptional cases at all.
+// (RCB Alg 8 / Alg 5), so there are no doublings and no exceptional cases at all.  The sign of a digit
+// is folded into the addition formula (no separate negation).
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __restrict__ table, int w, int nwin,
              uint32_t* __restrict__ proj_out, int* status) {
     using G = Group<C>;
-    using F = Field<C>;
     constexpr int N = C::N;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
-    Fe<N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
     uint32_t carry = 0;
     const size_t half = (size_t)1 << (w - 1);
@@ -219,12 +262,8 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
         int d = signed_window_step(get_bits<N>(k, j * w, w), w, &carry);
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            const uint32_t* e = table + ((size_t)j * half + (mag - 1)) * (2 * N);
-            Affine<C> q;
-            load_limbs_vec<N>(q.x.v, e);
-            load_limbs_vec<N>(q.y.v, e + N);
-            if (d < 0) q.y = F::neg(q.y);
-            acc = G::add_mixed(acc, q, b);
+            Affine<C> q = load_packed_affine<C>(table + ((size_t)j * half + (mag - 1)) * (2 * N));
+            acc = G::add_mixed(acc, q, b, d < 0);
         }
     }
     store_proj<C>(proj_out, i, acc);
@@ -240,30 +279,30 @@ __global__ void __launch_bounds__(BLOCK) k_load_proj(const uint8_t* xyz, size_t 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Proj<C> p;
-    Fe<N> c;
+    uint32_t c[N];
     bool ok = true;
-    load_be_vec<N>(c.v, xyz + i * (12 * N));           ok = ok && !mp_geq<N>(c.v, C::P); p.x = F::from_canonical(c);
-    load_be_vec<N>(c.v, xyz + i * (12 * N) + 4 * N);   ok = ok && !mp_geq<N>(c.v, C::P); p.y = F::from_canonical(c);
-    load_be_vec<N>(c.v, xyz + i * (12 * N) + 8 * N);   ok = ok && !mp_geq<N>(c.v, C::P); p.z = F::from_canonical(c);
+    load_be_vec<N>(c, xyz + i * (12 * N));           ok = ok && !mp_geq<N>(c, C::P); p.x = F::from_canonical(c).e;
+    load_be_vec<N>(c, xyz + i * (12 * N) + 4 * N);   ok = ok && !mp_geq<N>(c, C::P); p.y = F::from_canonical(c).e;
+    load_be_vec<N>(c, xyz + i * (12 * N) + 8 * N);   ok = ok && !mp_geq<N>(c, C::P); p.z = F::from_canonical(c).e;
     if (!ok) atomicOr(status, ST_BAD_POINT);
     store_proj<C>(proj_out, i, p);
 }
 
 // workgroup-wide sum of one projective point per lane (LDS tree); result valid in lane 0
 template <class C>
-__device__ __forceinline__ Proj<C> block_sum(Proj<C> acc, uint32_t* lds, const Fe<C::N>& b) {
+__device__ __forceinline__ Proj<C> block_sum(Proj<C> acc, uint32_t* lds, const Fe<C::NL>& b) {
     using G = Group<C>;
-    constexpr int N = C::N;
-    uint32_t* mine = lds + threadIdx.x * (3 * N);
+    constexpr int NL = C::NL;
+    uint32_t* mine = lds + threadIdx.x * (3 * NL);
     for (int s = blockDim.x / 2; s > 0; s >>= 1) {
 #pragma unroll
-        for (int l = 0; l < N; l++) { mine[l] = acc.x.v[l]; mine[N + l] = acc.y.v[l]; mine[2 * N + l] = acc.z.v[l]; }
+        for (int l = 0; l < NL; l++) { mine[l] = acc.x.v[l]; mine[NL + l] = acc.y.v[l]; mine[2 * NL + l] = acc.z.v[l]; }
         __syncthreads();
         if ((int)threadIdx.x < s) {
-            const uint32_t* o = lds + (threadIdx.x + s) * (3 * N);
+            const uint32_t* o = lds + (threadIdx.x + s) * (3 * NL);
             Proj<C> q;
 #pragma unroll
-            for (int l = 0; l < N; l++) { q.x.v[l] = o[l]; q.y.v[l] = o[N + l]; q.z.v[l] = o[2 * N + l]; }
+            for (int l = 0; l < NL; l++) { q.x.v[l] = o[l]; q.y.v[l] = o[NL + l]; q.z.v[l] = o[2 * NL + l]; }
             acc = G::add(acc, q, b);
         }
         __syncthreads();
@@ -276,9 +315,8 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_point_sum(const uint8_t* points_xy, const uint8_t* points_inf, size_t n, uint32_t* proj_out, int* status) {
     using G = Group<C>;
-    constexpr int N = C::N;
-    __shared__ uint32_t lds[BLOCK * 3 * N];
-    Fe<N> b = G::curve_b();
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
     for (size_t i = threadIdx.x; i < n; i += BLOCK) {
         Affine<C> a;
@@ -294,7 +332,7 @@ __global__ void __launch_bounds__(BLOCK) k_proj_add_pairs(uint32_t* pa, const ui
     using G = Group<C>;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fe<C::N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     store_proj<C>(pa, i, G::add(load_proj<C>(pa, i), load_proj<C>(pb, i), b));
 }
 

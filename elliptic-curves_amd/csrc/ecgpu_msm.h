@@ -5,10 +5,10 @@
 // interleaving: Theta(N * bits/5) additions and ~2 KB of tables per term.  On the GPU the same
 // group element is computed with the bucket method:
 //
-//   sum_i k_i P_i = sum_w 2^(c w) * sum_b b * ( sum_{i : digit_w(k_i) = +-b} +-P_i )
+//   sum_i k_i P_i = sum_w 2^(c w) * sum_b weight(b) * ( sum_{i : bucket_w(k_i) = b} +-P_i )
 //
-//   prepare     one lane per term: decode + validate scalar and point once, keep the point in
-//               internal form, recode k into nwin signed c-bit digits, histogram the buckets
+//   prepare     one lane per term: decode + validate scalar and point once, keep the point in packed
+//               internal form, recode k into nwin digits (msm_digit, ecgpu_recode.h), histogram the buckets
 //   scan        exclusive prefix sum of the bucket sizes, per window
 //   scatter     counting sort of (sign, term index) by bucket — every bucket becomes a contiguous
 //               run, so accumulation needs no atomics and no conflict handling
@@ -16,8 +16,8 @@
 //   reduce      running-sum trick on segments of buckets, segment sums, window sums
 //   combine     Horner over the windows (c doublings each)
 //
-// Workspace layout (one allocation, offsets in MsmPlan): internal affine points [n][2N] u32,
-// ranks [nwin][n] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB] u32, buckets [nwin][NB][3N],
+// Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
+// ranks [nwin][n] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB] u32, buckets [nwin][NB][3 NS],
 // segment sums, window sums.
 #pragma once
 
@@ -39,7 +39,7 @@ inline int msm_window_bits(size_t n) {
 
 template <class C>
 MsmPlan msm_plan(size_t n, int force_c) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, NS = Field<C>::NS;
     MsmPlan p;
     p.c = force_c ? force_c : msm_window_bits(n);
     p.nwin = signed_window_count(32 * N, p.c);
@@ -53,9 +53,9 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
     p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
-    p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * N * 4);
-    p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * N * 4);
-    p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * N * 4);
+    p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * NS * 4);
+    p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * NS * 4);
+    p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * NS * 4);
     p.workspace_bytes = o + 256;
     return p;
 }
@@ -72,11 +72,10 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
-    Fe<N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Affine<C> a;
     if (!load_affine<C>(&a, points_xy, points_inf, i, b, status)) return;   // identity contributes nothing
-    store_limbs_vec<N>(pts + i * (2 * N), a.x.v);
-    store_limbs_vec<N>(pts + i * (2 * N) + N, a.y.v);
+    store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
     const size_t nb = (size_t)1 << (c - 1);
     uint32_t carry = 0;
 #pragma unroll 1
@@ -88,7 +87,7 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
 
 // ---- scan: offsets[w][b] = sum_{b' < b} counts[w][b'] -------------------------------------------------------
 static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                   size_t nb) {
+                                                          size_t nb) {
     __shared__ uint32_t part[1024];
     const uint32_t* cw = counts + (size_t)blockIdx.x * nb;
     uint32_t* ow = offsets + (size_t)blockIdx.x * nb;
@@ -141,35 +140,31 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
                  int nwin, uint32_t* __restrict__ buckets) {
     using G = Group<C>;
-    using F = Field<C>;
     constexpr int N = C::N;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nb * nwin) return;
     size_t w = gid / nb;
     const uint32_t* run = sorted + w * n + offsets[gid];
     uint32_t cnt = counts[gid];
-    Fe<N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
-    Affine<C> q;
+    uint32_t qw[2 * N];                                   // packed words of the prefetched point
     uint32_t e = 0;
     if (cnt) {
         e = run[0];
-        const uint32_t* src = pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N);
-        load_limbs_vec<N>(q.x.v, src);
-        load_limbs_vec<N>(q.y.v, src + N);
+        load_words_vec<2 * N>(qw, pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N));
     }
 #pragma unroll 1
     for (uint32_t t = 0; t < cnt; t++) {
-        Affine<C> cur = q;
+        Affine<C> cur;
+        cur.x = Field<C>::unpack(qw).e;
+        cur.y = Field<C>::unpack(qw + N).e;
         uint32_t ecur = e;
         if (t + 1 < cnt) {                               // fetch the next point under the current addition
             e = run[t + 1];
-            const uint32_t* src = pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N);
-            load_limbs_vec<N>(q.x.v, src);
-            load_limbs_vec<N>(q.y.v, src + N);
+            load_words_vec<2 * N>(qw, pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N));
         }
-        if (ecur >> 31) cur.y = F::neg(cur.y);
-        acc = G::add_mixed(acc, cur, b);
+        acc = G::add_mixed(acc, cur, b, (ecur >> 31) != 0);
     }
     store_proj<C>(buckets, gid, acc);
 }
@@ -178,7 +173,7 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
 
 // k * P for a small non-negative k (double-and-add, k < 2^31)
 template <class C>
-__device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const Fe<C::N>& b) {
+__device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const Fe<C::NL>& b) {
     using G = Group<C>;
     Proj<C> acc = G::identity();
     if (k == 0) return acc;
@@ -203,7 +198,7 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nseg * nwin) return;
     size_t w = gid / nseg, s = gid % nseg;
-    Fe<C::N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Proj<C> running = G::identity(), local = G::identity();
     size_t base = s * seg;
     const int sh = (int)w == nwin - 1 ? top_shift : 0;
@@ -223,8 +218,8 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, uint32_t* __restrict__ wins) {
     using G = Group<C>;
-    __shared__ uint32_t lds[BLOCK * 3 * C::N];
-    Fe<C::N> b = G::curve_b();
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
     for (size_t s = threadIdx.x; s < nseg; s += BLOCK)
         acc = G::add(acc, load_proj<C>(segs, (size_t)blockIdx.x * nseg + s), b);
@@ -237,7 +232,7 @@ template <class C>
 __global__ void k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    Fe<C::N> b = G::curve_b();
+    Fe<C::NL> b = G::curve_b();
     Proj<C> acc = load_proj<C>(wins, nwin - 1);
     for (int w = nwin - 2; w >= 0; w--) {
         for (int s = 0; s < c; s++) acc = G::dbl(acc, b);

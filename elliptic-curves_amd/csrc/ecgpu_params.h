@@ -1,0 +1,237 @@
+// ecgpu_params.h — limb helpers and curve parameter packs shared by host and device code.
+// (Split out of ecgpu_field.h; constants: SURVEY.md Appendix A, reference lines cited per constant.)
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ECGPU_HD __host__ __device__ __forceinline__
+#define ECGPU_CONST static constexpr
+#else
+#define ECGPU_HD inline
+#define ECGPU_CONST static constexpr
+#endif
+
+namespace ecgpu {
+
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2 };
+
+// in-register field representations (ecgpu_field.h)
+enum Repr : int {
+    REPR_SAT_MONT = 0,   // saturated 32-bit limbs, Montgomery form, fully reduced (p384)
+    REPR_U29_K256 = 1,   // 9 x 29-bit limbs, plain residues, lazily reduced, 2^261 folding (k256)
+    REPR_U28_MONT = 2    // 10 x 28-bit limbs, Montgomery form R = 2^280, lazily reduced (p256)
+};
+
+template <int N>
+struct Fe {
+    uint32_t v[N];
+};
+
+// ---------------------------------------------------------------------------------------------
+// small multi-limb helpers
+// ---------------------------------------------------------------------------------------------
+
+template <int N>
+ECGPU_HD uint32_t mp_add(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (uint64_t)a[i] + b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)c;
+}
+
+template <int N>
+ECGPU_HD uint32_t mp_sub(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        c += (int64_t)a[i] - (int64_t)b[i];
+        r[i] = (uint32_t)c;
+        c >>= 32;  // arithmetic shift: 0 or -1
+    }
+    return (uint32_t)(c & 1);
+}
+
+// returns 1 if a >= b
+template <int N>
+ECGPU_HD bool mp_geq(const uint32_t* a, const uint32_t* b) {
+    uint32_t t[N];
+    return mp_sub<N>(t, a, b) == 0;
+}
+
+template <int N>
+ECGPU_HD bool mp_is_zero(const uint32_t* a) {
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) z |= a[i];
+    return z == 0;
+}
+
+// r[0..2N) = a * b, operand scanning; one v_mad_u64_u32 per limb pair
+template <int N>
+ECGPU_HD void mp_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            uint64_t t = (uint64_t)a[i] * b[j] + r[i + j] + carry;
+            r[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        r[i + N] = carry;
+    }
+}
+
+// r[0..2N) = a^2: off-diagonal products once, doubled, plus the diagonal
+template <int N>
+ECGPU_HD void mp_sqr(uint32_t* r, const uint32_t* a) {
+#pragma unroll
+    for (int i = 0; i < 2 * N; i++) r[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = i + 1; j < N; j++) {
+            uint64_t t = (uint64_t)a[i] * a[j] + r[i + j] + carry;
+            r[i + j] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+        r[i + N] = carry;
+    }
+    // double
+    uint32_t top = 0;
+#pragma unroll
+    for (int i = 1; i < 2 * N; i++) {
+        uint32_t w = r[i];
+        r[i] = (w << 1) | top;
+        top = w >> 31;
+    }
+    // add squares on the diagonal
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t sq = (uint64_t)a[i] * a[i];
+        c += (uint64_t)r[2 * i] + (uint32_t)sq;
+        r[2 * i] = (uint32_t)c;
+        c >>= 32;
+        c += (uint64_t)r[2 * i + 1] + (uint32_t)(sq >> 32);
+        r[2 * i + 1] = (uint32_t)c;
+        c >>= 32;
+    }
+}
+
+ECGPU_HD uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// big-endian bytes (4-byte aligned) -> little-endian limbs
+template <int N>
+ECGPU_HD void load_be(uint32_t* limbs, const uint8_t* bytes) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(bytes);
+#pragma unroll
+    for (int i = 0; i < N; i++) limbs[i] = bswap32(w[N - 1 - i]);
+}
+template <int N>
+ECGPU_HD void store_be(uint8_t* bytes, const uint32_t* limbs) {
+    uint32_t* w = reinterpret_cast<uint32_t*>(bytes);
+#pragma unroll
+    for (int i = 0; i < N; i++) w[N - 1 - i] = bswap32(limbs[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// curve parameter packs (constants: SURVEY.md Appendix A, reference lines cited there)
+// ---------------------------------------------------------------------------------------------
+
+struct K256Params {
+    ECGPU_CONST int ID = CURVE_K256;
+    ECGPU_CONST int N = 8;            // 32-bit words per canonical field element / scalar
+    ECGPU_CONST int NL = 9;           // limbs held in registers
+    ECGPU_CONST int REPR = REPR_U29_K256;
+    ECGPU_CONST bool A_IS_ZERO = true;
+    ECGPU_CONST bool MONTGOMERY = false;
+    // p = 2^256 - 0x1000003D1                      k256/src/arithmetic/field.rs:41-42
+    ECGPU_CONST uint32_t P[8] = {0xFFFFFC2Fu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order n                                k256/src/lib.rs:71
+    ECGPU_CONST uint32_t ORDER[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
+                                     0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // generator, canonical little-endian limbs     k256/src/arithmetic/affine.rs:65-79
+    ECGPU_CONST uint32_t GX[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
+                                  0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
+    ECGPU_CONST uint32_t GY[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
+                                  0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
+    ECGPU_CONST uint32_t B_SMALL = 7;  // y^2 = x^3 + 7   k256/src/arithmetic.rs
+};
+
+struct P256Params {
+    ECGPU_CONST int ID = CURVE_P256;
+    ECGPU_CONST int N = 8;
+    ECGPU_CONST int NL = 10;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p256/src/arithmetic.rs:44
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^256 - 2^224 + 2^192 + 2^96 - 1         p256/src/arithmetic/field.rs:35
+    ECGPU_CONST uint32_t P[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u,
+                                 0x00000000u, 0x00000000u, 0x00000001u, 0xFFFFFFFFu};
+    // n                                            p256/src/lib.rs:60
+    ECGPU_CONST uint32_t ORDER[8] = {0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu,
+                                     0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu};
+    // R^2 mod p, R = 2^256                         p256/src/arithmetic/field.rs:183-185
+    ECGPU_CONST uint32_t R2[8] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFBu,
+                                  0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFDu, 0x00000004u};
+    // R mod p = 2^256 - p
+    ECGPU_CONST uint32_t ONE[8] = {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu,
+                                   0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0x00000000u};
+    // curve b, canonical                           p256/src/arithmetic.rs:55-57
+    ECGPU_CONST uint32_t B[8] = {0x27D2604Bu, 0x3BCE3C3Eu, 0xCC53B0F6u, 0x651D06B0u,
+                                 0x769886BCu, 0xB3EBBD55u, 0xAA3A93E7u, 0x5AC635D8u};
+    // generator, canonical                         p256/src/arithmetic.rs:67-74
+    ECGPU_CONST uint32_t GX[8] = {0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u,
+                                  0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u};
+    ECGPU_CONST uint32_t GY[8] = {0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u,
+                                  0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u};
+};
+
+struct P384Params {
+    ECGPU_CONST int ID = CURVE_P384;
+    ECGPU_CONST int N = 12;
+    ECGPU_CONST int NL = 12;
+    ECGPU_CONST int REPR = REPR_SAT_MONT;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p384/src/arithmetic.rs:44
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^384 - 2^128 - 2^96 + 2^32 - 1          p384/src/arithmetic/field.rs:34
+    ECGPU_CONST uint32_t P[12] = {0xFFFFFFFFu, 0x00000000u, 0x00000000u, 0xFFFFFFFFu,
+                                  0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                  0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // n                                            p384/src/lib.rs:14
+    ECGPU_CONST uint32_t ORDER[12] = {0xCCC52973u, 0xECEC196Au, 0x48B0A77Au, 0x581A0DB2u,
+                                      0xF4372DDFu, 0xC7634D81u, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                      0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // R^2 mod p, R = 2^384: (2^128 + 2^96 - 2^32 + 1)^2
+    ECGPU_CONST uint32_t R2[12] = {0x00000001u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,
+                                   0x00000000u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,
+                                   0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u};
+    // R mod p = 2^128 + 2^96 - 2^32 + 1
+    ECGPU_CONST uint32_t ONE[12] = {0x00000001u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u,
+                                    0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u,
+                                    0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u};
+    // curve b, canonical                           p384/src/arithmetic.rs:57-59
+    ECGPU_CONST uint32_t B[12] = {0xD3EC2AEFu, 0x2A85C8EDu, 0x8A2ED19Du, 0xC656398Du,
+                                  0x5013875Au, 0x0314088Fu, 0xFE814112u, 0x181D9C6Eu,
+                                  0xE3F82D19u, 0x988E056Bu, 0xE23EE7E4u, 0xB3312FA7u};
+    // generator, canonical                         p384/src/arithmetic.rs:71-78
+    ECGPU_CONST uint32_t GX[12] = {0x72760AB7u, 0x3A545E38u, 0xBF55296Cu, 0x5502F25Du,
+                                   0x82542A38u, 0x59F741E0u, 0x8BA79B98u, 0x6E1D3B62u,
+                                   0xF320AD74u, 0x8EB1C71Eu, 0xBE8B0537u, 0xAA87CA22u};
+    ECGPU_CONST uint32_t GY[12] = {0x90EA0E5Fu, 0x7A431D7Cu, 0x1D7E819Du, 0x0A60B1CEu,
+                                   0xB5F0B8C0u, 0xE9DA3113u, 0x289A147Cu, 0xF8F41DBDu,
+                                   0x9292DC29u, 0x5D9E98BFu, 0x96262C6Fu, 0x3617DE4Au};
+};
+
+}  // namespace ecgpu

@@ -1,14 +1,21 @@
 // ecgpu_point.h — short-Weierstrass group law on homogeneous projective coordinates with the
-// Renes–Costello–Batina complete formulas, exactly the coordinate system and formulas the
-// reference uses (so there are no exceptional cases to special-case on the GPU either):
+// Renes–Costello–Batina complete formulas, exactly the coordinate system and formulas the reference
+// uses (so there are no exceptional cases to special-case on the GPU either):
 //
-//   a = 0  (k256)       k256/src/arithmetic/projective.rs:96-131 (Alg 7 add), :142-176 (Alg 8
-//                       mixed add), :189-217 (Alg 9 double); b3 = 3*7 = 21 as a small constant
+//   a = 0  (k256)       k256/src/arithmetic/projective.rs:96-131 (Alg 7 add), :142-176 (Alg 8 mixed
+//                       add), :189-217 (Alg 9 double); b3 = 3*7 = 21 as a small constant
 //   a = -3 (p256/p384)  primeorder/src/point_arithmetic.rs:222-245 (Alg 4), :254-280 (Alg 5),
 //                       :289-318 (Alg 6)
 //   identity            (0 : 1 : 0)   k256 projective.rs:49-53, primeorder projective.rs:60-64
 //
-// `__host__ __device__` for the same reason as ecgpu_field.h.
+// The formulas are written once against the magnitude-typed field interface (ecgpu_field.h): every
+// intermediate carries its limb/value bounds in its type, `norm` is inserted exactly where the lazily
+// reduced representations need it (it is the identity for the saturated p384 field), and the sums of two
+// products that end every formula are evaluated with ONE reduction (`mul2`).  This is the same
+// bookkeeping the reference does by hand with `negate(m)` / `normalize_weak()` in
+// k256/src/arithmetic/projective.rs.
+//
+// Coordinates of stored points (Proj / Affine) always have magnitude (1, 1).
 #pragma once
 
 #include "ecgpu_field.h"
@@ -17,192 +24,215 @@ namespace ecgpu {
 
 template <class C>
 struct Affine {  // identity is NOT representable here; callers carry a flag / skip
-    Fe<C::N> x, y;
+    Fe<C::NL> x, y;
 };
 
 template <class C>
 struct Proj {
-    Fe<C::N> x, y, z;
+    Fe<C::NL> x, y, z;
 };
 
 template <class C>
 struct Group {
     using F = Field<C>;
-    using E = Fe<C::N>;
+    using E = Fe<C::NL>;
+    using M1 = typename F::M1;
     using P = Proj<C>;
     using A = Affine<C>;
 
+    static ECGPU_HD M1 m(const E& e) { return F::template wrap<1, 1>(e); }
+
     static ECGPU_HD P identity() {
         P r;
-        r.x = F::zero();
-        r.y = F::one();
-        r.z = F::zero();
+        r.x = F::zero().e;
+        r.y = F::one().e;
+        r.z = F::zero().e;
         return r;
     }
-    static ECGPU_HD bool is_identity(const P& p) { return F::is_zero(p.z); }
+    static ECGPU_HD bool is_identity(const P& p) { return F::is_zero(m(p.z)); }
 
     static ECGPU_HD P from_affine(const A& a) {
         P r;
         r.x = a.x;
         r.y = a.y;
-        r.z = F::one();
+        r.z = F::one().e;
         return r;
+    }
+    // -y as a stored coordinate of magnitude (1, 1).  For the Montgomery-lazy field the value magnitude is
+    // brought back to 1 by a multiplication with the Montgomery one; the hot loops never call this — they
+    // pass the sign into add / add_mixed instead.
+    static ECGPU_HD E neg_coord(const E& y) {
+        if constexpr (C::REPR == REPR_U28_MONT) return F::mul(F::neg(m(y)), F::one()).e;
+        else return F::norm(F::neg(m(y))).e;
     }
     static ECGPU_HD P neg(const P& p) {
         P r = p;
-        r.y = F::neg(p.y);
+        r.y = neg_coord(p.y);
         return r;
     }
     static ECGPU_HD A neg(const A& p) {
         A r = p;
-        r.y = F::neg(p.y);
+        r.y = neg_coord(p.y);
         return r;
     }
-    static ECGPU_HD E curve_b() {  // Montgomery form of b for the a = -3 curves
-        E b;
-        if constexpr (C::MONTGOMERY) {
-#pragma unroll
-            for (int i = 0; i < C::N; i++) b.v[i] = C::B[i];
-            b = F::from_canonical(b);
+    static ECGPU_HD E curve_b() {  // curve b in internal form (a = -3 curves); unused for k256
+        if constexpr (C::REPR == REPR_U28_MONT) {
+            return F::p_const(consts::P256U::BM);
+        } else if constexpr (C::REPR == REPR_SAT_MONT) {
+            return F::from_canonical(C::B).e;
         } else {
-            b = F::zero();
+            E b = F::zero().e;
             b.v[0] = C::B_SMALL;
+            return b;
         }
-        return b;
     }
 
-    // ---- a = 0 -------------------------------------------------------------------------------
-    static ECGPU_HD P add_a0(const P& p, const P& q) {
-        const uint32_t b3 = 3 * C::B_SMALL;
-        E xx = F::mul(p.x, q.x);
-        E yy = F::mul(p.y, q.y);
-        E zz = F::mul(p.z, q.z);
-        E xy = F::sub(F::mul(F::add(p.x, p.y), F::add(q.x, q.y)), F::add(xx, yy));
-        E yz = F::sub(F::mul(F::add(p.y, p.z), F::add(q.y, q.z)), F::add(yy, zz));
-        E xz = F::sub(F::mul(F::add(p.x, p.z), F::add(q.x, q.z)), F::add(xx, zz));
-        E bzz3 = F::mul_small(zz, b3);
-        E yy_m = F::sub(yy, bzz3);
-        E yy_p = F::add(yy, bzz3);
-        E byz3 = F::mul_small(yz, b3);
-        E xx3 = F::add(F::dbl(xx), xx);
-        E bxx9 = F::mul_small(xx3, b3);
+    // ---- a = 0 (k256) ------------------------------------------------------------------------
+    // b3 = 21.  Magnitudes in comments are limb magnitudes; the product limit is 7.
+    // negq: add -q instead of q (the sign is folded into Y2, no separate negation pass)
+    static ECGPU_HD P add_a0(const P& p, const P& q, bool negq) {
+        constexpr uint32_t b3 = 3 * C::B_SMALL;
+        auto X1 = m(p.x), Y1 = m(p.y), Z1 = m(p.z), X2 = m(q.x), Z2 = m(q.z);
+        auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));       // 2
+        auto xx = F::mul(X1, X2);
+        auto yy = F::mul(Y1, Y2);
+        auto zz = F::mul(Z1, Z2);
+        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto yz = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(yy, zz)));
+        auto xz = F::norm(F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(xx, zz)));
+        auto bzz3 = F::template mul_small<b3>(zz);
+        auto yy_m = F::sub(yy, bzz3);                       // 3
+        auto yy_p = F::add(yy, bzz3);                       // 2
+        auto byz3 = F::template mul_small<b3>(yz);
+        auto xx3 = F::add(F::dbl(xx), xx);                  // 3
+        auto bxx9 = F::template mul_small<3 * b3>(xx);
         P r;
-        r.x = F::sub(F::mul(xy, yy_m), F::mul(byz3, xz));
-        r.y = F::add(F::mul(yy_p, yy_m), F::mul(bxx9, xz));
-        r.z = F::add(F::mul(yz, yy_p), F::mul(xx3, xy));
+        r.x = F::mul2(xy, yy_m, F::neg(byz3), xz).e;        // 1*3 + 2*1 = 5
+        r.y = F::mul2(yy_p, yy_m, bxx9, xz).e;              // 2*3 + 1*1 = 7
+        r.z = F::mul2(yz, yy_p, xx3, xy).e;                 // 1*2 + 3*1 = 5
         return r;
     }
-    static ECGPU_HD P add_mixed_a0(const P& p, const A& q) {
-        const uint32_t b3 = 3 * C::B_SMALL;
-        E xx = F::mul(p.x, q.x);
-        E yy = F::mul(p.y, q.y);
-        E xy = F::sub(F::mul(F::add(p.x, p.y), F::add(q.x, q.y)), F::add(xx, yy));
-        E yz = F::add(F::mul(q.y, p.z), p.y);
-        E xz = F::add(F::mul(q.x, p.z), p.x);
-        E bzz3 = F::mul_small(p.z, b3);
-        E yy_m = F::sub(yy, bzz3);
-        E yy_p = F::add(yy, bzz3);
-        E byz3 = F::mul_small(yz, b3);
-        E xx3 = F::add(F::dbl(xx), xx);
-        E bxx9 = F::mul_small(xx3, b3);
+    static ECGPU_HD P add_mixed_a0(const P& p, const A& q, bool negq) {
+        constexpr uint32_t b3 = 3 * C::B_SMALL;
+        auto X1 = m(p.x), Y1 = m(p.y), Z1 = m(p.z), X2 = m(q.x);
+        auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));       // 2
+        auto xx = F::mul(X1, X2);
+        auto yy = F::mul(Y1, Y2);
+        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto yz = F::add(F::mul(Y2, Z1), Y1);               // 2
+        auto xz = F::add(F::mul(X2, Z1), X1);               // 2
+        auto bzz3 = F::template mul_small<b3>(Z1);
+        auto yy_m = F::sub(yy, bzz3);                       // 3
+        auto yy_p = F::add(yy, bzz3);                       // 2
+        auto byz3 = F::template mul_small<b3>(yz);
+        auto xx3 = F::add(F::dbl(xx), xx);                  // 3
+        auto bxx9 = F::template mul_small<3 * b3>(xx);
+        auto yy_mn = F::norm(yy_m);                         // 1
         P r;
-        r.x = F::sub(F::mul(xy, yy_m), F::mul(byz3, xz));
-        r.y = F::add(F::mul(yy_p, yy_m), F::mul(bxx9, xz));
-        r.z = F::add(F::mul(yz, yy_p), F::mul(xx3, xy));
+        r.x = F::mul2(xy, yy_m, F::neg(byz3), xz).e;        // 1*3 + 2*2 = 7
+        r.y = F::mul2(yy_p, yy_mn, bxx9, xz).e;             // 2*1 + 1*2 = 4
+        r.z = F::mul2(yz, yy_p, xx3, xy).e;                 // 2*2 + 3*1 = 7
         return r;
     }
     static ECGPU_HD P dbl_a0(const P& p) {
-        const uint32_t b3 = 3 * C::B_SMALL;
-        E yy = F::sqr(p.y);
-        E zz = F::sqr(p.z);
-        E xy2 = F::dbl(F::mul(p.x, p.y));
-        E bzz3 = F::mul_small(zz, b3);
-        E bzz9 = F::add(F::dbl(bzz3), bzz3);
-        E yy_m9 = F::sub(yy, bzz9);
-        E yy_p3 = F::add(yy, bzz3);
-        E t = F::mul_small(F::mul(yy, zz), 8 * b3);  // 24*b*yy*zz
+        constexpr uint32_t b3 = 3 * C::B_SMALL;
+        auto X = m(p.x), Y = m(p.y), Z = m(p.z);
+        auto yy = F::sqr(Y);
+        auto zz = F::sqr(Z);
+        auto xy2 = F::dbl(F::mul(X, Y));                    // 2
+        auto bzz3 = F::template mul_small<b3>(zz);
+        auto bzz9 = F::template mul_small<3 * b3>(zz);
+        auto yy_m9 = F::sub(yy, bzz9);                      // 3
+        auto yy_p3 = F::add(yy, bzz3);                      // 2
+        auto yy24b = F::template mul_small<8 * b3>(yy);     // 24 b yy
+        auto z8 = F::template mul_small<8>(Z);
         P r;
-        r.x = F::mul(xy2, yy_m9);
-        E yyy_z = F::mul(F::mul(yy, p.y), p.z);
-        r.z = F::dbl(F::dbl(F::dbl(yyy_z)));
-        r.y = F::add(F::mul(yy_m9, yy_p3), t);
+        r.x = F::mul(xy2, yy_m9).e;                         // 2*3 = 6
+        r.y = F::mul2(yy_m9, yy_p3, yy24b, zz).e;           // 3*2 + 1*1 = 7
+        r.z = F::mul(F::mul(yy, Y), z8).e;
         return r;
     }
 
-    // ---- a = -3 ------------------------------------------------------------------------------
-    static ECGPU_HD P add_am3(const P& l, const P& r, const E& b) {
-        E xx = F::mul(l.x, r.x);
-        E yy = F::mul(l.y, r.y);
-        E zz = F::mul(l.z, r.z);
-        E xy = F::sub(F::mul(F::add(l.x, l.y), F::add(r.x, r.y)), F::add(xx, yy));
-        E yz = F::sub(F::mul(F::add(l.y, l.z), F::add(r.y, r.z)), F::add(yy, zz));
-        E xz = F::sub(F::mul(F::add(l.x, l.z), F::add(r.x, r.z)), F::add(xx, zz));
-        E bzz = F::sub(xz, F::mul(b, zz));
-        E bzz3 = F::add(F::dbl(bzz), bzz);
-        E yy_m = F::sub(yy, bzz3);
-        E yy_p = F::add(yy, bzz3);
-        E zz3 = F::add(F::dbl(zz), zz);
-        E bxz = F::sub(F::mul(b, xz), F::add(zz3, xx));
-        E bxz3 = F::add(F::dbl(bxz), bxz);
-        E xx3_m_zz3 = F::sub(F::add(F::dbl(xx), xx), zz3);
+    // ---- a = -3 (p256: product limit 24, magnitude limit 15; p384: saturated, everything is 1) ----
+    static ECGPU_HD P add_am3(const P& l, const P& r, const E& be, bool negq) {
+        auto b = m(be);
+        auto X1 = m(l.x), Y1 = m(l.y), Z1 = m(l.z), X2 = m(r.x), Z2 = m(r.z);
+        auto Y2 = F::sel(negq, F::neg(m(r.y)), m(r.y));
+        auto xx = F::mul(X1, X2);
+        auto yy = F::mul(Y1, Y2);
+        auto zz = F::mul(Z1, Z2);
+        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto yz = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(yy, zz)));   // 4 -> 1
+        auto xz = F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(xx, zz));            // 4
+        auto bzz = F::norm(F::sub(xz, F::mul(b, zz)));      // 6 -> 1
+        auto bzz3 = F::add(F::dbl(bzz), bzz);               // 3
+        auto yy_m = F::sub(yy, bzz3);                       // 5
+        auto yy_p = F::add(yy, bzz3);                       // 4
+        auto zz3 = F::add(F::dbl(zz), zz);                  // 3
+        auto bxz = F::norm(F::sub(F::mul(b, xz), F::add(zz3, xx)));                           // 6 -> 1
+        auto bxz3 = F::add(F::dbl(bxz), bxz);               // 3
+        auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), zz3));                        // 7 -> 1
         P o;
-        o.x = F::sub(F::mul(yy_p, xy), F::mul(yz, bxz3));
-        o.y = F::add(F::mul(yy_p, yy_m), F::mul(xx3_m_zz3, bxz3));
-        o.z = F::add(F::mul(yy_m, yz), F::mul(xy, xx3_m_zz3));
+        o.x = F::mul2(yy_p, xy, F::neg(yz), bxz3).e;        // 4*1 + 2*3 = 10
+        o.y = F::mul2(yy_p, yy_m, xx3_m_zz3, bxz3).e;       // 4*5 + 1*3 = 23
+        o.z = F::mul2(yy_m, yz, xy, xx3_m_zz3).e;           // 5*1 + 1*1 = 6
         return o;
     }
-    static ECGPU_HD P add_mixed_am3(const P& l, const A& r, const E& b) {
-        E xx = F::mul(l.x, r.x);
-        E yy = F::mul(l.y, r.y);
-        E xy = F::sub(F::mul(F::add(l.x, l.y), F::add(r.x, r.y)), F::add(xx, yy));
-        E yz = F::add(F::mul(r.y, l.z), l.y);
-        E xz = F::add(F::mul(r.x, l.z), l.x);
-        E bz = F::sub(xz, F::mul(b, l.z));
-        E bz3 = F::add(F::dbl(bz), bz);
-        E yy_m = F::sub(yy, bz3);
-        E yy_p = F::add(yy, bz3);
-        E z3 = F::add(F::dbl(l.z), l.z);
-        E bxz = F::sub(F::mul(b, xz), F::add(z3, xx));
-        E bxz3 = F::add(F::dbl(bxz), bxz);
-        E xx3_m_zz3 = F::sub(F::add(F::dbl(xx), xx), z3);
+    static ECGPU_HD P add_mixed_am3(const P& l, const A& r, const E& be, bool negq) {
+        auto b = m(be);
+        auto X1 = m(l.x), Y1 = m(l.y), Z1 = m(l.z), X2 = m(r.x);
+        auto Y2 = F::sel(negq, F::neg(m(r.y)), m(r.y));
+        auto xx = F::mul(X1, X2);
+        auto yy = F::mul(Y1, Y2);
+        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto yz = F::add(F::mul(Y2, Z1), Y1);               // 2
+        auto xz = F::add(F::mul(X2, Z1), X1);               // 2
+        auto bz = F::norm(F::sub(xz, F::mul(b, Z1)));       // 4 -> 1
+        auto bz3 = F::add(F::dbl(bz), bz);                  // 3
+        auto yy_m = F::sub(yy, bz3);                        // 5
+        auto yy_p = F::add(yy, bz3);                        // 4
+        auto z3 = F::add(F::dbl(Z1), Z1);                   // 3
+        auto bxz = F::norm(F::sub(F::mul(b, xz), F::add(z3, xx)));                            // 6 -> 1
+        auto bxz3 = F::add(F::dbl(bxz), bxz);               // 3
+        auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), z3));                         // 7 -> 1
         P o;
-        o.x = F::sub(F::mul(yy_p, xy), F::mul(yz, bxz3));
-        o.y = F::add(F::mul(yy_p, yy_m), F::mul(xx3_m_zz3, bxz3));
-        o.z = F::add(F::mul(yy_m, yz), F::mul(xy, xx3_m_zz3));
+        o.x = F::mul2(yy_p, xy, F::neg(yz), bxz3).e;        // 4*1 + 3*3 = 13
+        o.y = F::mul2(yy_p, yy_m, xx3_m_zz3, bxz3).e;       // 4*5 + 1*3 = 23
+        o.z = F::mul2(yy_m, yz, xy, xx3_m_zz3).e;           // 5*2 + 1*1 = 11
         return o;
     }
-    static ECGPU_HD P dbl_am3(const P& p, const E& b) {
-        E xx = F::sqr(p.x);
-        E yy = F::sqr(p.y);
-        E zz = F::sqr(p.z);
-        E xy2 = F::dbl(F::mul(p.x, p.y));
-        E xz2 = F::dbl(F::mul(p.x, p.z));
-        E bzz = F::sub(F::mul(b, zz), xz2);
-        E bzz3 = F::add(F::dbl(bzz), bzz);
-        E yy_m = F::sub(yy, bzz3);
-        E yy_p = F::add(yy, bzz3);
-        E y_frag = F::mul(yy_p, yy_m);
-        E x_frag = F::mul(yy_m, xy2);
-        E zz3 = F::add(F::dbl(zz), zz);
-        E bxz2 = F::sub(F::mul(b, xz2), F::add(zz3, xx));
-        E bxz6 = F::add(F::dbl(bxz2), bxz2);
-        E xx3_m_zz3 = F::sub(F::add(F::dbl(xx), xx), zz3);
+    static ECGPU_HD P dbl_am3(const P& p, const E& be) {
+        auto b = m(be);
+        auto X = m(p.x), Y = m(p.y), Z = m(p.z);
+        auto xx = F::sqr(X);
+        auto yy = F::sqr(Y);
+        auto zz = F::sqr(Z);
+        auto xy2 = F::dbl(F::mul(X, Y));                    // 2
+        auto xz2 = F::dbl(F::mul(X, Z));                    // 2
+        auto bzz = F::norm(F::sub(F::mul(b, zz), xz2));     // 4 -> 1
+        auto bzz3 = F::add(F::dbl(bzz), bzz);               // 3
+        auto yy_m = F::sub(yy, bzz3);                       // 5
+        auto yy_p = F::add(yy, bzz3);                       // 4
+        auto zz3 = F::add(F::dbl(zz), zz);                  // 3
+        auto bxz2 = F::norm(F::sub(F::mul(b, xz2), F::add(zz3, xx)));                         // 6 -> 1
+        auto bxz6 = F::add(F::dbl(bxz2), bxz2);             // 3
+        auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), zz3));                        // 7 -> 1
+        auto yz2 = F::dbl(F::mul(Y, Z));                    // 2
         P o;
-        o.y = F::add(y_frag, F::mul(xx3_m_zz3, bxz6));
-        E yz2 = F::dbl(F::mul(p.y, p.z));
-        o.x = F::sub(x_frag, F::mul(bxz6, yz2));
-        o.z = F::dbl(F::dbl(F::mul(yz2, yy)));
+        o.x = F::mul2(yy_m, xy2, F::neg(bxz6), yz2).e;      // 5*2 + 4*2 = 18
+        o.y = F::mul2(yy_p, yy_m, xx3_m_zz3, bxz6).e;       // 4*5 + 1*3 = 23
+        o.z = F::mul(yz2, F::dbl(F::dbl(yy))).e;            // 2*4 = 8
         return o;
     }
 
     // ---- curve-generic entry points (b is ignored for a = 0) -----------------------------------
-    static ECGPU_HD P add(const P& p, const P& q, const E& b) {
-        if constexpr (C::A_IS_ZERO) return add_a0(p, q);
-        else return add_am3(p, q, b);
+    static ECGPU_HD P add(const P& p, const P& q, const E& b, bool negq = false) {
+        if constexpr (C::A_IS_ZERO) return add_a0(p, q, negq);
+        else return add_am3(p, q, b, negq);
     }
-    static ECGPU_HD P add_mixed(const P& p, const A& q, const E& b) {
-        if constexpr (C::A_IS_ZERO) return add_mixed_a0(p, q);
-        else return add_mixed_am3(p, q, b);
+    static ECGPU_HD P add_mixed(const P& p, const A& q, const E& b, bool negq = false) {
+        if constexpr (C::A_IS_ZERO) return add_mixed_a0(p, q, negq);
+        else return add_mixed_am3(p, q, b, negq);
     }
     static ECGPU_HD P dbl(const P& p, const E& b) {
         if constexpr (C::A_IS_ZERO) return dbl_a0(p);
@@ -210,17 +240,16 @@ struct Group {
     }
 
     // y^2 == x^3 + a x + b   (primeorder/src/affine.rs:100-109)
-    static ECGPU_HD bool on_curve(const A& p, const E& b) {
-        E lhs = F::sqr(p.y);
-        E x3 = F::mul(F::sqr(p.x), p.x);
-        E rhs;
+    static ECGPU_HD bool on_curve(const A& p, const E& be) {
+        auto x = m(p.x), y = m(p.y);
+        auto lhs = F::sqr(y);
+        auto x3 = F::mul(F::sqr(x), x);
         if constexpr (C::A_IS_ZERO) {
-            rhs = F::add(x3, b);
+            return F::eq(lhs, F::add(x3, m(be)));
         } else {
-            E x3x = F::add(F::dbl(p.x), p.x);
-            rhs = F::add(F::sub(x3, x3x), b);
+            auto x3x = F::add(F::dbl(x), x);
+            return F::eq(lhs, F::add(F::norm(F::sub(x3, x3x)), m(be)));
         }
-        return F::eq(lhs, rhs);
     }
 };
 

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pyec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "elliptic-curves_amd", "csrc", "ecgpu_field.h")
+HEADER = os.path.join(ROOT, "elliptic-curves_amd", "csrc", "ecgpu_params.h")
 
 
 def arrays(src, struct):

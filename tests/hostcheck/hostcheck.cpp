@@ -18,23 +18,35 @@ bool load_affine(Affine<C>* a, const uint8_t* xy, int inf) {
     using F = Field<C>;
     if (inf) return false;
     bool ok1, ok2;
-    a->x = F::from_bytes(xy, &ok1);
-    a->y = F::from_bytes(xy + 4 * C::N, &ok2);
+    a->x = F::from_bytes(xy, &ok1).e;
+    a->y = F::from_bytes(xy + 4 * C::N, &ok2).e;
     return true;
 }
 
 template <class C>
 void store_affine(const Proj<C>& p, uint8_t* xy, uint8_t* inf) {
     using F = Field<C>;
-    if (F::is_zero(p.z)) {
+    using G = Group<C>;
+    if (F::is_zero(G::m(p.z))) {
         std::memset(xy, 0, 8 * C::N);
         if (inf) *inf = 1;
         return;
     }
-    auto zi = F::inv(p.z);
-    F::to_bytes(xy, F::mul(p.x, zi));
-    F::to_bytes(xy + 4 * C::N, F::mul(p.y, zi));
+    auto zi = F::inv(G::m(p.z));
+    F::to_bytes(xy, F::mul(G::m(p.x), zi));
+    F::to_bytes(xy + 4 * C::N, F::mul(G::m(p.y), zi));
     if (inf) *inf = 0;
+}
+
+template <class C>
+typename Field<C>::M1 times21(const typename Field<C>::M1& y) {
+    using F = Field<C>;
+    if constexpr (C::REPR == REPR_U29_K256) {
+        return F::template mul_small<21>(y);
+    } else {
+        uint32_t w[C::N] = {21};
+        return F::mul(y, F::from_canonical(w));
+    }
 }
 
 template <class C>
@@ -43,25 +55,31 @@ int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     bool ok;
     auto x = F::from_bytes(a, &ok);
     if (!ok) return -3;
-    Fe<C::N> y = F::zero();
+    auto y = F::zero();
     if (b) { y = F::from_bytes(b, &ok); if (!ok) return -3; }
-    Fe<C::N> r;
     switch (op) {
-    case 0: r = F::add(x, y); break;
-    case 1: r = F::sub(x, y); break;
-    case 2: r = F::mul(x, y); break;
-    case 3: r = F::sqr(x); break;
-    case 4: r = F::inv(x); break;
-    case 5: r = F::neg(x); break;
-    case 6: r = F::mul_small(x, 21); break;
-    case 7: r = F::dbl(x); break;
+    case 0: F::to_bytes(out, F::add(x, y)); break;
+    case 1: F::to_bytes(out, F::norm(F::sub(x, y))); break;
+    case 2: F::to_bytes(out, F::mul(x, y)); break;
+    case 3: F::to_bytes(out, F::sqr(x)); break;
+    case 4: F::to_bytes(out, F::inv(x)); break;
+    case 5: F::to_bytes(out, F::neg(x)); break;
+    case 6: F::to_bytes(out, times21<C>(x)); break;
+    case 7: F::to_bytes(out, F::dbl(x)); break;
+    case 8: {   // pack / unpack round trip of a lazy value
+        uint32_t w[C::N];
+        F::pack(w, F::norm(F::add(F::dbl(x), y)));
+        F::to_bytes(out, F::unpack(w));
+        break;
+    }
+    case 9: F::to_bytes(out, F::mul2(x, y, F::add(x, y), F::neg(y))); break;   // x*y - (x+y)*y
     default: return -1;
     }
-    F::to_bytes(out, r);
     return 0;
 }
 
-// chains of operations keep values in their lazy (weakly reduced) internal form between steps
+// chains of operations keep values in their lazy internal form between steps and run the magnitudes
+// up to the limits the point formulas use
 template <class C>
 int field_chain(const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
     using F = Field<C>;
@@ -69,9 +87,10 @@ int field_chain(const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
     auto x = F::from_bytes(a, &ok), y = F::from_bytes(b, &ok);
     for (int i = 0; i < steps; i++) {
         auto t = F::mul(x, y);
-        auto u = F::sub(F::add(t, x), F::dbl(y));
+        auto u = F::norm(F::sub(F::add(t, x), F::dbl(y)));
+        auto v = F::norm(F::neg(F::add(t, times21<C>(y))));
         x = F::sqr(u);
-        y = F::neg(F::add(t, F::mul_small(y, 21)));
+        y = F::mul(v, F::one());          // back to value magnitude 1 for the Montgomery-lazy field
     }
     F::to_bytes(out, F::add(x, y));
     return 0;
@@ -85,12 +104,14 @@ int point_op(int op, const uint8_t* pxy, int pinf, const uint8_t* qxy, int qinf,
     Proj<C> p = G::identity(), r;
     if (load_affine<C>(&pa, pxy, pinf)) p = G::from_affine(pa);
     bool qfinite = false;
-    if (op == 0 || op == 1) qfinite = load_affine<C>(&qa, qxy, qinf);
+    if (op == 0 || op == 1 || op == 4 || op == 5) qfinite = load_affine<C>(&qa, qxy, qinf);
     switch (op) {
     case 0: r = G::add(p, qfinite ? G::from_affine(qa) : G::identity(), b); break;
     case 1: r = qfinite ? G::add_mixed(p, qa, b) : p; break;
     case 2: r = G::dbl(p, b); break;
     case 3: r = G::neg(p); break;
+    case 4: r = G::add(p, qfinite ? G::from_affine(qa) : G::identity(), b, true); break;     // p - q
+    case 5: r = qfinite ? G::add_mixed(p, qa, b, true) : p; break;                            // p - q (mixed)
     default: return -1;
     }
     store_affine<C>(r, out, oinf);
@@ -103,8 +124,8 @@ int on_curve(const uint8_t* xy) {
     using F = Field<C>;
     bool ok1, ok2;
     Affine<C> a;
-    a.x = F::from_bytes(xy, &ok1);
-    a.y = F::from_bytes(xy + 4 * C::N, &ok2);
+    a.x = F::from_bytes(xy, &ok1).e;
+    a.y = F::from_bytes(xy + 4 * C::N, &ok2).e;
     return ok1 && ok2 && G::on_curve(a, G::curve_b());
 }
 
@@ -127,17 +148,19 @@ void build_table(BaseTable<C>& t, int w) {
     size_t half = (size_t)1 << (w - 1);
     t.e.resize(half * t.nwin);
     Affine<C> g;
-    for (int i = 0; i < C::N; i++) { g.x.v[i] = C::GX[i]; g.y.v[i] = C::GY[i]; }
-    g.x = F::from_canonical(g.x);
-    g.y = F::from_canonical(g.y);
+    g.x = F::from_canonical(C::GX).e;
+    g.y = F::from_canonical(C::GY).e;
     Proj<C> base = G::from_affine(g);
     for (int j = 0; j < t.nwin; j++) {
         // running multiples instead of per-entry double-and-add: same group elements, cheaper on one core
         Proj<C> cur = base;
         for (size_t e = 0; e < half; e++) {
-            auto zi = F::inv(cur.z);
-            t.e[j * half + e].x = F::mul(cur.x, zi);
-            t.e[j * half + e].y = F::mul(cur.y, zi);
+            auto zi = F::inv(G::m(cur.z));
+            uint32_t w[C::N];                       // entries go through the packed storage form like on the GPU
+            F::pack(w, F::mul(G::m(cur.x), zi));
+            t.e[j * half + e].x = F::unpack(w).e;
+            F::pack(w, F::mul(G::m(cur.y), zi));
+            t.e[j * half + e].y = F::unpack(w).e;
             cur = G::add(cur, base, b);
         }
         for (int s = 0; s < w; s++) base = G::dbl(base, b);
@@ -172,8 +195,7 @@ Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k) {
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             Affine<C> q = t.e[j * half + (mag - 1)];
-            if (d < 0) q.y = F::neg(q.y);
-            acc = G::add_mixed(acc, q, b);
+            acc = G::add_mixed(acc, q, b, d < 0);
         }
     }
     return acc;
@@ -199,8 +221,7 @@ Proj<C> var_base_one(const Affine<C>& a, const uint32_t* k) {
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             Proj<C> q = tab[mag - 1];
-            if (d < 0) q = G::neg(q);
-            acc = G::add(acc, q, b);
+            acc = G::add(acc, q, b, d < 0);
         }
     }
     return acc;
@@ -210,28 +231,29 @@ Proj<C> var_base_one(const Affine<C>& a, const uint32_t* k) {
 template <class C>
 void normalize(const std::vector<Proj<C>>& proj, size_t nthreads, uint8_t* out_xy, uint8_t* out_inf) {
     using F = Field<C>;
+    using G = Group<C>;
     constexpr int N = C::N;
     size_t n = proj.size();
-    std::vector<Fe<N>> prefix(n);
+    std::vector<Fe<C::NL>> prefix(n);
     for (size_t t = 0; t < nthreads; t++) {
-        Fe<N> acc = F::one();
+        typename F::M1 acc = F::one();
         for (size_t j = t; j < n; j += nthreads) {
-            prefix[j] = acc;
-            if (!F::is_zero(proj[j].z)) acc = F::mul(acc, proj[j].z);
+            prefix[j] = acc.e;
+            if (!F::is_zero(G::m(proj[j].z))) acc = F::mul(acc, G::m(proj[j].z));
         }
-        Fe<N> inv = F::inv(acc);
+        typename F::M1 inv = F::inv(acc);
         if (n <= t) continue;
         size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
         for (size_t j = last;; j -= nthreads) {
             const Proj<C>& p = proj[j];
-            if (F::is_zero(p.z)) {
+            if (F::is_zero(G::m(p.z))) {
                 std::memset(out_xy + j * 8 * N, 0, 8 * N);
                 out_inf[j] = 1;
             } else {
-                Fe<N> zinv = F::mul(prefix[j], inv);
-                inv = F::mul(inv, p.z);
-                F::to_bytes(out_xy + j * 8 * N, F::mul(p.x, zinv));
-                F::to_bytes(out_xy + j * 8 * N + 4 * N, F::mul(p.y, zinv));
+                typename F::M1 zinv = F::mul(G::m(prefix[j]), inv);
+                inv = F::mul(inv, G::m(p.z));
+                F::to_bytes(out_xy + j * 8 * N, F::mul(G::m(p.x), zinv));
+                F::to_bytes(out_xy + j * 8 * N + 4 * N, F::mul(G::m(p.y), zinv));
                 out_inf[j] = 0;
             }
             if (j < nthreads) break;
@@ -298,6 +320,11 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         if (!load_scalar<C>(ks[i].data(), scalars + i * 4 * N)) return -2;
         if (!load_affine<C>(&pts[i], pxy + i * 8 * N, pinf ? pinf[i] : 0)) continue;
         if (!G::on_curve(pts[i], b)) return -3;
+        {
+            uint32_t w[N];                                              // packed storage form, as on the GPU
+            F::pack(w, G::m(pts[i].x)); pts[i].x = F::unpack(w).e;
+            F::pack(w, G::m(pts[i].y)); pts[i].y = F::unpack(w).e;
+        }
         finite[i] = 1;
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
@@ -327,8 +354,7 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         Proj<C> acc = G::identity();
         for (uint32_t t = 0; t < counts[gid]; t++) {
             Affine<C> q = pts[run[t] & 0x7FFFFFFFu];
-            if (run[t] >> 31) q.y = F::neg(q.y);
-            acc = G::add_mixed(acc, q, b);
+            acc = G::add_mixed(acc, q, b, (run[t] >> 31) != 0);
         }
         buckets[gid] = acc;
     }
@@ -373,9 +399,8 @@ int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
     using F = Field<C>;
     auto b = G::curve_b();
     Affine<C> g;
-    for (int i = 0; i < C::N; i++) { g.x.v[i] = C::GX[i]; g.y.v[i] = C::GY[i]; }
-    g.x = F::from_canonical(g.x);
-    g.y = F::from_canonical(g.y);
+    g.x = F::from_canonical(C::GX).e;
+    g.y = F::from_canonical(C::GY).e;
     Proj<C> base = G::from_affine(g);
     for (int s = 0; s < w * j; s++) base = G::dbl(base, b);
     uint8_t inf;

@@ -35,6 +35,8 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
             got = hc.field_op(c.cid, op, A, B)
             assert int.from_bytes(got, "big") == want, (curve, op, hex(a), hex(b))
             assert got == oracle.field_op(c.cid, op, A, B)
+        assert int.from_bytes(hc.field_op(c.cid, 8, A, B), "big") == (2 * a + b) % c.p      # pack/unpack of a lazy value
+        assert int.from_bytes(hc.field_op(c.cid, 9, A, B), "big") == (-b * b) % c.p         # fused a*b + c*d
         assert int.from_bytes(hc.field_op(c.cid, 3, A), "big") == a * a % c.p
         assert int.from_bytes(hc.field_op(c.cid, 5, A), "big") == (-a) % c.p
         assert int.from_bytes(hc.field_op(c.cid, 6, A), "big") == 21 * a % c.p
@@ -80,6 +82,10 @@ def test_point_ops_complete_formulas(oracle, curve):
                 got, inf = hc.point_op(c.cid, op, pe, pi, qe, qi)
                 assert pyec.dec_point(c, got, inf) == want, (curve, op)
             assert (got, inf) == oracle.point_op(c.cid, 0, pe, pi, qe, qi)
+            diff = pyec.add(c, P, pyec.neg(c, Q))
+            for op in (4, 5):                        # sign folded into the addition formula
+                got, inf = hc.point_op(c.cid, op, pe, pi, qe, qi)
+                assert pyec.dec_point(c, got, inf) == diff, (curve, op)
     assert hc.on_curve(c.cid, pyec.enc_point(c, G)[0])
     bad = bytearray(pyec.enc_point(c, G)[0]); bad[-1] ^= 1
     assert not hc.on_curve(c.cid, bytes(bad))

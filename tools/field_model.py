@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Exact integer models of the unsaturated-limb field multiplications used on the GPU, with every
+64-bit accumulator checked for overflow.  Used (a) to validate the bound analysis in DESIGN.md §3 with
+adversarial (maximal-limb) inputs, and (b) by tools/gen_field_consts.py to derive constants.
+
+k256:  9 limbs x 29 bits, plain residues, value < M * 2^261, fold with 2^261 = 2^37 + 31264 (mod p)
+p256: 10 limbs x 28 bits, Montgomery form R = 2^280, p' = 1 (p = -1 mod 2^28), value < M * 2p
+"""
+import random
+
+U64 = (1 << 64) - 1
+
+
+def chk64(x):
+    assert 0 <= x <= U64, "64-bit accumulator overflow: %x" % x
+    return x
+
+
+def chk32(x):
+    assert 0 <= x < (1 << 32), "32-bit limb overflow: %x" % x
+    return x
+
+
+def to_limbs(v, nl, b):
+    return [(v >> (b * i)) & ((1 << b) - 1) for i in range(nl - 1)] + [v >> (b * (nl - 1))]
+
+
+def from_limbs(l, b):
+    return sum(x << (b * i) for i, x in enumerate(l))
+
+
+# ------------------------------------------------------------------------------------------------
+# k256, 9 x 29
+# ------------------------------------------------------------------------------------------------
+K_P = 2 ** 256 - 2 ** 32 - 977
+K_NL, K_B = 9, 29
+K_MASK = (1 << K_B) - 1
+K_F0, K_F1 = 31264, 256            # 2^261 = 2^5 * (2^32 + 977) = 256 * 2^29 + 31264
+K_G1, K_G2 = 8 * 31264, 8 * 256    # 2^(261+32) = 2^3 * 2^29 * 2^261: hi halves of 64-bit columns
+K_LB = (1 << 29) + (1 << 20)       # limb bound of a magnitude-1 element (small slack over 2^29)
+
+
+def k256_columns(a, b):
+    c = [0] * 17
+    for i in range(9):
+        for j in range(9):
+            c[i + j] = chk64(c[i + j] + chk32(a[i]) * chk32(b[j]))
+    return c
+
+
+def k256_reduce(c):
+    """17 64-bit columns -> 9 limbs, magnitude 1 (limbs < K_LB, value congruent mod p)."""
+    lo = c[:9] + [0, 0]
+    for k in range(9, 17):                     # fold high columns through their 32-bit halves
+        cl, ch = c[k] & 0xFFFFFFFF, c[k] >> 32
+        j = k - 9
+        lo[j] = chk64(lo[j] + cl * K_F0)
+        lo[j + 1] = chk64(lo[j + 1] + cl * K_F1 + ch * K_G1)
+        lo[j + 2] = chk64(lo[j + 2] + ch * K_G2)
+    # columns 9 and 10 (weights 2^261, 2^290) are folded once more, again by halves
+    for k in (9, 10):
+        cl, ch = lo[k] & 0xFFFFFFFF, lo[k] >> 32
+        j = k - 9
+        lo[j] = chk64(lo[j] + cl * K_F0)
+        lo[j + 1] = chk64(lo[j + 1] + cl * K_F1 + ch * K_G1)
+        lo[j + 2] = chk64(lo[j + 2] + ch * K_G2)
+    lo = lo[:9]
+    # sequential carry propagation 0 -> 8
+    r = [0] * 9
+    carry = 0
+    for k in range(9):
+        v = chk64(lo[k] + carry)
+        if k < 8:
+            r[k] = v & K_MASK
+            carry = v >> K_B
+        else:
+            r[8] = v & K_MASK
+            top = v >> K_B                      # weight 2^261, < 2^36
+    # fold the top once more (halves), then a short carry 0 -> 3
+    tl, th = top & 0xFFFFFFFF, top >> 32
+    t0 = chk64(r[0] + tl * K_F0)
+    t1 = chk64(r[1] + tl * K_F1 + th * K_G1)
+    t2 = chk64(r[2] + th * K_G2)
+    r[0] = t0 & K_MASK
+    t1 = chk64(t1 + (t0 >> K_B))
+    r[1] = t1 & K_MASK
+    t2 = chk64(t2 + (t1 >> K_B))
+    r[2] = t2 & K_MASK
+    r[3] = chk32(r[3] + (t2 >> K_B))           # no further propagation: slack absorbed by K_LB
+    assert all(x < K_LB for x in r), [hex(x) for x in r]
+    return r
+
+
+def k256_mul(a, b):
+    return k256_reduce(k256_columns(a, b))
+
+
+def k256_norm(a):
+    """carry-propagate a lazy element (limbs < 2^32) and fold the top: magnitude 1."""
+    r = [0] * 9
+    carry = 0
+    for k in range(9):
+        v = chk32(a[k]) + carry
+        r[k] = v & K_MASK
+        carry = v >> K_B
+    # carry has weight 2^261, < 2^4
+    r[0] = chk32(r[0] + carry * K_F0)
+    r[1] = chk32(r[1] + carry * K_F1)
+    assert all(x < K_LB for x in r)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# p256, 10 x 28, Montgomery R = 2^280
+# ------------------------------------------------------------------------------------------------
+P_P = 2 ** 256 - 2 ** 224 + 2 ** 192 + 2 ** 96 - 1
+P_NL, P_B = 10, 28
+P_MASK = (1 << P_B) - 1
+P_R = 1 << (P_NL * P_B)
+P_LIMBS = to_limbs(P_P, P_NL, P_B)
+assert P_LIMBS[0] == P_MASK                      # p = -1 mod 2^28  =>  p' = 1
+P_LB = (1 << 28) + (1 << 19)
+
+
+def p256_mont_mul(a, b):
+    c = [0] * 21
+    for i in range(10):
+        for j in range(10):
+            c[i + j] = chk64(c[i + j] + chk32(a[i]) * chk32(b[j]))
+    for i in range(10):
+        u = c[i] & P_MASK
+        # c[i] + u * p0 = c[i] - u + u * 2^28, so (c[i] + u*p0) >> 28 = (c[i] >> 28) + u:
+        # the j = 0 term and the carry are merged into the j = 1 multiply-add (limb p1 + 1)
+        c[i + 1] = chk64(c[i + 1] + (c[i] >> P_B) + u * (P_LIMBS[1] + 1))
+        for j in range(2, 10):
+            if P_LIMBS[j]:
+                c[i + j] = chk64(c[i + j] + u * P_LIMBS[j])
+    r = [0] * 10
+    carry = 0
+    for k in range(10):
+        v = chk64(c[10 + k] + carry)
+        if k < 9:
+            r[k] = v & P_MASK
+            carry = v >> P_B
+        else:
+            r[9] = chk32(v)
+    assert all(x < (1 << 28) for x in r[:9]) and r[9] < 32, [hex(x) for x in r]
+    return r
+
+
+def p256_norm(a):
+    r = [0] * 10
+    carry = 0
+    for k in range(10):
+        v = chk32(a[k]) + carry
+        if k < 9:
+            r[k] = v & P_MASK
+            carry = v >> P_B
+        else:
+            r[9] = chk32(v)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# subtraction constants: a multiple of p whose limbs all dominate a magnitude-M element
+# ------------------------------------------------------------------------------------------------
+def sub_constant(p, nl, b, m, lb, top_bound):
+    """limbs l_j in [m*lb, m*lb + 2^b) for j < nl-1, top limb >= m*top_bound, sum = 0 mod p."""
+    base = sum((m * lb) << (b * j) for j in range(nl - 1)) + ((m * top_bound) << (b * (nl - 1)))
+    k = -(-base // p)
+    rest = k * p - base
+    d = to_limbs(rest, nl, b)
+    limbs = [d[j] + m * lb for j in range(nl - 1)] + [d[nl - 1] + m * top_bound]
+    assert from_limbs(limbs, b) == k * p and all(x < (1 << 32) for x in limbs)
+    return limbs, k
+
+
+def selftest(trials=300, seed=1):
+    rng = random.Random(seed)
+    # k256: adversarial maxima at the magnitude-product limit 7 (e.g. 7 x 1, 3 x 2) and random values
+    for ma, mb in ((7, 1), (1, 7), (3, 2), (2, 3), (1, 1), (2, 2)):
+        assert ma * mb <= 7
+        a = [ma * K_LB - 1] * 9
+        b = [mb * K_LB - 1] * 9
+        r = k256_mul(a, b)
+        assert from_limbs(r, K_B) % K_P == from_limbs(a, K_B) * from_limbs(b, K_B) % K_P
+    for _ in range(trials):
+        ma, mb = rng.choice([(1, 1), (2, 2), (3, 2), (7, 1), (2, 3)])
+        a = [rng.randrange(ma * K_LB) for _ in range(9)]
+        b = [rng.randrange(mb * K_LB) for _ in range(9)]
+        r = k256_mul(a, b)
+        assert from_limbs(r, K_B) % K_P == from_limbs(a, K_B) * from_limbs(b, K_B) % K_P
+        n = k256_norm([rng.randrange(1 << 32) for _ in range(9)])
+    # p256: limb-magnitude product limit 24
+    rinv = pow(P_R, -1, P_P)
+    for ma, mb in ((15, 1), (1, 15), (4, 6), (5, 4), (1, 1), (3, 8), (12, 2), (2, 12)):
+        top_a, top_b = 32 * ma, 32 * mb
+        a = [ma * P_LB - 1] * 9 + [top_a - 1]
+        b = [mb * P_LB - 1] * 9 + [top_b - 1]
+        r = p256_mont_mul(a, b)
+        assert from_limbs(r, P_B) % P_P == from_limbs(a, P_B) * from_limbs(b, P_B) * rinv % P_P
+        assert from_limbs(r, P_B) < 2 * P_P
+    for _ in range(trials):
+        ma, mb = rng.choice([(1, 1), (4, 6), (15, 1), (2, 12)])
+        a = [rng.randrange(ma * P_LB) for _ in range(9)] + [rng.randrange(32 * ma)]
+        b = [rng.randrange(mb * P_LB) for _ in range(9)] + [rng.randrange(32 * mb)]
+        r = p256_mont_mul(a, b)
+        assert from_limbs(r, P_B) % P_P == from_limbs(a, P_B) * from_limbs(b, P_B) * rinv % P_P
+        assert from_limbs(r, P_B) < 2 * P_P
+    for m in range(1, 8):
+        limbs, k = sub_constant(K_P, 9, 29, m, K_LB, K_LB)
+        assert all(m * K_LB <= x < (m + 1) * K_LB + (1 << 29) for x in limbs), (m, [hex(x) for x in limbs])
+    for m in range(1, 14):
+        limbs, k = sub_constant(P_P, 10, 28, m, P_LB, 32)
+        assert all(m * P_LB <= x < m * P_LB + (1 << 28) for x in limbs[:9]) and 32 * m <= limbs[9] < 32 * (m + 1) + 16, (m, limbs[9], k)
+    return True
+
+
+if __name__ == "__main__":
+    print("field model selftest:", selftest())
