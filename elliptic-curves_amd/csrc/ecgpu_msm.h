@@ -8,17 +8,20 @@
 //   sum_i k_i P_i = sum_w 2^(c w) * sum_b weight(b) * ( sum_{i : bucket_w(k_i) = b} +-P_i )
 //
 //   prepare     one lane per term: decode + validate scalar and point once, keep the point in packed
-//               internal form, recode k into nwin digits (msm_digit, ecgpu_recode.h), histogram the buckets
-//   scan        exclusive prefix sum of the bucket sizes, per window
-//   scatter     counting sort of (sign, term index) by bucket — every bucket becomes a contiguous
-//               run, so accumulation needs no atomics and no conflict handling
+//               internal form, recode k into nwin 16-bit (bucket, sign) digits (msm_digit, ecgpu_recode.h)
+//   sort        counting sort of (sign, term index) by bucket, per window, with the histogram of a whole
+//               window (2^(c-1) counters = 128 KiB at c = 16) held in ONE workgroup's LDS: a workgroup owns a
+//               (tile of terms, window) pair, counts with LDS atomics (hist), a scan over tiles and buckets
+//               turns the counts into offsets (tile_scan, scan), and the same workgroup shape scatters with
+//               LDS cursors (scatter).  No global atomics; every bucket becomes a contiguous run, so
+//               accumulation needs no atomics and no conflict handling
 //   accumulate  one lane per (window, bucket): complete mixed additions over its run   <- the hot loop
 //   reduce      running-sum trick on segments of buckets, segment sums, window sums
 //   combine     Horner over the windows (c doublings each)
 //
 // Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
-// ranks [nwin][n] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB] u32, buckets [nwin][NB][3 NS],
-// segment sums, window sums.
+// digits [nwin][n] u16, tile histograms [nwin][ntiles][NB] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB]
+// u32, buckets [nwin][NB][3 NS], segment sums, window sums.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -48,8 +51,12 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.nseg = p.nb / p.seg;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
+    p.tile = (size_t)1 << 19;
+    p.ntiles = (n + p.tile - 1) / p.tile;
+    if (p.ntiles == 0) p.ntiles = 1;
     p.off_points = o;  o = align(o + n * 2 * N * 4);
-    p.off_rank = o;    o = align(o + (size_t)p.nwin * n * 4);
+    p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
+    p.off_tilehist = o; o = align(o + (size_t)p.nwin * p.ntiles * p.nb * 4);
     p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
     p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
@@ -61,11 +68,13 @@ MsmPlan msm_plan(size_t n, int force_c) {
 }
 
 // ---- prepare ----------------------------------------------------------------------------------------------
+constexpr uint16_t MSM_NO_DIGIT = 0xFFFFu;   // (bucket 0x7FFF, negative) cannot occur: negative digits stop at 2^(c-1) - 1
+
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, int c, int nwin, uint32_t* __restrict__ pts,
-              uint32_t* __restrict__ ranks, uint32_t* __restrict__ counts, int* status) {
+              uint16_t* __restrict__ digits, int* status) {
     using G = Group<C>;
     constexpr int N = C::N;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,15 +83,49 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     load_scalar<C>(k, scalars, i, status);
     Fe<C::NL> b = G::curve_b();
     Affine<C> a;
-    if (!load_affine<C>(&a, points_xy, points_inf, i, b, status)) return;   // identity contributes nothing
-    store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
-    const size_t nb = (size_t)1 << (c - 1);
+    bool finite = load_affine<C>(&a, points_xy, points_inf, i, b, status);
+    if (finite) store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
     uint32_t carry = 0;
 #pragma unroll 1
     for (int w = 0; w < nwin; w++) {
         MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i);
-        if (d.nonzero) ranks[(size_t)w * n + i] = atomicAdd(&counts[(size_t)w * nb + d.bucket], 1u);
+        digits[(size_t)w * n + i] = (finite && d.nonzero) ? (uint16_t)(d.bucket | (d.neg << 15)) : MSM_NO_DIGIT;
     }
+}
+
+// ---- counting sort ---------------------------------------------------------------------------------------------
+// grid (ntiles, nwin), 1024 lanes, dynamic LDS = nb * 4 bytes: tile_hist[w][tile][b] = #terms of the tile in bucket b
+static __global__ void __launch_bounds__(1024)
+k_msm_hist(const uint16_t* __restrict__ digits, size_t n, size_t tile, size_t nb, uint32_t* __restrict__ tile_hist) {
+    extern __shared__ uint32_t lds_hist[];
+    const size_t w = blockIdx.y, t = blockIdx.x;
+    for (size_t b = threadIdx.x; b < nb; b += blockDim.x) lds_hist[b] = 0;
+    __syncthreads();
+    size_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
+    const uint16_t* dw = digits + w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint16_t d = dw[i];
+        if (d != MSM_NO_DIGIT) atomicAdd(&lds_hist[d & 0x7FFFu], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = tile_hist + (w * gridDim.x + t) * nb;
+    for (size_t b = threadIdx.x; b < nb; b += blockDim.x) out[b] = lds_hist[b];
+}
+
+// one lane per (window, bucket): exclusive prefix over the tiles in place, bucket totals to counts
+static __global__ void __launch_bounds__(BLOCK)
+k_msm_tile_scan(uint32_t* __restrict__ tile_hist, size_t ntiles, size_t nb, int nwin, uint32_t* __restrict__ counts) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nb * nwin) return;
+    size_t w = gid / nb, b = gid % nb;
+    uint32_t run = 0;
+    for (size_t t = 0; t < ntiles; t++) {
+        uint32_t* p = tile_hist + (w * ntiles + t) * nb + b;
+        uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    counts[gid] = run;
 }
 
 // ---- scan: offsets[w][b] = sum_{b' < b} counts[w][b'] -------------------------------------------------------
@@ -93,6 +136,7 @@ static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __rest
     uint32_t* ow = offsets + (size_t)blockIdx.x * nb;
     size_t per = (nb + 1023) / 1024;
     size_t lo = (size_t)threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    if (lo > nb) lo = nb;
     uint32_t s = 0;
     for (size_t j = lo; j < hi; j++) s += cw[j];
     part[threadIdx.x] = s;
@@ -110,25 +154,24 @@ static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __rest
     }
 }
 
-// ---- scatter ---------------------------------------------------------------------------------------------------
-template <class C>
-__global__ void __launch_bounds__(BLOCK)
-k_msm_scatter(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_inf, size_t n, int c, int nwin,
-              const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
-    constexpr int N = C::N;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (points_inf != nullptr && points_inf[i]) return;
-    uint32_t k[N];
-    load_be_vec<N>(k, scalars + i * (4 * N));
-    const size_t nb = (size_t)1 << (c - 1);
-    uint32_t carry = 0;
-#pragma unroll 1
-    for (int w = 0; w < nwin; w++) {
-        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i);
-        if (d.nonzero) {
-            uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * n + i];
-            sorted[(size_t)w * n + pos] = (uint32_t)i | (d.neg << 31);
+// grid (ntiles, nwin), 1024 lanes, dynamic LDS = nb * 4: scatter the tile's terms to their bucket runs
+static __global__ void __launch_bounds__(1024)
+k_msm_scatter(const uint16_t* __restrict__ digits, size_t n, size_t tile, size_t nb, const uint32_t* __restrict__ tile_hist,
+              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t lds_cursor[];
+    const size_t w = blockIdx.y, t = blockIdx.x;
+    const uint32_t* th = tile_hist + (w * gridDim.x + t) * nb;
+    const uint32_t* ow = offsets + w * nb;
+    for (size_t b = threadIdx.x; b < nb; b += blockDim.x) lds_cursor[b] = ow[b] + th[b];
+    __syncthreads();
+    size_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
+    const uint16_t* dw = digits + w * n;
+    uint32_t* sw = sorted + w * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        uint16_t d = dw[i];
+        if (d != MSM_NO_DIGIT) {
+            uint32_t pos = atomicAdd(&lds_cursor[d & 0x7FFFu], 1u);
+            sw[pos] = (uint32_t)i | ((uint32_t)(d >> 15) << 31);
         }
     }
 }
@@ -259,7 +302,8 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     }
     uint8_t* ws = (uint8_t*)workspace;
     uint32_t* pts = (uint32_t*)(ws + p.off_points);
-    uint32_t* ranks = (uint32_t*)(ws + p.off_rank);
+    uint16_t* digits = (uint16_t*)(ws + p.off_digits);
+    uint32_t* tile_hist = (uint32_t*)(ws + p.off_tilehist);
     uint32_t* sorted = (uint32_t*)(ws + p.off_sorted);
     uint32_t* counts = (uint32_t*)(ws + p.off_count);
     uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
@@ -267,12 +311,24 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     uint32_t* wins = (uint32_t*)(ws + p.off_wins);
     unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
-    (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
+    const size_t lds_bytes = p.nb * 4;
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // the window histogram may take 128 KiB of the 160 KiB LDS
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_attr_set = true;
+    }
     hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.c, p.nwin, pts,
-                       ranks, counts, d_status);
+                       digits, d_status);
+    hipLaunchKernelGGL(k_msm_hist, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
+                       (const uint16_t*)digits, n, p.tile, p.nb, tile_hist);
+    size_t nbk0 = p.nb * p.nwin;
+    hipLaunchKernelGGL(k_msm_tile_scan, dim3((unsigned)((nbk0 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, tile_hist,
+                       p.ntiles, p.nb, p.nwin, counts);
     hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
-    hipLaunchKernelGGL(k_msm_scatter<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_inf, n, p.c, p.nwin,
-                       (const uint32_t*)ranks, (const uint32_t*)offsets, sorted);
+    hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
+                       (const uint16_t*)digits, n, p.tile, p.nb, (const uint32_t*)tile_hist, (const uint32_t*)offsets,
+                       sorted);
     (void)hipEventRecord(ev_sorted, stream);
     size_t nbk = p.nb * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,

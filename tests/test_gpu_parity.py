@@ -290,6 +290,39 @@ def test_full_size_variable_base_p256_sample(eng):
     assert bytes(out[: 64 * 64]) == bytes(wo)
 
 
+@pytest.mark.parametrize("curve", ["k256", "p256"])
+def test_msm_multi_tile_ragged(eng, curve):
+    """More than one counting-sort tile with a ragged tail (n = 2^19 + 12345), identities sprinkled in, both
+    the automatic window and c = 16: split linearity + all-G checksum."""
+    c = pyec.CURVES[curve]
+    n = (1 << 19) + 12345
+    k = rand_scalars(c.cid, n, 0xEC0000A4 + c.cid)
+    s = rand_scalars(c.cid, n, 0xEC0000B4 + c.cid)
+    pts, _ = eng.mul_by_generator(c.cid, s)
+    pts = pts.copy()
+    inf = np.zeros(n, np.uint8)
+    inf[::1001] = 1
+    pts.reshape(n, 2 * c.L)[::1001] = 0
+    h = (1 << 19) - 7
+    for cbits in (0, 16):
+        eng.set_msm_window(cbits)
+        full, ff = eng.lincomb(c.cid, k, pts, inf)
+        a, af = eng.lincomb(c.cid, k[: c.L * h], pts[: 2 * c.L * h], inf[:h])
+        b, bf = eng.lincomb(c.cid, k[c.L * h:], pts[2 * c.L * h:], inf[h:])
+        sm, sf = eng.point_sum(c.cid, np.concatenate([a, b]), np.array([af, bf], np.uint8))
+        assert bytes(sm) == bytes(full) and sf == ff
+        gxy = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+        o, f = eng.lincomb(c.cid, k, np.tile(gxy, n))
+        w, wf = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, scalars_to_int_sum(k, c.L, c.n)))
+        assert bytes(o) == bytes(w) and f == int(wf[0])
+    eng.set_msm_window(0)
+    # oracle on a sample of the same data
+    m = 3000
+    o, f = eng.lincomb(c.cid, k[: c.L * m], pts[: 2 * c.L * m], inf[:m])
+    w, wf = oracle_lib.msm(c.cid, k[: c.L * m], pts[: 2 * c.L * m], inf[:m], vartime=True)
+    assert bytes(o) == bytes(w) and f == wf
+
+
 def test_full_size_msm_k256_properties(eng):
     """config 4 shape at 2^20 terms (2^24 is exercised by bench.py --workload msm_k256 --check):
     (a) all points = G: MSM == (sum k_i) G;  (b) distinct points P_i = s_i G: MSM == (sum k_i s_i) G;
