@@ -29,7 +29,6 @@
 // magnitude checker (k256/src/arithmetic/field/field_impl.rs:17-22).
 #pragma once
 
-#include "ecgpu_field_consts.h"
 #include "ecgpu_params.h"
 
 namespace ecgpu {
@@ -49,8 +48,8 @@ struct Field {
     using M1 = Mag<C, 1, 1>;
 
     // largest allowed sum of limb-magnitude products in one column accumulation, largest limb magnitude
-    ECGPU_CONST int MAXPROD = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? 24 : 1);
-    ECGPU_CONST int MAXMAG = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? 15 : 1);
+    ECGPU_CONST int MAXPROD = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? C::UC::MAXPROD : 1);
+    ECGPU_CONST int MAXMAG = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? C::UC::MAXMAG : 1);
     ECGPU_CONST bool LAZY = REPR != REPR_SAT_MONT;
 
     // =============================================================================================
@@ -285,106 +284,108 @@ struct Field {
     }
 
     // =============================================================================================
-    // p256, 10 x 28 Montgomery  (model: tools/field_model.py p256_*)
+    // unsaturated Montgomery: p256 10 x 28 (R = 2^280), p384 15 x 27 (R = 2^405); p = -1 mod 2^B so p' = 1
+    // (models: tools/field_model.py p256_mont_mul / umont_mul)
     // =============================================================================================
-    using PC = consts::P256U;
-    ECGPU_CONST uint32_t PMASK = (1u << 28) - 1;
+    using PC = typename C::UC;
+    ECGPU_CONST int UN = PC::NL, UB = PC::B;
+    ECGPU_CONST uint32_t PMASK = (1u << PC::B) - 1;
 
-    // 19 product columns (in c[0..18], c[19], c[20] zero) -> Montgomery-reduced 10 limbs, value < 2p
+    // 2*UN-1 product columns (c[2*UN-1], c[2*UN] zero) -> Montgomery-reduced UN limbs, value < 2p
     static ECGPU_HD E p_reduce(uint64_t* c) {
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
+        for (int i = 0; i < UN; i++) {
             uint32_t u = (uint32_t)c[i] & PMASK;
-            // (c[i] + u * p0) >> 28 = (c[i] >> 28) + u since p0 = 2^28 - 1: merged into the p1 term
-            c[i + 1] += (c[i] >> 28);
+            // (c[i] + u * p0) >> B = (c[i] >> B) + u since p0 = 2^B - 1: merged into the p1 term
+            c[i + 1] += (c[i] >> UB);
             c[i + 1] += (uint64_t)u * (PC::P[1] + 1u);
 #pragma unroll
-            for (int j = 2; j < 10; j++) {
+            for (int j = 2; j < UN; j++) {
                 if (PC::P[j] != 0) c[i + j] += (uint64_t)u * PC::P[j];
             }
         }
         E r;
-        uint64_t v = c[10];
+        uint64_t v = c[UN];
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < UN - 1; k++) {
             r.v[k] = (uint32_t)v & PMASK;
-            v = c[11 + k] + (v >> 28);
+            v = c[UN + 1 + k] + (v >> UB);
         }
-        r.v[9] = (uint32_t)v;
+        r.v[UN - 1] = (uint32_t)v;
         return r;
     }
     static ECGPU_HD void p_columns(uint64_t* c, const uint32_t* a, const uint32_t* b, bool accumulate) {
         if (!accumulate) {
 #pragma unroll
-            for (int k = 0; k < 21; k++) c[k] = 0;
+            for (int k = 0; k < 2 * UN + 1; k++) c[k] = 0;
         }
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
+        for (int i = 0; i < UN; i++) {
 #pragma unroll
-            for (int j = 0; j < 10; j++) c[i + j] += (uint64_t)a[i] * b[j];
+            for (int j = 0; j < UN; j++) c[i + j] += (uint64_t)a[i] * b[j];
         }
     }
     static ECGPU_HD void p_columns_sqr(uint64_t* c, const uint32_t* a) {
-        uint32_t a2[10];
+        uint32_t a2[UN];
 #pragma unroll
-        for (int k = 0; k < 21; k++) c[k] = 0;
+        for (int k = 0; k < 2 * UN + 1; k++) c[k] = 0;
 #pragma unroll
-        for (int j = 0; j < 10; j++) a2[j] = a[j] << 1;
+        for (int j = 0; j < UN; j++) a2[j] = a[j] << 1;
 #pragma unroll
-        for (int i = 0; i < 10; i++) {
+        for (int i = 0; i < UN; i++) {
             c[2 * i] += (uint64_t)a[i] * a[i];
 #pragma unroll
-            for (int j = i + 1; j < 10; j++) c[i + j] += (uint64_t)a[i] * a2[j];
+            for (int j = i + 1; j < UN; j++) c[i + j] += (uint64_t)a[i] * a2[j];
         }
     }
     static ECGPU_HD E p_norm(const E& a) {             // carry propagation only; the value is unchanged
         E r;
         uint32_t carry = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < UN - 1; k++) {
             uint32_t v = a.v[k] + carry;
             r.v[k] = v & PMASK;
-            carry = v >> 28;
+            carry = v >> UB;
         }
-        r.v[9] = a.v[9] + carry;
+        r.v[UN - 1] = a.v[UN - 1] + carry;
         return r;
     }
-    // value in [0, 2p) with strict 28-bit limbs -> [0, p)
+    // value in [0, 2p) with strict limbs -> [0, p)
     static ECGPU_HD E p_cond_sub(const E& a) {
         E d;
         int32_t borrow = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < UN - 1; k++) {
             int32_t t = (int32_t)a.v[k] - (int32_t)PC::P[k] + borrow;
             d.v[k] = (uint32_t)t & PMASK;
-            borrow = t >> 28;                          // 0 or -1
+            borrow = t >> UB;                          // 0 or -1
         }
-        int32_t t9 = (int32_t)a.v[9] - (int32_t)PC::P[9] + borrow;
-        d.v[9] = (uint32_t)t9;
-        bool lt = t9 < 0;
+        int32_t tt = (int32_t)a.v[UN - 1] - (int32_t)PC::P[UN - 1] + borrow;
+        d.v[UN - 1] = (uint32_t)tt;
+        bool lt = tt < 0;
         E r;
 #pragma unroll
-        for (int k = 0; k < 10; k++) r.v[k] = lt ? a.v[k] : d.v[k];
+        for (int k = 0; k < UN; k++) r.v[k] = lt ? a.v[k] : d.v[k];
         return r;
     }
-    static ECGPU_HD void p_limbs_to_words(uint32_t* w, const E& r) {   // strict limbs, value < 2^256
+    static ECGPU_HD void p_limbs_to_words(uint32_t* w, const E& r) {   // strict limbs, value < 2^(32 N)
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int bit = 32 * i, l = bit / 28, sh = bit % 28;
+        for (int i = 0; i < N; i++) {
+            int bit = 32 * i, l = bit / UB, sh = bit % UB;
             uint64_t x = (uint64_t)r.v[l] >> sh;
-            x |= (uint64_t)r.v[l + 1] << (28 - sh);
-            if (l + 2 < 10) x |= (uint64_t)r.v[l + 2] << (56 - sh);
+            if (l + 1 < UN) x |= (uint64_t)r.v[l + 1] << (UB - sh);
+            if (l + 2 < UN) x |= (uint64_t)r.v[l + 2] << (2 * UB - sh);
             w[i] = (uint32_t)x;
         }
     }
     static ECGPU_HD E p_const(const uint32_t* limbs) {
         E r;
 #pragma unroll
-        for (int k = 0; k < 10; k++) r.v[k] = limbs[k];
+        for (int k = 0; k < UN; k++) r.v[k] = limbs[k];
         return r;
     }
     static ECGPU_HD E p_mont_mul(const E& a, const E& b) {
-        uint64_t c[21];
+        uint64_t c[2 * UN + 1];
         p_columns(c, a.v, b.v, false);
         return p_reduce(c);
     }
@@ -404,7 +405,7 @@ struct Field {
         } else if constexpr (REPR == REPR_U28_MONT) {
             for (int i = 0; i < NL - 1; i++)
                 if ((uint64_t)e.v[i] > (uint64_t)L * PC::LB) { __builtin_trap(); }
-            if ((uint64_t)e.v[NL - 1] > (uint64_t)V * PC::TOP1 + 16) { __builtin_trap(); }
+            if ((uint64_t)e.v[NL - 1] > (uint64_t)V * PC::TOP1 + PC::TOP1 / 2) { __builtin_trap(); }
         }
 #else
         (void)e;
@@ -505,8 +506,8 @@ struct Field {
             return wrap<1, 1>(k_reduce(c));
         } else {
             static_assert(LA * LB <= MAXPROD, "p256 mul: limb magnitude product too large");
-            static_assert((long)VA * VB <= (1L << 20), "p256 mul: value magnitude product too large");
-            uint64_t c[21];
+            static_assert((long)VA * VB <= (1L << PC::VLIMIT_LOG2), "mul: value magnitude product too large");
+            uint64_t c[2 * UN + 1];
             p_columns(c, a.e.v, b.e.v, false);
             return wrap<1, 1>(p_reduce(c));
         }
@@ -522,7 +523,7 @@ struct Field {
             return wrap<1, 1>(k_reduce(c));
         } else {
             static_assert(LA * LA <= MAXPROD, "p256 sqr: limb magnitude too large");
-            uint64_t c[21];
+            uint64_t c[2 * UN + 1];
             p_columns_sqr(c, a.e.v);
             return wrap<1, 1>(p_reduce(c));
         }
@@ -541,8 +542,8 @@ struct Field {
             return wrap<1, 1>(k_reduce(col));
         } else {
             static_assert(LA * LB + LC * LD <= MAXPROD, "p256 mul2: limb magnitude products too large");
-            static_assert((long)VA * VB + (long)VC * VD <= (1L << 20), "p256 mul2: value magnitudes too large");
-            uint64_t col[21];
+            static_assert((long)VA * VB + (long)VC * VD <= (1L << PC::VLIMIT_LOG2), "mul2: value magnitudes too large");
+            uint64_t col[2 * UN + 1];
             p_columns(col, a.e.v, b.e.v, false);
             p_columns(col, c.e.v, d.e.v, true);
             return wrap<1, 1>(p_reduce(col));
@@ -574,7 +575,7 @@ struct Field {
         } else if constexpr (REPR == REPR_U29_K256) {
             return wrap<1, 1>(words_to_limbs<9, 29>(w));
         } else {
-            E a = words_to_limbs<10, 28>(w);
+            E a = words_to_limbs<UN, UB>(w);
             return wrap<1, 1>(p_mont_mul(a, p_const(PC::R2)));
         }
     }
@@ -593,7 +594,7 @@ struct Field {
             static_assert(LA <= MAXPROD, "normalise before to_canonical");
             E onep;                                       // plain 1: a * 1 * R^-1 leaves the Montgomery domain
 #pragma unroll
-            for (int k = 0; k < 10; k++) onep.v[k] = k == 0 ? 1u : 0u;
+            for (int k = 0; k < UN; k++) onep.v[k] = k == 0 ? 1u : 0u;
             E r = p_cond_sub(p_mont_mul(a.e, onep));
             p_limbs_to_words(w, r);
         }
@@ -621,7 +622,7 @@ struct Field {
         } else if constexpr (REPR == REPR_U29_K256) {
             return wrap<1, 1>(words_to_limbs<9, 29>(w));
         } else {
-            return wrap<1, 1>(words_to_limbs<10, 28>(w));
+            return wrap<1, 1>(words_to_limbs<UN, UB>(w));
         }
     }
 
@@ -650,26 +651,68 @@ struct Field {
         store_be<N>(be, w);
     }
 
-    // a^(p-2), fixed 4-bit window over the constant exponent; a == 0 -> 0.  (The reference inverts with
-    // crypto-bigint's safegcd — k256 field.rs:178-184, primefield monty.rs:373-375; the inverse is unique.)
+    static ECGPU_HD M1 sqr_n(M1 x, int n) {
+#pragma unroll 1
+        for (int i = 0; i < n; i++) x = sqr(x);
+        return x;
+    }
+    // a^(p-2); a == 0 -> 0.  (The reference inverts with crypto-bigint's safegcd — k256 field.rs:178-184,
+    // primefield monty.rs:373-375; the inverse is unique, so any method agrees.)  k256 and p256 use addition
+    // chains over the runs of ones of p-2 (255 squarings + 15 resp. 12 multiplications); p384 a fixed 4-bit
+    // window over the constant exponent (384 squarings + <= 110 multiplications).
     static ECGPU_HD M1 inv(const M1& a) {
-        M1 tab[16];
-        tab[0] = one();
-        tab[1] = a;
+        if constexpr (REPR == REPR_U29_K256) {
+            // p-2 = 2^256 - 2^32 - 979: 223 ones, 0, 22 ones, 0000 1 0 11 0 1
+            M1 x2 = mul(sqr(a), a);
+            M1 x3 = mul(sqr(x2), a);
+            M1 x6 = mul(sqr_n(x3, 3), x3);
+            M1 x9 = mul(sqr_n(x6, 3), x3);
+            M1 x11 = mul(sqr_n(x9, 2), x2);
+            M1 x22 = mul(sqr_n(x11, 11), x11);
+            M1 x44 = mul(sqr_n(x22, 22), x22);
+            M1 x88 = mul(sqr_n(x44, 44), x44);
+            M1 x176 = mul(sqr_n(x88, 88), x88);
+            M1 x220 = mul(sqr_n(x176, 44), x44);
+            M1 x223 = mul(sqr_n(x220, 3), x3);
+            M1 t = mul(sqr_n(x223, 23), x22);
+            t = mul(sqr_n(t, 5), a);
+            t = mul(sqr_n(t, 3), x2);
+            t = mul(sqr_n(t, 2), a);
+            return t;
+        } else if constexpr (REPR == REPR_U28_MONT && C::ID == CURVE_P256) {
+            // p-2 = ffffffff 00000001 00000000 00000000 00000000 ffffffff ffffffff fffffffd
+            M1 x2 = mul(sqr(a), a);
+            M1 x3 = mul(sqr(x2), a);
+            M1 x6 = mul(sqr_n(x3, 3), x3);
+            M1 x12 = mul(sqr_n(x6, 6), x6);
+            M1 x15 = mul(sqr_n(x12, 3), x3);
+            M1 x30 = mul(sqr_n(x15, 15), x15);
+            M1 x32 = mul(sqr_n(x30, 2), x2);
+            M1 t = mul(sqr_n(x32, 32), a);
+            t = mul(sqr_n(t, 128), x32);
+            t = mul(sqr_n(t, 32), x32);
+            t = mul(sqr_n(t, 30), x30);
+            t = mul(sqr_n(t, 2), a);
+            return t;
+        } else {
+            M1 tab[16];
+            tab[0] = one();
+            tab[1] = a;
 #pragma unroll 1
-        for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
-        uint32_t e[N];
+            for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+            uint32_t e[N];
 #pragma unroll
-        for (int i = 0; i < N; i++) e[i] = C::P[i];
-        e[0] -= 2;   // p is odd and its low word is >= 2 for all three curves
-        M1 r = one();
+            for (int i = 0; i < N; i++) e[i] = C::P[i];
+            e[0] -= 2;   // p is odd and its low word is >= 2
+            M1 r = one();
 #pragma unroll 1
-        for (int i = 8 * N - 1; i >= 0; i--) {
-            uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 0xF;
-            r = sqr(sqr(sqr(sqr(r))));
-            if (nib) r = mul(r, tab[nib]);
+            for (int i = 8 * N - 1; i >= 0; i--) {
+                uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 0xF;
+                r = sqr(sqr(sqr(sqr(r))));
+                if (nib) r = mul(r, tab[nib]);
+            }
+            return r;
         }
-        return r;
     }
 };
 

@@ -26,6 +26,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
 
@@ -51,7 +53,12 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.nseg = p.nb / p.seg;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    p.tile = (size_t)1 << 19;
+    int tile_log2 = 19;                                   // terms per counting-sort tile (tuning knob)
+    if (const char* e = getenv("ECGPU_MSM_TILE_LOG2")) {
+        int v = atoi(e);
+        if (v >= 12 && v <= 24) tile_log2 = v;
+    }
+    p.tile = (size_t)1 << tile_log2;
     p.ntiles = (n + p.tile - 1) / p.tile;
     if (p.ntiles == 0) p.ntiles = 1;
     p.off_points = o;  o = align(o + n * 2 * N * 4);

@@ -4,6 +4,8 @@
 
 #include <stdint.h>
 
+#include "ecgpu_field_consts.h"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define ECGPU_HD __host__ __device__ __forceinline__
@@ -19,9 +21,9 @@ enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
-    REPR_SAT_MONT = 0,   // saturated 32-bit limbs, Montgomery form, fully reduced (p384)
+    REPR_SAT_MONT = 0,   // saturated 32-bit limbs, Montgomery form, fully reduced (first version; kept for A/B runs)
     REPR_U29_K256 = 1,   // 9 x 29-bit limbs, plain residues, lazily reduced, 2^261 folding (k256)
-    REPR_U28_MONT = 2    // 10 x 28-bit limbs, Montgomery form R = 2^280, lazily reduced (p256)
+    REPR_U28_MONT = 2    // unsaturated limbs, Montgomery form, lazily reduced: 10 x 28 bit (p256), 15 x 27 bit (p384)
 };
 
 template <int N>
@@ -153,6 +155,7 @@ struct K256Params {
     ECGPU_CONST int N = 8;            // 32-bit words per canonical field element / scalar
     ECGPU_CONST int NL = 9;           // limbs held in registers
     ECGPU_CONST int REPR = REPR_U29_K256;
+    using UC = consts::P256U;         // (unused for k256; keeps the field template well-formed)
     ECGPU_CONST bool A_IS_ZERO = true;
     ECGPU_CONST bool MONTGOMERY = false;
     // p = 2^256 - 0x1000003D1                      k256/src/arithmetic/field.rs:41-42
@@ -174,6 +177,7 @@ struct P256Params {
     ECGPU_CONST int N = 8;
     ECGPU_CONST int NL = 10;
     ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::P256U;
     ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p256/src/arithmetic.rs:44
     ECGPU_CONST bool MONTGOMERY = true;
     // p = 2^256 - 2^224 + 2^192 + 2^96 - 1         p256/src/arithmetic/field.rs:35
@@ -201,8 +205,9 @@ struct P256Params {
 struct P384Params {
     ECGPU_CONST int ID = CURVE_P384;
     ECGPU_CONST int N = 12;
-    ECGPU_CONST int NL = 12;
-    ECGPU_CONST int REPR = REPR_SAT_MONT;
+    ECGPU_CONST int NL = 15;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::P384U;
     ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p384/src/arithmetic.rs:44
     ECGPU_CONST bool MONTGOMERY = true;
     // p = 2^384 - 2^128 - 2^96 + 2^32 - 1          p384/src/arithmetic/field.rs:34

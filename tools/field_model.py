@@ -162,6 +162,44 @@ def p256_norm(a):
 
 
 # ------------------------------------------------------------------------------------------------
+# p384, 15 x 27, Montgomery R = 2^405 (same algorithm as p256, generic in NL / B)
+# ------------------------------------------------------------------------------------------------
+Q_P = 2 ** 384 - 2 ** 128 - 2 ** 96 + 2 ** 32 - 1
+Q_NL, Q_B = 15, 27
+Q_MASK = (1 << Q_B) - 1
+Q_R = 1 << (Q_NL * Q_B)
+Q_LIMBS = to_limbs(Q_P, Q_NL, Q_B)
+assert Q_LIMBS[0] == Q_MASK                      # p = -1 mod 2^27  =>  p' = 1
+Q_LB = (1 << 27) + (1 << 18)
+Q_TOP1 = 128                                     # top limb (bits 378..) of a value < 2p
+
+
+def umont_mul(a, b, nl, bits, plimbs):
+    """generic unsaturated Montgomery multiplication (p = -1 mod 2^bits), every accumulator checked"""
+    mask = (1 << bits) - 1
+    c = [0] * (2 * nl + 1)
+    for i in range(nl):
+        for j in range(nl):
+            c[i + j] = chk64(c[i + j] + chk32(a[i]) * chk32(b[j]))
+    for i in range(nl):
+        u = c[i] & mask
+        c[i + 1] = chk64(c[i + 1] + (c[i] >> bits) + u * (plimbs[1] + 1))
+        for j in range(2, nl):
+            if plimbs[j]:
+                c[i + j] = chk64(c[i + j] + u * plimbs[j])
+    r = [0] * nl
+    carry = 0
+    for k in range(nl):
+        v = chk64(c[nl + k] + carry)
+        if k < nl - 1:
+            r[k] = v & mask
+            carry = v >> bits
+        else:
+            r[k] = chk32(v)
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
 # subtraction constants: a multiple of p whose limbs all dominate a magnitude-M element
 # ------------------------------------------------------------------------------------------------
 def sub_constant(p, nl, b, m, lb, top_bound):
@@ -207,6 +245,26 @@ def selftest(trials=300, seed=1):
         r = p256_mont_mul(a, b)
         assert from_limbs(r, P_B) % P_P == from_limbs(a, P_B) * from_limbs(b, P_B) * rinv % P_P
         assert from_limbs(r, P_B) < 2 * P_P
+    # p384: limb-magnitude product limit 60, single magnitudes <= 28
+    qinv = pow(Q_R, -1, Q_P)
+    for ma, mb in ((28, 2), (2, 28), (7, 8), (1, 1), (10, 6), (60, 1) if False else (20, 3)):
+        a = [ma * Q_LB - 1] * 14 + [Q_TOP1 * ma - 1]
+        b = [mb * Q_LB - 1] * 14 + [Q_TOP1 * mb - 1]
+        r = umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
+        assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
+        assert from_limbs(r, Q_B) < 2 * Q_P and all(x < (1 << 27) for x in r[:14]) and r[14] < Q_TOP1
+    for _ in range(trials // 3):
+        ma, mb = rng.choice([(1, 1), (7, 8), (28, 2), (4, 15)])
+        a = [rng.randrange(ma * Q_LB) for _ in range(14)] + [rng.randrange(Q_TOP1 * ma)]
+        b = [rng.randrange(mb * Q_LB) for _ in range(14)] + [rng.randrange(Q_TOP1 * mb)]
+        r = umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
+        assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
+        assert from_limbs(r, Q_B) < 2 * Q_P
+    # the generic routine agrees with the p256-specific model
+    for _ in range(20):
+        a = [rng.randrange(P_LB) for _ in range(9)] + [rng.randrange(32)]
+        b = [rng.randrange(P_LB) for _ in range(9)] + [rng.randrange(32)]
+        assert umont_mul(a, b, P_NL, P_B, P_LIMBS) == p256_mont_mul(a, b)
     for m in range(1, 8):
         limbs, k = sub_constant(K_P, 9, 29, m, K_LB, K_LB)
         assert all(m * K_LB <= x < (m + 1) * K_LB + (1 << 29) for x in limbs), (m, [hex(x) for x in limbs])
