@@ -126,7 +126,7 @@ int ensure_table(ecgpu_ctx* ctx) {
         t.d = nullptr;
     }
     const int bits = 32 * N;
-    const int nwin = signed_window_count(bits, w);
+    const int nwin = signed_window_count(bits - 1, w);       // scalars are folded to bits - 1 bits (fold_scalar)
     const size_t half = (size_t)1 << (w - 1);
     const size_t entries = half * nwin;
     int rc;

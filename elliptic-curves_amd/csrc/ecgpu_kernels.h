@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
 // ---- fixed base: out[i] = k[i] * G -----------------------------------------------------------------
 // Drop-in for `mul_by_generator` (k256 mul.rs:180-197; primeorder basepoint.rs:82-99).  The reference
 // walks 65 signed nibbles over a 33x8 projective table with full additions; here each lane walks
-// nwin = bits/W + 1 signed W-bit windows over the affine table with complete *mixed* additions
+// nwin = (bits-1)/W + 1 signed W-bit windows (scalars folded to bits-1 bits) over the affine table with complete *mixed* additions
 // (RCB Alg 8 / Alg 5), so there are no doublings and no exceptional cases at all.  The sign of a digit
 // is folded into the addition formula (no separate negation).
 template <class C>
@@ -253,6 +253,9 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
+    // scalar folding: k G = -((n - k) G); a folded scalar has 32 N - 1 bits, i.e. nwin = (32 N - 1) / w + 1
+    // windows (exactly 16 at w = 16) and the top one never carries out
+    const bool flip = fold_scalar<N>(k, C::ORDER);
     Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
     uint32_t carry = 0;
@@ -263,7 +266,7 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             Affine<C> q = load_packed_affine<C>(table + ((size_t)j * half + (mag - 1)) * (2 * N));
-            acc = G::add_mixed(acc, q, b, d < 0);
+            acc = G::add_mixed(acc, q, b, (d < 0) != flip);
         }
     }
     store_proj<C>(proj_out, i, acc);

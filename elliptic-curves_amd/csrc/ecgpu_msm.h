@@ -20,7 +20,7 @@
 //   combine     Horner over the windows (c doublings each)
 //
 // Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
-// digits [nwin][n] u16, tile histograms [nwin][ntiles][NB] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB]
+// digits [nwin][n] u16 + validity bits [nwin][n/64] u64, tile histograms [nwin][ntiles][NB] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB]
 // u32, buckets [nwin][NB][3 NS], segment sums, window sums.
 #pragma once
 
@@ -47,13 +47,13 @@ MsmPlan msm_plan(size_t n, int force_c) {
     constexpr int N = C::N, NS = Field<C>::NS;
     MsmPlan p;
     p.c = force_c ? force_c : msm_window_bits(n);
-    p.nwin = signed_window_count(32 * N, p.c);
+    p.nwin = signed_window_count(32 * N - 1, p.c);          // scalars are folded to 32 N - 1 bits
     p.nb = (size_t)1 << (p.c - 1);
     p.seg = p.nb < 32 ? (int)p.nb : 32;
     p.nseg = p.nb / p.seg;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
-    int tile_log2 = 19;                                   // terms per counting-sort tile (tuning knob)
+    int tile_log2 = 18;                                   // terms per counting-sort tile (tuning knob)
     if (const char* e = getenv("ECGPU_MSM_TILE_LOG2")) {
         int v = atoi(e);
         if (v >= 12 && v <= 24) tile_log2 = v;
@@ -63,6 +63,7 @@ MsmPlan msm_plan(size_t n, int force_c) {
     if (p.ntiles == 0) p.ntiles = 1;
     p.off_points = o;  o = align(o + n * 2 * N * 4);
     p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
+    p.off_vmask = o;   o = align(o + (size_t)p.nwin * ((n + 63) / 64) * 8);
     p.off_tilehist = o; o = align(o + (size_t)p.nwin * p.ntiles * p.nb * 4);
     p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
     p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
@@ -75,44 +76,49 @@ MsmPlan msm_plan(size_t n, int force_c) {
 }
 
 // ---- prepare ----------------------------------------------------------------------------------------------
-constexpr uint16_t MSM_NO_DIGIT = 0xFFFFu;   // (bucket 0x7FFF, negative) cannot occur: negative digits stop at 2^(c-1) - 1
-
+// A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether term i has a digit in
+// window w at all (non-zero digit, finite point) is one bit of vmask[w][i / 64], written with a wave ballot.
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, int c, int nwin, uint32_t* __restrict__ pts,
-              uint16_t* __restrict__ digits, int* status) {
+              uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status) {
     using G = Group<C>;
     constexpr int N = C::N;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
+    const bool flip = fold_scalar<N>(k, C::ORDER);                  // k P = (n - k)(-P)
     Fe<C::NL> b = G::curve_b();
     Affine<C> a;
     bool finite = load_affine<C>(&a, points_xy, points_inf, i, b, status);
     if (finite) store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
     uint32_t carry = 0;
+    const size_t nmask = (n + 63) / 64;
 #pragma unroll 1
     for (int w = 0; w < nwin; w++) {
-        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i);
-        digits[(size_t)w * n + i] = (finite && d.nonzero) ? (uint16_t)(d.bucket | (d.neg << 15)) : MSM_NO_DIGIT;
+        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i, flip);
+        digits[(size_t)w * n + i] = (uint16_t)(d.bucket | (d.neg << 15));
+        unsigned long long m = __ballot(finite && d.nonzero);          // lanes past n have already returned
+        if ((threadIdx.x & 63) == 0) vmask[(size_t)w * nmask + (i >> 6)] = m;
     }
 }
 
 // ---- counting sort ---------------------------------------------------------------------------------------------
 // grid (ntiles, nwin), 1024 lanes, dynamic LDS = nb * 4 bytes: tile_hist[w][tile][b] = #terms of the tile in bucket b
 static __global__ void __launch_bounds__(1024)
-k_msm_hist(const uint16_t* __restrict__ digits, size_t n, size_t tile, size_t nb, uint32_t* __restrict__ tile_hist) {
+k_msm_hist(const uint16_t* __restrict__ digits, const unsigned long long* __restrict__ vmask, size_t n, size_t tile,
+           size_t nb, uint32_t* __restrict__ tile_hist) {
     extern __shared__ uint32_t lds_hist[];
     const size_t w = blockIdx.y, t = blockIdx.x;
     for (size_t b = threadIdx.x; b < nb; b += blockDim.x) lds_hist[b] = 0;
     __syncthreads();
     size_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
     const uint16_t* dw = digits + w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint16_t d = dw[i];
-        if (d != MSM_NO_DIGIT) atomicAdd(&lds_hist[d & 0x7FFFu], 1u);
+    const unsigned long long* vw = vmask + w * ((n + 63) / 64);
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {       // tiles start at multiples of 64
+        if ((vw[i >> 6] >> (i & 63)) & 1) atomicAdd(&lds_hist[dw[i] & 0x7FFFu], 1u);
     }
     __syncthreads();
     uint32_t* out = tile_hist + (w * gridDim.x + t) * nb;
@@ -163,8 +169,9 @@ static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __rest
 
 // grid (ntiles, nwin), 1024 lanes, dynamic LDS = nb * 4: scatter the tile's terms to their bucket runs
 static __global__ void __launch_bounds__(1024)
-k_msm_scatter(const uint16_t* __restrict__ digits, size_t n, size_t tile, size_t nb, const uint32_t* __restrict__ tile_hist,
-              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+k_msm_scatter(const uint16_t* __restrict__ digits, const unsigned long long* __restrict__ vmask, size_t n, size_t tile,
+              size_t nb, const uint32_t* __restrict__ tile_hist, const uint32_t* __restrict__ offsets,
+              uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t lds_cursor[];
     const size_t w = blockIdx.y, t = blockIdx.x;
     const uint32_t* th = tile_hist + (w * gridDim.x + t) * nb;
@@ -174,9 +181,10 @@ k_msm_scatter(const uint16_t* __restrict__ digits, size_t n, size_t tile, size_t
     size_t lo = t * tile, hi = lo + tile < n ? lo + tile : n;
     const uint16_t* dw = digits + w * n;
     uint32_t* sw = sorted + w * n;
+    const unsigned long long* vw = vmask + w * ((n + 63) / 64);
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint16_t d = dw[i];
-        if (d != MSM_NO_DIGIT) {
+        if ((vw[i >> 6] >> (i & 63)) & 1) {
+            uint16_t d = dw[i];
             uint32_t pos = atomicAdd(&lds_cursor[d & 0x7FFFu], 1u);
             sw[pos] = (uint32_t)i | ((uint32_t)(d >> 15) << 31);
         }
@@ -282,11 +290,17 @@ template <class C>
 __global__ void k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    // Everything here is wave-uniform, and left alone the compiler moves the whole 240-doubling chain to the
+    // scalar ALU (no 32x32+64 multiply-add there: 10x the instructions).  An opaque zero in a VGPR makes the
+    // addresses, hence the data, formally divergent, which keeps the arithmetic on the vector ALU.
+    uint32_t vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    const uint32_t* vw = wins + vzero;
     Fe<C::NL> b = G::curve_b();
-    Proj<C> acc = load_proj<C>(wins, nwin - 1);
+    Proj<C> acc = load_proj<C>(vw, nwin - 1);
     for (int w = nwin - 2; w >= 0; w--) {
         for (int s = 0; s < c; s++) acc = G::dbl(acc, b);
-        acc = G::add(acc, load_proj<C>(wins, w), b);
+        acc = G::add(acc, load_proj<C>(vw, w), b);
     }
     store_proj<C>(out, 0, acc);
 }
@@ -310,6 +324,7 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     uint8_t* ws = (uint8_t*)workspace;
     uint32_t* pts = (uint32_t*)(ws + p.off_points);
     uint16_t* digits = (uint16_t*)(ws + p.off_digits);
+    unsigned long long* vmask = (unsigned long long*)(ws + p.off_vmask);
     uint32_t* tile_hist = (uint32_t*)(ws + p.off_tilehist);
     uint32_t* sorted = (uint32_t*)(ws + p.off_sorted);
     uint32_t* counts = (uint32_t*)(ws + p.off_count);
@@ -326,16 +341,16 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
         lds_attr_set = true;
     }
     hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.c, p.nwin, pts,
-                       digits, d_status);
+                       digits, vmask, d_status);
     hipLaunchKernelGGL(k_msm_hist, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                       (const uint16_t*)digits, n, p.tile, p.nb, tile_hist);
+                       (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb, tile_hist);
     size_t nbk0 = p.nb * p.nwin;
     hipLaunchKernelGGL(k_msm_tile_scan, dim3((unsigned)((nbk0 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, tile_hist,
                        p.ntiles, p.nb, p.nwin, counts);
     hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
     hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                       (const uint16_t*)digits, n, p.tile, p.nb, (const uint32_t*)tile_hist, (const uint32_t*)offsets,
-                       sorted);
+                       (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb,
+                       (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
     (void)hipEventRecord(ev_sorted, stream);
     size_t nbk = p.nb * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
@@ -344,7 +359,7 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(32 * C::N, p.c), segs);
+                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(32 * C::N - 1, p.c), segs);
     hipLaunchKernelGGL(k_msm_reduce_windows<C>, dim3(p.nwin), dim3(BLOCK), 0, stream, (const uint32_t*)segs, p.nseg, wins);
     hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
 }

@@ -44,14 +44,30 @@ ECGPU_HD int signed_window_step(uint32_t raw, int w, uint32_t* carry) {
 ECGPU_HD int signed_window_count(int bits, int w) { return bits / w + 1; }
 
 // ---- Pippenger bucket keys -----------------------------------------------------------------------
-// A `bits`-bit scalar is cut into nwin = bits/c + 1 windows.  Windows 0..nwin-2 carry signed c-bit
+// A folded scalar of kbits = bits - 1 significant bits is cut into nwin = kbits/c + 1 windows.  Windows 0..nwin-2 carry signed c-bit
 // digits d in (-2^(c-1), 2^(c-1)], bucket = |d| - 1, weight = bucket + 1.  The last window holds the
-// remaining r = bits % c bits plus the carry as an UNSIGNED digit in [0, 2^r].  It has only 2^r distinct
-// values, so without care all n terms of that window would pile into 2^r buckets (for 256-bit scalars
-// and c = 16: half of all terms into ONE bucket).  Its terms are therefore spread over all 2^(c-1)
+// remaining r = kbits % c bits plus the carry as an UNSIGNED digit in [0, 2^r].  It has only 2^r distinct
+// values, so without care all n terms of that window would pile into 2^r buckets (before folding, 256-bit
+// scalars at c = 16 put half of all terms into ONE bucket: measured 85 s instead of 30 ms).  Its terms are therefore spread over all 2^(c-1)
 // buckets with the low `shift = c-1-r` bits of the term index as a sub-bucket:
 //     bucket = ((d - 1) << shift) | (index mod 2^shift),   weight(bucket) = (bucket >> shift) + 1.
-ECGPU_HD int msm_top_shift(int bits, int c) { return c - 1 - bits % c; }
+//
+// Scalar folding: a scalar with its top bit set is replaced by n - k (< 2^(bits-1) for all three curves,
+// whose orders exceed 2^(bits-1)) and the sign of every digit is flipped: k P = (n - k)(-P).  The digits
+// then cover only kbits = bits - 1 bits, so for c = 16 there are exactly 16 full windows instead of 16 plus
+// a carry-only 17th.
+ECGPU_HD int msm_top_shift(int kbits, int c) { return c - 1 - kbits % c; }
+
+// k <- n - k if the top bit of k is set; returns whether it did.  (k must be < n.)
+template <int NL>
+ECGPU_HD bool fold_scalar(uint32_t* k, const uint32_t* order) {
+    bool high = (k[NL - 1] >> 31) != 0;
+    uint32_t d[NL];
+    mp_sub<NL>(d, order, k);
+#pragma unroll
+    for (int i = 0; i < NL; i++) k[i] = high ? d[i] : k[i];
+    return high;
+}
 
 struct MsmDigit {
     uint32_t bucket;
@@ -59,25 +75,27 @@ struct MsmDigit {
     bool nonzero;
 };
 
+// k: folded scalar (< 2^(32 NL - 1)), flip: its fold flag.  The returned sign already includes the flip.
 template <int NL>
-ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t* carry, uint32_t term_index) {
+ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t* carry, uint32_t term_index, bool flip) {
     MsmDigit r;
     r.bucket = 0; r.neg = 0; r.nonzero = false;
     if (w < nwin - 1) {
         int d = signed_window_step(get_bits<NL>(k, w * c, c), c, carry);
         if (d != 0) {
             r.nonzero = true;
-            r.neg = d < 0;
+            r.neg = (d < 0) != flip;
             r.bucket = (uint32_t)(d < 0 ? -d : d) - 1;
         }
     } else {
-        const int bits = 32 * NL;
-        const int rem = bits % c;
+        const int kbits = 32 * NL - 1;
+        const int rem = kbits % c;
         const int shift = c - 1 - rem;
         uint32_t d = (rem ? get_bits<NL>(k, w * c, rem) : 0u) + *carry;
         *carry = 0;
         if (d != 0) {
             r.nonzero = true;
+            r.neg = flip;
             r.bucket = ((d - 1) << shift) | (term_index & ((1u << shift) - 1));
         }
     }

@@ -144,7 +144,7 @@ void build_table(BaseTable<C>& t, int w) {
     using F = Field<C>;
     auto b = G::curve_b();
     t.w = w;
-    t.nwin = signed_window_count(32 * C::N, w);
+    t.nwin = signed_window_count(32 * C::N - 1, w);
     size_t half = (size_t)1 << (w - 1);
     t.e.resize(half * t.nwin);
     Affine<C> g;
@@ -183,10 +183,13 @@ Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e) {
 
 // k_fixed_base
 template <class C>
-Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k) {
+Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k_in) {
     using G = Group<C>;
     using F = Field<C>;
     auto b = G::curve_b();
+    uint32_t k[C::N];
+    for (int i = 0; i < C::N; i++) k[i] = k_in[i];
+    const bool flip = fold_scalar<C::N>(k, C::ORDER);
     Proj<C> acc = G::identity();
     uint32_t carry = 0;
     size_t half = (size_t)1 << (t.w - 1);
@@ -195,7 +198,7 @@ Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k) {
         if (d != 0) {
             uint32_t mag = (uint32_t)(d < 0 ? -d : d);
             Affine<C> q = t.e[j * half + (mag - 1)];
-            acc = G::add_mixed(acc, q, b, d < 0);
+            acc = G::add_mixed(acc, q, b, (d < 0) != flip);
         }
     }
     return acc;
@@ -307,14 +310,14 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
     using F = Field<C>;
     constexpr int N = C::N;
     auto b = G::curve_b();
-    int nwin = signed_window_count(32 * N, c);
+    int nwin = signed_window_count(32 * N - 1, c);
     size_t nb = (size_t)1 << (c - 1);
     int seg = nb < 32 ? (int)nb : 32;
     size_t nseg = nb / seg;
     std::vector<Affine<C>> pts(n);
     std::vector<uint32_t> ranks((size_t)nwin * n), sorted((size_t)nwin * n), counts((size_t)nwin * nb, 0),
         offsets((size_t)nwin * nb);
-    std::vector<uint8_t> finite(n, 0);
+    std::vector<uint8_t> finite(n, 0), flips(n, 0);
     std::vector<std::vector<uint32_t>> ks(n, std::vector<uint32_t>(N));
     for (size_t i = 0; i < n; i++) {                                    // prepare
         if (!load_scalar<C>(ks[i].data(), scalars + i * 4 * N)) return -2;
@@ -326,9 +329,10 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
             F::pack(w, G::m(pts[i].y)); pts[i].y = F::unpack(w).e;
         }
         finite[i] = 1;
+        flips[i] = fold_scalar<N>(ks[i].data(), C::ORDER);
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
-            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i);
+            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i, flips[i]);
             if (d.nonzero) ranks[(size_t)w * n + i] = counts[(size_t)w * nb + d.bucket]++;
         }
     }
@@ -340,7 +344,7 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         if (!finite[i]) continue;
         uint32_t carry = 0;
         for (int w = 0; w < nwin; w++) {
-            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i);
+            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i, flips[i]);
             if (d.nonzero) {
                 uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * n + i];
                 sorted[(size_t)w * n + pos] = (uint32_t)i | (d.neg << 31);
@@ -364,7 +368,7 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
         for (size_t s = 0; s < nseg; s++) {
             Proj<C> running = G::identity(), local = G::identity();
             size_t base = s * seg;
-            const int sh = w == nwin - 1 ? msm_top_shift(32 * N, c) : 0;
+            const int sh = w == nwin - 1 ? msm_top_shift(32 * N - 1, c) : 0;
             for (int j = seg - 1; j >= 0; j--) {
                 running = G::add(running, buckets[(size_t)w * nb + base + j], b);
                 if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);

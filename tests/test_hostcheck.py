@@ -138,7 +138,11 @@ def test_table_entry_rule(curve):
 def _scalars(c, rng, n, edge=True):
     ks = []
     if edge:
-        ks = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, 2 ** (8 * c.L - 1) % c.n, int("80" * c.L, 16) % c.n]
+        half = 1 << (8 * c.L - 1)
+        ks = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, half % c.n, int("80" * c.L, 16) % c.n,
+              # around the fold threshold 2^(bits-1), and folded values with an all-ones top window
+              half - 1, half + 1, c.n - half, c.n - half + 1, c.n - (half - (1 << (8 * c.L - 17))) - 1,
+              c.n - (half - 1), (c.n + 1) // 2]
     ks += [rng.randrange(c.n) for _ in range(n - len(ks))]
     return ks
 
