@@ -187,7 +187,7 @@ int mul_var_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, 
     int rc;
     size_t tstride = var_base_slots<C>(n);
     if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * C::NL * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
@@ -435,7 +435,7 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
         if (n == 0) return (int)ECGPU_OK;
         size_t tstride = var_base_slots<C>(n);
         if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->vtab, tstride * 8 * 3 * C::NL * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
         if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
         const Table& t = ctx->table[C::ID];
         uint32_t* pa = (uint32_t*)ctx->proj.p;

@@ -556,6 +556,14 @@ struct Field {
         else if constexpr (REPR == REPR_U29_K256) return wrap<1, 1>(k_norm(a.e));
         else return wrap<1, VA>(p_norm(a.e));
     }
+    // norm(a) only if its limb magnitude exceeds LIM (compile-time decision); SQLIM is the largest limb
+    // magnitude that may still be squared
+    ECGPU_CONST int SQLIM = MAXPROD >= 49 ? 7 : (MAXPROD >= 16 ? 4 : (MAXPROD >= 4 ? 2 : 1));
+    template <int LIM, int LA, int VA>
+    static ECGPU_HD auto fit(const Mag<C, LA, VA>& a) {
+        if constexpr (LA > LIM) return norm(a);
+        else return a;
+    }
     // a * K for a small compile-time constant, result magnitude (1, 1); k256 only (b3 = 21 and friends)
     template <uint32_t K, int LA, int VA>
     static ECGPU_HD M1 mul_small(const Mag<C, LA, VA>& a) {

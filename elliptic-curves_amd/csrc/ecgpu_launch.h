@@ -35,6 +35,7 @@ template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const
 
 // ---- group "var": variable-base kernel ----
 template <class C> size_t var_base_slots(size_t n);     // table slots (threads) the launch will use
+template <class C> size_t var_base_tab_words();         // 32-bit words of table scratch per slot
 template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf,
                                         size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
 

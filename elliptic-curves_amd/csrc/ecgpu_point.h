@@ -18,6 +18,8 @@
 // Coordinates of stored points (Proj / Affine) always have magnitude (1, 1).
 #pragma once
 
+#include <type_traits>
+
 #include "ecgpu_field.h"
 
 namespace ecgpu {
@@ -31,6 +33,21 @@ template <class C>
 struct Proj {
     Fe<C::NL> x, y, z;
 };
+
+// Jacobian coordinates (x = X/Z^2, y = Y/Z^3) for the variable-base ladder, where the accumulator is provably
+// never the identity and never +-(the table entry) before the last digit (see ecgpu_varmul.h); the identity is
+// NOT representable.  Coordinates have limb magnitude 1 and value magnitude <= Group::JV.
+template <class C>
+struct Jac {
+    Fe<C::NL> x, y, z;
+};
+template <class C>
+struct JacTab {  // table entry: the point plus Z^2 and Z^3, which every addition with it needs
+    Fe<C::NL> x, y, z, zz, zzz;
+};
+
+template <class C, int L, int V>
+std::integral_constant<int, V> magv(const Mag<C, L, V>&);
 
 template <class C>
 struct Group {
@@ -222,6 +239,125 @@ struct Group {
         o.x = F::mul2(yy_m, xy2, F::neg(bxz6), yz2).e;      // 5*2 + 4*2 = 18
         o.y = F::mul2(yy_p, yy_m, xx3_m_zz3, bxz6).e;       // 4*5 + 1*3 = 23
         o.z = F::mul(yz2, F::dbl(F::dbl(yy))).e;            // 2*4 = 8
+        return o;
+    }
+
+    // ---- Jacobian ladder arithmetic (incomplete formulas; preconditions in ecgpu_varmul.h) -----------
+    // The reference's variable-base path uses the complete projective formulas throughout
+    // (primeorder/src/projective.rs:532-557); here the 4 doublings per digit — 80% of the work — use the
+    // cheaper Jacobian doubling (a = -3: 3M + 5S, a = 0: 2M + 5S) and only the final addition, the one place
+    // an exceptional case can occur, is the complete one.
+    // value magnitudes: ladder outputs (and so table entries) <= JTV, accumulator <= JV (a negated table entry)
+    ECGPU_CONST int JTV = C::REPR == REPR_U28_MONT ? 10 : 1;
+    ECGPU_CONST int JV = C::REPR == REPR_U28_MONT ? JTV + 1 : 1;
+    using J = Jac<C>;
+    using JT = JacTab<C>;
+    static ECGPU_HD Mag<C, 1, JV> mj(const E& e) { return F::template wrap<1, JV>(e); }
+    static ECGPU_HD Mag<C, 1, JTV> mt(const E& e) { return F::template wrap<1, JTV>(e); }
+    template <int L, int V>
+    static ECGPU_HD E jstore(const Mag<C, L, V>& a) {
+        static_assert(L == 1 && V <= JTV, "Jacobian coordinate magnitude");
+        return a.e;
+    }
+    static ECGPU_HD J jac_from_affine(const A& a) {
+        J r;
+        r.x = a.x;
+        r.y = a.y;
+        r.z = F::one().e;
+        return r;
+    }
+    static ECGPU_HD JT jac_tab(const J& p) {
+        JT t;
+        auto Z = mj(p.z);
+        auto zz = F::sqr(Z);
+        t.x = p.x;
+        t.y = p.y;
+        t.z = p.z;
+        t.zz = zz.e;
+        t.zzz = F::mul(Z, zz).e;
+        return t;
+    }
+    // value-magnitude-1 copy of a Jacobian coordinate (a no-op where JV = 1)
+    static ECGPU_HD E j_unit(const E& c) {
+        if constexpr (JV == 1) return c;
+        else return F::mul(mj(c), F::one()).e;
+    }
+    static ECGPU_HD J jac_from_tab(const JT& t, bool negate) {
+        auto yn = F::norm(F::neg(mt(t.y)));
+        static_assert(decltype(magv(yn))::value <= JV, "negated table coordinate");
+        J r;
+        r.x = t.x;
+        r.y = F::sel(negate, yn, mt(t.y)).e;
+        r.z = t.z;
+        return r;
+    }
+    // (X : Y : Z) Jacobian -> (X Z : Y : Z^3) homogeneous
+    static ECGPU_HD P jac_to_proj(const J& p) {
+        auto X = mj(p.x), Z = mj(p.z);
+        P r;
+        r.x = F::mul(X, Z).e;
+        r.y = j_unit(p.y);
+        r.z = F::mul(Z, F::sqr(Z)).e;
+        return r;
+    }
+    static ECGPU_HD P jac_tab_to_proj(const JT& t) {
+        P r;
+        r.x = F::mul(mt(t.x), mt(t.z)).e;
+        r.y = j_unit(t.y);
+        r.z = t.zzz;
+        return r;
+    }
+    // dbl-2001-b (a = -3) / dbl-2009-l (a = 0); valid for every finite point of odd order
+    static ECGPU_HD J jac_dbl(const J& p) {
+        auto X = mj(p.x), Y = mj(p.y), Z = mj(p.z);
+        J o;
+        if constexpr (C::A_IS_ZERO) {
+            auto aa = F::sqr(X);
+            auto bb = F::sqr(Y);
+            auto cc = F::sqr(bb);
+            auto d = F::dbl(F::norm(F::sub(F::sqr(F::add(X, bb)), F::add(aa, cc))));     // 2
+            auto e3 = F::template mul_small<3>(aa);
+            auto X3 = F::norm(F::sub(F::sqr(e3), F::dbl(d)));                             // 6 -> 1
+            o.x = jstore(X3);
+            o.y = jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
+            o.z = jstore(F::mul(F::dbl(Y), Z));
+        } else {
+            auto delta = F::sqr(Z);
+            auto gamma = F::sqr(Y);
+            auto beta = F::mul(X, gamma);
+            auto alpha = F::mul(F::sub(X, delta), F::add(X, delta));                      // 3 * 2
+            auto alpha3 = F::add(F::dbl(alpha), alpha);                                   // 3
+            auto beta4 = F::dbl(F::dbl(beta));                                            // 4
+            auto X3 = F::norm(F::sub(F::sqr(alpha3), F::dbl(beta4)));                     // 10 -> 1
+            auto gg8 = F::dbl(F::dbl(F::dbl(F::sqr(gamma))));                             // 8
+            o.x = jstore(X3);
+            o.y = jstore(F::norm(F::sub(F::mul(alpha3, F::sub(beta4, X3)), gg8)));        // 3 * 6; 10 -> 1
+            o.z = jstore(F::norm(F::sub(F::sqr(F::add(Y, Z)), F::add(gamma, delta))));    // 4 -> 1
+        }
+        return o;
+    }
+    // add-1998-cmo-2 with the table entry's Z^2, Z^3 cached (10M + 3S + one fused pair).  Requires p != +-q and
+    // both finite.  negq adds -q.
+    static ECGPU_HD J jac_add(const J& p, const JT& q, bool negq) {
+        auto X1 = mj(p.x), Y1 = mj(p.y), Z1 = mj(p.z);
+        auto X2 = mt(q.x), Z2 = mt(q.z);
+        auto ZZ2 = m(q.zz), ZZZ2 = m(q.zzz);
+        auto Y2 = F::sel(negq, F::neg(mt(q.y)), mt(q.y));
+        auto zz1 = F::sqr(Z1);
+        auto U1 = F::mul(X1, ZZ2);
+        auto U2 = F::mul(X2, zz1);
+        auto S1 = F::mul(Y1, ZZZ2);
+        auto S2 = F::mul(Y2, F::mul(Z1, zz1));
+        auto H = F::template fit<F::SQLIM>(F::sub(U2, U1));                               // 3
+        auto r = F::template fit<F::SQLIM>(F::sub(S2, S1));                               // 3
+        auto HH = F::sqr(H);
+        auto HHH = F::mul(H, HH);
+        auto V = F::mul(U1, HH);
+        auto X3 = F::norm(F::sub(F::sqr(r), F::add(HHH, F::dbl(V))));                     // 5 -> 1
+        J o;
+        o.x = jstore(X3);
+        o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(S1), HHH));                         // 3*3 + 2*1
+        o.z = jstore(F::mul(F::mul(Z1, Z2), H));
         return o;
     }
 

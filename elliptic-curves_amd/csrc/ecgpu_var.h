@@ -2,17 +2,51 @@
 #pragma once
 
 #include "ecgpu_kernels.h"
+#include "ecgpu_varmul.h"
 
 namespace ecgpu {
 
 // ---- variable base: out[i] = k[i] * P[i] -------------------------------------------------------------
-// Drop-in for `ProjectivePoint * Scalar` (primeorder projective.rs:133-137 + lincomb :532-557; k256
-// mul.rs:236-238).  Same structure as the reference: per-point table [P..8P], signed radix-16 digits
-// (bit-identical to Radix16Decomposition via Radix16Msb), 4 doublings + 1 table addition per digit.
-// The 8-entry table lives in HBM scratch, lane-minor, instead of the CPU stack; a negative digit is
-// folded into the addition formula.
+// One lane per scalar multiplication (ecgpu_varmul.h has the algorithm and the reference citations).  The
+// 8-entry table lives in HBM scratch, lane-minor (consecutive lanes touch consecutive words), instead of
+// the CPU stack.
+constexpr int VAR_TAB_ELEMS = 5;   // X, Y, Z, Z^2, Z^3 per entry
+
 template <class C>
-__global__ void __launch_bounds__(BLOCK)
+struct VarTabHbm {
+    // [wave][entry][row][lane]: one wave's rows are 256 contiguous bytes, and every row of an entry is a
+    // compile-time offset from the entry's base, so a whole entry costs one address computation
+    uint32_t* base;     // wave block + lane
+    static constexpr int NL = C::NL;
+    static constexpr int ROWS = VAR_TAB_ELEMS * NL;
+    __device__ void put(int e, const JacTab<C>& t) {
+        uint32_t* row = base + (size_t)e * (ROWS * 64);
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            row[l * 64] = t.x.v[l];
+            row[(NL + l) * 64] = t.y.v[l];
+            row[(2 * NL + l) * 64] = t.z.v[l];
+            row[(3 * NL + l) * 64] = t.zz.v[l];
+            row[(4 * NL + l) * 64] = t.zzz.v[l];
+        }
+    }
+    __device__ JacTab<C> get(int e) const {
+        const uint32_t* row = base + (size_t)e * (ROWS * 64);
+        JacTab<C> t;
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+            t.x.v[l] = row[l * 64];
+            t.y.v[l] = row[(NL + l) * 64];
+            t.z.v[l] = row[(2 * NL + l) * 64];
+            t.zz.v[l] = row[(3 * NL + l) * 64];
+            t.zzz.v[l] = row[(4 * NL + l) * 64];
+        }
+        return t;
+    }
+};
+
+template <class C>
+__global__ void __launch_bounds__(BLOCK, 2)
 k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
            const uint8_t* __restrict__ points_inf, size_t n, uint32_t* __restrict__ tab, size_t tstride,
            uint32_t* __restrict__ proj_out, int* status) {
@@ -20,6 +54,7 @@ k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poin
     constexpr int N = C::N, NL = C::NL;
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // < tstride
     Fe<NL> b = G::curve_b();
+    VarTabHbm<C> io{tab + (slot / 64) * (size_t)(8 * VarTabHbm<C>::ROWS * 64) + (slot % 64)};
     for (size_t i = slot; i < n; i += tstride) {
         uint32_t k[N];
         load_scalar<C>(k, scalars, i, status);
@@ -29,43 +64,7 @@ k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poin
             store_proj<C>(proj_out, i, G::identity());
             continue;
         }
-        // table: e*P for e = 1..8  (LookupTable::new, primeorder/src/tables/lookup.rs:30-38)
-        Proj<C> m = G::from_affine(a);
-#pragma unroll 1
-        for (int e = 0; e < 8; e++) {
-            uint32_t* row = tab + (size_t)e * (3 * NL) * tstride + slot;
-#pragma unroll
-            for (int l = 0; l < NL; l++) {
-                row[(size_t)l * tstride] = m.x.v[l];
-                row[(size_t)(NL + l) * tstride] = m.y.v[l];
-                row[(size_t)(2 * NL + l) * tstride] = m.z.v[l];
-            }
-            if (e < 7) m = G::add_mixed(m, a, b);
-        }
-        Radix16Msb<N> digits;
-        digits.init(k);
-        Proj<C> acc = G::identity();
-#pragma unroll 1
-        for (int di = 8 * N; di >= 0; di--) {
-            if (di != 8 * N) {
-                acc = G::dbl(acc, b); acc = G::dbl(acc, b);
-                acc = G::dbl(acc, b); acc = G::dbl(acc, b);
-            }
-            int d = digits.digit(di);
-            if (d != 0) {
-                uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-                const uint32_t* row = tab + (size_t)(mag - 1) * (3 * NL) * tstride + slot;
-                Proj<C> q;
-#pragma unroll
-                for (int l = 0; l < NL; l++) {
-                    q.x.v[l] = row[(size_t)l * tstride];
-                    q.y.v[l] = row[(size_t)(NL + l) * tstride];
-                    q.z.v[l] = row[(size_t)(2 * NL + l) * tstride];
-                }
-                acc = G::add(acc, q, b, d < 0);
-            }
-        }
-        store_proj<C>(proj_out, i, acc);
+        store_proj<C>(proj_out, i, var_base_mul<C>(a, k, b, io));
     }
 }
 

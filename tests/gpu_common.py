@@ -36,6 +36,19 @@ def edge_scalars(c):
     return ks
 
 
+def ladder_edge_scalars(c):
+    """Scalars that drive the variable-base ladder through its corner cases: accumulator = +-(table operand) at
+    the last digit (n - 2d), leading zero digits, digit -8 runs, carries into the top digit."""
+    ks = list(range(0, 41)) + [c.n - j for j in range(1, 41)]
+    for j in (1, 2, 5, 31, 2 * c.L - 2, 2 * c.L - 1):
+        for e in (-9, -8, -1, 0, 1, 7, 8):
+            ks.append((16 ** j + e) % c.n)
+    for pat in ("88", "08", "80", "f8", "78", "8f", "ff", "f7"):
+        ks.append(int(pat * c.L, 16) % c.n)
+        ks.append(int(pat * (c.L // 2), 16))
+    return ks
+
+
 def scalars_to_int_sum(scalars, L, n_mod):
     """sum of n big-endian L-byte integers mod n_mod, via 32-bit limb column sums (cheap for 2^24 terms)."""
     a = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, L // 4, 4)

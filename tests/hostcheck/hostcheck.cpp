@@ -8,6 +8,7 @@
 
 #include "../../elliptic-curves_amd/csrc/ecgpu_point.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_recode.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
 
 using namespace ecgpu;
 
@@ -204,30 +205,17 @@ Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k_in) {
     return acc;
 }
 
-// k_var_base
+// k_var_base: the shared per-lane body with a stack table
+template <class C>
+struct VarTabLocal {
+    JacTab<C> t[8];
+    void put(int e, const JacTab<C>& v) { t[e] = v; }
+    JacTab<C> get(int e) const { return t[e]; }
+};
 template <class C>
 Proj<C> var_base_one(const Affine<C>& a, const uint32_t* k) {
-    using G = Group<C>;
-    auto b = G::curve_b();
-    Proj<C> tab[8];
-    Proj<C> m = G::from_affine(a);
-    for (int e = 0; e < 8; e++) {
-        tab[e] = m;
-        if (e < 7) m = G::add_mixed(m, a, b);
-    }
-    Radix16Msb<C::N> digits;
-    digits.init(k);
-    Proj<C> acc = G::identity();
-    for (int di = 8 * C::N; di >= 0; di--) {
-        if (di != 8 * C::N) for (int s = 0; s < 4; s++) acc = G::dbl(acc, b);
-        int d = digits.digit(di);
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            Proj<C> q = tab[mag - 1];
-            acc = G::add(acc, q, b, d < 0);
-        }
-    }
-    return acc;
+    VarTabLocal<C> tab;
+    return var_base_mul<C>(a, k, Group<C>::curve_b(), tab);
 }
 
 // k_normalize<.., false> with `nthreads` strided lanes

@@ -6,7 +6,8 @@ import pytest
 
 import oracle_lib
 import pyec
-from gpu_common import CURVES, ecgpu_module, edge_scalars, load_golden, rand_scalars, scalars_to_int_sum
+from gpu_common import (CURVES, ecgpu_module, edge_scalars, ladder_edge_scalars, load_golden, rand_scalars,
+                        scalars_to_int_sum)
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +50,21 @@ def test_golden_group_vectors(eng, curve):
     for i in (0, 1, 19, 20, n - 1):
         o, f = eng.lincomb(c.cid, ks[i], gxy)
         assert bytes(o) == want[2 * c.L * i: 2 * c.L * (i + 1)] and f == 0
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_var_base_ladder_corner_cases(eng, oracle, curve):
+    """Scalars that put the incomplete Jacobian ladder at its limits (ecgpu_varmul.h): accumulator equal to
+    +-(table operand) at the last digit, late start, digit -8 runs, carry into the top digit."""
+    c = pyec.CURVES[curve]
+    ks = ladder_edge_scalars(c)
+    rng = np.random.default_rng(0x1ADDE5 + c.cid)
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    for P in (pyec.G(c), pyec.mul(c, int(rng.integers(2, 2 ** 62)), pyec.G(c))):
+        pxy = pyec.enc_point(c, P)[0] * len(ks)
+        out, inf = eng.mul(c.cid, scal, pxy)
+        want, winf = oracle.batch_mul(c.cid, scal, pxy, None)
+        assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
 
 
 @pytest.mark.parametrize("curve", CURVES)

@@ -185,6 +185,30 @@ def test_var_base_algorithm(oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_var_base_ladder_corner_cases(oracle, curve):
+    """The Jacobian ladder is incomplete by construction; these scalars hit every place the completeness
+    argument in ecgpu_varmul.h is needed (acc = +-operand at digit 0, late start, digit -8, top carry)."""
+    from gpu_common import ladder_edge_scalars
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xEDCE + c.cid)
+    ks = ladder_edge_scalars(c)
+    pts = [pyec.G(c), pyec.mul(c, rng.randrange(1, c.n), pyec.G(c))]
+    for P in pts:
+        scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+        xy, fl = pyec.enc_point(c, P)
+        pxy = xy * len(ks)
+        pinf = np.full(len(ks), fl, np.uint8)
+        rc, out, inf = hc.batch_mul(c.cid, scal, pxy, pinf, nthreads=3)
+        assert rc == 0
+        want, winf = oracle.batch_mul(c.cid, scal, pxy, pinf)
+        assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    # and against the independent big-int model for a few of them
+    for k in ks[:3] + ks[41:44]:
+        got = hc.batch_mul(c.cid, pyec.enc_scalar(c, k), pyec.enc_point(c, pts[1])[0], np.zeros(1, np.uint8))
+        assert (bytes(got[1]), int(got[2][0])) == pyec.enc_point(c, pyec.mul(c, k, pts[1]))
+
+
+@pytest.mark.parametrize("curve", CURVES)
 @pytest.mark.parametrize("cbits", [4, 7, 10, 13, 16])
 def test_pippenger_algorithm(oracle, curve, cbits):
     c = pyec.CURVES[curve]

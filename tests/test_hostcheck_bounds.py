@@ -35,4 +35,5 @@ def test_bounds_field_and_points(bounds_lib, oracle, curve):
 def test_bounds_drivers(bounds_lib, oracle, curve):
     T.test_fixed_base_algorithm(oracle, curve, 8)
     T.test_var_base_algorithm(oracle, curve)
+    T.test_var_base_ladder_corner_cases(oracle, curve)
     T.test_pippenger_algorithm(oracle, curve, 7)
