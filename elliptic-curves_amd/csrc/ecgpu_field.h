@@ -38,6 +38,17 @@ struct Mag {
     Fe<C::NL> e;
 };
 
+// A compile-time constant the optimiser must treat as unknown (device only).  v_mad_u64_u32 issues at the same
+// rate as ANY 64-bit VALU op, so multiplying a limb by 2^k or 2^k - 1 and accumulating is one instruction as a
+// multiply-add but three to five (moves, 64-bit shift, 64-bit add/sub) once the compiler strength-reduces it.
+// Routing such constants through an SGPR the compiler cannot see into keeps them as multiply-adds.
+static ECGPU_HD uint32_t opaque_const(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+s"(x));
+#endif
+    return x;
+}
+
 template <class C>
 struct Field {
     ECGPU_CONST int N = C::N;     // canonical 32-bit words
@@ -117,9 +128,9 @@ struct Field {
     static ECGPU_HD void k_fold(uint64_t* lo, int j, uint64_t col) {
         uint32_t cl = (uint32_t)col, ch = (uint32_t)(col >> 32);
         lo[j] += (uint64_t)cl * KC::F0;
-        lo[j + 1] += (uint64_t)cl * KC::F1;
+        lo[j + 1] += (uint64_t)cl * opaque_const(KC::F1);
         lo[j + 1] += (uint64_t)ch * KC::G1;
-        lo[j + 2] += (uint64_t)ch * KC::G2;
+        lo[j + 2] += (uint64_t)ch * opaque_const(KC::G2);
     }
     // 17 product columns -> 9 limbs of magnitude 1
     static ECGPU_HD E k_reduce(uint64_t* c) {
@@ -146,9 +157,9 @@ struct Field {
         uint64_t top = v >> 29;                       // weight 2^261, < 2^36
         uint32_t tl = (uint32_t)top, th = (uint32_t)(top >> 32);
         uint64_t t0 = (uint64_t)tl * KC::F0 + r.v[0];
-        uint64_t t1 = (uint64_t)tl * KC::F1 + r.v[1];
+        uint64_t t1 = (uint64_t)tl * opaque_const(KC::F1) + r.v[1];
         t1 += (uint64_t)th * KC::G1;
-        uint64_t t2 = (uint64_t)th * KC::G2 + r.v[2];
+        uint64_t t2 = (uint64_t)th * opaque_const(KC::G2) + r.v[2];
         r.v[0] = (uint32_t)t0 & KMASK;
         t1 += t0 >> 29;
         r.v[1] = (uint32_t)t1 & KMASK;
@@ -298,10 +309,10 @@ struct Field {
             uint32_t u = (uint32_t)c[i] & PMASK;
             // (c[i] + u * p0) >> B = (c[i] >> B) + u since p0 = 2^B - 1: merged into the p1 term
             c[i + 1] += (c[i] >> UB);
-            c[i + 1] += (uint64_t)u * (PC::P[1] + 1u);
+            c[i + 1] += (uint64_t)u * opaque_const(PC::P[1] + 1u);
 #pragma unroll
             for (int j = 2; j < UN; j++) {
-                if (PC::P[j] != 0) c[i + j] += (uint64_t)u * PC::P[j];
+                if (PC::P[j] != 0) c[i + j] += (uint64_t)u * opaque_const(PC::P[j]);
             }
         }
         E r;
