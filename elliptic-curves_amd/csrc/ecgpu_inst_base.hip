@@ -15,11 +15,13 @@ template <> void launch_table_entries<CurveT>(hipStream_t s, const uint32_t* bas
     size_t total = ((size_t)1 << (w - 1)) * nwin;
     hipLaunchKernelGGL(k_table_entries<CurveT>, dim3(grid_for(total)), dim3(BLOCK), 0, s, bases, entries, w, nwin);
 }
-// One inversion per thread, amortised over K = ceil(n / 32768) <= 64 points (Montgomery's trick).
+// One inversion per lane, amortised over K points (Montgomery's trick).  The inversion is a serial chain of ~45k
+// instructions whatever K is, so the kernel is fastest when there is about one wave per SIMD (1024 of them):
+// K = ceil(n / 65536), capped at 64 for large batches.
 template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
                                           uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
     if (n == 0) return;
-    size_t k = (n + 32767) / 32768;
+    size_t k = (n + 65535) / 65536;
     if (k > 64) k = 64;
     size_t nthreads = (n + k - 1) / k;
     if (out_internal)

@@ -201,15 +201,25 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
     typename F::M1 acc = F::one();
     for (size_t j = t; j < n; j += nthreads) {
         Fe<C::NL> z = load_raw<C>(proj + j * (3 * NS) + 2 * NS);
-        store_raw<C>(prefix + j * NS, acc.e);
-        if (!F::is_zero(G::m(z))) acc = F::mul(acc, G::m(z));
+        const bool ident = F::is_zero(G::m(z));
+        {   // running product before this point, and whether the point is the identity, in the spare word
+            static_assert(NS > C::NL, "raw form has no spare word");
+            uint32_t w[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) w[i] = i < C::NL ? acc.e.v[i] : 0u;
+            w[NS - 1] = ident ? 1u : 0u;
+            store_words_vec<NS>(prefix + j * NS, w);
+        }
+        if (!ident) acc = F::mul(acc, G::m(z));
     }
     typename F::M1 inv = F::inv(acc);
     if (n <= t) return;
     size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
     for (size_t j = last;; j -= nthreads) {
         Proj<C> p = load_proj<C>(proj, j);
-        if (F::is_zero(G::m(p.z))) {
+        uint32_t pw[NS];
+        load_words_vec<NS>(pw, prefix + j * NS);
+        if (pw[NS - 1]) {
             if constexpr (!OUT_PACKED) {
                 uint32_t zero[2 * N];
 #pragma unroll
@@ -218,7 +228,10 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
                 if (out_inf) out_inf[j] = 1;
             }
         } else {
-            typename F::M1 pre = G::m(load_raw<C>(prefix + j * NS));
+            Fe<C::NL> pre_e;
+#pragma unroll
+            for (int i = 0; i < C::NL; i++) pre_e.v[i] = pw[i];
+            typename F::M1 pre = G::m(pre_e);
             typename F::M1 zinv = F::mul(pre, inv);
             inv = F::mul(inv, G::m(p.z));
             typename F::M1 x = F::mul(G::m(p.x), zinv), y = F::mul(G::m(p.y), zinv);

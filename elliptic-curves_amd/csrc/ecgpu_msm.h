@@ -15,13 +15,16 @@
 //               turns the counts into offsets (tile_scan, scan), and the same workgroup shape scatters with
 //               LDS cursors (scatter).  No global atomics; every bucket becomes a contiguous run, so
 //               accumulation needs no atomics and no conflict handling
-//   accumulate  one lane per (window, bucket): complete mixed additions over its run   <- the hot loop
+//   accumulate  one lane per `chunk` consecutive sorted entries of a window (ecgpu_msm_chunk.h): complete mixed
+//               additions, a partial sum written at every bucket boundary   <- the hot loop; perfectly balanced
+//               for ANY scalar distribution
+//   finish      one lane per (window, bucket): adds the bucket's 1-2 (or, for a skewed input, many) partial sums
 //   reduce      running-sum trick on segments of buckets, segment sums, window sums
 //   combine     Horner over the windows (c doublings each)
 //
 // Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
 // digits [nwin][n] u16 + validity bits [nwin][n/64] u64, tile histograms [nwin][ntiles][NB] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB]
-// u32, buckets [nwin][NB][3 NS], segment sums, window sums.
+// u32, partial sums [nwin][NB + nchunks][3 NS], buckets [nwin][NB][3 NS], segment sums, window sums.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -30,50 +33,9 @@
 
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_msm_chunk.h"
 
 namespace ecgpu {
-
-inline int msm_window_bits(size_t n) {
-    int lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg - 7;
-    if (c < 4) c = 4;
-    if (c > 16) c = 16;
-    return c;
-}
-
-template <class C>
-MsmPlan msm_plan(size_t n, int force_c) {
-    constexpr int N = C::N, NS = Field<C>::NS;
-    MsmPlan p;
-    p.c = force_c ? force_c : msm_window_bits(n);
-    p.nwin = signed_window_count(32 * N - 1, p.c);          // scalars are folded to 32 N - 1 bits
-    p.nb = (size_t)1 << (p.c - 1);
-    p.seg = p.nb < 32 ? (int)p.nb : 32;
-    p.nseg = p.nb / p.seg;
-    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t o = 0;
-    int tile_log2 = 18;                                   // terms per counting-sort tile (tuning knob)
-    if (const char* e = getenv("ECGPU_MSM_TILE_LOG2")) {
-        int v = atoi(e);
-        if (v >= 12 && v <= 24) tile_log2 = v;
-    }
-    p.tile = (size_t)1 << tile_log2;
-    p.ntiles = (n + p.tile - 1) / p.tile;
-    if (p.ntiles == 0) p.ntiles = 1;
-    p.off_points = o;  o = align(o + n * 2 * N * 4);
-    p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
-    p.off_vmask = o;   o = align(o + (size_t)p.nwin * ((n + 63) / 64) * 8);
-    p.off_tilehist = o; o = align(o + (size_t)p.nwin * p.ntiles * p.nb * 4);
-    p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
-    p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
-    p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
-    p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * NS * 4);
-    p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * NS * 4);
-    p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * NS * 4);
-    p.workspace_bytes = o + 256;
-    return p;
-}
 
 // ---- prepare ----------------------------------------------------------------------------------------------
 // A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether term i has a digit in
@@ -193,38 +155,48 @@ k_msm_scatter(const uint16_t* __restrict__ digits, const unsigned long long* __r
 
 // ---- accumulate: the hot loop --------------------------------------------------------------------------------------
 template <class C>
+struct MsmPointsHbm {
+    const uint32_t* pts;
+    __device__ void load(PackedPoint<2 * C::N>& p, uint32_t term) const {
+        load_words_vec<2 * C::N>(p.w, pts + (size_t)term * (2 * C::N));
+    }
+};
+template <class C>
+struct MsmPartialsHbm {
+    uint32_t* base;
+    __device__ void put(size_t slot, const Proj<C>& p) { store_proj<C>(base, slot, p); }
+    __device__ Proj<C> get(size_t slot) const { return load_proj<C>(base, slot); }
+};
+
+// one lane per (window, chunk)
+template <class C>
 __global__ void __launch_bounds__(64)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
-                 int nwin, uint32_t* __restrict__ buckets) {
+                 int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials) {
     using G = Group<C>;
-    constexpr int N = C::N;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nchunks * nwin) return;
+    size_t w = gid / nchunks, q = gid % nchunks;
+    const uint32_t* ow = offsets + w * nb;
+    const uint32_t total = ow[nb - 1] + counts[w * nb + nb - 1];
+    MsmPointsHbm<C> points{pts};
+    MsmPartialsHbm<C> sink{partials + w * (nb + nchunks) * (3 * Field<C>::NS)};
+    msm_chunk_accumulate<C>(sorted + w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, G::curve_b(), points, sink);
+}
+
+// one lane per (window, bucket)
+template <class C>
+__global__ void __launch_bounds__(64)
+k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                    const uint32_t* __restrict__ offsets, size_t nb, int nwin, size_t chunk, size_t nchunks,
+                    uint32_t* __restrict__ buckets) {
+    using G = Group<C>;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nb * nwin) return;
-    size_t w = gid / nb;
-    const uint32_t* run = sorted + w * n + offsets[gid];
-    uint32_t cnt = counts[gid];
-    Fe<C::NL> b = G::curve_b();
-    Proj<C> acc = G::identity();
-    uint32_t qw[2 * N];                                   // packed words of the prefetched point
-    uint32_t e = 0;
-    if (cnt) {
-        e = run[0];
-        load_words_vec<2 * N>(qw, pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N));
-    }
-#pragma unroll 1
-    for (uint32_t t = 0; t < cnt; t++) {
-        Affine<C> cur;
-        cur.x = Field<C>::unpack(qw).e;
-        cur.y = Field<C>::unpack(qw + N).e;
-        uint32_t ecur = e;
-        if (t + 1 < cnt) {                               // fetch the next point under the current addition
-            e = run[t + 1];
-            load_words_vec<2 * N>(qw, pts + (size_t)(e & 0x7FFFFFFFu) * (2 * N));
-        }
-        acc = G::add_mixed(acc, cur, b, (ecur >> 31) != 0);
-    }
-    store_proj<C>(buckets, gid, acc);
+    size_t w = gid / nb, b = gid % nb;
+    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (3 * Field<C>::NS)};
+    store_proj<C>(buckets, gid, msm_bucket_finish<C>((uint32_t)b, offsets[gid], counts[gid], (uint32_t)chunk, G::curve_b(), src));
 }
 
 // ---- reduce ------------------------------------------------------------------------------------------------------------
@@ -310,6 +282,74 @@ __global__ void k_store_identity(uint32_t* out) {
     if (blockIdx.x == 0 && threadIdx.x == 0) store_proj<C>(out, 0, Group<C>::identity());
 }
 
+// ---- plan ------------------------------------------------------------------------------------------------------------
+inline int msm_window_bits(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = lg - 7;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+
+template <class C>
+MsmPlan msm_plan(size_t n, int force_c) {
+    constexpr int N = C::N, NS = Field<C>::NS;
+    MsmPlan p;
+    p.c = force_c ? force_c : msm_window_bits(n);
+    p.nwin = signed_window_count(32 * N - 1, p.c);          // scalars are folded to 32 N - 1 bits
+    p.nb = (size_t)1 << (p.c - 1);
+    p.seg = p.nb < 32 ? (int)p.nb : 32;
+    p.nseg = p.nb / p.seg;
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    int tile_log2 = 18;                                   // terms per counting-sort tile (tuning knob)
+    if (const char* e = getenv("ECGPU_MSM_TILE_LOG2")) {
+        int v = atoi(e);
+        if (v >= 12 && v <= 24) tile_log2 = v;
+    }
+    p.tile = (size_t)1 << tile_log2;
+    p.ntiles = (n + p.tile - 1) / p.tile;
+    if (p.ntiles == 0) p.ntiles = 1;
+    // Accumulation lanes: about three rounds of the wave slots the kernel can occupy (measured on MI355X: chunks
+    // of ~500 entries beat one exactly-filling round of ~1400 by 2%, and anything that leaves slots empty loses
+    // badly), but at least 32 entries per lane so that partial sums stay a small overhead.
+    {
+        static size_t wave_slots = 0;                       // resident waves of k_msm_accumulate<C> on this device
+        if (!wave_slots) {
+            int dev = 0, cus = 256, blocks = 0;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_msm_accumulate<C>, 64, 0) != hipSuccess || blocks < 1)
+                blocks = 8;
+            wave_slots = (size_t)cus * blocks;
+        }
+        size_t lanes = wave_slots * 64 * 3;
+        size_t per_window = (lanes + p.nwin - 1) / p.nwin;
+        p.chunk = (n + per_window - 1) / per_window;
+        if (p.chunk < 32) p.chunk = 32;
+        if (const char* e = getenv("ECGPU_MSM_CHUNK")) {
+            long v = atol(e);
+            if (v >= 1 && v <= (1L << 30)) p.chunk = (size_t)v;
+        }
+        p.nchunks = (n + p.chunk - 1) / p.chunk;
+        if (p.nchunks == 0) p.nchunks = 1;
+    }
+    p.off_points = o;  o = align(o + n * 2 * N * 4);
+    p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
+    p.off_vmask = o;   o = align(o + (size_t)p.nwin * ((n + 63) / 64) * 8);
+    p.off_tilehist = o; o = align(o + (size_t)p.nwin * p.ntiles * p.nb * 4);
+    p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
+    p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
+    p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
+    p.off_partials = o; o = align(o + (size_t)p.nwin * (p.nb + p.nchunks) * 3 * NS * 4);
+    p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * NS * 4);
+    p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * NS * 4);
+    p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * NS * 4);
+    p.workspace_bytes = o + 256;
+    return p;
+}
+
 // Enqueues the whole pipeline on `stream`; the result (projective, internal form) lands in out[0].
 template <class C>
 void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, const uint8_t* d_xy,
@@ -329,6 +369,7 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     uint32_t* sorted = (uint32_t*)(ws + p.off_sorted);
     uint32_t* counts = (uint32_t*)(ws + p.off_count);
     uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
+    uint32_t* partials = (uint32_t*)(ws + p.off_partials);
     uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     uint32_t* wins = (uint32_t*)(ws + p.off_wins);
@@ -352,10 +393,13 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
                        (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb,
                        (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
     (void)hipEventRecord(ev_sorted, stream);
-    size_t nbk = p.nb * p.nwin;
-    hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
+    size_t nbk = p.nb * p.nwin, nlanes = p.nchunks * p.nwin;
+    hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
-                       (const uint32_t*)offsets, n, p.nb, p.nwin, buckets);
+                       (const uint32_t*)offsets, n, p.nb, p.nwin, p.chunk, p.nchunks, partials);
+    hipLaunchKernelGGL(k_msm_bucket_finish<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
+                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, p.nb, p.nwin, p.chunk,
+                       p.nchunks, buckets);
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,

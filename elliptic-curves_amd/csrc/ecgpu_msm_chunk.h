@@ -1,0 +1,89 @@
+// ecgpu_msm_chunk.h — the per-lane body of the Pippenger bucket accumulation (host + device; tests/hostcheck
+// runs exactly this code on the CPU).
+//
+// After the counting sort every window holds one sorted run of (sign, term index) entries in which each bucket
+// is a contiguous stretch.  A lane does NOT own a bucket: it owns `chunk` consecutive entries of the run,
+// wherever the bucket boundaries fall, so every lane performs the same number of additions no matter how
+// the scalars are distributed (a bucket that received all 2^24 terms is spread over thousands of lanes).
+// Whenever the lane leaves a bucket — or its chunk ends inside one — it writes the partial sum of the stretch to
+//
+//      partial[b + q]          b = bucket, q = chunk index within the window
+//
+// Buckets and chunks both advance monotonically along the run, so distinct (b, q) stretches get distinct
+// slots, nb + nchunks slots suffice, and the stretches of one bucket occupy consecutive slots
+// b + q_first .. b + q_last, which msm_bucket_finish adds up.
+#pragma once
+
+#include "ecgpu_point.h"
+
+namespace ecgpu {
+
+template <int N2>
+struct PackedPoint {   // affine point in packed storage form (2 x N words)
+    uint32_t w[N2];
+};
+
+// Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Proj<C>&).
+// `ow` = bucket start offsets of this window (nb entries), `total` = length of the window's run.
+template <class C, class Points, class Sink>
+ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint32_t* __restrict__ ow, uint32_t total,
+                                   uint32_t nb, uint32_t chunk, uint32_t q, const Fe<C::NL>& curve_b,
+                                   const Points& points, Sink& sink) {
+    using G = Group<C>;
+    using F = Field<C>;
+    constexpr int N = C::N;
+    const uint32_t start = q * chunk;
+    if (start >= total) return;
+    const uint32_t end = total - start < chunk ? total : start + chunk;
+    // bucket containing `start`: the last b with ow[b] <= start (an empty bucket never qualifies as "last")
+    uint32_t lo = 0, hi = nb;                       // invariant: ow[lo] <= start, (hi == nb or ow[hi] > start)
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        if (ow[mid] <= start) lo = mid;
+        else hi = mid;
+    }
+    uint32_t b = lo;
+    uint32_t bend = b + 1 < nb ? ow[b + 1] : total;
+    Proj<C> acc = G::identity();
+    PackedPoint<2 * N> pw;
+    uint32_t e = run[start];
+    points.load(pw, e & 0x7FFFFFFFu);
+#pragma unroll 1
+    for (uint32_t pos = start; pos < end;) {
+        Affine<C> cur;
+        cur.x = F::unpack(pw.w).e;
+        cur.y = F::unpack(pw.w + N).e;
+        const uint32_t ecur = e;
+        pos++;
+        if (pos < end) {                             // fetch the next point under the current addition
+            e = run[pos];
+            points.load(pw, e & 0x7FFFFFFFu);
+        }
+        acc = G::add_mixed(acc, cur, curve_b, (ecur >> 31) != 0);
+        if (pos == bend || pos == end) {             // leaving the bucket, or the chunk ends inside it
+            sink.put((size_t)b + q, acc);
+            if (pos == bend && pos < end) {
+                acc = G::identity();
+                do {
+                    b++;
+                    bend = b + 1 < nb ? ow[b + 1] : total;
+                } while (bend == pos);               // skip empty buckets; pos < end <= total terminates this
+            }
+        }
+    }
+}
+
+// sum of the stretches of bucket b: slots b + first/chunk .. b + (first + count - 1)/chunk
+template <class C, class Source>
+ECGPU_HD Proj<C> msm_bucket_finish(uint32_t b, uint32_t first, uint32_t count, uint32_t chunk, const Fe<C::NL>& curve_b,
+                                   const Source& partial) {
+    using G = Group<C>;
+    if (count == 0) return G::identity();
+    const uint32_t q0 = first / chunk, q1 = (first + count - 1) / chunk;
+    Proj<C> acc = partial.get((size_t)b + q0);
+#pragma unroll 1
+    for (uint32_t q = q0 + 1; q <= q1; q++) acc = G::add(acc, partial.get((size_t)b + q), curve_b);
+    return acc;
+}
+
+}  // namespace ecgpu

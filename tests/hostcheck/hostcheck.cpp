@@ -9,6 +9,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_point.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_recode.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 
 using namespace ecgpu;
 
@@ -292,7 +293,7 @@ int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, s
 
 // the Pippenger pipeline of ecgpu_msm.h: prepare/scan/scatter/accumulate/reduce/combine, sequentially
 template <class C>
-int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy,
+int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy,
         uint8_t* out_inf) {
     using G = Group<C>;
     using F = Field<C>;
@@ -339,16 +340,44 @@ int msm(int c, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, 
             }
         }
     }
-    std::vector<Proj<C>> buckets((size_t)nwin * nb);
-    for (size_t gid = 0; gid < (size_t)nwin * nb; gid++) {              // accumulate
-        size_t w = gid / nb;
-        const uint32_t* run = sorted.data() + w * n + offsets[gid];
-        Proj<C> acc = G::identity();
-        for (uint32_t t = 0; t < counts[gid]; t++) {
-            Affine<C> q = pts[run[t] & 0x7FFFFFFFu];
-            acc = G::add_mixed(acc, q, b, (run[t] >> 31) != 0);
+    // accumulate + finish: the lane bodies of k_msm_accumulate / k_msm_bucket_finish (ecgpu_msm_chunk.h)
+    if (chunk == 0) chunk = 32;
+    size_t nchunks = (n + chunk - 1) / chunk;
+    if (nchunks == 0) nchunks = 1;
+    struct Points {
+        const std::vector<Affine<C>>* pts;
+        void load(PackedPoint<2 * N>& p, uint32_t term) const {
+            F::pack(p.w, G::m((*pts)[term].x));
+            F::pack(p.w + N, G::m((*pts)[term].y));
         }
-        buckets[gid] = acc;
+    };
+    struct Partials {
+        std::vector<Proj<C>>* v;
+        std::vector<uint8_t>* written;
+        size_t base;
+        void put(size_t slot, const Proj<C>& p) {
+            if ((*written)[base + slot]) __builtin_trap();          // slots must be unique
+            (*written)[base + slot] = 1;
+            (*v)[base + slot] = p;
+        }
+        Proj<C> get(size_t slot) const {
+            if (!(*written)[base + slot]) __builtin_trap();         // and every slot read must have been written
+            return (*v)[base + slot];
+        }
+    };
+    std::vector<Proj<C>> partials((size_t)nwin * (nb + nchunks));
+    std::vector<uint8_t> written(partials.size(), 0);
+    std::vector<Proj<C>> buckets((size_t)nwin * nb);
+    for (int w = 0; w < nwin; w++) {
+        const uint32_t* ow = offsets.data() + (size_t)w * nb;
+        uint32_t total = ow[nb - 1] + counts[(size_t)w * nb + nb - 1];
+        Points points{&pts};
+        Partials sink{&partials, &written, (size_t)w * (nb + nchunks)};
+        for (size_t q = 0; q < nchunks; q++)
+            msm_chunk_accumulate<C>(sorted.data() + (size_t)w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, b,
+                                    points, sink);
+        for (size_t j = 0; j < nb; j++)
+            buckets[(size_t)w * nb + j] = msm_bucket_finish<C>((uint32_t)j, ow[j], counts[(size_t)w * nb + j], (uint32_t)chunk, b, sink);
     }
     std::vector<Proj<C>> wins(nwin);
     for (int w = 0; w < nwin; w++) {                                    // reduce
@@ -431,9 +460,10 @@ int hc_batch_mul(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* p
     DISPATCH(curve, batch_mul<K256Params>(s, p, pi, n, nthreads, o, oi), batch_mul<P256Params>(s, p, pi, n, nthreads, o, oi),
              batch_mul<P384Params>(s, p, pi, n, nthreads, o, oi))
 }
-int hc_msm(int curve, int c, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o, uint8_t* oi) {
-    DISPATCH(curve, msm<K256Params>(c, s, p, pi, n, o, oi), msm<P256Params>(c, s, p, pi, n, o, oi),
-             msm<P384Params>(c, s, p, pi, n, o, oi))
+int hc_msm(int curve, int c, size_t chunk, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o,
+           uint8_t* oi) {
+    DISPATCH(curve, msm<K256Params>(c, chunk, s, p, pi, n, o, oi), msm<P256Params>(c, chunk, s, p, pi, n, o, oi),
+             msm<P384Params>(c, chunk, s, p, pi, n, o, oi))
 }
 int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {
     DISPATCH(curve, table_rule_check<K256Params>(w, j, e, out_xy), table_rule_check<P256Params>(w, j, e, out_xy),

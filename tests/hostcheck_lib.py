@@ -16,7 +16,7 @@ _lib = None
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", LIB, SRC])
@@ -91,12 +91,12 @@ def batch_mul(curve, scalars, pxy, pinf=None, nthreads=1):
     return rc, out, inf[:n]
 
 
-def msm(curve, c, scalars, pxy, pinf=None):
+def msm(curve, c, scalars, pxy, pinf=None, chunk=32):
     s, p, pi = _a(scalars), _a(pxy), _a(pinf)
     n = s.size // L[curve]
     out = np.zeros(2 * L[curve], np.uint8)
     inf = np.zeros(1, np.uint8)
-    rc = lib().hc_msm(curve, c, _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
+    rc = lib().hc_msm(curve, c, ctypes.c_size_t(chunk), _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
     return rc, bytes(out), int(inf[0])
 
 

@@ -190,6 +190,39 @@ def test_msm_vs_oracle(eng, curve, n):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
+    """The accumulation lanes own fixed-size chunks of the sorted run, not buckets.  Sweep the chunk size (1 entry
+    per lane .. everything in one lane) against the oracle, then feed scalar sets that put every term of a window
+    into ONE bucket (all scalars equal / all ones): sum_i k P_i = k * sum_i P_i."""
+    import time
+    c = pyec.CURVES[curve]
+    n = 3000
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xEC000015 + c.cid))
+    scal = rand_scalars(c.cid, n, 0xEC000005 + c.cid)
+    want, winf = oracle_lib.msm(c.cid, scal, pts, None, vartime=True)
+    for chunk in ("1", "33", "100000"):
+        monkeypatch.setenv("ECGPU_MSM_CHUNK", chunk)
+        for cbits in (0, 9):
+            eng.set_msm_window(cbits)
+            o, f = eng.lincomb(c.cid, scal, pts)
+            assert bytes(o) == bytes(want) and f == winf, (chunk, cbits)
+    monkeypatch.delenv("ECGPU_MSM_CHUNK")
+    eng.set_msm_window(0)
+    n = 1 << 18
+    pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xEC000016 + c.cid))
+    total, tf = eng.point_sum(c.cid, pts)
+    assert tf == 0
+    k0 = bytes(rand_scalars(c.cid, 1, 0xEC000017 + c.cid))
+    for k in (k0, pyec.enc_scalar(c, 1), pyec.enc_scalar(c, c.n - 1)):
+        t0 = time.time()
+        o, f = eng.lincomb(c.cid, np.tile(np.frombuffer(k, np.uint8), n), pts)
+        dt = time.time() - t0
+        w, wf = eng.mul(c.cid, k, total)
+        assert bytes(o) == bytes(w) and f == int(wf[0])
+        assert dt < 5.0, "skewed MSM took %.1f s: one lane is walking a whole bucket" % dt
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_msm_cancels_to_identity(eng, curve):
     c = pyec.CURVES[curve]
     n = 64

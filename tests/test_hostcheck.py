@@ -185,6 +185,26 @@ def test_var_base_algorithm(oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_pippenger_skewed_scalars(oracle, curve):
+    """Every term in the same bucket of every window (equal scalars), all-ones scalars, and a half/half mix: the
+    chunked accumulation spreads one bucket over many lanes and the partial sums must add up."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0x5CE3 + c.cid)
+    G = pyec.G(c)
+    n = 45
+    pts = [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(n)]
+    enc = [pyec.enc_point(c, P) for P in pts]
+    pxy = b"".join(e[0] for e in enc)
+    k0 = rng.randrange(c.n)
+    for ks in ([k0] * n, [1] * n, [k0] * (n // 2) + [c.n - k0] * (n - n // 2), [c.n - 1] * n):
+        scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+        want, winf = oracle.msm(c.cid, scal, pxy, None)
+        for cbits, chunk in ((4, 1), (5, 4), (9, 16)):
+            rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, None, chunk=chunk)
+            assert rc == 0 and out == bytes(want) and inf == winf
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_var_base_ladder_corner_cases(oracle, curve):
     """The Jacobian ladder is incomplete by construction; these scalars hit every place the completeness
     argument in ecgpu_varmul.h is needed (acc = +-operand at digit 0, late start, digit -8, top carry)."""
@@ -225,10 +245,11 @@ def test_pippenger_algorithm(oracle, curve, cbits):
     enc = [pyec.enc_point(c, P) for P in pts]
     pxy = b"".join(e[0] for e in enc)
     pinf = np.array([e[1] for e in enc], np.uint8)
-    rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, pinf)
-    assert rc == 0
     want, winf = oracle.msm(c.cid, scal, pxy, pinf)
-    assert out == bytes(want) and inf == winf
+    for chunk in ((1, 7, 64) if cbits <= 7 else (5,)):      # accumulation lanes of 1..64 sorted entries
+        rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, pinf, chunk=chunk)
+        assert rc == 0
+        assert out == bytes(want) and inf == winf
     assert pyec.dec_point(c, out, inf) == pyec.msm(c, ks, pts)
     # all-zero scalars and the empty sum give the identity
     rc, out, inf = hc.msm(c.cid, cbits, bytes(c.L * 4), pxy[: 8 * c.L], None)

@@ -37,3 +37,4 @@ def test_bounds_drivers(bounds_lib, oracle, curve):
     T.test_var_base_algorithm(oracle, curve)
     T.test_var_base_ladder_corner_cases(oracle, curve)
     T.test_pippenger_algorithm(oracle, curve, 7)
+    T.test_pippenger_skewed_scalars(oracle, curve)
