@@ -38,7 +38,7 @@ struct ecgpu_ctx {
     int* d_status = nullptr;
     int* h_status = nullptr;
     Table table[3];
-    int want_w[3] = {16, 16, 16};
+    int want_w[3] = {20, 20, 20};   // fixed-base comb width: 13 additions per 256-bit scalar, 436 MB table
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     hipEvent_t ev[6] = {};
@@ -142,6 +142,14 @@ int ensure_table(ecgpu_ctx* ctx) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     t.w = w;
     t.nwin = nwin;
+    // the build scratch (entries x 192 B) is far larger than any batch needs: give it back
+    for (DevBuf* b : {&ctx->proj, &ctx->prefix}) {
+        if (b->cap > ((size_t)64 << 20)) {
+            HIP_TRY(ctx, hipFree(b->p));
+            b->p = nullptr;
+            b->cap = 0;
+        }
+    }
     return ECGPU_OK;
 }
 
@@ -351,7 +359,7 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
     if (!ctx || curve < 0 || curve > 2) return ECGPU_ERR_CURVE;
-    if (window_bits < 4 || window_bits > 16) return ECGPU_ERR_ARG;
+    if (window_bits < 4 || window_bits > 22) return ECGPU_ERR_ARG;
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
 }

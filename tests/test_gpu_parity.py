@@ -112,11 +112,11 @@ def test_golden_ecdsa_vectors(eng, curve):
 # ---------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("window", [16, 13, 4])
+@pytest.mark.parametrize("window", [20, 16, 13, 4])
 def test_fixed_base_vs_oracle(eng, curve, window):
     c = pyec.CURVES[curve]
     eng.set_base_window(c.cid, window)
-    n = 3000 if window == 16 else 700
+    n = 3000 if window >= 16 else 700
     scal = rand_scalars(c.cid, n, 0xEC000002 + c.cid)
     edge = b"".join(pyec.enc_scalar(c, k) for k in edge_scalars(c))
     scal = np.concatenate([np.frombuffer(edge, np.uint8), scal])
@@ -124,7 +124,7 @@ def test_fixed_base_vs_oracle(eng, curve, window):
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
-    eng.set_base_window(c.cid, 16)
+    eng.set_base_window(c.cid, 20)
 
 
 @pytest.mark.parametrize("curve", CURVES)
