@@ -8,8 +8,7 @@ namespace ecgpu {
 
 // ---- variable base: out[i] = k[i] * P[i] -------------------------------------------------------------
 // One lane per scalar multiplication (ecgpu_varmul.h has the algorithm and the reference citations).  The
-// 8-entry table lives in HBM scratch, lane-minor (consecutive lanes touch consecutive words), instead of
-// the CPU stack.
+// 8-entry table lives in HBM scratch instead of the CPU stack.
 constexpr int VAR_TAB_ELEMS = 5;   // X, Y, Z, Z^2, Z^3 per entry
 
 template <class C>
