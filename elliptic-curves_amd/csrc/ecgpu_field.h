@@ -30,6 +30,7 @@
 #pragma once
 
 #include "ecgpu_params.h"
+#include "ecgpu_modinv.h"
 
 namespace ecgpu {
 
@@ -675,11 +676,28 @@ struct Field {
         for (int i = 0; i < n; i++) x = sqr(x);
         return x;
     }
-    // a^(p-2); a == 0 -> 0.  (The reference inverts with crypto-bigint's safegcd — k256 field.rs:178-184,
-    // primefield monty.rs:373-375; the inverse is unique, so any method agrees.)  k256 and p256 use addition
-    // chains over the runs of ones of p-2 (255 squarings + 15 resp. 12 multiplications); p384 a fixed 4-bit
-    // window over the constant exponent (384 squarings + <= 110 multiplications).
+    // 1/a; a == 0 -> 0.  Like the reference (crypto-bigint's safegcd — k256 field.rs:178-184, primefield
+    // monty.rs:373-375) this runs Bernstein–Yang division steps (ecgpu_modinv.h) on the canonical value; for the
+    // Montgomery fields (aR)^-1 is brought back to a^-1 R by two multiplications with R^2.
     static ECGPU_HD M1 inv(const M1& a) {
+        if constexpr (REPR == REPR_SAT_MONT) {
+            return inv_fermat(a);
+        } else {
+            uint32_t w[N], r[N];
+            pack(w, a);
+            ModInv<N>::invert(r, w, C::P);
+            M1 x = unpack(r);
+            if constexpr (REPR == REPR_U28_MONT) {
+                M1 r2 = wrap<1, 1>(p_const(PC::R2));
+                x = mul(mul(x, r2), r2);
+            }
+            return x;
+        }
+    }
+    // a^(p-2), the first implementation, kept as an independent check of `inv` (tests/hostcheck).  k256 and p256
+    // use addition chains over the runs of ones of p-2 (255 squarings + 15 resp. 12 multiplications); p384 a fixed
+    // 4-bit window over the constant exponent (384 squarings + <= 110 multiplications).
+    static ECGPU_HD M1 inv_fermat(const M1& a) {
         if constexpr (REPR == REPR_U29_K256) {
             // p-2 = 2^256 - 2^32 - 979: 223 ones, 0, 22 ones, 0000 1 0 11 0 1
             M1 x2 = mul(sqr(a), a);

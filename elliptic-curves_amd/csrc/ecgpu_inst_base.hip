@@ -1,4 +1,6 @@
 // ecgpu_inst_base.hip — instantiates the "base" kernel group for -DECGPU_CURVE=<K256Params|P256Params|P384Params>.
+#include <cstdlib>
+
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
 
@@ -23,6 +25,10 @@ template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, cons
     if (n == 0) return;
     size_t k = (n + 65535) / 65536;
     if (k > 64) k = 64;
+    if (const char* e = getenv("ECGPU_NORM_K")) {          // tuning knob: points per lane
+        long v = atol(e);
+        if (v >= 1 && v <= 1024) k = (size_t)v;
+    }
     size_t nthreads = (n + k - 1) / k;
     if (out_internal)
         hipLaunchKernelGGL((k_normalize<CurveT, true>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,

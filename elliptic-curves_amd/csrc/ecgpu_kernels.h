@@ -18,6 +18,7 @@
 
 #include "ecgpu_point.h"
 #include "ecgpu_recode.h"
+#include "ecgpu_fixedmul.h"
 
 namespace ecgpu {
 
@@ -251,13 +252,17 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
 }
 
 // ---- fixed base: out[i] = k[i] * G -----------------------------------------------------------------
-// Drop-in for `mul_by_generator` (k256 mul.rs:180-197; primeorder basepoint.rs:82-99).  The reference
-// walks 65 signed nibbles over a 33x8 projective table with full additions; here each lane walks
-// nwin = (bits-1)/W + 1 signed W-bit windows (scalars folded to bits-1 bits) over the affine table with complete *mixed* additions
-// (RCB Alg 8 / Alg 5), so there are no doublings and no exceptional cases at all.  The sign of a digit
-// is folded into the addition formula (no separate negation).
+// One lane per scalar; the algorithm and the reference citations are in ecgpu_fixedmul.h.
 template <class C>
-__global__ void __launch_bounds__(BLOCK)
+struct BaseTableHbm {
+    const uint32_t* table;    // [nwin][2^(w-1)][2] packed elements
+    size_t half;
+    __device__ Affine<C> load(int window, uint32_t index) const {
+        return load_packed_affine<C>(table + ((size_t)window * half + index) * (2 * C::N));
+    }
+};
+template <class C>
+__global__ void __launch_bounds__(BLOCK, C::A_IS_ZERO ? 4 : 1)      // k256 fits 4 waves per SIMD (128 VGPRs)
 k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __restrict__ table, int w, int nwin,
              uint32_t* __restrict__ proj_out, int* status) {
     using G = Group<C>;
@@ -266,23 +271,8 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
-    // scalar folding: k G = -((n - k) G); a folded scalar has 32 N - 1 bits, i.e. nwin = (32 N - 1) / w + 1
-    // windows (exactly 16 at w = 16) and the top one never carries out
-    const bool flip = fold_scalar<N>(k, C::ORDER);
-    Fe<C::NL> b = G::curve_b();
-    Proj<C> acc = G::identity();
-    uint32_t carry = 0;
-    const size_t half = (size_t)1 << (w - 1);
-#pragma unroll 1
-    for (int j = 0; j < nwin; j++) {
-        int d = signed_window_step(get_bits<N>(k, j * w, w), w, &carry);
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            Affine<C> q = load_packed_affine<C>(table + ((size_t)j * half + (mag - 1)) * (2 * N));
-            acc = G::add_mixed(acc, q, b, (d < 0) != flip);
-        }
-    }
-    store_proj<C>(proj_out, i, acc);
+    BaseTableHbm<C> tab{table, (size_t)1 << (w - 1)};
+    store_proj<C>(proj_out, i, fixed_base_mul<C>(k, tab, w, nwin, G::curve_b()));
 }
 
 // ---- helpers for batch_normalize / point_sum ----------------------------------------------------------

@@ -8,6 +8,7 @@
 
 #include "../../elliptic-curves_amd/csrc/ecgpu_point.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_recode.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_fixedmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 
@@ -65,6 +66,7 @@ int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 2: F::to_bytes(out, F::mul(x, y)); break;
     case 3: F::to_bytes(out, F::sqr(x)); break;
     case 4: F::to_bytes(out, F::inv(x)); break;
+    case 10: F::to_bytes(out, F::inv_fermat(x)); break;    // independent check of the safegcd inversion
     case 5: F::to_bytes(out, F::neg(x)); break;
     case 6: F::to_bytes(out, times21<C>(x)); break;
     case 7: F::to_bytes(out, F::dbl(x)); break;
@@ -183,27 +185,16 @@ Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e) {
     return acc;
 }
 
-// k_fixed_base
+// k_fixed_base: the shared per-lane body over the CPU-built table
+template <class C>
+struct BaseTableLocal {
+    const BaseTable<C>* t;
+    Affine<C> load(int window, uint32_t index) const { return t->e[(size_t)window * ((size_t)1 << (t->w - 1)) + index]; }
+};
 template <class C>
 Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k_in) {
-    using G = Group<C>;
-    using F = Field<C>;
-    auto b = G::curve_b();
-    uint32_t k[C::N];
-    for (int i = 0; i < C::N; i++) k[i] = k_in[i];
-    const bool flip = fold_scalar<C::N>(k, C::ORDER);
-    Proj<C> acc = G::identity();
-    uint32_t carry = 0;
-    size_t half = (size_t)1 << (t.w - 1);
-    for (int j = 0; j < t.nwin; j++) {
-        int d = signed_window_step(get_bits<C::N>(k, j * t.w, t.w), t.w, &carry);
-        if (d != 0) {
-            uint32_t mag = (uint32_t)(d < 0 ? -d : d);
-            Affine<C> q = t.e[j * half + (mag - 1)];
-            acc = G::add_mixed(acc, q, b, (d < 0) != flip);
-        }
-    }
-    return acc;
+    BaseTableLocal<C> tab{&t};
+    return fixed_base_mul<C>(k_in, tab, t.w, t.nwin, Group<C>::curve_b());
 }
 
 // k_var_base: the shared per-lane body with a stack table

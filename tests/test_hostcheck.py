@@ -41,8 +41,13 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
         assert int.from_bytes(hc.field_op(c.cid, 5, A), "big") == (-a) % c.p
         assert int.from_bytes(hc.field_op(c.cid, 6, A), "big") == 21 * a % c.p
         assert int.from_bytes(hc.field_op(c.cid, 7, A), "big") == 2 * a % c.p
-    for a in _edge_values(c)[:8] + [rng.randrange(c.p) for _ in range(12)]:
+    # inversion: safegcd division steps (op 4) and the Fermat chain (op 10) against the big-int inverse
+    shapes = [rng.randrange(2 ** k) % c.p for k in range(1, 8 * c.L, 5)] + [2 ** k % c.p for k in range(0, 8 * c.L, 29)]
+    for a in _edge_values(c) + shapes + [rng.randrange(c.p) for _ in range(300)]:
         inv = int.from_bytes(hc.field_op(c.cid, 4, a.to_bytes(c.L, "big")), "big")
+        assert inv == (pow(a, -1, c.p) if a else 0), hex(a)
+    for a in _edge_values(c)[:8] + [rng.randrange(c.p) for _ in range(12)]:
+        inv = int.from_bytes(hc.field_op(c.cid, 10, a.to_bytes(c.L, "big")), "big")
         assert inv == (pow(a, -1, c.p) if a else 0)
 
 
