@@ -44,6 +44,8 @@ WORKLOADS = {
                        imad_per_unit=812 * 136, bytes_per_unit=96, kernel="k_fixed_base<K256Params>", scaling="weak"),
     "var_p256": dict(curve="p256", kind="var", n=1 << 20, metric="p256 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
+    "var_k256": dict(curve="k256", kind="var", n=1 << 20, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
+                     imad_per_unit=1984 * 136, bytes_per_unit=160, kernel="k_var_base<K256Params>", scaling="weak"),
     "var_p384": dict(curve="p384", kind="var", n=1 << 20, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=6448 * 300, bytes_per_unit=240, kernel="k_var_base<P384Params>", scaling="weak"),
     "msm_k256": dict(curve="k256", kind="msm", n=1 << 24, metric="k256 MSM terms/sec", unit="terms/s",
@@ -153,7 +155,7 @@ def main():
             eng.set_base_window(cid, args.window)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
-    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5}[args.workload] + 1000 * rank
+    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6}[args.workload] + 1000 * rank
     d_scal = device_random_scalars(torch, n, L, seed, device)
     d_pts = d_out = None
     if kind in ("var", "msm"):
@@ -164,9 +166,7 @@ def main():
     n_out = 1 if kind == "msm" else n
     d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
     d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
-    if kind == "msm" and world > 1:
-        d_rec = torch.zeros((2 * L + 16,), dtype=torch.uint8, device=device)
-        d_all = torch.zeros((world, 2 * L + 16), dtype=torch.uint8, device=device)
+    exchange = ecgpu.TensorExchange(torch, dist, L, device) if kind == "msm" and world > 1 else None
 
     main_ms = []
 
@@ -178,13 +178,8 @@ def main():
         else:
             eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
         main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
-        if kind == "msm" and world > 1:                                # the one exchange step
-            d_rec[: 2 * L] = d_out[0]
-            d_rec[2 * L] = d_inf[0]
-            dist.all_gather_into_tensor(d_all.view(-1), d_rec)
-            pts = d_all[:, : 2 * L].contiguous()
-            flags = d_all[:, 2 * L].contiguous()
-            eng.point_sum_dev(cid, pts, flags, world, d_out, d_inf)
+        if exchange is not None:                                       # the one exchange step: all-gather + EC sum
+            exchange.combine(lambda pts, flags, w, oxy, oinf: eng.point_sum_dev(cid, pts, flags, w, oxy, oinf), d_out, d_inf)
 
     def fence():
         if world > 1:

@@ -226,4 +226,4 @@ def version():
     return load_library().ecgpu_version().decode()
 
 
-from .sharded import lincomb_sharded, shard_range  # noqa: E402,F401
+from .sharded import TensorExchange, lincomb_sharded, shard_range  # noqa: E402,F401

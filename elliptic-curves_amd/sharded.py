@@ -59,3 +59,25 @@ def lincomb_sharded(L, local_lincomb, point_sum, scalars, points_xy, points_inf=
     flags = np.ascontiguousarray(allrec[:, 2 * L])
     out_xy, out_inf = point_sum(pts, flags)
     return np.asarray(out_xy, dtype=np.uint8), int(out_inf)
+
+
+class TensorExchange:
+    """The exchange step of the sharded MSM on torch tensors that stay on their device (bench.py: HBM + RCCL; the
+    gloo test: CPU tensors).  One record of 2L + 16 bytes (x || y || flag, padded to 16 bytes) per rank."""
+
+    def __init__(self, torch, dist, L, device):
+        self.torch, self.dist, self.L = torch, dist, L
+        self.world = dist.get_world_size()
+        self.rec = torch.zeros((2 * L + 16,), dtype=torch.uint8, device=device)
+        self.all = torch.zeros((self.world, 2 * L + 16), dtype=torch.uint8, device=device)
+
+    def combine(self, point_sum, out_xy, out_inf):
+        """out_xy[0] (2L bytes) / out_inf[0] hold this rank's partial sum; on return they hold the sum over all
+        ranks.  point_sum(points[world, 2L], flags[world], world, out_xy, out_inf) adds the gathered points."""
+        L = self.L
+        self.rec[: 2 * L] = out_xy.view(-1)[: 2 * L]
+        self.rec[2 * L] = out_inf.view(-1)[0]
+        self.dist.all_gather_into_tensor(self.all.view(-1), self.rec)
+        pts = self.all[:, : 2 * L].contiguous()
+        flags = self.all[:, 2 * L].contiguous()
+        point_sum(pts, flags, self.world, out_xy, out_inf)

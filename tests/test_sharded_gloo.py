@@ -66,3 +66,51 @@ def test_lincomb_sharded_world2_gloo(oracle, tmp_path, curve, n):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert " ok " in o
+
+
+WORKER_TENSOR = r'''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_lib
+ecgpu = importlib.import_module("elliptic-curves_amd")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=int(sys.argv[2]))
+curve = int(sys.argv[3]); n = int(sys.argv[4])
+L = oracle_lib.FIELD_BYTES[curve]
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(4321)
+scal = oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8))
+pts, _ = oracle_lib.batch_mul_base(curve, oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8)))
+lo, hi = ecgpu.shard_range(n, rank, world)                      # bench.py's term partition
+xy, inf = oracle_lib.msm(curve, scal[lo * L: hi * L], pts[lo * 2 * L: hi * 2 * L])
+out_xy = torch.from_numpy(np.asarray(xy, np.uint8).copy()).reshape(1, 2 * L)
+out_inf = torch.zeros(16, dtype=torch.uint8); out_inf[0] = int(inf)
+def point_sum(p, f, w, oxy, oinf):                             # stands in for Engine.point_sum_dev
+    ones = np.tile(np.array([0] * (L - 1) + [1], np.uint8), w)
+    sxy, sinf = oracle_lib.msm(curve, ones, p.numpy().reshape(-1), f.numpy())
+    oxy.view(-1)[: 2 * L] = torch.from_numpy(np.asarray(sxy, np.uint8).copy()); oinf[0] = int(sinf)
+ex = ecgpu.TensorExchange(torch, dist, L, "cpu")
+for _ in range(2):                                             # the buffers are reused every step
+    out_xy.view(-1)[: 2 * L] = torch.from_numpy(np.asarray(xy, np.uint8).copy()); out_inf[0] = int(inf)
+    ex.combine(point_sum, out_xy, out_inf)
+want, wi = oracle_lib.msm(curve, scal, pts)
+assert bytes(out_xy.numpy().reshape(-1)) == bytes(want) and int(out_inf[0]) == wi, "rank %d mismatch" % rank
+print("rank", rank, "ok")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("curve,n", [(0, 33), (2, 9)])
+def test_tensor_exchange_world2_gloo(oracle, tmp_path, curve, n):
+    """bench.py's exchange step (all_gather_into_tensor of one record per rank + point sum) on CPU tensors."""
+    port = 31500 + (os.getpid() + curve * 11 + n) % 2000
+    script = tmp_path / "worker_tensor.py"
+    script.write_text(WORKER_TENSOR.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(curve), str(n)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok" in o
