@@ -170,6 +170,9 @@ struct K256Params {
     ECGPU_CONST uint32_t GY[8] = {0xFB10D4B8u, 0x9C47D08Fu, 0xA6855419u, 0xFD17B448u,
                                   0x0E1108A8u, 0x5DA4FBFCu, 0x26A3C465u, 0x483ADA77u};
     ECGPU_CONST uint32_t B_SMALL = 7;  // y^2 = x^3 + 7   k256/src/arithmetic.rs
+    // beta: lambda * (x, y) = (beta x, y)            k256/src/arithmetic/projective.rs:31-37
+    ECGPU_CONST uint32_t BETA[8] = {0x719501EEu, 0xC1396C28u, 0x12F58995u, 0x9CF04975u,
+                                    0xAC3434E9u, 0x6E64479Eu, 0x657C0710u, 0x7AE96A2Bu};
 };
 
 struct P256Params {

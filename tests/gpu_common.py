@@ -46,6 +46,12 @@ def ladder_edge_scalars(c):
     for pat in ("88", "08", "80", "f8", "78", "8f", "ff", "f7"):
         ks.append(int(pat * c.L, 16) % c.n)
         ks.append(int(pat * (c.L // 2), 16))
+    if c.name == "k256":
+        # GLV halves: k = r1 + r2*lambda with one half zero, tiny, or with the digit patterns above
+        lam = pyec.K256_LAMBDA
+        for r1 in (0, 1, -1, 8, -8, 16, 2 ** 127, -(2 ** 127) + 1, int("88" * 16, 16), int("f8" * 16, 16)):
+            for r2 in (0, 1, -1, 9, -16, 2 ** 127 - 1, int("08" * 16, 16), -int("78" * 16, 16)):
+                ks.append((r1 + r2 * lam) % c.n)
     return ks
 
 
