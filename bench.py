@@ -53,6 +53,21 @@ WORKLOADS = {
                      imad_per_unit=int(16.06 * 11 * 136), bytes_per_unit=96 + 16 * 64, kernel="k_msm_accumulate<K256Params>",
                      scaling="strong"),
 }
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01/pmc_traffic_v6.json: rocprofv3
+    --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same command).  PMC counters cannot be collected
+    from inside the timed process, so the figure is the committed measurement, valid for the default sizes."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_v6.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None, None
+    if not rec:
+        return None, None
+    return rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01/pmc_traffic_v6.json (%s)" % rec["workload"]
+
+
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 
 
@@ -210,6 +225,8 @@ def main():
         units_per_launch = n
         achieved = wl["imad_per_unit"] * units_per_launch / (kernel_ms * 1e-3) if kernel_ms else None
         hbm_gbps = wl["bytes_per_unit"] * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+        default_size = (args.n == 0 and not args.window and world == 1)
+        traffic, traffic_src = pmc_traffic(wl["kernel"]) if default_size else (None, None)
         result = {
             "metric": wl["metric"], "value": value, "unit": wl["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -218,7 +235,8 @@ def main():
                        "window_bits": args.window or "default", "parallelism": "shard%d" % world},
             "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms,
                          "achieved": achieved / 1e12 if achieved else None, "peak": peak / 1e12, "unit": "TIMAD32/s",
-                         "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "algorithmic_imad32_per_unit": wl["imad_per_unit"], "units_per_launch": units_per_launch,
                          "peak_source": "ecgpu_valu_probe(v_mad_u64_u32) measured in this run",
                          "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

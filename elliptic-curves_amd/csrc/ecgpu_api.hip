@@ -591,8 +591,26 @@ int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, u
 
 int ecgpu_valu_probe(ecgpu_ctx* ctx, int which, double* ops_per_sec) {
     if (!check_ctx(ctx) || !ops_per_sec) return ECGPU_ERR_ARG;
-    const int blocks = 256 * 8, iters = 2048;
     int rc;
+    if (which == 200) {
+        // random 64-byte gathers over the k256 comb table (2^20 lanes x 16 entries): returns bytes per second
+        if ((rc = ensure_table<K256Params>(ctx)) != ECGPU_OK) return rc;
+        const Table& t = ctx->table[ECGPU_K256];
+        const int gblocks = 4096, per_lane = 16;
+        const size_t entries = ((size_t)1 << (t.w - 1)) * t.nwin;
+        if ((rc = ensure(ctx, ctx->out0, (size_t)gblocks * BLOCK * 4)) != ECGPU_OK) return rc;
+        launch_gather_probe(ctx->stream, (const uint32_t*)t.d, entries, 2, (uint32_t*)ctx->out0.p, gblocks);
+        record(ctx, 0);
+        launch_gather_probe(ctx->stream, (const uint32_t*)t.d, entries, per_lane, (uint32_t*)ctx->out0.p, gblocks);
+        record(ctx, 1);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float gms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&gms, ctx->ev[0], ctx->ev[1]));
+        *ops_per_sec = (double)gblocks * BLOCK * per_lane * 64.0 / (gms * 1e-3);
+        return ECGPU_OK;
+    }
+    const int blocks = 256 * 8, iters = 2048;
     if ((rc = ensure(ctx, ctx->out0, (size_t)blocks * BLOCK * 4)) != ECGPU_OK) return rc;
     // which >= 100: exact inline-asm instruction probes (which - 100 selects the instruction, see ecgpu_misc.hip);
     // the result is then wave64-instructions per second x 64 (i.e. lane-operations per second).

@@ -50,5 +50,6 @@ template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status);
 void launch_valu_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
 void launch_isa_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
+void launch_gather_probe(hipStream_t s, const uint32_t* table, size_t entries, int per_lane, uint32_t* out, int blocks);
 
 }  // namespace ecgpu

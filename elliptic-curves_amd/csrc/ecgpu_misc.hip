@@ -162,6 +162,30 @@ void launch_isa_probe(hipStream_t s, int which, uint32_t* o, int blocks, int it)
     }
 }
 
+// ---- HBM gather probe -----------------------------------------------------------------------------------------
+// The fixed-base kernel's memory access pattern in isolation: every lane reads `per_lane` pseudo-random 64-byte
+// entries (4 x 16-byte vector loads, like load_packed_affine) of a table.  The byte count is known exactly
+// (lanes x per_lane x 64), which calibrates rocprofv3's FETCH_SIZE for this pattern and measures the random-gather
+// throughput the W = 24 comb table relies on.
+__global__ void __launch_bounds__(BLOCK) k_gather_probe(const uint32_t* __restrict__ table, size_t entries, int per_lane,
+                                                        uint32_t* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t x = 0x9E3779B97F4A7C15ull * (t + 1);
+    uint32_t acc = 0;
+    for (int i = 0; i < per_lane; i++) {
+        x ^= x >> 27; x *= 0x3C79AC492BA7B653ull; x ^= x >> 33;
+        const uint32_t* e = table + (size_t)(x % entries) * 16;
+        uint32_t w[16];
+        load_words_vec<16>(w, e);
+#pragma unroll
+        for (int j = 0; j < 16; j++) acc ^= w[j];
+    }
+    out[t] = acc;
+}
+void launch_gather_probe(hipStream_t s, const uint32_t* table, size_t entries, int per_lane, uint32_t* out, int blocks) {
+    hipLaunchKernelGGL(k_gather_probe, dim3(blocks), dim3(BLOCK), 0, s, table, entries, per_lane, out);
+}
+
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status) {
     hipLaunchKernelGGL(k_k256_glv, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, scalars, n, r1, r2, status);
 }

@@ -160,7 +160,10 @@ int ecgpu_k256_glv_decompose(ecgpu_ctx *ctx, const uint8_t *scalars, size_t n, u
 /* Integer-VALU roof probe: runs a dependency-free v_mad_u64_u32 stream on every CU and returns
  * the measured 32x32->64 multiply-add rate in operations per second (SURVEY.md §8d "peak to
  * divide by").  `which` selects the instruction: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32,
- * 3 v_add_u32, 4 v_lshl_add_u64, 5 v_mad_u32_u24, 6 v_fma_f64, 7 v_addc_co_u32 chain. */
+ * 3 v_add_u32, 4 v_lshl_add_u64, 5 v_mad_u32_u24, 6 v_fma_f64, 7 v_addc_co_u32 chain; 100 + i: exact
+ * inline-asm instruction streams; 200: HBM gather probe — 2^20 lanes x 16 random 64-byte reads of the k256
+ * comb table, returns BYTES per second (a known byte count in the fixed-base kernel's access pattern, used
+ * to calibrate rocprofv3's FETCH_SIZE). */
 int ecgpu_valu_probe(ecgpu_ctx *ctx, int which, double *ops_per_sec);
 
 /* Milliseconds the device spent in the kernels of the last *_dev / host call on this context,
