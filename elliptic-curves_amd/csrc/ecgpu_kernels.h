@@ -257,8 +257,8 @@ template <class C>
 struct BaseTableHbm {
     const uint32_t* table;    // [nwin][2^(w-1)][2] packed elements
     size_t half;
-    __device__ Affine<C> load(int window, uint32_t index) const {
-        return load_packed_affine<C>(table + ((size_t)window * half + index) * (2 * C::N));
+    __device__ void load(PackedPoint<2 * C::N>& p, int window, uint32_t index) const {
+        load_words_vec<2 * C::N>(p.w, table + ((size_t)window * half + index) * (2 * C::N));
     }
 };
 template <class C>

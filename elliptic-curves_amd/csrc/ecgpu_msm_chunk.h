@@ -18,11 +18,6 @@
 
 namespace ecgpu {
 
-template <int N2>
-struct PackedPoint {   // affine point in packed storage form (2 x N words)
-    uint32_t w[N2];
-};
-
 // Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Proj<C>&).
 // `ow` = bucket start offsets of this window (nb entries), `total` = length of the window's run.
 template <class C, class Points, class Sink>

@@ -29,6 +29,11 @@ struct Affine {  // identity is NOT representable here; callers carry a flag / s
     Fe<C::NL> x, y;
 };
 
+template <int N2>
+struct PackedPoint {   // affine point in packed storage form (2 x N fully reduced words), as gathered from HBM
+    uint32_t w[N2];
+};
+
 template <class C>
 struct Proj {
     Fe<C::NL> x, y, z;

@@ -189,7 +189,11 @@ Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e) {
 template <class C>
 struct BaseTableLocal {
     const BaseTable<C>* t;
-    Affine<C> load(int window, uint32_t index) const { return t->e[(size_t)window * ((size_t)1 << (t->w - 1)) + index]; }
+    void load(PackedPoint<2 * C::N>& p, int window, uint32_t index) const {
+        const Affine<C>& a = t->e[(size_t)window * ((size_t)1 << (t->w - 1)) + index];
+        Field<C>::pack(p.w, Group<C>::m(a.x));
+        Field<C>::pack(p.w + C::N, Group<C>::m(a.y));
+    }
 };
 template <class C>
 Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k_in) {
