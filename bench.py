@@ -46,6 +46,9 @@ WORKLOADS = {
                      imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
     "var_k256": dict(curve="k256", kind="var", n=1 << 20, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=1984 * 136, bytes_per_unit=160, kernel="k_var_base<K256Params>", scaling="weak"),
+    # batch ECDSA verification: u1 G + u2 Q per signature = fixed-base + variable-base + 1 addition
+    "ecdsa_p256": dict(curve="p256", kind="ecdsa", n=1 << 20, metric="p256 ECDSA verifications/sec", unit="verifications/s",
+                       imad_per_unit=(962 + 4336 + 14) * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
     "var_p384": dict(curve="p384", kind="var", n=1 << 20, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=6448 * 300, bytes_per_unit=240, kernel="k_var_base<P384Params>", scaling="weak"),
     "msm_k256": dict(curve="k256", kind="msm", n=1 << 24, metric="k256 MSM terms/sec", unit="terms/s",
@@ -83,7 +86,7 @@ def device_random_scalars(torch, n, L, seed, device):
     return b.contiguous()
 
 
-def cpu_baseline(wl, cid, L, sample_scalars, sample_points):
+def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None):
     """Oracle ("port" of the reference's CPU algorithm) on the host cores, bounded to ~10-20 s of CPU work."""
     import oracle_lib
     oracle_lib.build()
@@ -96,6 +99,9 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points):
             oracle_lib.batch_mul_base(cid, s)
         elif kind == "var":
             oracle_lib.batch_mul(cid, s, sample_points[lo * 2 * L: hi * 2 * L])
+        elif kind == "ecdsa":
+            oracle_lib.ecdsa_verify(cid, s, extra[0][lo * L: hi * L], extra[1][lo * L: hi * L],
+                                    sample_points[lo * 2 * L: hi * 2 * L])
         else:
             oracle_lib.msm(cid, s, sample_points[lo * 2 * L: hi * 2 * L], vartime=True)
 
@@ -114,7 +120,8 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points):
         list(ex.map(lambda i: run(i * chunk, (i + 1) * chunk), range(cores)))
     dt = time.perf_counter() - t0
     algo = {"fixed": "mul_by_generator (33/49-LUT basepoint table)", "var": "ProjectivePoint * Scalar (LUT + radix-16)",
-            "msm": "lincomb_vartime (GLV + wNAF-5 Straus), per-thread chunks summed"}[kind]
+            "msm": "lincomb_vartime (GLV + wNAF-5 Straus), per-thread chunks summed",
+            "ecdsa": "verify_prehashed: s^-1, u1 G + u2 Q (mul_by_generator_and_mul_add_vartime), x mod n == r"}[kind]
     return {"value": total / dt, "unit": wl["unit"], "cores": cores, "kind": "port",
             "sample": "%d units of the same seeded workload, %s, oracle/ C restatement, %d threads" % (total, algo, cores),
             "single_thread_value": single}
@@ -170,7 +177,7 @@ def main():
             eng.set_base_window(cid, args.window)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
-    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6}[args.workload] + 1000 * rank
+    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7}[args.workload] + 1000 * rank
     d_scal = device_random_scalars(torch, n, L, seed, device)
     d_pts = d_out = None
     if kind in ("var", "msm"):
@@ -178,6 +185,32 @@ def main():
         d_pts = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
         eng.mul_by_generator_dev(cid, d_s2, n, d_pts, None)          # P_i = s_i * G (untimed setup)
         del d_s2
+    d_r = d_s = d_ok = None
+    if kind == "ecdsa":
+        # valid signatures: 2^16 distinct (d, k, z) triples signed on the host from k*G computed here, tiled to n
+        m = min(n, 1 << 16)
+        d_d = device_random_scalars(torch, m, L, seed + 50, device)
+        d_k = device_random_scalars(torch, m, L, seed + 51, device)
+        d_Q = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
+        d_R = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
+        eng.mul_by_generator_dev(cid, d_d, m, d_Q, None)
+        eng.mul_by_generator_dev(cid, d_k, m, d_R, None)
+        torch.cuda.synchronize()
+        n_order = ecgpu.GROUP_ORDERS[cid]
+        dh, kh, zh, rx = (t.cpu().numpy() for t in (d_d, d_k, d_scal[:m], d_R[:, :L].contiguous()))
+        rb, sb = bytearray(), bytearray()
+        for i in range(m):
+            di, ki = int.from_bytes(dh[i].tobytes(), "big"), int.from_bytes(kh[i].tobytes(), "big") or 1
+            zi, ri = int.from_bytes(zh[i].tobytes(), "big"), int.from_bytes(rx[i].tobytes(), "big") % n_order
+            si = pow(ki, -1, n_order) * (zi + ri * di) % n_order
+            rb += ri.to_bytes(L, "big"); sb += si.to_bytes(L, "big")
+        reps = (n + m - 1) // m
+        d_r = torch.frombuffer(rb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
+        d_s = torch.frombuffer(sb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
+        d_scal = d_scal[:m].repeat(reps, 1)[:n].contiguous()
+        d_pts = d_Q.repeat(reps, 1)[:n].contiguous()
+        d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device)
+        del d_d, d_k, d_R, d_Q
     n_out = 1 if kind == "msm" else n
     d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
     d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
@@ -190,6 +223,8 @@ def main():
             eng.mul_by_generator_dev(cid, d_scal, n, d_out, d_inf)
         elif kind == "var":
             eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
+        elif kind == "ecdsa":
+            eng.ecdsa_verify_dev(cid, d_scal, d_r, d_s, d_pts, n, False, d_ok)
         else:
             eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
         main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
@@ -247,7 +282,8 @@ def main():
             ns = min(n, 1 << 17 if kind == "fixed" else (1 << 14 if kind == "var" else 1 << 15))
             s_host = d_scal[:ns].cpu().numpy().reshape(-1)
             p_host = d_pts[:ns].cpu().numpy().reshape(-1) if d_pts is not None else None
-            result["cpu_baseline"] = cpu_baseline(wl, cid, L, s_host, p_host)
+            extra = (d_r[:ns].cpu().numpy().reshape(-1), d_s[:ns].cpu().numpy().reshape(-1)) if kind == "ecdsa" else None
+            result["cpu_baseline"] = cpu_baseline(wl, cid, L, s_host, p_host, extra)
         if args.check:
             import oracle_lib
             oracle_lib.build()
@@ -257,6 +293,11 @@ def main():
                     ok = bytes(w) == bytes(d_out[0].cpu().numpy()) and wf == int(d_inf[0].item())
                 else:
                     ok = None
+            elif kind == "ecdsa":
+                m = min(n, 256)
+                w = oracle_lib.ecdsa_verify(cid, d_scal[:m].cpu().numpy().reshape(-1), d_r[:m].cpu().numpy().reshape(-1),
+                                            d_s[:m].cpu().numpy().reshape(-1), d_pts[:m].cpu().numpy().reshape(-1))
+                ok = bool(w.all()) and bool(d_ok[:n].all().item())       # every synthetic signature is valid
             else:
                 m = min(n, 256)
                 got = d_out[:m].cpu().numpy().reshape(-1)

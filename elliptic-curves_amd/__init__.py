@@ -37,8 +37,15 @@ ABI_SYMBOLS = [
     "ecgpu_batch_mul_base_and_mul_add", "ecgpu_batch_normalize", "ecgpu_batch_mul_base_dev",
     "ecgpu_batch_mul_dev", "ecgpu_msm_dev", "ecgpu_batch_mul_base_and_mul_add_dev", "ecgpu_batch_normalize_dev",
     "ecgpu_point_sum", "ecgpu_point_sum_dev", "ecgpu_k256_glv_decompose", "ecgpu_valu_probe",
-    "ecgpu_last_timing", "ecgpu_version",
+    "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
 ]
+
+
+GROUP_ORDERS = {   # k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73
+    0: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141,
+    1: 0xFFFFFFFF00000000FFFFFFFFFFFFFFFFBCE6FAADA7179E84F3B9CAC2FC632551,
+    2: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7634D81F4372DDF581A0DB248B0A77AECEC196ACCC52973,
+}
 
 
 class EcgpuError(RuntimeError):
@@ -178,6 +185,16 @@ class Engine:
                                                              ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
 
+    def ecdsa_verify(self, curve, z, r, s, q_xy, reject_high_s=False):
+        """Batch ECDSA verification: z, r, s are n*L big-endian bytes each, q_xy n*2L; returns uint8[n] (1 = valid)."""
+        L = _field_bytes(curve)
+        zz, rr, ss, qq = _host(z), _host(r), _host(s), _host(q_xy)
+        n = zz.size // L
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_ecdsa_verify_batch(self._ctx, curve, _hp(zz), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n),
+                                                     int(bool(reject_high_s)), _hp(ok)))
+        return ok
+
     def batch_normalize(self, curve, points_xyz):
         L = _field_bytes(curve)
         x = _host(points_xyz)
@@ -216,6 +233,10 @@ class Engine:
     def lincomb_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_msm_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
                                           ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
+    def ecdsa_verify_dev(self, curve, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok):
+        self._chk(self._lib.ecgpu_ecdsa_verify_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_q_xy),
+                                                         ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_ok)))
 
     def point_sum_dev(self, curve, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_point_sum_dev(self._ctx, curve, _dp(d_points_xy), _dp(d_points_inf), ctypes.c_size_t(n),

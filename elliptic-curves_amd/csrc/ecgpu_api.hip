@@ -43,6 +43,7 @@ struct ecgpu_ctx {
     int want_w[3] = {24, 24, 20};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
+    DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf;   // ECDSA verification scratch
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
 };
@@ -339,7 +340,8 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3,
-                      &ctx->out0, &ctx->out1, &ctx->msm_ws})
+                      &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
+                      &ctx->ec_inf})
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->table)
         if (t.d) (void)hipFree(t.d);
@@ -464,6 +466,54 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
     });
 }
 
+int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, const void* d_r, const void* d_s,
+                                 const void* d_q_xy, size_t n, int reject_high_s, void* d_ok) {
+    // per element: u1 = z/s, u2 = r/s (mod n), R = u1 G + u2 Q (the kernels of ecgpu_batch_mul_base_and_mul_add),
+    // ok = x(R) mod n == r.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_z || !d_r || !d_s || !d_q_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
+              !aligned16(d_q_xy)))
+        return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
+        using C = decltype(c);
+        constexpr int NS = Field<C>::NS;
+        const size_t L = 4 * C::N;
+        int rc;
+        if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+        if (n == 0) return (int)ECGPU_OK;
+        size_t tstride = var_base_slots<C>(n);
+        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_u1, n * L)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_u2, n * L)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_q, n * 2 * L)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_valid, n + 16)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
+        if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+        const Table& t = ctx->table[C::ID];
+        uint32_t* pa = (uint32_t*)ctx->proj.p;
+        uint32_t* pb = pa + n * 3 * NS;
+        record(ctx, 0);
+        launch_ecdsa_prepare<C>(ctx->stream, (const uint8_t*)d_z, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                                (const uint8_t*)d_q_xy, n, reject_high_s, (uint8_t*)ctx->ec_u1.p, (uint8_t*)ctx->ec_u2.p,
+                                (uint8_t*)ctx->ec_q.p, (uint8_t*)ctx->ec_valid.p);
+        record(ctx, 3);
+        launch_fixed_base<C>(ctx->stream, (const uint8_t*)ctx->ec_u1.p, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
+        launch_var_base<C>(ctx->stream, (const uint8_t*)ctx->ec_u2.p, (const uint8_t*)ctx->ec_q.p, nullptr, n,
+                           (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
+        launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+        record(ctx, 1);
+        if ((rc = normalize_out<C>(ctx, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
+        launch_ecdsa_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
+                               (const uint8_t*)ctx->ec_valid.p, n, (uint8_t*)d_ok);
+        record(ctx, 2);
+        rc = finish(ctx);
+        collect_timing(ctx, {{"recode", {0, 3}}, {"main", {3, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+        return rc;
+    });
+}
+
 // ---- host-pointer entry points ----
 
 int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy,
@@ -539,6 +589,24 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
         return rc;
     if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s,
+                             const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!z || !r || !s || !q_xy || !ok)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, z, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, s, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_ecdsa_verify_batch_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, reject_high_s,
+                                           ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    return download(ctx, ok, ctx->out1, n);
 }
 
 int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, size_t n, uint8_t* out_xy,

@@ -1,0 +1,87 @@
+// ecgpu_ecdsa.h — batch ECDSA verification around the aG + bP kernels (HIP only).
+//
+// the dominant caller of `mul_by_generator_and_mul_add_vartime`
+// (primeorder/src/mul_backend.rs:29-40, k256/src/arithmetic/mul.rs:303-310).  The verification equation itself
+// lives in the un-vendored `ecdsa` crate 0.17.0 (Cargo.lock:428-429, `hazmat::verify_prehashed`, instantiated at
+// p256/src/ecdsa.rs:69,161-169, p384/src/ecdsa.rs:179-187, k256/src/ecdsa.rs:104-106); it is the published
+// algorithm of SEC1 v2 §4.1.4 / FIPS 186-5 §6.4.2:
+//     z = the leftmost bits of the digest as an integer, reduced mod n        (`Reduce<FieldBytes>`)
+//     reject unless 1 <= r, s < n   (and, where the curve sets NORMALIZE_S, unless s <= (n-1)/2)
+//     w = s^-1 mod n,  u1 = z w,  u2 = r w,  R = u1 G + u2 Q;  accept iff R != identity and x(R) mod n == r
+// One lane per signature; an invalid element never fails the batch, it just gets ok = 0.
+#pragma once
+
+#include "ecgpu_kernels.h"
+#include "ecgpu_scalar.h"
+
+namespace ecgpu {
+
+// prepare: range checks, public-key validation, u1 / u2 as wire-format scalars for the scalar-mul kernels.
+// Elements that are already known to fail get u1 = u2 = 0 and Q = G so that the arithmetic kernels see valid input.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
+                const uint8_t* __restrict__ q_xy, size_t n, int reject_high_s, uint8_t* __restrict__ u1_out,
+                uint8_t* __restrict__ u2_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+    using S = ScalarN<C>;
+    using F = Field<C>;
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N];
+    load_be_vec<N>(zw, z + i * (4 * N));
+    load_be_vec<N>(rw, r + i * (4 * N));
+    load_be_vec<N>(sw, s + i * (4 * N));
+    load_be_vec<N>(cx, q_xy + i * (8 * N));
+    load_be_vec<N>(cy, q_xy + i * (8 * N) + 4 * N);
+    bool ok = !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
+    if (reject_high_s) ok = ok && !S::is_high(sw);
+    ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
+    {
+        Affine<C> a;
+        a.x = F::from_canonical(cx).e;                   // (values >= p wrap; ok is already false for them)
+        a.y = F::from_canonical(cy).e;
+        ok = ok && Group<C>::on_curve(a, Group<C>::curve_b());
+    }
+    uint32_t u1[N], u2[N];
+    {
+        uint32_t zr[N], w[N];
+        S::reduce_once(zr, zw);
+        S::inv(w, sw);
+        S::mul(u1, zr, w);
+        S::mul(u2, rw, w);
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        u1[j] = ok ? u1[j] : 0u;
+        u2[j] = ok ? u2[j] : 0u;
+        cx[j] = ok ? cx[j] : C::GX[j];
+        cy[j] = ok ? cy[j] : C::GY[j];
+    }
+    store_be_vec<N>(u1_out + i * (4 * N), u1);
+    store_be_vec<N>(u2_out + i * (4 * N), u2);
+    store_be_vec<N>(q_out + i * (8 * N), cx);
+    store_be_vec<N>(q_out + i * (8 * N) + 4 * N, cy);
+    valid[i] = ok ? 1 : 0;
+}
+
+// finish: x(R) mod n == r
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf, const uint8_t* __restrict__ r,
+               const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x[N], xr[N], rw[N];
+    load_be_vec<N>(x, r_xy + i * (8 * N));
+    load_be_vec<N>(rw, r + i * (4 * N));
+    S::reduce_once(xr, x);                                // x < p < 2n
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) eq = eq && (xr[j] == rw[j]);
+    ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
+}
+
+}  // namespace ecgpu

@@ -2,6 +2,7 @@
 #include <cstdlib>
 
 #include "ecgpu_kernels.h"
+#include "ecgpu_ecdsa.h"
 #include "ecgpu_launch.h"
 
 namespace ecgpu {
@@ -50,6 +51,16 @@ template <> void launch_point_sum<CurveT>(hipStream_t s, const uint8_t* xy, cons
 }
 template <> void launch_proj_add_pairs<CurveT>(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n) {
     hipLaunchKernelGGL(k_proj_add_pairs<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, pa, pb, n);
+}
+template <> void launch_ecdsa_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
+                                              const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2,
+                                              uint8_t* q_out, uint8_t* valid) {
+    hipLaunchKernelGGL(k_ecdsa_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, z, r, sig_s, q_xy, n, reject_high_s, u1, u2,
+                       q_out, valid);
+}
+template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
+                                             const uint8_t* valid, size_t n, uint8_t* ok) {
+    hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
 }
 
 }  // namespace ecgpu

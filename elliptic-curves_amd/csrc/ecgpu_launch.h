@@ -33,6 +33,10 @@ template <class C> void launch_load_proj(hipStream_t s, const uint8_t* xyz, size
 template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
                                          int* status);
 template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n);
+template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
+                                             size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid);
+template <class C> void launch_ecdsa_finish(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
+                                            const uint8_t* valid, size_t n, uint8_t* ok);
 
 // ---- group "var": variable-base kernel ----
 template <class C> size_t var_base_slots(size_t n);     // table slots (threads) the launch will use

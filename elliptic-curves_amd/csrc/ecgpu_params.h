@@ -164,6 +164,11 @@ struct K256Params {
     // group order n                                k256/src/lib.rs:71
     ECGPU_CONST uint32_t ORDER[8] = {0xD0364141u, 0xBFD25E8Cu, 0xAF48A03Bu, 0xBAAEDCE6u,
                                      0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^256): R^2 mod n and -n^-1 mod 2^32, for the scalar arithmetic of the
+    // ECDSA verification path (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[8] = {0x67D7D140u, 0x896CF214u, 0x0E7CF878u, 0x741496C2u,
+                                           0x5BCD07C6u, 0xE697F5E4u, 0x81C69BC5u, 0x9D671CD5u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x5588B13Fu;
     // generator, canonical little-endian limbs     k256/src/arithmetic/affine.rs:65-79
     ECGPU_CONST uint32_t GX[8] = {0x16F81798u, 0x59F2815Bu, 0x2DCE28D9u, 0x029BFCDBu,
                                   0xCE870B07u, 0x55A06295u, 0xF9DCBBACu, 0x79BE667Eu};
@@ -189,6 +194,11 @@ struct P256Params {
     // n                                            p256/src/lib.rs:60
     ECGPU_CONST uint32_t ORDER[8] = {0xFC632551u, 0xF3B9CAC2u, 0xA7179E84u, 0xBCE6FAADu,
                                      0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^256): R^2 mod n and -n^-1 mod 2^32, for the scalar arithmetic of the
+    // ECDSA verification path (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[8] = {0xBE79EEA2u, 0x83244C95u, 0x49BD6FA6u, 0x4699799Cu,
+                                           0x2B6BEC59u, 0x2845B239u, 0xF3D95620u, 0x66E12D94u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0xEE00BC4Fu;
     // R^2 mod p, R = 2^256                         p256/src/arithmetic/field.rs:183-185
     ECGPU_CONST uint32_t R2[8] = {0x00000003u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFBu,
                                   0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFDu, 0x00000004u};
@@ -221,6 +231,12 @@ struct P384Params {
     ECGPU_CONST uint32_t ORDER[12] = {0xCCC52973u, 0xECEC196Au, 0x48B0A77Au, 0x581A0DB2u,
                                       0xF4372DDFu, 0xC7634D81u, 0xFFFFFFFFu, 0xFFFFFFFFu,
                                       0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^384): R^2 mod n and -n^-1 mod 2^32, for the scalar arithmetic of the
+    // ECDSA verification path (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[12] = {0x19B409A9u, 0x2D319B24u, 0xDF1AA419u, 0xFF3D81E5u,
+                                           0xFCB82947u, 0xBC3E483Au, 0x4AAB1CC5u, 0xD40D4917u,
+                                           0x28266895u, 0x3FB05B7Au, 0x2B39BF21u, 0x0C84EE01u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0xE88FDC45u;
     // R^2 mod p, R = 2^384: (2^128 + 2^96 - 2^32 + 1)^2
     ECGPU_CONST uint32_t R2[12] = {0x00000001u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,
                                    0x00000000u, 0xFFFFFFFEu, 0x00000000u, 0x00000002u,

@@ -48,6 +48,9 @@ unsafe extern "C" {
                                  out_xy: *mut u8, out_inf: *mut u8) -> c_int;
     pub fn ecgpu_point_sum(ctx: *mut EcgpuCtx, curve: c_int, points_xy: *const u8, points_inf: *const u8,
                            n: usize, out_xy: *mut u8, out_inf: *mut u8) -> c_int;
+    /// Batch form of `ecdsa::hazmat::verify_prehashed`; `reject_high_s` = `C::NORMALIZE_S`.
+    pub fn ecgpu_ecdsa_verify_batch(ctx: *mut EcgpuCtx, curve: c_int, z: *const u8, r: *const u8, s: *const u8,
+                                    q_xy: *const u8, n: usize, reject_high_s: c_int, ok: *mut u8) -> c_int;
 }
 
 /// Process-wide context: the analogue of `static BASEPOINT_TABLE: LazyLock<..>`

@@ -157,6 +157,24 @@ int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
 int ecgpu_k256_glv_decompose(ecgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *r1,
                              uint8_t *r2);
 
+/* Batch ECDSA verification — SURVEY.md §8(f) rank 1, the dominant caller of
+ * `mul_by_generator_and_mul_add_vartime` (primeorder/src/mul_backend.rs:29-40, k256/src/arithmetic/mul.rs:303-310).
+ * The equation is `ecdsa::hazmat::verify_prehashed` (ecdsa 0.17.0, un-vendored, Cargo.lock:428-429; instantiated
+ * at p256/src/ecdsa.rs:69, p384/src/ecdsa.rs, k256/src/ecdsa.rs:104-106), i.e. SEC1 v2 §4.1.4.  Per element i:
+ *   z  L bytes big-endian: the leftmost L bytes of the message digest as an integer (`bits2field`); it is
+ *      reduced mod n on the device like `Scalar::reduce`
+ *   r, s  L bytes big-endian each; q_xy  the public key, affine x||y
+ *   ok[i] = 1 iff 1 <= r, s < n, (reject_high_s == 0 or s <= (n-1)/2 — pass the curve's `NORMALIZE_S`,
+ *      true for k256), Q is a valid non-identity curve point, R = (z/s) G + (r/s) Q is not the identity and
+ *      x(R) mod n == r;  otherwise 0.  A bad element never fails the batch: the return value reports only
+ *      argument / device errors. */
+int ecgpu_ecdsa_verify_batch(ecgpu_ctx *ctx, int curve, const uint8_t *z, const uint8_t *r,
+                             const uint8_t *s, const uint8_t *q_xy, size_t n, int reject_high_s,
+                             uint8_t *ok);
+int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_z, const void *d_r,
+                                 const void *d_s, const void *d_q_xy, size_t n, int reject_high_s,
+                                 void *d_ok);
+
 /* Integer-VALU roof probe: runs a dependency-free v_mad_u64_u32 stream on every CU and returns
  * the measured 32x32->64 multiply-add rate in operations per second (SURVEY.md §8d "peak to
  * divide by").  `which` selects the instruction: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32,

@@ -82,6 +82,12 @@ int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_
                                        const uint8_t *p_xy, int p_inf, uint8_t *out_xy,
                                        uint8_t *out_inf);
 
+/* ok[i] = ECDSA verification of (r_i, s_i) on digest integer z_i under public key Q_i — see ecref_ecdsa.c for the
+ * algorithm and its provenance (ecdsa 0.17.0 hazmat::verify_prehashed, SEC1 4.1.4).  All fields L bytes big-endian,
+ * q_xy affine x||y.  reject_high_s = the curve's NORMALIZE_S (k256/src/ecdsa.rs:104-106). */
+int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
+                             const uint8_t *q_xy, size_t n, int reject_high_s, uint8_t *ok);
+
 /* ---- smaller pieces, exposed so device-side code can be unit-checked against them ------- */
 
 /* out = a (+,-,*) b mod p ; op: 0 add, 1 sub, 2 mul, 3 square(a), 4 invert(a) (0 -> 0),

@@ -1,0 +1,175 @@
+/* ecref_ecdsa.c — CPU restatement of ECDSA verification over the oracle's own a*G + b*P driver.
+ * TEST INFRASTRUCTURE ONLY (see ecref.h).
+ *
+ * The verification equation is not in /root/reference: it lives in the un-vendored crate `ecdsa` 0.17.0
+ * (Cargo.lock:428-429), `hazmat::verify_prehashed`, which the reference instantiates at p256/src/ecdsa.rs:69,
+ * p384/src/ecdsa.rs and k256/src/ecdsa.rs:99-106 (NORMALIZE_S = true) and tests with its own vectors
+ * ({p256,p384,k256}/src/test_vectors/ecdsa.rs via `new_verification_test!`, p256/src/ecdsa.rs:161-164).  Its published
+ * algorithm (SEC1 v2 section 4.1.4, FIPS 186-5 section 6.4.2) is restated here:
+ *     z = digest as an integer, reduced mod n  (Reduce<FieldBytes>: one conditional subtraction,
+ *         k256/src/arithmetic/scalar.rs:618-631)
+ *     reject unless 1 <= r, s < n (Signature::from_scalars) and, for NORMALIZE_S curves, s <= (n-1)/2
+ *     u1 = z/s, u2 = r/s mod n;  R = u1*G + u2*Q  (mul_by_generator_and_mul_add_vartime,
+ *         primeorder/src/mul_backend.rs:29-40, k256/src/arithmetic/mul.rs:303-310 -> ecref_mul_base_and_mul_add_vartime)
+ *     accept iff R is not the identity and x(R) mod n == r.
+ * Parity is pinned by the reference's 31 ECDSA vectors in tests/golden/ (accept) and by an independent big-integer
+ * model (tests/pyec.py) on random accept / reject cases.
+ *
+ * Scalar arithmetic mod n: Montgomery multiplication on 64-bit words, inversion as a^(n-2).  (The reference inverts
+ * with safegcd; the value is the same.) */
+#include <string.h>
+
+#include "ecref.h"
+
+typedef unsigned __int128 u128;
+
+/* group orders, little-endian 64-bit words: k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73 */
+static const uint64_t ORDER_K256[6] = {0xBFD25E8CD0364141ull, 0xBAAEDCE6AF48A03Bull, 0xFFFFFFFFFFFFFFFEull,
+                                       0xFFFFFFFFFFFFFFFFull, 0, 0};
+static const uint64_t ORDER_P256[6] = {0xF3B9CAC2FC632551ull, 0xBCE6FAADA7179E84ull, 0xFFFFFFFFFFFFFFFFull,
+                                       0xFFFFFFFF00000000ull, 0, 0};
+static const uint64_t ORDER_P384[6] = {0xECEC196ACCC52973ull, 0x581A0DB248B0A77Aull, 0xC7634D81F4372DDFull,
+                                       0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull};
+
+typedef struct {
+    int nl;               /* 64-bit words */
+    const uint64_t *n;
+    uint64_t ninv;        /* -n^-1 mod 2^64 */
+    uint64_t r2[6];       /* 2^(128 nl) mod n */
+} modn_t;
+
+static int geq(const uint64_t *a, const uint64_t *b, int nl) {
+    for (int i = nl - 1; i >= 0; i--) {
+        if (a[i] != b[i]) return a[i] > b[i];
+    }
+    return 1;
+}
+static void sub_n(uint64_t *a, const uint64_t *b, int nl) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < nl; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        a[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+static int is_zero(const uint64_t *a, int nl) {
+    uint64_t z = 0;
+    for (int i = 0; i < nl; i++) z |= a[i];
+    return z == 0;
+}
+/* a = 2a mod n */
+static void dbl_mod(uint64_t *a, const modn_t *m) {
+    uint64_t carry = 0;
+    for (int i = 0; i < m->nl; i++) {
+        uint64_t hi = a[i] >> 63;
+        a[i] = (a[i] << 1) | carry;
+        carry = hi;
+    }
+    if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
+}
+static void modn_init(modn_t *m, int curve) {
+    m->nl = curve == ECREF_P384 ? 6 : 4;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : (curve == ECREF_P256 ? ORDER_P256 : ORDER_P384);
+    uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
+    for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
+    m->ninv = 0 - x;
+    memset(m->r2, 0, sizeof m->r2);
+    m->r2[0] = 1;
+    for (int i = 0; i < 128 * m->nl; i++) dbl_mod(m->r2, m);
+}
+/* r = a*b*2^(-64 nl) mod n */
+static void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const modn_t *m) {
+    uint64_t t[8] = {0};
+    const int nl = m->nl;
+    for (int i = 0; i < nl; i++) {
+        u128 c = 0;
+        for (int j = 0; j < nl; j++) {
+            c += (u128)a[j] * b[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[nl];
+        t[nl] = (uint64_t)c;
+        t[nl + 1] = (uint64_t)(c >> 64);
+        uint64_t q = t[0] * m->ninv;
+        c = (u128)q * m->n[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < nl; j++) {
+            c += (u128)q * m->n[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[nl];
+        t[nl - 1] = (uint64_t)c;
+        t[nl] = t[nl + 1] + (uint64_t)(c >> 64);
+    }
+    if (t[nl] || geq(t, m->n, nl)) sub_n(t, m->n, nl);
+    memcpy(r, t, 8 * nl);
+}
+static void mul_mod(uint64_t *r, const uint64_t *a, const uint64_t *b, const modn_t *m) {
+    uint64_t t[6];
+    mont_mul(t, a, b, m);
+    mont_mul(r, t, m->r2, m);
+}
+/* r = a^(n-2) mod n */
+static void inv_mod(uint64_t *r, const uint64_t *a, const modn_t *m) {
+    uint64_t e[6], acc[6] = {1, 0, 0, 0, 0, 0}, base[6];
+    memcpy(e, m->n, 8 * m->nl);
+    e[0] -= 2;                                   /* n is odd and > 2 */
+    memcpy(base, a, 8 * m->nl);
+    for (int i = 64 * m->nl - 1; i >= 0; i--) {
+        mul_mod(acc, acc, acc, m);
+        if ((e[i / 64] >> (i % 64)) & 1) mul_mod(acc, acc, base, m);
+    }
+    memcpy(r, acc, 8 * m->nl);
+}
+static void from_be(uint64_t *w, const uint8_t *b, int nl) {
+    for (int i = 0; i < nl; i++) {
+        uint64_t v = 0;
+        for (int j = 0; j < 8; j++) v = (v << 8) | b[8 * (nl - 1 - i) + j];
+        w[i] = v;
+    }
+}
+static void to_be(uint8_t *b, const uint64_t *w, int nl) {
+    for (int i = 0; i < nl; i++)
+        for (int j = 0; j < 8; j++) b[8 * (nl - 1 - i) + j] = (uint8_t)(w[i] >> (56 - 8 * j));
+}
+
+int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
+                             size_t n, int reject_high_s, uint8_t *ok) {
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384) return ECREF_ERR_CURVE;
+    modn_t m;
+    modn_init(&m, curve);
+    const int nl = m.nl;
+    const size_t L = 8 * (size_t)nl;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t zw[6], rw[6], sw[6], w[6], u1[6], u2[6];
+        ok[i] = 0;
+        from_be(zw, z + L * i, nl);
+        from_be(rw, r + L * i, nl);
+        from_be(sw, s + L * i, nl);
+        if (is_zero(rw, nl) || geq(rw, m.n, nl) || is_zero(sw, nl) || geq(sw, m.n, nl)) continue;
+        if (reject_high_s) {
+            uint64_t twice[6];
+            memcpy(twice, sw, 8 * nl);
+            uint64_t top = twice[nl - 1] >> 63;
+            for (int k = nl - 1; k > 0; k--) twice[k] = (twice[k] << 1) | (twice[k - 1] >> 63);
+            twice[0] <<= 1;
+            if (top || geq(twice, m.n, nl)) continue;            /* 2s >= n  <=>  s > (n-1)/2 */
+        }
+        if (geq(zw, m.n, nl)) sub_n(zw, m.n, nl);
+        inv_mod(w, sw, &m);
+        mul_mod(u1, zw, w, &m);
+        mul_mod(u2, rw, w, &m);
+        uint8_t a[48], b[48], xy[96], inf = 0;
+        to_be(a, u1, nl);
+        to_be(b, u2, nl);
+        if (ecref_mul_base_and_mul_add_vartime(curve, a, b, q_xy + 2 * L * i, 0, xy, &inf) != ECREF_OK) continue;
+        if (inf) continue;
+        uint64_t x[6];
+        from_be(x, xy, nl);
+        if (geq(x, m.n, nl)) sub_n(x, m.n, nl);                 /* x < p < 2n */
+        ok[i] = memcmp(x, rw, 8 * nl) == 0;
+    }
+    return ECREF_OK;
+}

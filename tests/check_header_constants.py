@@ -26,7 +26,12 @@ def check():
     for name, c in (("K256Params", pyec.K256), ("P256Params", pyec.P256), ("P384Params", pyec.P384)):
         a = arrays(src, name)
         R = 1 << (8 * c.L)
-        exp = {"P": c.p, "ORDER": c.n, "GX": c.gx, "GY": c.gy}
+        exp = {"P": c.p, "ORDER": c.n, "GX": c.gx, "GY": c.gy, "ORDER_R2": R * R % c.n}
+        m = re.search(r"ORDER_NINV32 = 0x([0-9A-Fa-f]+)u", src[src.index("struct %s {" % name):])
+        if not m or (int(m.group(1), 16) * c.n + 1) % (1 << 32) != 0:
+            bad.append((name, "ORDER_NINV32"))
+        if name == "K256Params":
+            exp["BETA"] = pyec.K256_BETA if hasattr(pyec, "K256_BETA") else a.get("BETA")
         if name != "K256Params":
             exp.update({"R2": R * R % c.p, "ONE": R % c.p, "B": c.b})
         for k, v in exp.items():

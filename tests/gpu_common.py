@@ -65,3 +65,54 @@ def scalars_to_int_sum(scalars, L, n_mod):
         col = int(words[:, j].sum(dtype=np.uint64)) if words.shape[0] < (1 << 31) else sum(int(x) for x in words[:, j])
         total += col << (32 * (ncol - 1 - j))
     return total % n_mod
+
+
+def ecdsa_cases(c, seed, nvalid=12):
+    """(z, r, s, qxy bytes, expected bool) tuples: valid signatures by the big-int model plus every way of breaking
+    one that the verification equation distinguishes.  z is an L-byte integer that may exceed n (reduced on use)."""
+    import random
+    rng = random.Random(seed)
+    L = c.L
+    cases = []
+    G = pyec.G(c)
+
+    def enc(z, r, s, Q, exp):
+        qxy = pyec.enc_point(c, Q)[0] if not isinstance(Q, bytes) else Q
+        cases.append((z.to_bytes(L, "big"), r.to_bytes(L, "big"), s.to_bytes(L, "big"), qxy, exp))
+
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n)
+        z = rng.randrange(1 << (8 * L)) if i % 3 else rng.randrange(c.n, 1 << (8 * L))   # also digests >= n
+        k = rng.randrange(1, c.n)
+        Q = pyec.mul(c, d, G)
+        r, s = pyec.ecdsa_sign(c, d, z, k)
+        if r == 0 or s == 0:
+            continue
+        enc(z, r, s, Q, True)
+        enc(z, r, c.n - s, Q, True)                                  # the other s: also valid (high-S policy aside)
+        enc(z ^ 1, r, s, Q, False)                                   # wrong digest
+        enc(z, r, (s + 1) % c.n or 1, Q, False)                      # wrong s
+        enc(z, (r + 1) % c.n or 1, s, Q, False)                      # wrong r
+        enc(z, r, s, pyec.mul(c, d + 1, G), False)                   # wrong key
+        enc(z, r, s, pyec.neg(c, Q), False)
+        if i < 4:
+            enc(z, 0, s, Q, False)                                   # range failures
+            enc(z, r, 0, Q, False)
+            enc(z, c.n, s, Q, False)
+            enc(z, r, c.n, Q, False)
+            if r + c.n < (1 << (8 * L)):
+                enc(z, r + c.n, s, Q, False)                         # r + n: same residue, out of range
+            bad = bytearray(pyec.enc_point(c, Q)[0]); bad[-1] ^= 1
+            enc(z, r, s, bytes(bad), False)                          # off-curve key
+            enc(z, r, s, (c.p).to_bytes(L, "big") + pyec.enc_point(c, Q)[0][L:], False)   # coordinate >= p
+            enc(z, r, s, bytes(2 * L), False)                        # (0, 0)
+    return cases
+
+
+def ecdsa_pack(cases):
+    z = b"".join(t[0] for t in cases)
+    r = b"".join(t[1] for t in cases)
+    s = b"".join(t[2] for t in cases)
+    q = b"".join(t[3] for t in cases)
+    exp = np.array([1 if t[4] else 0 for t in cases], np.uint8)
+    return z, r, s, q, exp

@@ -11,6 +11,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_fixedmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_scalar.h"
 
 using namespace ecgpu;
 
@@ -408,6 +409,26 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     return 0;
 }
 
+// ScalarN<C>: op 0 a*b mod n, 1 1/a mod n, 2 a mod n (a < 2^(32N)), 3 is_high(a) -> out[last byte]
+template <class C>
+int scalar_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    uint32_t x[N], y[N], r[N];
+    load_be<N>(x, a);
+    for (int i = 0; i < N; i++) r[i] = 0;
+    if (b) load_be<N>(y, b);
+    switch (op) {
+    case 0: S::mul(r, x, y); break;
+    case 1: S::inv(r, x); break;
+    case 2: S::reduce_once(r, x); break;
+    case 3: r[0] = S::is_high(x) ? 1u : 0u; break;
+    default: return -1;
+    }
+    store_be<N>(out, r);
+    return 0;
+}
+
 template <class C>
 int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
     // e * 2^(w*j) * G via k_window_bases' doubling chain + k_table_entries' rule
@@ -434,6 +455,10 @@ extern "C" {
 int hc_field_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     DISPATCH(curve, field_op<K256Params>(op, a, b, out), field_op<P256Params>(op, a, b, out),
              field_op<P384Params>(op, a, b, out))
+}
+int hc_scalar_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    DISPATCH(curve, scalar_op<K256Params>(op, a, b, out), scalar_op<P256Params>(op, a, b, out),
+             scalar_op<P384Params>(op, a, b, out))
 }
 int hc_field_chain(int curve, const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
     DISPATCH(curve, field_chain<K256Params>(a, b, steps, out), field_chain<P256Params>(a, b, steps, out),

@@ -101,6 +101,16 @@ def mul_base_and_mul_add_vartime(curve, a, b, p_xy, p_inf=0):
     return out, int(inf[0])
 
 
+def ecdsa_verify(curve, z, r, s, q_xy, reject_high_s=False):
+    L = FIELD_BYTES[curve]
+    zz, rr, ss, qq = _arr(z), _arr(r), _arr(s), _arr(q_xy)
+    n = zz.size // L
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_ecdsa_verify_batch(curve, _buf(zz), _buf(rr), _buf(ss), _buf(qq), ctypes.c_size_t(n),
+                                        int(bool(reject_high_s)), _buf(ok)))
+    return ok
+
+
 def field_op(curve, op, a, b=None):
     L = FIELD_BYTES[curve]
     out = np.zeros(L, np.uint8)

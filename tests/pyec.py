@@ -125,3 +125,25 @@ def dec_point(c, xy, inf):
         assert xy == bytes(2 * c.L), "identity must be encoded as zeros"
         return INF
     return (int.from_bytes(xy[: c.L], "big"), int.from_bytes(xy[c.L:], "big"))
+
+
+# ---- ECDSA (SEC1 v2 4.1.3 / 4.1.4), the independent model for the verification tests --------------------------
+
+def ecdsa_sign(c, d, z, k):
+    """(r, s) for private key d, digest integer z, nonce k (no low-S normalisation)."""
+    R = mul(c, k, G(c))
+    r = R[0] % c.n
+    s = pow(k, -1, c.n) * (z + r * d) % c.n
+    return r, s
+
+
+def ecdsa_verify(c, Q, z, r, s, reject_high_s=False):
+    if not (1 <= r < c.n and 1 <= s < c.n):
+        return False
+    if reject_high_s and s > (c.n - 1) // 2:
+        return False
+    if Q is INF or not on_curve(c, Q):
+        return False
+    w = pow(s, -1, c.n)
+    R = add(c, mul(c, z % c.n * w % c.n, G(c)), mul(c, r * w % c.n, Q))
+    return R is not INF and R[0] % c.n == r

@@ -6,8 +6,8 @@ import pytest
 
 import oracle_lib
 import pyec
-from gpu_common import (CURVES, ecgpu_module, edge_scalars, ladder_edge_scalars, load_golden, rand_scalars,
-                        scalars_to_int_sum)
+from gpu_common import (CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, edge_scalars, ladder_edge_scalars, load_golden,
+                        rand_scalars, scalars_to_int_sum)
 
 pytestmark = pytest.mark.gpu
 
@@ -402,3 +402,62 @@ def test_full_size_msm_k256_properties(eng):
     pp = pts.reshape(n, 64)[perm].reshape(-1)
     p2, pf = eng.lincomb(0, kp, pp)
     assert bytes(p2) == bytes(full) and pf == ff
+
+
+# ---------------------------------------------------------------------------------------------------
+# batch ECDSA verification
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ecdsa_verify_golden_vectors(eng, curve):
+    """Every signature of {p256,p384,k256}/src/test_vectors/ecdsa.rs verifies; disturbing any field breaks it."""
+    c = pyec.CURVES[curve]
+    vec = load_golden(curve)["ecdsa"]
+    z = b"".join(bytes.fromhex(v["m"]) for v in vec)
+    r = b"".join(bytes.fromhex(v["r"]) for v in vec)
+    s = b"".join(bytes.fromhex(v["s"]) for v in vec)
+    q = b"".join(bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"]) for v in vec)
+    assert eng.ecdsa_verify(c.cid, z, r, s, q).all()
+    for field in range(4):
+        bufs = [bytearray(z), bytearray(r), bytearray(s), bytearray(q)]
+        width = len(bufs[field]) // len(vec)
+        for i in range(len(vec)):
+            bufs[field][i * width + width - 1] ^= 1 << (i % 7)
+        assert not eng.ecdsa_verify(c.cid, *[bytes(b) for b in bufs]).any()
+    assert eng.ecdsa_verify(c.cid, b"", b"", b"", b"").size == 0
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ecdsa_verify_vs_oracle_and_model(eng, curve):
+    """Valid signatures, wrong digest / r / s / key, range failures (0, n, r + n), off-curve and out-of-range keys,
+    digests >= n, both high-S policies: bit-for-bit the oracle's and the big-integer model's verdicts."""
+    c = pyec.CURVES[curve]
+    z, r, s, q, exp = ecdsa_pack(ecdsa_cases(c, 0x5EC1 + c.cid, nvalid=24))
+    got = eng.ecdsa_verify(c.cid, z, r, s, q)
+    assert bytes(got) == bytes(exp)
+    assert bytes(got) == bytes(oracle_lib.ecdsa_verify(c.cid, z, r, s, q))
+    got_hs = eng.ecdsa_verify(c.cid, z, r, s, q, reject_high_s=True)
+    assert bytes(got_hs) == bytes(oracle_lib.ecdsa_verify(c.cid, z, r, s, q, reject_high_s=True))
+    assert 0 < int(got_hs.sum()) < int(got.sum())
+    # a larger mixed batch against the oracle: signatures built from k*G and (z + r d)/k with numpy-free big ints
+    rng = np.random.default_rng(0xECD5A + c.cid)
+    n = 600
+    ds = rand_scalars(c.cid, n, 0xD0 + c.cid)
+    ks = rand_scalars(c.cid, n, 0xD1 + c.cid)
+    zs = rng.integers(0, 256, n * c.L, dtype=np.uint8)
+    Q, _ = eng.mul_by_generator(c.cid, ds)
+    R, _ = eng.mul_by_generator(c.cid, ks)
+    rr, ss = bytearray(), bytearray()
+    for i in range(n):
+        d = int.from_bytes(bytes(ds[i * c.L:(i + 1) * c.L]), "big")
+        k = int.from_bytes(bytes(ks[i * c.L:(i + 1) * c.L]), "big") or 1
+        zi = int.from_bytes(bytes(zs[i * c.L:(i + 1) * c.L]), "big")
+        ri = int.from_bytes(bytes(R[2 * c.L * i: 2 * c.L * i + c.L]), "big") % c.n
+        si = pow(k, -1, c.n) * (zi + ri * d) % c.n
+        if i % 5 == 4:
+            si = (si + 1) % c.n                                  # every fifth signature is wrong
+        rr += ri.to_bytes(c.L, "big"); ss += si.to_bytes(c.L, "big")
+    got = eng.ecdsa_verify(c.cid, zs, bytes(rr), bytes(ss), Q)
+    want = oracle_lib.ecdsa_verify(c.cid, zs, bytes(rr), bytes(ss), Q)
+    assert bytes(got) == bytes(want)
+    assert int(got.sum()) >= n - n // 5 - 3 and not got[4::5].any()

@@ -52,6 +52,23 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_scalar_field_ops(curve):
+    """ScalarN (ecgpu_scalar.h): the mod-n arithmetic of the ECDSA verification path."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0x5CA1 + c.cid)
+    vals = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 2 ** 128, 2 ** (8 * c.L - 1) % c.n] + \
+           [rng.randrange(c.n) for _ in range(200)]
+    enc = lambda v: v.to_bytes(c.L, "big")
+    for i, a in enumerate(vals):
+        b = vals[(7 * i + 3) % len(vals)]
+        assert int.from_bytes(hc.scalar_op(c.cid, 0, enc(a), enc(b)), "big") == a * b % c.n
+        assert int.from_bytes(hc.scalar_op(c.cid, 1, enc(a)), "big") == (pow(a, -1, c.n) if a else 0)
+        assert hc.scalar_op(c.cid, 3, enc(a))[-1] == (1 if a > (c.n - 1) // 2 else 0)
+    for a in [c.n, c.n + 1, 2 ** (8 * c.L) - 1, c.n - 1, 5] + [rng.randrange(1 << (8 * c.L)) for _ in range(50)]:
+        assert int.from_bytes(hc.scalar_op(c.cid, 2, enc(a)), "big") == a % c.n
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_field_lazy_chain(curve):
     """Long mixed chains: exercises the weakly-reduced k256 residues and every carry/fold path."""
     c = pyec.CURVES[curve]

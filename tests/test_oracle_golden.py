@@ -81,6 +81,34 @@ def test_ecdsa_vectors_fixed_base_and_verify(oracle, curve):
         assert pinf == 0 and int.from_bytes(bytes(pt[: c.L]), "big") % c.n == r
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_ecdsa_verify_golden_and_model(oracle, curve):
+    """ecref_ecdsa_verify_batch: accepts every signature of the reference's ECDSA vectors
+    ({p256,p384,k256}/src/test_vectors/ecdsa.rs, run there through `new_verification_test!`), rejects them once any
+    field is disturbed, and agrees with the big-integer model on valid / invalid / out-of-range cases."""
+    from gpu_common import ecdsa_cases, ecdsa_pack
+    c = pyec.CURVES[curve]
+    vec = load(curve)["ecdsa"]
+    z = b"".join(bytes.fromhex(v["m"]) for v in vec)
+    r = b"".join(bytes.fromhex(v["r"]) for v in vec)
+    s = b"".join(bytes.fromhex(v["s"]) for v in vec)
+    q = b"".join(bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"]) for v in vec)
+    assert oracle.ecdsa_verify(c.cid, z, r, s, q).all()
+    for field in range(4):
+        bufs = [bytearray(z), bytearray(r), bytearray(s), bytearray(q)]
+        for i in range(len(vec)):
+            width = len(bufs[field]) // len(vec)
+            bufs[field][i * width + width - 1] ^= 1 << (i % 7)
+        assert not oracle.ecdsa_verify(c.cid, *[bytes(b) for b in bufs]).any()
+    zz, rr, ss, qq, exp = ecdsa_pack(ecdsa_cases(c, 0xEC5A + c.cid))
+    assert bytes(oracle.ecdsa_verify(c.cid, zz, rr, ss, qq)) == bytes(exp)
+    # NORMALIZE_S (k256/src/ecdsa.rs:104-106): high-S signatures are rejected when the caller asks for it
+    got = oracle.ecdsa_verify(c.cid, zz, rr, ss, qq, reject_high_s=True)
+    half = (c.n - 1) // 2
+    want = [int(e and int.from_bytes(ss[i * c.L:(i + 1) * c.L], "big") <= half) for i, e in enumerate(exp)]
+    assert list(got) == want and 0 < sum(want) < int(exp.sum())
+
+
 @pytest.mark.parametrize("curve", ["k256", "p256"])
 def test_field_doubling_vectors(oracle, curve):
     """k256 field.rs tests / p256 field.rs:219-245: repeated doubling of 1."""
