@@ -38,6 +38,8 @@ ABI_SYMBOLS = [
     "ecgpu_batch_mul_dev", "ecgpu_msm_dev", "ecgpu_batch_mul_base_and_mul_add_dev", "ecgpu_batch_normalize_dev",
     "ecgpu_point_sum", "ecgpu_point_sum_dev", "ecgpu_k256_glv_decompose", "ecgpu_valu_probe",
     "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
+    "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
+    "ecgpu_batch_decompress_dev",
 ]
 
 
@@ -194,6 +196,24 @@ class Engine:
         self._chk(self._lib.ecgpu_ecdsa_verify_batch(self._ctx, curve, _hp(zz), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n),
                                                      int(bool(reject_high_s)), _hp(ok)))
         return ok
+
+    def schnorr_verify(self, e, r, s, p_xy):
+        """Batch BIP340 verification (k256): e = challenge hash as 32 bytes, (r, s) signature halves, p_xy lifted key."""
+        ee, rr, ss, pp = _host(e), _host(r), _host(s), _host(p_xy)
+        n = ee.size // 32
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_schnorr_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(pp), ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
+    def decompress(self, curve, xs, y_is_odd):
+        """DecompressPoint::decompress for a batch: returns (xy uint8[n*2L], ok uint8[n])."""
+        L = _field_bytes(curve)
+        x, odd = _host(xs), _host(y_is_odd)
+        n = x.size // L
+        out = np.zeros(n * 2 * L, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_decompress(self._ctx, curve, _hp(x), _hp(odd), ctypes.c_size_t(n), _hp(out), _hp(ok)))
+        return out, ok
 
     def batch_normalize(self, curve, points_xyz):
         L = _field_bytes(curve)

@@ -295,6 +295,57 @@ bool check_ctx(ecgpu_ctx* ctx) {
 // C ABI
 // ================================================================================================================
 
+namespace {
+// shared driver of the two verification shapes: prepare -> a*G + b*Q -> normalise -> compare
+template <class C>
+int verify_dev(ecgpu_ctx* ctx, bool schnorr, const void* d_h, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
+               int reject_high_s, void* d_ok) {
+    constexpr int NS = Field<C>::NS;
+    const size_t L = 4 * C::N;
+    int rc;
+    if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+    if (n == 0) return (int)ECGPU_OK;
+    size_t tstride = var_base_slots<C>(n);
+    if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_u1, n * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_u2, n * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_q, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_valid, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    const Table& t = ctx->table[C::ID];
+    uint32_t* pa = (uint32_t*)ctx->proj.p;
+    uint32_t* pb = pa + n * 3 * NS;
+    uint8_t *u1 = (uint8_t*)ctx->ec_u1.p, *u2 = (uint8_t*)ctx->ec_u2.p, *q = (uint8_t*)ctx->ec_q.p;
+    uint8_t* valid = (uint8_t*)ctx->ec_valid.p;
+    record(ctx, 0);
+    if (schnorr)
+        launch_schnorr_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                                  (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
+    else
+        launch_ecdsa_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                                (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
+    record(ctx, 3);
+    launch_fixed_base<C>(ctx->stream, u1, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
+    launch_var_base<C>(ctx->stream, u2, q, nullptr, n, (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
+    launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
+    if (schnorr)
+        launch_schnorr_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
+                                 valid, n, (uint8_t*)d_ok);
+    else
+        launch_ecdsa_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
+                               valid, n, (uint8_t*)d_ok);
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"recode", {0, 3}}, {"main", {3, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+}  // namespace
+
 extern "C" {
 
 const char* ecgpu_version(void) { return "ecgpu 0.1 (gfx950)"; }
@@ -475,41 +526,34 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
               !aligned16(d_q_xy)))
         return ECGPU_ERR_ARG;
     return dispatch(curve, [&](auto c) {
+        return verify_dev<decltype(c)>(ctx, false, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
+    });
+}
+
+int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_p_xy,
+                                   size_t n, void* d_ok) {
+    // BIP340 over secp256k1: R = s G - e P, ok = R finite, y(R) even, x(R) == r.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_e || !d_r || !d_s || !d_p_xy || !d_ok || !aligned16(d_e) || !aligned16(d_r) || !aligned16(d_s) ||
+              !aligned16(d_p_xy)))
+        return ECGPU_ERR_ARG;
+    return verify_dev<K256Params>(ctx, true, d_e, d_r, d_s, d_p_xy, n, 0, d_ok);
+}
+
+int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, const void* d_y_is_odd, size_t n, void* d_out_xy,
+                               void* d_ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_xs || !d_y_is_odd || !d_out_xy || !d_ok || !aligned16(d_xs) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) {
         using C = decltype(c);
-        constexpr int NS = Field<C>::NS;
-        const size_t L = 4 * C::N;
-        int rc;
-        if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
         if (n == 0) return (int)ECGPU_OK;
-        size_t tstride = var_base_slots<C>(n);
-        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_u1, n * L)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_u2, n * L)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_q, n * 2 * L)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_valid, n + 16)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
-        if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
+        int rc;
         if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
-        const Table& t = ctx->table[C::ID];
-        uint32_t* pa = (uint32_t*)ctx->proj.p;
-        uint32_t* pb = pa + n * 3 * NS;
         record(ctx, 0);
-        launch_ecdsa_prepare<C>(ctx->stream, (const uint8_t*)d_z, (const uint8_t*)d_r, (const uint8_t*)d_s,
-                                (const uint8_t*)d_q_xy, n, reject_high_s, (uint8_t*)ctx->ec_u1.p, (uint8_t*)ctx->ec_u2.p,
-                                (uint8_t*)ctx->ec_q.p, (uint8_t*)ctx->ec_valid.p);
-        record(ctx, 3);
-        launch_fixed_base<C>(ctx->stream, (const uint8_t*)ctx->ec_u1.p, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
-        launch_var_base<C>(ctx->stream, (const uint8_t*)ctx->ec_u2.p, (const uint8_t*)ctx->ec_q.p, nullptr, n,
-                           (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
-        launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+        launch_decompress<C>(ctx->stream, (const uint8_t*)d_xs, (const uint8_t*)d_y_is_odd, n, (uint8_t*)d_out_xy, (uint8_t*)d_ok);
         record(ctx, 1);
-        if ((rc = normalize_out<C>(ctx, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
-        launch_ecdsa_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
-                               (const uint8_t*)ctx->ec_valid.p, n, (uint8_t*)d_ok);
-        record(ctx, 2);
         rc = finish(ctx);
-        collect_timing(ctx, {{"recode", {0, 3}}, {"main", {3, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+        collect_timing(ctx, {{"main", {0, 1}}, {"total", {0, 1}}});
         return rc;
     });
 }
@@ -606,6 +650,38 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
     if ((rc = ecgpu_ecdsa_verify_batch_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, reject_high_s,
                                            ctx->out1.p)) != ECGPU_OK)
         return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* p_xy,
+                               size_t n, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    const size_t L = 32;
+    if (n && (!e || !r || !s || !p_xy || !ok)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, e, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, s, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, p_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_schnorr_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const uint8_t* y_is_odd, size_t n, uint8_t* out_xy,
+                           uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!xs || !y_is_odd || !out_xy || !ok)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, xs, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, y_is_odd, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_decompress_dev(ctx, curve, ctx->in0.p, ctx->in2.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

@@ -84,4 +84,119 @@ k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_i
     ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
 }
 
+// ---- Schnorr (BIP340) verification: k256/src/schnorr/verifying.rs:76-99 ---------------------------------------------
+//     e = tagged_hash("BIP0340/challenge", r || pk || m) reduced mod n   (computed by the caller; reduced here)
+//     R = s*G + (-e)*P  via mul_by_generator_and_mul_add_vartime;  accept iff R != identity, y(R) even, x(R) == r
+// Signature parsing (k256/src/schnorr.rs:132-150): r < p, 0 < s < n.  P is the verifying key's stored affine point
+// (lifted with even y by VerifyingKey::from_bytes — ecgpu_batch_decompress with y_is_odd = 0).
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
+                  const uint8_t* __restrict__ p_xy, size_t n, uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out,
+                  uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+    using S = ScalarN<C>;
+    using F = Field<C>;
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ew[N], rw[N], sw[N], cx[N], cy[N];
+    load_be_vec<N>(ew, e + i * (4 * N));
+    load_be_vec<N>(rw, r + i * (4 * N));
+    load_be_vec<N>(sw, s + i * (4 * N));
+    load_be_vec<N>(cx, p_xy + i * (8 * N));
+    load_be_vec<N>(cy, p_xy + i * (8 * N) + 4 * N);
+    bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw);
+    ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
+    {
+        Affine<C> a;
+        a.x = F::from_canonical(cx).e;
+        a.y = F::from_canonical(cy).e;
+        ok = ok && Group<C>::on_curve(a, Group<C>::curve_b());
+    }
+    uint32_t er[N], ne[N];
+    S::reduce_once(er, ew);
+    {   // -e mod n
+        uint32_t d[N];
+        bool z = S::is_zero(er);
+        mp_sub<N>(d, C::ORDER, er);
+#pragma unroll
+        for (int j = 0; j < N; j++) ne[j] = z ? 0u : d[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        sw[j] = ok ? sw[j] : 0u;
+        ne[j] = ok ? ne[j] : 0u;
+        cx[j] = ok ? cx[j] : C::GX[j];
+        cy[j] = ok ? cy[j] : C::GY[j];
+    }
+    store_be_vec<N>(a_out + i * (4 * N), sw);
+    store_be_vec<N>(b_out + i * (4 * N), ne);
+    store_be_vec<N>(q_out + i * (8 * N), cx);
+    store_be_vec<N>(q_out + i * (8 * N) + 4 * N, cy);
+    valid[i] = ok ? 1 : 0;
+}
+
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_schnorr_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf, const uint8_t* __restrict__ r,
+                 const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x[N], y[N], rw[N];
+    load_be_vec<N>(x, r_xy + i * (8 * N));
+    load_be_vec<N>(y, r_xy + i * (8 * N) + 4 * N);
+    load_be_vec<N>(rw, r + i * (4 * N));
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) eq = eq && (x[j] == rw[j]);
+    ok_out[i] = (valid[i] && !r_inf[i] && !(y[0] & 1u) && eq) ? 1 : 0;
+}
+
+// ---- point decompression: DecompressPoint::decompress(x_bytes, y_is_odd) -----------------------------------------------
+// primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280: alpha = x^3 + a x + b,
+// beta = sqrt(alpha), y = beta or -beta by the parity of the canonical value.  ok = 0 (zero record) for x >= p or a
+// non-residue.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_odd, size_t n, uint8_t* __restrict__ out_xy,
+             uint8_t* __restrict__ ok_out) {
+    using F = Field<C>;
+    using G = Group<C>;
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cx[N], cy[N];
+    load_be_vec<N>(cx, xs + i * (4 * N));
+    bool ok = !mp_geq<N>(cx, C::P);
+    auto x = F::from_canonical(cx);
+    auto x3 = F::mul(F::sqr(x), x);
+    typename F::M1 alpha;
+    if constexpr (C::A_IS_ZERO) {
+        alpha = F::norm(F::add(x3, G::m(G::curve_b())));
+    } else {
+        auto x3x = F::add(F::dbl(x), x);
+        alpha = F::mul(F::add(F::norm(F::sub(x3, x3x)), G::m(G::curve_b())), F::one());   // back to magnitude (1, 1)
+    }
+    bool root;
+    auto beta = F::sqrt(alpha, &root);
+    ok = ok && root;
+    F::to_canonical(cy, beta);
+    if (((cy[0] & 1u) != 0) != (y_is_odd[i] != 0)) {            // the other root: p - beta (beta != 0 here, or parity
+        uint32_t d[N];                                          // 0 was asked for and beta = 0 stays)
+        bool z = mp_is_zero<N>(cy);
+        mp_sub<N>(d, C::P, cy);
+#pragma unroll
+        for (int j = 0; j < N; j++) cy[j] = z ? 0u : d[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        cx[j] = ok ? cx[j] : 0u;
+        cy[j] = ok ? cy[j] : 0u;
+    }
+    store_be_vec<N>(out_xy + i * (8 * N), cx);
+    store_be_vec<N>(out_xy + i * (8 * N) + 4 * N, cy);
+    ok_out[i] = ok ? 1 : 0;
+}
+
 }  // namespace ecgpu

@@ -751,6 +751,71 @@ struct Field {
             return r;
         }
     }
+    // square root: a^((p+1)/4) (all three primes are 3 mod 4), *ok = whether the result squares back to a.
+    // k256/src/arithmetic/field.rs:200-235 and p256/src/arithmetic/field.rs:121-147 (the same addition chains);
+    // p384 delegates to crypto-bigint (primefield/src/monty.rs:467-469): a fixed 4-bit window over the exponent.
+    static ECGPU_HD M1 sqrt(const M1& a, bool* ok) {
+        M1 r;
+        if constexpr (REPR == REPR_U29_K256) {
+            M1 x2 = mul(sqr(a), a);
+            M1 x3 = mul(sqr(x2), a);
+            M1 x6 = mul(sqr_n(x3, 3), x3);
+            M1 x9 = mul(sqr_n(x6, 3), x3);
+            M1 x11 = mul(sqr_n(x9, 2), x2);
+            M1 x22 = mul(sqr_n(x11, 11), x11);
+            M1 x44 = mul(sqr_n(x22, 22), x22);
+            M1 x88 = mul(sqr_n(x44, 44), x44);
+            M1 x176 = mul(sqr_n(x88, 88), x88);
+            M1 x220 = mul(sqr_n(x176, 44), x44);
+            M1 x223 = mul(sqr_n(x220, 3), x3);
+            r = mul(sqr_n(x223, 23), x22);
+            r = mul(sqr_n(r, 6), x2);
+            r = sqr_n(r, 2);
+        } else if constexpr (REPR == REPR_U28_MONT && C::ID == CURVE_P256) {
+            M1 t11 = mul(a, sqr(a));
+            M1 t1111 = mul(t11, sqr_n(t11, 2));
+            M1 t8 = mul(t1111, sqr_n(t1111, 4));
+            M1 x16 = mul(sqr_n(t8, 8), t8);
+            r = mul(sqr_n(x16, 16), x16);
+            r = mul(sqr_n(r, 32), a);
+            r = mul(sqr_n(r, 96), a);
+            r = sqr_n(r, 94);
+        } else {
+            M1 tab[16];
+            tab[0] = one();
+            tab[1] = a;
+#pragma unroll 1
+            for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+            uint32_t e[N];                               // (p + 1) / 4; p + 1 does not carry out for these primes
+            {
+                uint64_t c = 1;
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    c += C::P[i];
+                    e[i] = (uint32_t)c;
+                    c >>= 32;
+                }
+#pragma unroll
+                for (int i = 0; i < N; i++) e[i] = (e[i] >> 2) | (i + 1 < N ? e[i + 1] << 30 : 0u);
+            }
+            r = one();
+#pragma unroll 1
+            for (int i = 8 * N - 1; i >= 0; i--) {
+                uint32_t nib = (e[i >> 3] >> ((i & 7) * 4)) & 0xF;
+                r = sqr(sqr(sqr(sqr(r))));
+                if (nib) r = mul(r, tab[nib]);
+            }
+        }
+        *ok = eq(sqr(r), a);
+        return r;
+    }
+    // parity of the canonical value
+    template <int LA, int VA>
+    static ECGPU_HD bool is_odd(const Mag<C, LA, VA>& a) {
+        uint32_t w[N];
+        to_canonical(w, a);
+        return (w[0] & 1u) != 0;
+    }
 };
 
 }  // namespace ecgpu

@@ -58,6 +58,19 @@ template <> void launch_ecdsa_prepare<CurveT>(hipStream_t s, const uint8_t* z, c
     hipLaunchKernelGGL(k_ecdsa_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, z, r, sig_s, q_xy, n, reject_high_s, u1, u2,
                        q_out, valid);
 }
+template <> void launch_schnorr_prepare<CurveT>(hipStream_t s, const uint8_t* e, const uint8_t* r, const uint8_t* sig_s,
+                                                const uint8_t* p_xy, size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out,
+                                                uint8_t* valid) {
+    hipLaunchKernelGGL(k_schnorr_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, e, r, sig_s, p_xy, n, a, b, q_out, valid);
+}
+template <> void launch_schnorr_finish<CurveT>(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
+                                               const uint8_t* valid, size_t n, uint8_t* ok) {
+    hipLaunchKernelGGL(k_schnorr_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
+}
+template <> void launch_decompress<CurveT>(hipStream_t s, const uint8_t* xs, const uint8_t* y_is_odd, size_t n,
+                                           uint8_t* out_xy, uint8_t* ok) {
+    hipLaunchKernelGGL(k_decompress<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xs, y_is_odd, n, out_xy, ok);
+}
 template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                              const uint8_t* valid, size_t n, uint8_t* ok) {
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);

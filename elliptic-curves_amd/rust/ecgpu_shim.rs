@@ -51,6 +51,12 @@ unsafe extern "C" {
     /// Batch form of `ecdsa::hazmat::verify_prehashed`; `reject_high_s` = `C::NORMALIZE_S`.
     pub fn ecgpu_ecdsa_verify_batch(ctx: *mut EcgpuCtx, curve: c_int, z: *const u8, r: *const u8, s: *const u8,
                                     q_xy: *const u8, n: usize, reject_high_s: c_int, ok: *mut u8) -> c_int;
+    /// Batch form of `schnorr::VerifyingKey::verify_raw` (k256); `e` is the BIP340 challenge hash.
+    pub fn ecgpu_schnorr_verify_batch(ctx: *mut EcgpuCtx, e: *const u8, r: *const u8, s: *const u8, p_xy: *const u8,
+                                      n: usize, ok: *mut u8) -> c_int;
+    /// Batch form of `DecompressPoint::decompress(x_bytes, y_is_odd)`.
+    pub fn ecgpu_batch_decompress(ctx: *mut EcgpuCtx, curve: c_int, xs: *const u8, y_is_odd: *const u8, n: usize,
+                                  out_xy: *mut u8, ok: *mut u8) -> c_int;
 }
 
 /// Process-wide context: the analogue of `static BASEPOINT_TABLE: LazyLock<..>`

@@ -175,6 +175,30 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_z, con
                                  const void *d_s, const void *d_q_xy, size_t n, int reject_high_s,
                                  void *d_ok);
 
+/* Batch BIP340 Schnorr verification over secp256k1 — `VerifyingKey::verify_raw`
+ * (k256/src/schnorr/verifying.rs:76-99) without the hash: per element
+ *   e  32 bytes big-endian = tagged_hash("BIP0340/challenge", r || pk || m), computed by the caller; reduced
+ *      mod n on the device like `<Scalar as Reduce<FieldBytes>>::reduce`
+ *   r, s  the two halves of the signature (k256/src/schnorr.rs:132-150: r < p, 0 < s < n)
+ *   p_xy  the verifying key's affine point, i.e. the even-y lift of the 32-byte public key
+ *      (`VerifyingKey::from_bytes`; use ecgpu_batch_decompress with y_is_odd = 0)
+ *   ok[i] = 1 iff the fields are in range, P is on the curve, R = s G - e P is not the identity, y(R) is even
+ *      and x(R) == r. */
+int ecgpu_schnorr_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *r, const uint8_t *s,
+                               const uint8_t *p_xy, size_t n, uint8_t *ok);
+int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s,
+                                   const void *d_p_xy, size_t n, void *d_ok);
+
+/* Batch point decompression — `DecompressPoint::decompress(x_bytes, y_is_odd)`
+ * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;
+ * BIP340 `decompact` = y_is_odd 0).  xs n*L bytes big-endian, y_is_odd n bytes.  out_xy[i] = (x, y) with
+ * y^2 = x^3 + a x + b and the requested parity and ok[i] = 1, or a zero record and ok[i] = 0 when x >= p or
+ * no such y exists (the reference's `CtOption::None`). */
+int ecgpu_batch_decompress(ecgpu_ctx *ctx, int curve, const uint8_t *xs, const uint8_t *y_is_odd,
+                           size_t n, uint8_t *out_xy, uint8_t *ok);
+int ecgpu_batch_decompress_dev(ecgpu_ctx *ctx, int curve, const void *d_xs, const void *d_y_is_odd,
+                               size_t n, void *d_out_xy, void *d_ok);
+
 /* Integer-VALU roof probe: runs a dependency-free v_mad_u64_u32 stream on every CU and returns
  * the measured 32x32->64 multiply-add rate in operations per second (SURVEY.md §8d "peak to
  * divide by").  `which` selects the instruction: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32,

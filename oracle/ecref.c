@@ -123,6 +123,10 @@ int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_
              ecref_p256_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi),
              ecref_p384_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi))
 }
+int ecref_batch_decompress(int curve, const uint8_t *xs, const uint8_t *odd, size_t n, uint8_t *o, uint8_t *ok) {
+    DISPATCH(curve, ecref_k256_batch_decompress(xs, odd, n, o, ok), ecref_p256_batch_decompress(xs, odd, n, o, ok),
+             ecref_p384_batch_decompress(xs, odd, n, o, ok))
+}
 int ecref_field_op(int curve, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     DISPATCH(curve, ecref_k256_field_op(op, a, b, out), ecref_p256_field_op(op, a, b, out),
              ecref_p384_field_op(op, a, b, out))

@@ -88,6 +88,17 @@ int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
                              const uint8_t *q_xy, size_t n, int reject_high_s, uint8_t *ok);
 
+/* BIP340 verification over secp256k1 (k256/src/schnorr/verifying.rs:76-99) with the challenge hash e supplied by the
+ * caller; see ecref_ecdsa.c. */
+int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *p_xy,
+                               size_t n, uint8_t *ok);
+
+/* out[i] = (x_i, y_i) with y_i the square root of x^3 + a x + b of the requested parity —
+ * `DecompressPoint::decompress(x_bytes, y_is_odd)` (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280).
+ * xs n*L bytes big-endian, y_is_odd n bytes; ok[i] = 0 and a zero record when x >= p or no root exists. */
+int ecref_batch_decompress(int curve, const uint8_t *xs, const uint8_t *y_is_odd, size_t n,
+                           uint8_t *out_xy, uint8_t *ok);
+
 /* ---- smaller pieces, exposed so device-side code can be unit-checked against them ------- */
 
 /* out = a (+,-,*) b mod p ; op: 0 add, 1 sub, 2 mul, 3 square(a), 4 invert(a) (0 -> 0),

@@ -173,3 +173,36 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
     }
     return ECREF_OK;
 }
+
+/* BIP340 Schnorr verification over secp256k1 — `VerifyingKey::verify_raw`, k256/src/schnorr/verifying.rs:76-99, without
+ * the hash: e is the challenge tagged_hash("BIP0340/challenge", r || pk || m) as 32 bytes (reduced mod n here like
+ * `<Scalar as Reduce<FieldBytes>>::reduce`), (r, s) the signature halves parsed as in k256/src/schnorr.rs:132-150
+ * (r < p, 0 < s < n), p_xy the verifying key's affine point.  R = s*G + (-e)*P
+ * (mul_by_generator_and_mul_add_vartime); accept iff R is not the identity, y(R) is even and x(R) == r. */
+static const uint64_t K256_FIELD_P[4] = {0xFFFFFFFEFFFFFC2Full, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull,
+                                         0xFFFFFFFFFFFFFFFFull};     /* k256/src/arithmetic/field.rs:41-42 */
+
+int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *p_xy, size_t n,
+                               uint8_t *ok) {
+    modn_t m;
+    modn_init(&m, ECREF_K256);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t ew[4], rw[4], sw[4], ne[4];
+        ok[i] = 0;
+        from_be(ew, e + 32 * i, 4);
+        from_be(rw, r + 32 * i, 4);
+        from_be(sw, s + 32 * i, 4);
+        if (geq(rw, K256_FIELD_P, 4)) continue;
+        if (is_zero(sw, 4) || geq(sw, m.n, 4)) continue;
+        if (geq(ew, m.n, 4)) sub_n(ew, m.n, 4);
+        memcpy(ne, m.n, 32);
+        if (is_zero(ew, 4)) memset(ne, 0, 32); else sub_n(ne, ew, 4);
+        uint8_t a[32], b[32], xy[64], inf = 0;
+        to_be(a, sw, 4);
+        to_be(b, ne, 4);
+        if (ecref_mul_base_and_mul_add_vartime(ECREF_K256, a, b, p_xy + 64 * i, 0, xy, &inf) != ECREF_OK) continue;
+        if (inf || (xy[63] & 1)) continue;
+        ok[i] = memcmp(xy, r + 32 * i, 32) == 0;
+    }
+    return ECREF_OK;
+}

@@ -95,6 +95,7 @@ static inline void ecref_mp_mul(uint64_t *r, const uint64_t *a, const uint64_t *
     int ecref_##pfx##_mul_base_and_mul_add_vartime(const uint8_t *, const uint8_t *,                \
                                                    const uint8_t *, int, uint8_t *, uint8_t *);     \
     int ecref_##pfx##_field_op(int, const uint8_t *, const uint8_t *, uint8_t *);                   \
+    int ecref_##pfx##_batch_decompress(const uint8_t *, const uint8_t *, size_t, uint8_t *, uint8_t *); \
     int ecref_##pfx##_point_op(int, const uint8_t *, int, const uint8_t *, int, uint8_t *,          \
                                uint8_t *);                                                          \
     int ecref_##pfx##_batch_normalize(const uint8_t *, size_t, uint8_t *, uint8_t *);               \

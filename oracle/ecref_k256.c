@@ -229,6 +229,31 @@ static int fe5_invert(fe5 *out, const fe5 *a) {
     return 1;
 }
 
+/* sqrt — field.rs:200-235: a^((p+1)/4) by the reference's addition chain (blocks of 223, 22 and 2 ones), then the
+ * is-it-a-root check.  The result has magnitude 1 and is not normalized.  Returns 0 when a is a non-residue. */
+static int fe5_sqrt(fe5 *out, const fe5 *a) {
+    fe5 x = *a;
+    fe5 x2 = fe5_pow2k(x, 1);      x2 = fe5_mul(&x2, &x);
+    fe5 x3 = fe5_pow2k(x2, 1);     x3 = fe5_mul(&x3, &x);
+    fe5 x6 = fe5_pow2k(x3, 3);     x6 = fe5_mul(&x6, &x3);
+    fe5 x9 = fe5_pow2k(x6, 3);     x9 = fe5_mul(&x9, &x3);
+    fe5 x11 = fe5_pow2k(x9, 2);    x11 = fe5_mul(&x11, &x2);
+    fe5 x22 = fe5_pow2k(x11, 11);  x22 = fe5_mul(&x22, &x11);
+    fe5 x44 = fe5_pow2k(x22, 22);  x44 = fe5_mul(&x44, &x22);
+    fe5 x88 = fe5_pow2k(x44, 44);  x88 = fe5_mul(&x88, &x44);
+    fe5 x176 = fe5_pow2k(x88, 88); x176 = fe5_mul(&x176, &x88);
+    fe5 x220 = fe5_pow2k(x176, 44); x220 = fe5_mul(&x220, &x44);
+    fe5 x223 = fe5_pow2k(x220, 3); x223 = fe5_mul(&x223, &x3);
+    fe5 res = fe5_pow2k(x223, 23); res = fe5_mul(&res, &x22);
+    res = fe5_pow2k(res, 6);       res = fe5_mul(&res, &x2);
+    res = fe5_pow2k(res, 2);
+    fe5 sq = fe5_mul(&res, &res);
+    fe5 nsq = fe5_negate(&sq, 1);
+    fe5 d = fe5_add(&nsq, a);
+    *out = res;
+    return fe5_normalizes_to_zero(&d);
+}
+
 static const fe5 FE5_ZERO = {{0, 0, 0, 0, 0}};
 static const fe5 FE5_ONE = {{1, 0, 0, 0, 0}};
 
@@ -814,6 +839,31 @@ int ecref_k256_mul_base_and_mul_add_vartime(const uint8_t *a, const uint8_t *b, 
     k256_pt r = k256_lincomb_vartime(xs, ks, 2);
     k256_aff o = k256_to_affine(&r);
     k256_aff_to_bytes(&o, out_xy, out_inf);
+    return ECREF_OK;
+}
+
+/* DecompressPoint::decompress — affine.rs:261-280: alpha = x^3 + 7, beta = sqrt(alpha) normalized, y = beta or -beta
+ * by parity.  ok[i] = 0 (and zeros out) when x >= p or alpha is a non-residue. */
+int ecref_k256_batch_decompress(const uint8_t *xs, const uint8_t *y_is_odd, size_t n, uint8_t *out_xy, uint8_t *ok) {
+    for (size_t i = 0; i < n; i++) {
+        fe5 x, beta;
+        ok[i] = 0;
+        memset(out_xy + 64 * i, 0, 64);
+        if (!fe5_from_bytes(&x, xs + 32 * i)) continue;
+        fe5 xx = fe5_mul(&x, &x);
+        fe5 x3 = fe5_mul(&xx, &x);
+        fe5 b = FE5_ZERO;
+        b.n[0] = K256_B_SINGLE;
+        fe5 alpha = fe5_add(&x3, &b);
+        if (!fe5_sqrt(&beta, &alpha)) continue;
+        beta = fe5_normalize(&beta);
+        int odd = (int)(beta.n[0] & 1);
+        fe5 y = beta;
+        if (odd != (y_is_odd[i] & 1)) { y = fe5_negate(&beta, 1); y = fe5_normalize(&y); }
+        fe5_to_bytes(out_xy + 64 * i, &x);
+        fe5_to_bytes(out_xy + 64 * i + 32, &y);
+        ok[i] = 1;
+    }
     return ECREF_OK;
 }
 

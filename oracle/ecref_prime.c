@@ -219,6 +219,33 @@ static int p256_fe_invert(fe256 *out, const fe256 *a) {
     return 1;
 }
 
+/* sqrt — p256/src/arithmetic/field.rs:121-147: a^((p+1)/4) by the reference's chain, then the root check. */
+static fe256 p256_fe_sqn(fe256 a, int n) {
+    for (int i = 0; i < n; i++) a = p256_fe_sqr(&a);
+    return a;
+}
+static int p256_fe_sqrt(fe256 *out, const fe256 *a) {
+    fe256 t = p256_fe_sqr(a);
+    fe256 t11 = p256_fe_mul(a, &t);
+    t = p256_fe_sqn(t11, 2);
+    fe256 t1111 = p256_fe_mul(&t11, &t);
+    t = p256_fe_sqn(t1111, 4);
+    fe256 t8 = p256_fe_mul(&t1111, &t);
+    t = p256_fe_sqn(t8, 8);
+    fe256 x16 = p256_fe_mul(&t, &t8);
+    t = p256_fe_sqn(x16, 16);
+    t = p256_fe_mul(&t, &x16);
+    t = p256_fe_sqn(t, 32);
+    t = p256_fe_mul(&t, a);
+    t = p256_fe_sqn(t, 96);
+    t = p256_fe_mul(&t, a);
+    t = p256_fe_sqn(t, 94);
+    fe256 sq = p256_fe_sqr(&t);
+    fe256 d = p256_fe_sub(&sq, a);
+    *out = t;
+    return p256_fe_is_zero(&d);
+}
+
 #define PO_PFX p256
 #define PO_NL 4
 #define PO_FE fe256
@@ -312,6 +339,23 @@ static int p384_fe_invert(fe384 *out, const fe384 *a) {          /* monty.rs:373
     }
     *out = r;
     return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int p384_fe_sqrt(fe384 *out, const fe384 *a) {
+    uint64_t e[6], one[6] = {1, 0, 0, 0, 0, 0};
+    ecref_mp_add(e, P384_P, one, 6);                         /* p + 1 < 2^384 */
+    for (int i = 0; i < 6; i++) e[i] = (e[i] >> 2) | (i + 1 < 6 ? e[i + 1] << 62 : 0);
+    fe384 r = p384_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = p384_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p384_fe_mul(&r, a);
+    }
+    fe384 sq = p384_fe_sqr(&r);
+    fe384 d = p384_fe_sub(&sq, a);
+    *out = r;
+    return p384_fe_is_zero(&d);
 }
 
 #define PO_PFX p384

@@ -10,6 +10,9 @@ Sources:
                                                MUL_TEST_VECTORS ((k, x, y) with k*G = (x, y))
   {k256,p256,p384}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
   {k256,p256}/src/test_vectors/field.rs        DBL_TEST_VECTORS (repeated doubling of 1 mod p)
+  k256/src/schnorr.rs                          BIP340_SIGN_VECTORS (index 0-3: public key, message, valid signature),
+                                               BIP340_VERIFY_VECTORS (index 4-14: public key, message, signature,
+                                               expected verdict) and the variable-length-message vectors 15-18
 
 Only the hex constants are taken (public NIST / point-at-infinity.org / FIPS 186-4 data); no
 reference source code is copied.
@@ -67,6 +70,40 @@ def field_vectors(curve):
     return hexes(const_block(open(path).read(), "DBL_TEST_VECTORS"))
 
 
+def schnorr_vectors():
+    """BIP340 vectors held by k256/src/schnorr.rs (the public bip-0340/test-vectors.csv data)."""
+    text = open(os.path.join(REF, "k256/src/schnorr.rs")).read()
+    clean = lambda h: re.sub(r"\s+", "", h).lower()
+    field = lambda body, name: clean(re.search(r'%s:\s*hex!\(\s*"([0-9A-Fa-f\s]+)"' % name, body).group(1))
+    out = []
+    for kind in ("SignVector", "VerifyVector"):
+        for body in re.findall(r"%s\s*\{(.*?)\n        \}," % kind, text, re.S):
+            if "index:" not in body or "hex!" not in body:
+                continue
+            v = {"index": int(re.search(r"index:\s*(\d+)", body).group(1)), "public_key": field(body, "public_key"),
+                 "message": field(body, "message"), "signature": field(body, "signature")}
+            m = re.search(r"valid:\s*(true|false)", body)
+            v["valid"] = True if kind == "SignVector" else (m.group(1) == "true")
+            out.append(v)
+    # index 15-18: one signing key, messages of 0 / 1 / 17 / 100 bytes; the public key is derived by the tests
+    sk = clean(re.search(r'SigningKey::from_bytes\(\s*&hex!\("([0-9A-Fa-f]+)"\)', text).group(1))
+    ext = text[text.index("let bip340_ext_sign_vectors"):]
+    ext = ext[: ext.index("];")]
+    for body in re.findall(r"Bip340ExtTest\s*\{(.*?)\n            \}", ext, re.S):
+        idx = int(re.search(r"index:\s*(\d+)", body).group(1))
+        sig = clean(re.search(r'signature:\s*hex!\(\s*"([0-9A-Fa-f\s]+)"', body).group(1))
+        m = re.search(r"msg:\s*(.*?),\n", body, re.S).group(1)
+        if m.startswith("vec![]"):
+            msg = ""
+        elif "hex!" in m:
+            msg = clean(re.search(r'hex!\("([0-9A-Fa-f]+)"\)', m).group(1))
+        else:                                   # vec![0x99; 100]
+            byte, count = re.search(r"vec!\[0x([0-9A-Fa-f]+);\s*(\d+)\]", m).groups()
+            msg = byte.lower() * int(count)
+        out.append({"index": idx, "secret_key": sk, "message": msg, "signature": sig, "valid": True})
+    return sorted(out, key=lambda v: v["index"])
+
+
 def main():
     summary = {}
     for curve in ("k256", "p256", "p384"):
@@ -78,6 +115,9 @@ def main():
         dbl = field_vectors(curve)
         if dbl is not None:
             data["field_dbl"] = dbl
+        if curve == "k256":
+            data["schnorr"] = schnorr_vectors()
+            print("k256: %d BIP340 vectors (indices %s)" % (len(data["schnorr"]), [v["index"] for v in data["schnorr"]]))
         with open(os.path.join(HERE, "%s.json" % curve), "w") as f:
             json.dump(data, f, indent=1)
             f.write("\n")

@@ -116,3 +116,27 @@ def ecdsa_pack(cases):
     q = b"".join(t[3] for t in cases)
     exp = np.array([1 if t[4] else 0 for t in cases], np.uint8)
     return z, r, s, q, exp
+
+
+def bip340_challenge(r32, pk32, msg):
+    """int(tagged_hash("BIP0340/challenge", r || pk || m)) as 32 big-endian bytes (k256/src/schnorr.rs tagged_hash)."""
+    import hashlib
+    tag = hashlib.sha256(b"BIP0340/challenge").digest()
+    return hashlib.sha256(tag + tag + r32 + pk32 + msg).digest()
+
+
+def schnorr_inputs(vectors, decompress, pubkey_of):
+    """BIP340 vectors -> (e, r, s, p_xy, liftable, expected).  `decompress(xs, odd)` lifts x-only keys (even y), and
+    `pubkey_of(sk32)` gives the x-only public key of a secret key (vectors 15-18 carry only the key pair's secret)."""
+    e = r = s = b""
+    pks = []
+    for v in vectors:
+        pk = bytes.fromhex(v["public_key"]) if "public_key" in v else pubkey_of(bytes.fromhex(v["secret_key"]))
+        sig = bytes.fromhex(v["signature"])
+        msg = bytes.fromhex(v["message"])
+        pks.append(pk)
+        r += sig[:32]; s += sig[32:]
+        e += bip340_challenge(sig[:32], pk, msg)
+    pxy, okl = decompress(b"".join(pks), np.zeros(len(pks), np.uint8))
+    exp = np.array([1 if v["valid"] else 0 for v in vectors], np.uint8)
+    return e, r, s, np.asarray(pxy, np.uint8), np.asarray(okl, np.uint8), exp

@@ -68,6 +68,12 @@ int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 3: F::to_bytes(out, F::sqr(x)); break;
     case 4: F::to_bytes(out, F::inv(x)); break;
     case 10: F::to_bytes(out, F::inv_fermat(x)); break;    // independent check of the safegcd inversion
+    case 11: {                                            // square root: the root, or zero if there is none
+        bool root;
+        auto r = F::sqrt(x, &root);
+        F::to_bytes(out, root ? r : F::zero());
+        break;
+    }
     case 5: F::to_bytes(out, F::neg(x)); break;
     case 6: F::to_bytes(out, times21<C>(x)); break;
     case 7: F::to_bytes(out, F::dbl(x)); break;

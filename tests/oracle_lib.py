@@ -111,6 +111,24 @@ def ecdsa_verify(curve, z, r, s, q_xy, reject_high_s=False):
     return ok
 
 
+def schnorr_verify(e, r, s, p_xy):
+    ee, rr, ss, pp = _arr(e), _arr(r), _arr(s), _arr(p_xy)
+    n = ee.size // 32
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_schnorr_verify_batch(_buf(ee), _buf(rr), _buf(ss), _buf(pp), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
+def batch_decompress(curve, xs, y_is_odd):
+    L = FIELD_BYTES[curve]
+    x, odd = _arr(xs), _arr(y_is_odd)
+    n = x.size // L
+    out = np.zeros(n * 2 * L, np.uint8)
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_batch_decompress(curve, _buf(x), _buf(odd), ctypes.c_size_t(n), _buf(out), _buf(ok)))
+    return out, ok
+
+
 def field_op(curve, op, a, b=None):
     L = FIELD_BYTES[curve]
     out = np.zeros(L, np.uint8)

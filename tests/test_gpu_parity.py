@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 import pyec
-from gpu_common import (CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, edge_scalars, ladder_edge_scalars, load_golden,
+from gpu_common import (CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, schnorr_inputs, edge_scalars, ladder_edge_scalars, load_golden,
                         rand_scalars, scalars_to_int_sum)
 
 pytestmark = pytest.mark.gpu
@@ -461,3 +461,60 @@ def test_ecdsa_verify_vs_oracle_and_model(eng, curve):
     want = oracle_lib.ecdsa_verify(c.cid, zs, bytes(rr), bytes(ss), Q)
     assert bytes(got) == bytes(want)
     assert int(got.sum()) >= n - n // 5 - 3 and not got[4::5].any()
+
+
+# ---------------------------------------------------------------------------------------------------
+# BIP340 Schnorr verification and point decompression
+# ---------------------------------------------------------------------------------------------------
+
+def test_schnorr_bip340_vectors(eng):
+    """All 19 BIP340 vectors of k256/src/schnorr.rs: x-only keys lifted on the device (decompress, even y), challenge
+    hashed on the host, verdicts equal to the reference's expectations and to the oracle's."""
+    c = pyec.CURVES["k256"]
+    vec = load_golden("k256")["schnorr"]
+
+    def pubkey_of(sk):
+        out, _ = eng.mul_by_generator(c.cid, sk)
+        return bytes(out[:32])
+
+    e, r, s, pxy, liftable, exp = schnorr_inputs(vec, lambda xs, odd: eng.decompress(c.cid, xs, odd), pubkey_of)
+    assert [v["index"] for v, l in zip(vec, liftable) if not l] == [5, 14]
+    pxy = pxy.reshape(-1, 64).copy()
+    assert not pxy[liftable == 0].any()                               # failed lifts are zero records ...
+    got = eng.schnorr_verify(e, r, s, pxy.reshape(-1))                # ... which are not on the curve: verdict 0
+    assert list(got) == list(exp)
+    pxy[liftable == 0] = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+    assert list(eng.schnorr_verify(e, r, s, pxy.reshape(-1)) & liftable) == list(oracle_lib.schnorr_verify(e, r, s, pxy.reshape(-1)) & liftable)
+    # out-of-range signature halves and a disturbed challenge
+    n = oracle_lib  # noqa: F841
+    bad_s = (c.n).to_bytes(32, "big")
+    one = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+    assert not eng.schnorr_verify(e[:32], r[:32], bad_s, pxy[0].tobytes()).any()
+    assert not eng.schnorr_verify(e[:32], (c.p).to_bytes(32, "big"), s[:32], pxy[0].tobytes()).any()
+    flipped = bytearray(e[:32]); flipped[31] ^= 1
+    assert not eng.schnorr_verify(bytes(flipped), r[:32], s[:32], pxy[0].tobytes()).any()
+    assert eng.schnorr_verify(e[:32], r[:32], s[:32], pxy[0].tobytes()).all()
+    assert one.size == 64
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_decompress_vs_oracle(eng, curve):
+    """DecompressPoint::decompress on a batch: residues and non-residues, both parities, x >= p, the generator; then
+    compress(k*G) -> decompress round trip over 4096 random points."""
+    c = pyec.CURVES[curve]
+    rng = np.random.default_rng(0xDEC0 + c.cid)
+    n = 2000
+    xs = rng.integers(0, 256, n * c.L, dtype=np.uint8)
+    xs[: c.L] = np.frombuffer((c.p).to_bytes(c.L, "big"), np.uint8)                 # x = p
+    xs[c.L: 2 * c.L] = 255                                                          # x = 2^(8L) - 1
+    xs[2 * c.L: 3 * c.L] = np.frombuffer(pyec.G(c)[0].to_bytes(c.L, "big"), np.uint8)
+    odd = rng.integers(0, 2, n, dtype=np.uint8)
+    got, gok = eng.decompress(c.cid, xs, odd)
+    want, wok = oracle_lib.batch_decompress(c.cid, xs, odd)
+    assert bytes(got) == bytes(want) and bytes(gok) == bytes(wok)
+    assert gok[0] == 0 and gok[1] == 0 and gok[2] == 1 and 0.3 < gok.mean() < 0.7
+    m = 4096
+    pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, m, 0xDEC1 + c.cid))
+    P = pts.reshape(m, 2 * c.L)
+    back, ok = eng.decompress(c.cid, P[:, : c.L].copy().reshape(-1), (P[:, 2 * c.L - 1] & 1).copy())
+    assert ok.all() and bytes(back) == bytes(pts)

@@ -49,6 +49,14 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
     for a in _edge_values(c)[:8] + [rng.randrange(c.p) for _ in range(12)]:
         inv = int.from_bytes(hc.field_op(c.cid, 10, a.to_bytes(c.L, "big")), "big")
         assert inv == (pow(a, -1, c.p) if a else 0)
+    # square root a^((p+1)/4): a root (either one) for residues, "none" (encoded as 0) for non-residues
+    for a in _edge_values(c)[:6] + [rng.randrange(c.p) for _ in range(40)] + [x * x % c.p for x in (2, 3, c.p - 5)]:
+        got = int.from_bytes(hc.field_op(c.cid, 11, a.to_bytes(c.L, "big")), "big")
+        root = pow(a, (c.p + 1) // 4, c.p)
+        if root * root % c.p == a:
+            assert got in (root, c.p - root) and got * got % c.p == a, hex(a)
+        else:
+            assert got == 0
 
 
 @pytest.mark.parametrize("curve", CURVES)

@@ -109,6 +109,56 @@ def test_ecdsa_verify_golden_and_model(oracle, curve):
     assert list(got) == want and 0 < sum(want) < int(exp.sum())
 
 
+def test_schnorr_bip340_vectors(oracle):
+    """The BIP340 vectors of k256/src/schnorr.rs (0-3 signing, 4-14 verification incl. every documented failure
+    mode, 15-18 variable-length messages) through decompress (lift_x) + Schnorr verification."""
+    from gpu_common import schnorr_inputs
+    c = pyec.CURVES["k256"]
+    vec = load("k256")["schnorr"]
+    assert len(vec) == 19
+
+    def pubkey_of(sk):
+        out, _ = oracle.batch_mul_base(c.cid, sk)
+        return bytes(out[:32])
+
+    e, r, s, pxy, liftable, exp = schnorr_inputs(vec, lambda xs, odd: oracle.batch_decompress(c.cid, xs, odd), pubkey_of)
+    # vectors 5 (key not on curve) and 14 (key >= p) fail at the lift, as VerifyingKey::from_bytes does
+    assert [v["index"] for v, l in zip(vec, liftable) if not l] == [5, 14]
+    pxy = pxy.reshape(-1, 64).copy()
+    pxy[liftable == 0] = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)     # any valid point: verdict stays 0
+    got = oracle.schnorr_verify(e, r, s, pxy.reshape(-1)) & liftable
+    assert list(got) == list(exp)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_decompress_vs_model(oracle, curve):
+    """DecompressPoint::decompress: generator round trip (p256/tests/affine.rs:12-28 compressed basepoint), random x
+    with and without a root, both parities, x >= p."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xDEC0 + c.cid)
+    xs, odd, exp = [], [], []
+    g = pyec.G(c)
+    cand = [g[0], pyec.mul(c, 2, g)[0], c.p, c.p + 1 if c.p + 1 < (1 << (8 * c.L)) else c.p, 0, 1, 2, 3] + \
+           [rng.randrange(c.p) for _ in range(120)]
+    for x in cand:
+        for o in (0, 1):
+            xs.append(x.to_bytes(c.L, "big")); odd.append(o)
+            rhs = (x ** 3 + c.a * x + c.b) % c.p
+            y = pow(rhs, (c.p + 1) // 4, c.p)
+            if x >= c.p or y * y % c.p != rhs:
+                exp.append(None)
+            else:
+                exp.append((x, y if y % 2 == o else (c.p - y) % c.p))
+    out, ok = oracle.batch_decompress(c.cid, b"".join(xs), np.array(odd, np.uint8))
+    for i, e in enumerate(exp):
+        rec = bytes(out[i * 2 * c.L:(i + 1) * 2 * c.L])
+        if e is None:
+            assert ok[i] == 0 and rec == bytes(2 * c.L)
+        else:
+            assert ok[i] == 1 and rec == e[0].to_bytes(c.L, "big") + e[1].to_bytes(c.L, "big")
+    assert bytes(out[: 2 * c.L]) == pyec.enc_point(c, g if g[1] % 2 == 0 else pyec.neg(c, g))[0]
+
+
 @pytest.mark.parametrize("curve", ["k256", "p256"])
 def test_field_doubling_vectors(oracle, curve):
     """k256 field.rs tests / p256 field.rs:219-245: repeated doubling of 1."""
