@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "ecgpu_point_sum", "ecgpu_point_sum_dev", "ecgpu_k256_glv_decompose", "ecgpu_valu_probe",
     "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
     "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
-    "ecgpu_batch_decompress_dev",
+    "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
 ]
 
 
@@ -204,6 +204,20 @@ class Engine:
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_schnorr_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(pp), ctypes.c_size_t(n), _hp(ok)))
         return ok
+
+    def ecdh(self, curve, scalars, points_xy):
+        """x-coordinates of k_i * P_i (ECDH shared secrets): returns (x uint8[n*L], ok uint8[n])."""
+        L = _field_bytes(curve)
+        k, p = _host(scalars), _host(points_xy)
+        n = k.size // L
+        out = np.zeros(n * L, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_ecdh(self._ctx, curve, _hp(k), _hp(p), ctypes.c_size_t(n), _hp(out), _hp(ok)))
+        return out, ok
+
+    def ecdh_dev(self, curve, d_scalars, d_points_xy, n, d_out_x, d_ok):
+        self._chk(self._lib.ecgpu_batch_ecdh_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), ctypes.c_size_t(n),
+                                                 _dp(d_out_x), _dp(d_ok)))
 
     def decompress(self, curve, xs, y_is_odd):
         """DecompressPoint::decompress for a batch: returns (xy uint8[n*2L], ok uint8[n])."""

@@ -540,6 +540,29 @@ int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* 
     return verify_dev<K256Params>(ctx, true, d_e, d_r, d_s, d_p_xy, n, 0, d_ok);
 }
 
+int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x,
+                         void* d_ok) {
+    // SharedSecret_i = x(k_i * P_i): the variable-base kernel, normalisation into scratch, x extraction
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_out_x || !d_ok || !aligned16(d_out_x))) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    int rc;
+    if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_dev(ctx, curve, d_scalars, d_points_xy, nullptr, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK)
+        return rc;
+    if (n == 0) return ECGPU_OK;
+    return dispatch(curve, [&](auto c) -> int {
+        using C = decltype(c);
+        launch_extract_x<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, n, (uint8_t*)d_out_x,
+                            (uint8_t*)d_ok);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return (int)ECGPU_OK;
+    });
+}
+
 int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, const void* d_y_is_odd, size_t n, void* d_out_xy,
                                void* d_ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
@@ -666,6 +689,22 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
     if ((rc = ecgpu_schnorr_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK)
         return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x,
+                     uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!scalars || !points_xy || !out_x || !ok)) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_ecdh_dev(ctx, curve, ctx->in0.p, ctx->in1.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_x, ctx->out0, n * L)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

@@ -153,6 +153,24 @@ k_schnorr_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r
     ok_out[i] = (valid[i] && !r_inf[i] && !(y[0] & 1u) && eq) ? 1 : 0;
 }
 
+// ---- ECDH: x-coordinate of k*P -----------------------------------------------------------------------------------------
+// `elliptic_curve::ecdh::diffie_hellman` (elliptic-curve 0.14.1, un-vendored; used through k256/src/ecdh.rs,
+// p256/src/ecdh.rs, p384/src/ecdh.rs): SharedSecret = x((public * secret).to_affine()).  The scalar multiplication is
+// k_var_base; this kernel keeps x and reports ok = 0 for an identity result (only k = 0 can produce one: the
+// reference's NonZeroScalar / PublicKey types exclude it).
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_extract_x(const uint8_t* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n, uint8_t* __restrict__ out_x,
+            uint8_t* __restrict__ ok) {
+    constexpr int N = C::N;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x[N];
+    load_words_vec<N>(x, reinterpret_cast<const uint32_t*>(xy + i * (8 * N)));      // bytes stay in wire order
+    store_words_vec<N>(reinterpret_cast<uint32_t*>(out_x + i * (4 * N)), x);
+    ok[i] = inf[i] ? 0 : 1;
+}
+
 // ---- point decompression: DecompressPoint::decompress(x_bytes, y_is_odd) -----------------------------------------------
 // primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280: alpha = x^3 + a x + b,
 // beta = sqrt(alpha), y = beta or -beta by the parity of the canonical value.  ok = 0 (zero record) for x >= p or a

@@ -67,6 +67,10 @@ template <> void launch_schnorr_finish<CurveT>(hipStream_t s, const uint8_t* r_x
                                                const uint8_t* valid, size_t n, uint8_t* ok) {
     hipLaunchKernelGGL(k_schnorr_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
 }
+template <> void launch_extract_x<CurveT>(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint8_t* out_x,
+                                          uint8_t* ok) {
+    hipLaunchKernelGGL(k_extract_x<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xy, inf, n, out_x, ok);
+}
 template <> void launch_decompress<CurveT>(hipStream_t s, const uint8_t* xs, const uint8_t* y_is_odd, size_t n,
                                            uint8_t* out_xy, uint8_t* ok) {
     hipLaunchKernelGGL(k_decompress<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xs, y_is_odd, n, out_xy, ok);

@@ -39,6 +39,7 @@ template <class C> void launch_schnorr_prepare(hipStream_t s, const uint8_t* e, 
                                                size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* valid);
 template <class C> void launch_schnorr_finish(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                               const uint8_t* valid, size_t n, uint8_t* ok);
+template <class C> void launch_extract_x(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint8_t* out_x, uint8_t* ok);
 template <class C> void launch_decompress(hipStream_t s, const uint8_t* xs, const uint8_t* y_is_odd, size_t n, uint8_t* out_xy,
                                           uint8_t* ok);
 template <class C> void launch_ecdsa_finish(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,

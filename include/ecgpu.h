@@ -189,6 +189,15 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s,
                                    const void *d_p_xy, size_t n, void *d_ok);
 
+/* Batch ECDH — `elliptic_curve::ecdh::diffie_hellman(secret, public)` (elliptic-curve 0.14.1, un-vendored; the
+ * curves re-export it: k256/src/ecdh.rs, p256/src/ecdh.rs, p384/src/ecdh.rs): out_x[i] = the x-coordinate of
+ * k_i * P_i as L big-endian bytes (`SharedSecret::raw_secret_bytes`), ok[i] = 1 unless the product is the identity
+ * (k_i = 0).  Scalars >= n and points off the curve fail the call like ecgpu_batch_mul. */
+int ecgpu_batch_ecdh(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy,
+                     size_t n, uint8_t *out_x, uint8_t *ok);
+int ecgpu_batch_ecdh_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,
+                         size_t n, void *d_out_x, void *d_ok);
+
 /* Batch point decompression — `DecompressPoint::decompress(x_bytes, y_is_odd)`
  * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;
  * BIP340 `decompact` = y_is_odd 0).  xs n*L bytes big-endian, y_is_odd n bytes.  out_xy[i] = (x, y) with

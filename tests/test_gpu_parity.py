@@ -518,3 +518,26 @@ def test_decompress_vs_oracle(eng, curve):
     P = pts.reshape(m, 2 * c.L)
     back, ok = eng.decompress(c.cid, P[:, : c.L].copy().reshape(-1), (P[:, 2 * c.L - 1] & 1).copy())
     assert ok.all() and bytes(back) == bytes(pts)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_ecdh_vs_node_openssl_and_oracle(eng, curve):
+    """Batch ECDH (x of k*P) against shared secrets computed by Node's crypto / OpenSSL (tests/golden/ecdh_node.json, an
+    implementation independent of the reference and of this repository) and against the oracle's variable-base path."""
+    import json
+    import os
+    from gpu_common import GOLDEN
+    c = pyec.CURVES[curve]
+    rows = json.load(open(os.path.join(GOLDEN, "ecdh_node.json")))[curve]
+    k = b"".join(bytes.fromhex(r["d"]) for r in rows)
+    p = b"".join(bytes.fromhex(r["qx"]) + bytes.fromhex(r["qy"]) for r in rows)
+    x, ok = eng.ecdh(c.cid, k, p)
+    assert ok.all() and bytes(x) == b"".join(bytes.fromhex(r["z"]) for r in rows)
+    n = 500
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xECD0 + c.cid))
+    ks = rand_scalars(c.cid, n, 0xECD1 + c.cid).copy()
+    ks[: c.L] = 0                                                        # k = 0 -> identity -> ok = 0
+    x, ok = eng.ecdh(c.cid, ks, pts)
+    want, winf = oracle_lib.batch_mul(c.cid, ks, pts)
+    assert bytes(x) == bytes(want.reshape(n, 2 * c.L)[:, : c.L].copy().reshape(-1))
+    assert list(ok) == [0 if f else 1 for f in winf] and ok[0] == 0 and ok[1:].all()

@@ -159,6 +159,21 @@ def test_decompress_vs_model(oracle, curve):
     assert bytes(out[: 2 * c.L]) == pyec.enc_point(c, g if g[1] % 2 == 0 else pyec.neg(c, g))[0]
 
 
+@pytest.mark.parametrize("curve", CURVES)
+def test_variable_base_vs_node_openssl_ecdh(oracle, curve):
+    """The oracle's `P * k` against ECDH shared secrets from Node's crypto / OpenSSL (tests/golden/ecdh_node.json,
+    generated by tests/golden/gen_ecdh_node.js): the third opinion SURVEY.md §8c asks for where the reference has no
+    known-answer test (variable base with P != G)."""
+    c = pyec.CURVES[curve]
+    rows = json.load(open(os.path.join(GOLDEN, "ecdh_node.json")))[curve]
+    k = b"".join(bytes.fromhex(r["d"]) for r in rows)
+    p = b"".join(bytes.fromhex(r["qx"]) + bytes.fromhex(r["qy"]) for r in rows)
+    for vt in (False, True):
+        out, inf = oracle.batch_mul(c.cid, k, p, vartime=vt)
+        got = np.asarray(out).reshape(len(rows), 2 * c.L)[:, : c.L]
+        assert not inf.any() and bytes(got.copy().reshape(-1)) == b"".join(bytes.fromhex(r["z"]) for r in rows)
+
+
 @pytest.mark.parametrize("curve", ["k256", "p256"])
 def test_field_doubling_vectors(oracle, curve):
     """k256 field.rs tests / p256 field.rs:219-245: repeated doubling of 1."""
