@@ -65,10 +65,11 @@ def pmc_traffic(kernel):
         with open(path) as f:
             rec = json.load(f).get(kernel)
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
     if not rec:
-        return None, None
-    return rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01/pmc_traffic_v6.json (%s)" % rec["workload"]
+        return None, None, None
+    return (rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01/pmc_traffic_v6.json (%s)" % rec["workload"],
+            rec.get("valu_busy"))
 
 
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
@@ -261,7 +262,7 @@ def main():
         achieved = wl["imad_per_unit"] * units_per_launch / (kernel_ms * 1e-3) if kernel_ms else None
         hbm_gbps = wl["bytes_per_unit"] * units_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
         default_size = (args.n == 0 and not args.window and world == 1)
-        traffic, traffic_src = pmc_traffic(wl["kernel"]) if default_size else (None, None)
+        traffic, traffic_src, valu_busy = pmc_traffic(wl["kernel"]) if default_size else (None, None, None)
         result = {
             "metric": wl["metric"], "value": value, "unit": wl["unit"], "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -271,7 +272,7 @@ def main():
             "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms,
                          "achieved": achieved / 1e12 if achieved else None, "peak": peak / 1e12, "unit": "TIMAD32/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": traffic, "traffic_unit": "bytes/launch",
-                         "traffic_source": traffic_src,
+                         "traffic_source": traffic_src, "valu_busy_pmc": valu_busy,
                          "algorithmic_imad32_per_unit": wl["imad_per_unit"], "units_per_launch": units_per_launch,
                          "peak_source": "ecgpu_valu_probe(v_mad_u64_u32) measured in this run",
                          "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

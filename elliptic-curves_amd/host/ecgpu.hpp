@@ -192,6 +192,62 @@ struct Curve {
         return unpack(xy, inf);
     }
 
+    // ---- the callers either side of the path, batch forms ------------------------------
+    // DecompressPoint::decompress(x_bytes, y_is_odd) -> CtOption<AffinePoint>   (primeorder/src/affine.rs:183-200)
+    static std::vector<AffinePoint> batch_decompress(const std::vector<FieldBytes>& xs, const std::vector<uint8_t>& y_is_odd) {
+        size_t n = xs.size();
+        if (y_is_odd.size() != n) throw Error(ECGPU_ERR_ARG, "batch_decompress: length mismatch");
+        std::vector<uint8_t> x(n * L), xy(n * 2 * L), ok(n);
+        for (size_t i = 0; i < n; i++) std::memcpy(&x[i * L], xs[i].data(), L);
+        Engine& e = Engine::global();
+        e.check(ecgpu_batch_decompress(e.ctx(), ID, x.data(), y_is_odd.data(), n, xy.data(), ok.data()));
+        std::vector<AffinePoint> out(n);                     // None is reported as the identity flag
+        for (size_t i = 0; i < n; i++) {
+            if (!ok[i]) continue;
+            std::memcpy(out[i].x_.data(), &xy[i * 2 * L], L);
+            std::memcpy(out[i].y_.data(), &xy[i * 2 * L + L], L);
+            out[i].infinity = 0;
+        }
+        return out;
+    }
+    // elliptic_curve::ecdh::diffie_hellman(secret, public).raw_secret_bytes()   ({k256,p256,p384}/src/ecdh.rs)
+    static std::vector<FieldBytes> batch_diffie_hellman(const std::vector<Scalar>& secrets, const std::vector<AffinePoint>& publics) {
+        size_t n = secrets.size();
+        if (publics.size() != n) throw Error(ECGPU_ERR_ARG, "batch_diffie_hellman: length mismatch");
+        std::vector<uint8_t> s(n * L), p(n * 2 * L), x(n * L), ok(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&s[i * L], secrets[i].repr.data(), L);
+            std::memcpy(&p[i * 2 * L], publics[i].x_.data(), L);
+            std::memcpy(&p[i * 2 * L + L], publics[i].y_.data(), L);
+        }
+        Engine& e = Engine::global();
+        e.check(ecgpu_batch_ecdh(e.ctx(), ID, s.data(), p.data(), n, x.data(), ok.data()));
+        std::vector<FieldBytes> out(n);
+        for (size_t i = 0; i < n; i++) std::memcpy(out[i].data(), &x[i * L], L);
+        return out;
+    }
+    // ecdsa::hazmat::verify_prehashed for a batch: (z, r, s) as field-sized big-endian integers, q the public keys;
+    // normalize_s = the curve's EcdsaCurve::NORMALIZE_S (k256/src/ecdsa.rs:104-106)
+    struct EcdsaSignature {
+        FieldBytes r{}, s{};
+    };
+    static std::vector<uint8_t> batch_verify_prehashed(const std::vector<AffinePoint>& q, const std::vector<FieldBytes>& z,
+                                                       const std::vector<EcdsaSignature>& sig, bool normalize_s) {
+        size_t n = q.size();
+        if (z.size() != n || sig.size() != n) throw Error(ECGPU_ERR_ARG, "batch_verify_prehashed: length mismatch");
+        std::vector<uint8_t> zb(n * L), rb(n * L), sb(n * L), qb(n * 2 * L), ok(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&zb[i * L], z[i].data(), L);
+            std::memcpy(&rb[i * L], sig[i].r.data(), L);
+            std::memcpy(&sb[i * L], sig[i].s.data(), L);
+            std::memcpy(&qb[i * 2 * L], q[i].x_.data(), L);
+            std::memcpy(&qb[i * 2 * L + L], q[i].y_.data(), L);
+        }
+        Engine& e = Engine::global();
+        e.check(ecgpu_ecdsa_verify_batch(e.ctx(), ID, zb.data(), rb.data(), sb.data(), qb.data(), n, normalize_s ? 1 : 0, ok.data()));
+        return ok;
+    }
+
     // ---- MulBackend<C> plug-in (primeorder/src/mul_backend.rs:11-40) ----------------------------------
     struct GpuBackend {
         static ProjectivePoint mul_by_generator(const Scalar& k) { return ProjectivePoint::mul_by_generator(k); }

