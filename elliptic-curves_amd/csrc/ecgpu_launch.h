@@ -18,7 +18,8 @@ struct MsmPlan {
     size_t ntiles = 0, tile = 0;   // counting-sort tiles (terms per tile)
     size_t chunk = 0, nchunks = 0; // accumulation: sorted entries per lane, lanes per window
     size_t off_points = 0, off_digits = 0, off_vmask = 0, off_tilehist = 0, off_sorted = 0, off_count = 0, off_offset = 0,
-           off_partials = 0, off_buckets = 0, off_segs = 0, off_wins = 0;
+           off_partials = 0, off_buckets = 0, off_segs = 0, off_wins = 0, off_biglist = 0;
+    size_t max_big = 0;            // upper bound on the number of buckets that have more than MSM_BIG_PARTIALS partial sums
     size_t workspace_bytes = 0;
 };
 

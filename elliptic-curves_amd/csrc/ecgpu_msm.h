@@ -18,7 +18,8 @@
 //   accumulate  one lane per `chunk` consecutive sorted entries of a window (ecgpu_msm_chunk.h): complete mixed
 //               additions, a partial sum written at every bucket boundary   <- the hot loop; perfectly balanced
 //               for ANY scalar distribution
-//   finish      one lane per (window, bucket): adds the bucket's 1-2 (or, for a skewed input, many) partial sums
+//   finish      one lane per (window, bucket): adds the bucket's 1-2 partial sums; a bucket with more than 32 of them
+//               (degenerate inputs) is handed to a whole workgroup
 //   reduce      running-sum trick on segments of buckets, segment sums, window sums
 //   combine     Horner over the windows (c doublings each)
 //
@@ -185,18 +186,52 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
     msm_chunk_accumulate<C>(sorted + w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, G::curve_b(), points, sink);
 }
 
-// one lane per (window, bucket)
+// A bucket normally has one or two partial sums.  A degenerate input (all scalars equal, all ones) gives ONE bucket
+// per window thousands of them; such buckets are handed to a whole workgroup each (k_msm_big_buckets) instead of
+// being walked by a single lane.
+constexpr uint32_t MSM_BIG_PARTIALS = 32;
+
+// one lane per (window, bucket); big_list[0] = number of deferred buckets, big_list[1..] their ids
 template <class C>
 __global__ void __launch_bounds__(64)
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                     const uint32_t* __restrict__ offsets, size_t nb, int nwin, size_t chunk, size_t nchunks,
-                    uint32_t* __restrict__ buckets) {
+                    uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_list, uint32_t max_big) {
     using G = Group<C>;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nb * nwin) return;
     size_t w = gid / nb, b = gid % nb;
+    const uint32_t first = offsets[gid], cnt = counts[gid];
+    if (cnt != 0 && (first + cnt - 1) / (uint32_t)chunk - first / (uint32_t)chunk >= MSM_BIG_PARTIALS) {
+        uint32_t slot = atomicAdd(big_list, 1u);
+        if (slot < max_big) {                                 // (always: max_big is an upper bound)
+            big_list[1 + slot] = (uint32_t)gid;
+            return;
+        }
+    }
     MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (3 * Field<C>::NS)};
-    store_proj<C>(buckets, gid, msm_bucket_finish<C>((uint32_t)b, offsets[gid], counts[gid], (uint32_t)chunk, G::curve_b(), src));
+    store_proj<C>(buckets, gid, msm_bucket_finish<C>((uint32_t)b, first, cnt, (uint32_t)chunk, G::curve_b(), src));
+}
+
+// one workgroup per deferred bucket: strided sums of its partials + an LDS tree
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                  const uint32_t* __restrict__ offsets, size_t nb, size_t chunk, size_t nchunks,
+                  uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_list) {
+    using G = Group<C>;
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    if (blockIdx.x >= big_list[0]) return;
+    const size_t gid = big_list[1 + blockIdx.x];
+    const size_t w = gid / nb, b = gid % nb;
+    const uint32_t first = offsets[gid], cnt = counts[gid];
+    const uint32_t q0 = first / (uint32_t)chunk, q1 = (first + cnt - 1) / (uint32_t)chunk;
+    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (3 * Field<C>::NS)};
+    const Fe<C::NL> cb = G::curve_b();
+    Proj<C> acc = G::identity();
+    for (uint32_t q = q0 + threadIdx.x; q <= q1; q += BLOCK) acc = G::add(acc, src.get(b + q), cb);
+    acc = block_sum<C>(acc, lds, cb);
+    if (threadIdx.x == 0) store_proj<C>(buckets, gid, acc);
 }
 
 // ---- reduce ------------------------------------------------------------------------------------------------------------
@@ -344,6 +379,8 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_partials = o; o = align(o + (size_t)p.nwin * (p.nb + p.nchunks) * 3 * NS * 4);
     p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * NS * 4);
+    p.max_big = (size_t)p.nwin * (p.nchunks / (MSM_BIG_PARTIALS - 1) + 1);   // a big bucket covers >= 31 whole chunks
+    p.off_biglist = o; o = align(o + (p.max_big + 1) * 4);
     p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * NS * 4);
     p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * NS * 4);
     p.workspace_bytes = o + 256;
@@ -371,6 +408,7 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
     uint32_t* partials = (uint32_t*)(ws + p.off_partials);
     uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
+    uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     uint32_t* wins = (uint32_t*)(ws + p.off_wins);
     unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
@@ -397,9 +435,13 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
                        (const uint32_t*)offsets, n, p.nb, p.nwin, p.chunk, p.nchunks, partials);
+    (void)hipMemsetAsync(big_list, 0, 4, stream);
     hipLaunchKernelGGL(k_msm_bucket_finish<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, p.nb, p.nwin, p.chunk,
-                       p.nchunks, buckets);
+                       p.nchunks, buckets, big_list, (uint32_t)p.max_big);
+    hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
+                       (const uint32_t*)counts, (const uint32_t*)offsets, p.nb, p.chunk, p.nchunks, buckets,
+                       (const uint32_t*)big_list);
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
