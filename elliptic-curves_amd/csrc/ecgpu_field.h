@@ -305,6 +305,28 @@ struct Field {
 
     // 2*UN-1 product columns (c[2*UN-1], c[2*UN] zero) -> Montgomery-reduced UN limbs, value < 2p
     static ECGPU_HD E p_reduce(uint64_t* c) {
+        if constexpr (C::ID == CURVE_P256) {
+            // p256 in sparse form: u p = -u + u 2^96 + u 2^192 + u 2^224 (2^32 - 1).  The -u clears the low 28 bits
+            // of c[i]; the other three terms are one multiply-add each into columns i+3, i+6, i+8 (3 per row
+            // instead of 6 for the limb form of p; model and bounds: tools/field_model.py p256_reduce_rows).
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                uint32_t u = (uint32_t)c[i] & PMASK;
+                c[i + 1] += (c[i] >> UB);
+                c[i + 3] += (uint64_t)u * opaque_const(1u << 12);
+                c[i + 6] += (uint64_t)u * opaque_const(1u << 24);
+                c[i + 8] += (uint64_t)u * opaque_const(0xFFFFFFFFu);
+            }
+            E r;
+            uint64_t v = c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
 #pragma unroll
         for (int i = 0; i < UN; i++) {
             uint32_t u = (uint32_t)c[i] & PMASK;
