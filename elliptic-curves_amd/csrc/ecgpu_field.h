@@ -327,6 +327,30 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
+        if constexpr (C::ID == CURVE_P384) {
+            // p384 in sparse form with SIGNED columns: u p = -u + u 2^32 - u 2^96 - u 2^128 + u 2^384, i.e. + u 2^5
+            // into column i+1 (with the arithmetic carry of c[i]), - u 2^15 into i+3, - u 2^20 into i+4, + u 2^6 into
+            // i+14: 4 multiply-adds per row instead of 13 (tools/field_model.py p384_mont_mul; the sign bit is why
+            // the product limit is 30).
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                const int64_t ci = (int64_t)c[i];
+                const int64_t u = (int64_t)((uint32_t)ci & PMASK);
+                c[i + 1] = (uint64_t)((int64_t)c[i + 1] + (ci >> UB) + u * (int64_t)(int32_t)opaque_const(1u << 5));
+                c[i + 3] = (uint64_t)((int64_t)c[i + 3] + u * (int64_t)(int32_t)opaque_const(0u - (1u << 15)));
+                c[i + 4] = (uint64_t)((int64_t)c[i + 4] + u * (int64_t)(int32_t)opaque_const(0u - (1u << 20)));
+                c[i + 14] = (uint64_t)((int64_t)c[i + 14] + u * (int64_t)(int32_t)opaque_const(1u << 6));
+            }
+            E r;
+            int64_t v = (int64_t)c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = (int64_t)c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
 #pragma unroll
         for (int i = 0; i < UN; i++) {
             uint32_t u = (uint32_t)c[i] & PMASK;

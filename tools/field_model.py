@@ -225,6 +225,37 @@ def sub_constant(p, nl, b, m, lb, top_bound):
     return limbs, k
 
 
+def chk_s64(x):
+    assert -(1 << 63) <= x < (1 << 63), "signed 64-bit accumulator overflow: %x" % x
+    return x
+
+
+def p384_mont_mul(a, b, c_extra=None):
+    """p384 with SIGNED column accumulators and the Montgomery rows in sparse form:
+    u p = -u + u 2^32 - u 2^96 - u 2^128 + u 2^384; in 27-bit columns relative to row i: the -u clears the low 27
+    bits of c[i] (carry = arithmetic c[i] >> 27 into column i+1), + u 2^5 into column i+1, - u 2^15 into column i+3,
+    - u 2^20 into column i+4, + u 2^6 into column i+14.  4 multiply-adds per row instead of 13 for the limb form of
+    p; the sign bit costs one bit of headroom, which is why the product limit of p384 is 30 and not 60."""
+    c = [0] * 31
+    for x, y in ((a, b),) + ((c_extra,) if c_extra is not None else ()):
+        for i in range(15):
+            for j in range(15):
+                c[i + j] = chk_s64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    for i in range(15):
+        u = c[i] & Q_MASK
+        c[i + 1] = chk_s64(c[i + 1] + (c[i] >> Q_B) + u * (1 << 5))
+        c[i + 3] = chk_s64(c[i + 3] - u * (1 << 15))
+        c[i + 4] = chk_s64(c[i + 4] - u * (1 << 20))
+        c[i + 14] = chk_s64(c[i + 14] + u * (1 << 6))
+    r = [0] * 15
+    v = c[15]
+    for k in range(14):
+        r[k] = v & Q_MASK
+        v = chk_s64(c[16 + k] + (v >> Q_B))
+    r[14] = chk32(v)
+    return r
+
+
 def selftest(trials=300, seed=1):
     rng = random.Random(seed)
     # k256: adversarial maxima at the magnitude-product limit 7 (e.g. 7 x 1, 3 x 2) and random values
@@ -262,19 +293,27 @@ def selftest(trials=300, seed=1):
         r = p256_mont_mul(a, b)
         assert from_limbs(r, P_B) % P_P == from_limbs(a, P_B) * from_limbs(b, P_B) * rinv % P_P
         assert from_limbs(r, P_B) < 2 * P_P
-    # p384: limb-magnitude product limit 60, single magnitudes <= 28
+    # p384: limb-magnitude product limit 30 (signed sparse rows), single magnitudes <= 28; the dense generic routine
+    # (unsigned columns, limit 60) is the cross-check
     qinv = pow(Q_R, -1, Q_P)
-    for ma, mb in ((28, 2), (2, 28), (7, 8), (1, 1), (10, 6), (60, 1) if False else (20, 3)):
+    for ma, mb in ((28, 1), (1, 28), (5, 6), (1, 1), (10, 3), (15, 2)):
         a = [ma * Q_LB - 1] * 14 + [Q_TOP1 * ma - 1]
         b = [mb * Q_LB - 1] * 14 + [Q_TOP1 * mb - 1]
-        r = umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
+        r = p384_mont_mul(a, b)
+        assert r == umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
         assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
         assert from_limbs(r, Q_B) < 2 * Q_P and all(x < (1 << 27) for x in r[:14]) and r[14] < Q_TOP1
+    for (ma, mb), (mc, md) in (((4, 5), (1, 3)), ((5, 5), (5, 1)), ((28, 1), (2, 1))):
+        a, b, x, y = ([m * Q_LB - 1] * 14 + [Q_TOP1 * m - 1] for m in (ma, mb, mc, md))
+        r = p384_mont_mul(a, b, (x, y))
+        want = (from_limbs(a, Q_B) * from_limbs(b, Q_B) + from_limbs(x, Q_B) * from_limbs(y, Q_B)) * qinv % Q_P
+        assert from_limbs(r, Q_B) % Q_P == want and from_limbs(r, Q_B) < 2 * Q_P
     for _ in range(trials // 3):
-        ma, mb = rng.choice([(1, 1), (7, 8), (28, 2), (4, 15)])
+        ma, mb = rng.choice([(1, 1), (5, 6), (28, 1), (2, 15)])
         a = [rng.randrange(ma * Q_LB) for _ in range(14)] + [rng.randrange(Q_TOP1 * ma)]
         b = [rng.randrange(mb * Q_LB) for _ in range(14)] + [rng.randrange(Q_TOP1 * mb)]
-        r = umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
+        r = p384_mont_mul(a, b)
+        assert r == umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
         assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
         assert from_limbs(r, Q_B) < 2 * Q_P
     # the generic routine agrees with the p256-specific model
