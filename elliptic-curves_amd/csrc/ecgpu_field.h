@@ -17,9 +17,8 @@
 //   REPR_U29_K256  k256: 9 limbs x 29 bits, plain residues, value < M * 2^261; products are folded with
 //                  2^261 = 256 * 2^29 + 31264 (mod p)
 //   REPR_U28_MONT  p256: 10 limbs x 28 bits, Montgomery form R = 2^280 (p = -1 mod 2^28, so p' = 1 as in
-//                  p256/src/arithmetic/field/field64.rs:59), value < M * 2p
-//   REPR_SAT_MONT  p384: 12 saturated 32-bit limbs, Montgomery form, fully reduced after every operation
-//                  (p384/src/arithmetic/field.rs:52-57 -> crypto-bigint ConstMontyForm)
+//                  p256/src/arithmetic/field/field64.rs:59), value < M * 2p; p384: 15 limbs x 27 bits, R = 2^405
+//                  (the reference: p384/src/arithmetic/field.rs:52-57 -> crypto-bigint ConstMontyForm)
 //
 // Lazy reduction needs bounds.  Elements carry their bounds in the type: Mag<C, L, V> has limbs
 // <= L * LB ("limb magnitude") and value <= V * (value unit) ("value magnitude"); add/sub/neg grow the
@@ -60,63 +59,8 @@ struct Field {
     using M1 = Mag<C, 1, 1>;
 
     // largest allowed sum of limb-magnitude products in one column accumulation, largest limb magnitude
-    ECGPU_CONST int MAXPROD = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? C::UC::MAXPROD : 1);
-    ECGPU_CONST int MAXMAG = REPR == REPR_U29_K256 ? 7 : (REPR == REPR_U28_MONT ? C::UC::MAXMAG : 1);
-    ECGPU_CONST bool LAZY = REPR != REPR_SAT_MONT;
-
-    // =============================================================================================
-    // saturated Montgomery (p384)
-    // =============================================================================================
-    static ECGPU_HD E sat_reduce_wide(uint32_t* t) {   // word-by-word, p' = 1 (p = -1 mod 2^32)
-        uint32_t top = 0;
-#pragma unroll
-        for (int i = 0; i < N; i++) {
-            uint32_t u = t[i];
-            uint32_t carry = 0;
-#pragma unroll
-            for (int j = 0; j < N; j++) {
-                uint64_t s = (uint64_t)u * C::P[j] + t[i + j] + carry;
-                t[i + j] = (uint32_t)s;
-                carry = (uint32_t)(s >> 32);
-            }
-            uint64_t s = (uint64_t)t[i + N] + carry + top;
-            t[i + N] = (uint32_t)s;
-            top = (uint32_t)(s >> 32);
-        }
-        E r;
-        uint32_t d[N];
-        uint32_t borrow = mp_sub<N>(d, t + N, C::P);
-        bool use_d = top || !borrow;
-#pragma unroll
-        for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : t[N + i];
-        return r;
-    }
-    static ECGPU_HD E sat_mul(const E& a, const E& b) {
-        uint32_t t[2 * N];
-        mp_mul<N>(t, a.v, b.v);
-        return sat_reduce_wide(t);
-    }
-    static ECGPU_HD E sat_sqr(const E& a) {
-        uint32_t t[2 * N];
-        mp_sqr<N>(t, a.v);
-        return sat_reduce_wide(t);
-    }
-    static ECGPU_HD E sat_add(const E& a, const E& b) {
-        E r;
-        uint32_t c = mp_add<N>(r.v, a.v, b.v);
-        uint32_t d[N];
-        uint32_t borrow = mp_sub<N>(d, r.v, C::P);
-        bool use_d = c || !borrow;
-#pragma unroll
-        for (int i = 0; i < N; i++) r.v[i] = use_d ? d[i] : r.v[i];
-        return r;
-    }
-    static ECGPU_HD E sat_sub(const E& a, const E& b) {
-        E r;
-        uint32_t borrow = mp_sub<N>(r.v, a.v, b.v);
-        if (borrow) mp_add<N>(r.v, r.v, C::P);
-        return r;
-    }
+    ECGPU_CONST int MAXPROD = REPR == REPR_U29_K256 ? 7 : C::UC::MAXPROD;
+    ECGPU_CONST int MAXMAG = REPR == REPR_U29_K256 ? 7 : C::UC::MAXMAG;
 
     // =============================================================================================
     // k256, 9 x 29  (model: tools/field_model.py k256_*)
@@ -484,10 +428,7 @@ struct Field {
     }
     static ECGPU_HD M1 one() {
         M1 r = zero();
-        if constexpr (REPR == REPR_SAT_MONT) {
-#pragma unroll
-            for (int i = 0; i < N; i++) r.e.v[i] = C::ONE[i];
-        } else if constexpr (REPR == REPR_U28_MONT) {
+        if constexpr (REPR == REPR_U28_MONT) {
             r.e = p_const(PC::ONE);
         } else {
             r.e.v[0] = 1;
@@ -497,16 +438,12 @@ struct Field {
 
     template <int LA, int VA, int LB, int VB>
     static ECGPU_HD auto add(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
-        if constexpr (!LAZY) {
-            return wrap<1, 1>(sat_add(a.e, b.e));
-        } else {
-            static_assert(LA + LB <= MAXMAG, "limb magnitude overflow in add: normalise an operand first");
-            Mag<C, LA + LB, VA + VB> r;
+        static_assert(LA + LB <= MAXMAG, "limb magnitude overflow in add: normalise an operand first");
+        Mag<C, LA + LB, VA + VB> r;
 #pragma unroll
-            for (int i = 0; i < NL; i++) r.e.v[i] = a.e.v[i] + b.e.v[i];
-            check_mag<LA + LB, VA + VB>(r.e);
-            return r;
-        }
+        for (int i = 0; i < NL; i++) r.e.v[i] = a.e.v[i] + b.e.v[i];
+        check_mag<LA + LB, VA + VB>(r.e);
+        return r;
     }
     template <int LA, int VA>
     static ECGPU_HD auto dbl(const Mag<C, LA, VA>& a) { return add(a, a); }
@@ -523,12 +460,7 @@ struct Field {
     // -b as (multiple of p) - b, limb-wise
     template <int LB, int VB>
     static ECGPU_HD auto neg(const Mag<C, LB, VB>& b) {
-        if constexpr (!LAZY) {
-            E z;
-#pragma unroll
-            for (int i = 0; i < NL; i++) z.v[i] = 0;
-            return wrap<1, 1>(sat_sub(z, b.e));
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             constexpr int m = LB > VB ? LB : VB;
             static_assert(m <= KC::ZMAX, "no subtraction constant for this magnitude: normalise first");
             Mag<C, m + 1, m + 1> r;
@@ -549,15 +481,12 @@ struct Field {
     }
     template <int LA, int VA, int LB, int VB>
     static ECGPU_HD auto sub(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
-        if constexpr (!LAZY) return wrap<1, 1>(sat_sub(a.e, b.e));
-        else return add(a, neg(b));
+        return add(a, neg(b));
     }
 
     template <int LA, int VA, int LB, int VB>
     static ECGPU_HD M1 mul(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            return wrap<1, 1>(sat_mul(a.e, b.e));
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             static_assert(LA * LB <= MAXPROD, "k256 mul: limb magnitude product too large");
             uint64_t c[17];
             k_columns(c, a.e.v, b.e.v, false);
@@ -572,9 +501,7 @@ struct Field {
     }
     template <int LA, int VA>
     static ECGPU_HD M1 sqr(const Mag<C, LA, VA>& a) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            return wrap<1, 1>(sat_sqr(a.e));
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             static_assert(LA * LA <= MAXPROD, "k256 sqr: limb magnitude too large");
             uint64_t c[17];
             k_columns_sqr(c, a.e.v);
@@ -590,9 +517,7 @@ struct Field {
     template <int LA, int VA, int LB, int VB, int LC, int VC, int LD, int VD>
     static ECGPU_HD M1 mul2(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b, const Mag<C, LC, VC>& c,
                             const Mag<C, LD, VD>& d) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            return wrap<1, 1>(sat_add(sat_mul(a.e, b.e), sat_mul(c.e, d.e)));
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             static_assert(LA * LB + LC * LD <= MAXPROD, "k256 mul2: limb magnitude products too large");
             uint64_t col[17];
             k_columns(col, a.e.v, b.e.v, false);
@@ -610,8 +535,7 @@ struct Field {
     // limb magnitude back to 1 (k256: value magnitude too; p256: the value is untouched)
     template <int LA, int VA>
     static ECGPU_HD auto norm(const Mag<C, LA, VA>& a) {
-        if constexpr (REPR == REPR_SAT_MONT) return a;
-        else if constexpr (REPR == REPR_U29_K256) return wrap<1, 1>(k_norm(a.e));
+        if constexpr (REPR == REPR_U29_K256) return wrap<1, 1>(k_norm(a.e));
         else return wrap<1, VA>(p_norm(a.e));
     }
     // norm(a) only if its limb magnitude exceeds LIM (compile-time decision); SQLIM is the largest limb
@@ -633,12 +557,7 @@ struct Field {
     // ---- canonical words / bytes -----------------------------------------------------------------
     // canonical value (< p, checked by the caller) as N little-endian words -> internal form
     static ECGPU_HD M1 from_canonical(const uint32_t* w) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            E a, r2;
-#pragma unroll
-            for (int i = 0; i < N; i++) { a.v[i] = w[i]; r2.v[i] = C::R2[i]; }
-            return wrap<1, 1>(sat_mul(a, r2));
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             return wrap<1, 1>(words_to_limbs<9, 29>(w));
         } else {
             E a = words_to_limbs<UN, UB>(w);
@@ -647,14 +566,7 @@ struct Field {
     }
     template <int LA, int VA>
     static ECGPU_HD void to_canonical(uint32_t* w, const Mag<C, LA, VA>& a) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            uint32_t t[2 * N];
-#pragma unroll
-            for (int i = 0; i < N; i++) { t[i] = a.e.v[i]; t[N + i] = 0; }
-            E r = sat_reduce_wide(t);
-#pragma unroll
-            for (int i = 0; i < N; i++) w[i] = r.v[i];
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             k_to_words(w, a.e);
         } else {
             static_assert(LA <= MAXPROD, "normalise before to_canonical");
@@ -668,10 +580,7 @@ struct Field {
     // internal-domain value fully reduced to [0, p), N words ("packed" storage form: table entries, MSM points)
     template <int LA, int VA>
     static ECGPU_HD void pack(uint32_t* w, const Mag<C, LA, VA>& a) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-#pragma unroll
-            for (int i = 0; i < N; i++) w[i] = a.e.v[i];
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             k_to_words(w, a.e);
         } else {
             static_assert(LA <= MAXPROD, "normalise before pack");
@@ -680,12 +589,7 @@ struct Field {
         }
     }
     static ECGPU_HD M1 unpack(const uint32_t* w) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            M1 r;
-#pragma unroll
-            for (int i = 0; i < N; i++) r.e.v[i] = w[i];
-            return r;
-        } else if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (REPR == REPR_U29_K256) {
             return wrap<1, 1>(words_to_limbs<9, 29>(w));
         } else {
             return wrap<1, 1>(words_to_limbs<UN, UB>(w));
@@ -726,19 +630,15 @@ struct Field {
     // monty.rs:373-375) this runs Bernstein–Yang division steps (ecgpu_modinv.h) on the canonical value; for the
     // Montgomery fields (aR)^-1 is brought back to a^-1 R by two multiplications with R^2.
     static ECGPU_HD M1 inv(const M1& a) {
-        if constexpr (REPR == REPR_SAT_MONT) {
-            return inv_fermat(a);
-        } else {
-            uint32_t w[N], r[N];
-            pack(w, a);
-            ModInv<N>::invert(r, w, C::P);
-            M1 x = unpack(r);
-            if constexpr (REPR == REPR_U28_MONT) {
-                M1 r2 = wrap<1, 1>(p_const(PC::R2));
-                x = mul(mul(x, r2), r2);
-            }
-            return x;
+        uint32_t w[N], r[N];
+        pack(w, a);
+        ModInv<N>::invert(r, w, C::P);
+        M1 x = unpack(r);
+        if constexpr (REPR == REPR_U28_MONT) {
+            M1 r2 = wrap<1, 1>(p_const(PC::R2));
+            x = mul(mul(x, r2), r2);
         }
+        return x;
     }
     // a^(p-2), the first implementation, kept as an independent check of `inv` (tests/hostcheck).  k256 and p256
     // use addition chains over the runs of ones of p-2 (255 squarings + 15 resp. 12 multiplications); p384 a fixed

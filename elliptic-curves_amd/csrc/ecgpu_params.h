@@ -21,7 +21,6 @@ enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
-    REPR_SAT_MONT = 0,   // saturated 32-bit limbs, Montgomery form, fully reduced (first version; kept for A/B runs)
     REPR_U29_K256 = 1,   // 9 x 29-bit limbs, plain residues, lazily reduced, 2^261 folding (k256)
     REPR_U28_MONT = 2    // unsaturated limbs, Montgomery form, lazily reduced: 10 x 28 bit (p256), 15 x 27 bit (p384)
 };
@@ -89,44 +88,6 @@ ECGPU_HD void mp_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
             carry = (uint32_t)(t >> 32);
         }
         r[i + N] = carry;
-    }
-}
-
-// r[0..2N) = a^2: off-diagonal products once, doubled, plus the diagonal
-template <int N>
-ECGPU_HD void mp_sqr(uint32_t* r, const uint32_t* a) {
-#pragma unroll
-    for (int i = 0; i < 2 * N; i++) r[i] = 0;
-#pragma unroll
-    for (int i = 0; i < N - 1; i++) {
-        uint32_t carry = 0;
-#pragma unroll
-        for (int j = i + 1; j < N; j++) {
-            uint64_t t = (uint64_t)a[i] * a[j] + r[i + j] + carry;
-            r[i + j] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
-        }
-        r[i + N] = carry;
-    }
-    // double
-    uint32_t top = 0;
-#pragma unroll
-    for (int i = 1; i < 2 * N; i++) {
-        uint32_t w = r[i];
-        r[i] = (w << 1) | top;
-        top = w >> 31;
-    }
-    // add squares on the diagonal
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        uint64_t sq = (uint64_t)a[i] * a[i];
-        c += (uint64_t)r[2 * i] + (uint32_t)sq;
-        r[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += (uint64_t)r[2 * i + 1] + (uint32_t)(sq >> 32);
-        r[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
     }
 }
 

@@ -100,8 +100,6 @@ struct Group {
     static ECGPU_HD E curve_b() {  // curve b in internal form (a = -3 curves); unused for k256
         if constexpr (C::REPR == REPR_U28_MONT) {
             return F::p_const(C::UC::BM);
-        } else if constexpr (C::REPR == REPR_SAT_MONT) {
-            return F::from_canonical(C::B).e;
         } else {
             E b = F::zero().e;
             b.v[0] = C::B_SMALL;
