@@ -10,7 +10,7 @@
 //
 // The formulas are written once against the magnitude-typed field interface (ecgpu_field.h): every
 // intermediate carries its limb/value bounds in its type, `norm` is inserted exactly where the lazily
-// reduced representations need it (it is the identity for the saturated p384 field), and the sums of two
+// reduced representations need it, and the sums of two
 // products that end every formula are evaluated with ONE reduction (`mul2`).  This is the same
 // bookkeeping the reference does by hand with `negate(m)` / `normalize_weak()` in
 // k256/src/arithmetic/projective.rs.
@@ -173,7 +173,7 @@ struct Group {
         return r;
     }
 
-    // ---- a = -3 (p256: product limit 24, magnitude limit 15; p384: saturated, everything is 1) ----
+    // ---- a = -3 (p256: product limit 23, magnitude limit 15; p384: product limit 30, magnitude limit 28) ----
     static ECGPU_HD P add_am3(const P& l, const P& r, const E& be, bool negq) {
         auto b = m(be);
         auto X1 = m(l.x), Y1 = m(l.y), Z1 = m(l.z), X2 = m(r.x), Z2 = m(r.z);
