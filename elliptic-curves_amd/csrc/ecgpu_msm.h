@@ -318,10 +318,13 @@ __global__ void k_store_identity(uint32_t* out) {
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
+// Window width from the term count, from a sweep on MI355X (tools/gpu_msm_window_sweep.sh, k256): 2^12 / 2^14 / 2^16 /
+// 2^18 / 2^20 / 2^22 terms are fastest at c = 5-7 / 8-10 / 11 / 11-15 / 16 / 16 (the curve is flat below 2^18, where the
+// 255-doubling Horner chain of the combine step, 0.76 ms, dominates whatever c is).
 inline int msm_window_bits(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg - 7;
+    int c = lg >= 17 ? lg - 4 : lg - 5;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;
