@@ -294,7 +294,7 @@ k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, uint32_t* _
 
 // out = sum_w 2^(c w) wins[w]   (Horner)
 template <class C>
-__global__ void k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     // Everything here is wave-uniform, and left alone the compiler moves the whole 240-doubling chain to the
@@ -306,7 +306,19 @@ __global__ void k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin
     Fe<C::NL> b = G::curve_b();
     Proj<C> acc = load_proj<C>(vw, nwin - 1);
     for (int w = nwin - 2; w >= 0; w--) {
-        for (int s = 0; s < c; s++) acc = G::dbl(acc, b);
+        // c doublings in Jacobian coordinates (2M + 5S resp. 3M + 5S instead of the complete 6M + 2S + .. / 8M + 3S + ..):
+        // (X : Y : Z) -> (X Z : Y Z^2 : Z) and back (X Z : Y : Z^3).  The identity has no Jacobian form here: skipped.
+        if (!G::is_identity(acc)) {
+            Jac<C> j;
+            {
+                auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
+                j.x = Field<C>::mul(X, Z).e;
+                j.y = Field<C>::mul(Y, Field<C>::sqr(Z)).e;
+                j.z = acc.z;
+            }
+            for (int s = 0; s < c; s++) j = G::jac_dbl(j);
+            acc = G::jac_to_proj(j);
+        }
         acc = G::add(acc, load_proj<C>(vw, w), b);
     }
     store_proj<C>(out, 0, acc);
@@ -337,7 +349,13 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.c = force_c ? force_c : msm_window_bits(n);
     p.nwin = signed_window_count(32 * N - 1, p.c);          // scalars are folded to 32 N - 1 bits
     p.nb = (size_t)1 << (p.c - 1);
-    p.seg = p.nb < 32 ? (int)p.nb : 32;
+    p.seg = 4;                                              // buckets per running-sum lane: 4 ... 8 measured best for
+                                                            // small MSMs (more lanes), neutral at 2^24 (tuning knob)
+    if (const char* e = getenv("ECGPU_MSM_SEG")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 1024 && (v & (v - 1)) == 0) p.seg = v;
+    }
+    if ((size_t)p.seg > p.nb) p.seg = (int)p.nb;
     p.nseg = p.nb / p.seg;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
