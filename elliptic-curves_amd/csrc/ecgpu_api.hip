@@ -39,7 +39,7 @@ struct ecgpu_ctx {
     int* h_status = nullptr;
     Table table[3];
     // fixed-base comb width: W = 24 is 11 windows = 10 additions per 256-bit scalar over a 5.9 GB table (built in
-    // 0.16 s); every addition removed is worth 8 % and HBM keeps up with the gathers.  p384: W = 20, 1.0 GB.
+    // 25 ms); every addition removed is worth 8 % and HBM keeps up with the gathers.  p384: W = 20, 1.0 GB.
     int want_w[3] = {24, 24, 20};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;

@@ -15,8 +15,10 @@ template <> void launch_window_bases<CurveT>(hipStream_t s, uint32_t* bases, int
     hipLaunchKernelGGL(k_window_bases<CurveT>, dim3(1), dim3(64), 0, s, bases, w, nwin);
 }
 template <> void launch_table_entries<CurveT>(hipStream_t s, const uint32_t* bases, uint32_t* entries, int w, int nwin) {
-    size_t total = ((size_t)1 << (w - 1)) * nwin;
-    hipLaunchKernelGGL(k_table_entries<CurveT>, dim3(grid_for(total)), dim3(BLOCK), 0, s, bases, entries, w, nwin);
+    int tlog = w - 1 > 6 ? w - 1 - 6 : 0;                     // 64 entries per lane ...
+    if (tlog > 17) tlog = 17;                                 // ... but no more lanes than fill the machine a few times
+    size_t total = ((size_t)1 << tlog) * nwin;
+    hipLaunchKernelGGL(k_table_entries<CurveT>, dim3(grid_for(total)), dim3(BLOCK), 0, s, bases, entries, w, nwin, tlog);
 }
 // One inversion per lane, amortised over K points (Montgomery's trick).  The inversion is a serial chain of ~45k
 // instructions whatever K is, so the kernel is fastest when there is about one wave per SIMD (1024 of them):

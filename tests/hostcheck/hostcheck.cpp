@@ -178,17 +178,21 @@ void build_table(BaseTable<C>& t, int w) {
     }
 }
 
-// k_table_entries' per-entry rule, for spot checks
+// k_table_entries' rule for entry e (1-based) of a window: lane t = (e - 1) mod T computes (t + 1) * base by
+// double-and-add and then adds T * base once per stride
 template <class C>
-Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e) {
+Proj<C> table_entry_rule(const Proj<C>& base, uint32_t e, int tlog = 3) {
     using G = Group<C>;
     auto b = G::curve_b();
+    const uint32_t T = 1u << tlog, e0 = ((e - 1) & (T - 1)) + 1;
+    Proj<C> step = base;
+    for (int s = 0; s < tlog; s++) step = G::dbl(step, b);
     Proj<C> acc = base;
-    int top = 31 - __builtin_clz(e);
-    for (int bit = top - 1; bit >= 0; bit--) {
+    for (int bit = 30 - __builtin_clz(e0); bit >= 0; bit--) {
         acc = G::dbl(acc, b);
-        if ((e >> bit) & 1) acc = G::add(acc, base, b);
+        if ((e0 >> bit) & 1) acc = G::add(acc, base, b);
     }
+    for (uint32_t x = e0; x < e; x += T) acc = G::add(acc, step, b);
     return acc;
 }
 
