@@ -38,9 +38,10 @@ struct ecgpu_ctx {
     int* d_status = nullptr;
     int* h_status = nullptr;
     Table table[3];
-    // fixed-base comb width: W = 24 is 11 windows = 10 additions per 256-bit scalar over a 5.9 GB table (built in
-    // 25 ms); every addition removed is worth 8 % and HBM keeps up with the gathers.  p384: W = 20, 1.0 GB.
-    int want_w[3] = {24, 24, 20};
+    // fixed-base comb width: every addition removed is worth 8 % and HBM keeps up with the gathers, so the tables are
+    // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
+    // p256: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
+    int want_w[3] = {26, 24, 20};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf;   // ECDSA verification scratch
@@ -133,19 +134,26 @@ int ensure_table(ecgpu_ctx* ctx) {
     const size_t half = (size_t)1 << (w - 1);
     const size_t entries = half * nwin;
     int rc;
+    // windows are built in slabs so that the projective scratch (192 B per entry, 3x the table) stays below ~2 GB
+    size_t slab = ((size_t)2 << 30) / (half * (4 * NS) * 4);
+    if (slab < 1) slab = 1;
+    if (slab > (size_t)nwin) slab = nwin;
     if ((rc = ensure(ctx, ctx->bases, (size_t)nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->proj, entries * 3 * NS * 4)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->prefix, entries * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, slab * half * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->prefix, slab * half * NS * 4)) != ECGPU_OK) return rc;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.d), entries * 2 * N * 4));
     launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, w, nwin);
-    launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, w, nwin);
-    launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, entries, nullptr, nullptr,
-                        t.d);
+    for (size_t j0 = 0; j0 < (size_t)nwin; j0 += slab) {
+        const size_t ws = j0 + slab <= (size_t)nwin ? slab : (size_t)nwin - j0;
+        launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p + j0 * (3 * NS), (uint32_t*)ctx->proj.p, w, (int)ws);
+        launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, ws * half, nullptr,
+                            nullptr, t.d + j0 * half * (2 * N));
+    }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     t.w = w;
     t.nwin = nwin;
-    // the build scratch (entries x 192 B) is far larger than any batch needs: give it back
+    // the build scratch is larger than most batches need: give it back
     for (DevBuf* b : {&ctx->proj, &ctx->prefix}) {
         if (b->cap > ((size_t)64 << 20)) {
             HIP_TRY(ctx, hipFree(b->p));
@@ -414,7 +422,7 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
     if (!ctx || curve < 0 || curve > 2) return ECGPU_ERR_CURVE;
-    if (window_bits < 4 || window_bits > 24) return ECGPU_ERR_ARG;
+    if (window_bits < 4 || window_bits > 26) return ECGPU_ERR_ARG;
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
 }

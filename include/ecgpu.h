@@ -74,9 +74,9 @@ size_t ecgpu_field_bytes(int curve);
  * context; NULL restores the context's own stream.  `stream` is a hipStream_t. */
 int ecgpu_set_stream(ecgpu_ctx *ctx, void *stream);
 
-/* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..24; default 24 for the
- * 256-bit curves: 10 additions per scalar over a 5.9 GB table, and 20 for p384: 1.0 GB; the table takes
- * ceil(bits/w) * 2^(w-1) * 2L bytes and about three times that transiently while it is built).
+/* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..26; defaults: k256 26 —
+ * 9 additions per scalar over a 21.5 GB table —, p256 24 — 10 additions, 5.9 GB —, p384 20 — 1.0 GB; the table takes
+ * ceil(bits/w) * 2^(w-1) * 2L bytes — 21.5 GB at 26 — plus at most 2 GB of scratch while it is built).
  * The table is rebuilt on next use. A tuning knob, like the reference's WINDOW_SIZE constants
  * (k256/src/arithmetic/tables.rs:12, p384/src/arithmetic/tables.rs:8). */
 int ecgpu_set_base_window(ecgpu_ctx *ctx, int curve, int window_bits);

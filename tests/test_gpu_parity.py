@@ -112,7 +112,7 @@ def test_golden_ecdsa_vectors(eng, curve):
 # ---------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("curve", CURVES)
-@pytest.mark.parametrize("window", [22, 16, 13, 4])
+@pytest.mark.parametrize("window", [24, 16, 13, 4])
 def test_fixed_base_vs_oracle(eng, curve, window):
     c = pyec.CURVES[curve]
     eng.set_base_window(c.cid, window)
@@ -124,7 +124,7 @@ def test_fixed_base_vs_oracle(eng, curve, window):
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
-    eng.set_base_window(c.cid, 24 if c.L == 32 else 20)        # back to the defaults
+    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20}[curve])        # back to the defaults
 
 
 @pytest.mark.parametrize("curve", CURVES)
