@@ -9,7 +9,7 @@
 //   "packed" field element   N u32 (8 / 8 / 12): the internal-domain value fully reduced to [0, p)
 //   projective scratch       [n][3] raw elements
 //   basepoint table          [nwin][2^(W-1)][2] packed elements, affine: entry (j, e) = e * 2^(W j) * G
-//                            (64 B per entry for the 256-bit curves: 436 MB at the default W = 20)
+//                            (64 B per entry for the 256-bit curves: 21.5 GB at k256's default W = 26)
 //   variable-base table      [wave][8][5 NL][64] u32 (ecgpu_var.h): multiples 1..8 of each lane's point in
 //                            Jacobian form + Z^2, Z^3; a wave's access to one limb is 256 contiguous bytes
 #pragma once
