@@ -37,11 +37,11 @@ struct ecgpu_ctx {
     std::string err;
     int* d_status = nullptr;
     int* h_status = nullptr;
-    Table table[3];
+    Table table[4];
     // fixed-base comb width: every addition removed is worth 8 % and HBM keeps up with the gathers, so the tables are
     // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
-    // p256: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
-    int want_w[3] = {26, 24, 20};
+    // p256 and sm2: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
+    int want_w[4] = {26, 24, 20, 24};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf;   // ECDSA verification scratch
@@ -80,6 +80,7 @@ int dispatch(int curve, F&& f) {
     case ECGPU_K256: return f(K256Params{});
     case ECGPU_P256: return f(P256Params{});
     case ECGPU_P384: return f(P384Params{});
+    case ECGPU_SM2: return f(Sm2Params{});
     default: return ECGPU_ERR_CURVE;
     }
 }
@@ -362,6 +363,7 @@ size_t ecgpu_field_bytes(int curve) {
     switch (curve) {
     case ECGPU_K256: case ECGPU_P256: return 32;
     case ECGPU_P384: return 48;
+    case ECGPU_SM2: return 32;
     default: return 0;
     }
 }
@@ -421,7 +423,7 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 }
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
-    if (!ctx || curve < 0 || curve > 2) return ECGPU_ERR_CURVE;
+    if (!ctx || curve < 0 || curve > 3) return ECGPU_ERR_CURVE;
     if (window_bits < 4 || window_bits > 26) return ECGPU_ERR_ARG;
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
@@ -533,6 +535,7 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     if (n && (!d_z || !d_r || !d_s || !d_q_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_q_xy)))
         return ECGPU_ERR_ARG;
+    if (curve == ECGPU_SM2) return ECGPU_ERR_CURVE;          // sm2 signatures are SM2DSA (sm2/src/dsa.rs), not ECDSA
     return dispatch(curve, [&](auto c) {
         return verify_dev<decltype(c)>(ctx, false, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
     });

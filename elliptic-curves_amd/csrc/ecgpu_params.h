@@ -17,7 +17,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -217,6 +217,35 @@ struct P384Params {
     ECGPU_CONST uint32_t GY[12] = {0x90EA0E5Fu, 0x7A431D7Cu, 0x1D7E819Du, 0x0A60B1CEu,
                                    0xB5F0B8C0u, 0xE9DA3113u, 0x289A147Cu, 0xF8F41DBDu,
                                    0x9292DC29u, 0x5D9E98BFu, 0x96262C6Fu, 0x3617DE4Au};
+};
+
+// SM2 (GB/T 32918.5): the fourth parameter set, SURVEY.md §8(f) rank 4.  Same code path as p256 (a = -3, p = -1 mod 2^64).
+struct Sm2Params {
+    ECGPU_CONST int ID = CURVE_SM2;
+    ECGPU_CONST int N = 8;
+    ECGPU_CONST int NL = 10;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::SM2U;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   sm2/src/arithmetic.rs:53-54
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^256 - 2^224 - 2^96 + 2^64 - 1          sm2/src/arithmetic/field.rs:34
+    ECGPU_CONST uint32_t P[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0x00000000u, 0xFFFFFFFFu,
+                                    0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu};
+    // n                                            sm2/src/lib.rs:86
+    ECGPU_CONST uint32_t ORDER[8] = {0x39D54123u, 0x53BBF409u, 0x21C6052Bu, 0x7203DF6Bu,
+                                    0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu};
+    // group order in Montgomery form (R = 2^256): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[8] = {0x7C114F20u, 0x901192AFu, 0xDE6FA2FAu, 0x3464504Au,
+                                    0x3AFFE0D4u, 0x620FC84Cu, 0xA22B3D3Bu, 0x1EB5E412u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x72350975u;
+    // curve b, canonical                           sm2/src/arithmetic.rs:57-59
+    ECGPU_CONST uint32_t B[8] = {0x4D940E93u, 0xDDBCBD41u, 0x15AB8F92u, 0xF39789F5u,
+                                    0xCF6509A7u, 0x4D5A9E4Bu, 0x9D9F5E34u, 0x28E9FA9Eu};
+    // generator, canonical                         sm2/src/arithmetic.rs:67-74
+    ECGPU_CONST uint32_t GX[8] = {0x334C74C7u, 0x715A4589u, 0xF2660BE1u, 0x8FE30BBFu,
+                                    0x6A39C994u, 0x5F990446u, 0x1F198119u, 0x32C4AE2Cu};
+    ECGPU_CONST uint32_t GY[8] = {0x2139F0A0u, 0x02DF32E5u, 0xC62A4740u, 0xD0A9877Cu,
+                                    0x6B692153u, 0x59BDCEE3u, 0xF4F6779Cu, 0xBC3736A2u};
 };
 
 }  // namespace ecgpu

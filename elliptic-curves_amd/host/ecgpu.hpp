@@ -288,5 +288,6 @@ struct Curve {
 using k256 = Curve<ECGPU_K256, 32>;
 using p256 = Curve<ECGPU_P256, 32>;
 using p384 = Curve<ECGPU_P384, 48>;
+using sm2 = Curve<ECGPU_SM2, 32>;
 
 }  // namespace ecgpu_host

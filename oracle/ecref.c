@@ -11,11 +11,12 @@ __attribute__((constructor)) static void ecref_init_all(void) {
     ecref_k256_init();
     ecref_p256_init();
     ecref_p384_init();
+    ecref_sm2_init();
 }
 
 size_t ecref_field_bytes(int curve) {
     switch (curve) {
-    case ECREF_K256: case ECREF_P256: return 32;
+    case ECREF_K256: case ECREF_P256: case ECREF_SM2: return 32;
     case ECREF_P384: return 48;
     default: return 0;
     }
@@ -89,66 +90,56 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     return (int)cursor;
 }
 
-#define DISPATCH(curve, call_k, call_p256, call_p384) \
+#define DISPATCH(curve, fn, args)                     \
     switch (curve) {                                  \
-    case ECREF_K256: return call_k;                   \
-    case ECREF_P256: return call_p256;                \
-    case ECREF_P384: return call_p384;                \
+    case ECREF_K256: return ecref_k256_##fn args;     \
+    case ECREF_P256: return ecref_p256_##fn args;     \
+    case ECREF_P384: return ecref_p384_##fn args;     \
+    case ECREF_SM2: return ecref_sm2_##fn args;       \
     default: return ECREF_ERR_CURVE;                  \
     }
 
 int ecref_batch_mul_base(int curve, const uint8_t *s, size_t n, uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_batch_mul_base(s, n, o, oi), ecref_p256_batch_mul_base(s, n, o, oi),
-             ecref_p384_batch_mul_base(s, n, o, oi))
+    DISPATCH(curve, batch_mul_base, (s, n, o, oi))
 }
 int ecref_batch_mul(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
                     uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_batch_mul(s, p, pi, n, 0, o, oi), ecref_p256_batch_mul(s, p, pi, n, 0, o, oi),
-             ecref_p384_batch_mul(s, p, pi, n, 0, o, oi))
+    DISPATCH(curve, batch_mul, (s, p, pi, n, 0, o, oi))
 }
 int ecref_batch_mul_vartime(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi,
                             size_t n, uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_batch_mul(s, p, pi, n, 1, o, oi), ecref_p256_batch_mul(s, p, pi, n, 1, o, oi),
-             ecref_p384_batch_mul(s, p, pi, n, 1, o, oi))
+    DISPATCH(curve, batch_mul, (s, p, pi, n, 1, o, oi))
 }
 int ecref_msm(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
               size_t chunk, int vartime, uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_msm(s, p, pi, n, chunk, vartime, o, oi),
-             ecref_p256_msm(s, p, pi, n, chunk, vartime, o, oi),
-             ecref_p384_msm(s, p, pi, n, chunk, vartime, o, oi))
+    DISPATCH(curve, msm, (s, p, pi, n, chunk, vartime, o, oi))
 }
 int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_t *b,
                                        const uint8_t *p, int pi, uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi),
-             ecref_p256_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi),
-             ecref_p384_mul_base_and_mul_add_vartime(a, b, p, pi, o, oi))
+    DISPATCH(curve, mul_base_and_mul_add_vartime, (a, b, p, pi, o, oi))
 }
 int ecref_batch_decompress(int curve, const uint8_t *xs, const uint8_t *odd, size_t n, uint8_t *o, uint8_t *ok) {
-    DISPATCH(curve, ecref_k256_batch_decompress(xs, odd, n, o, ok), ecref_p256_batch_decompress(xs, odd, n, o, ok),
-             ecref_p384_batch_decompress(xs, odd, n, o, ok))
+    DISPATCH(curve, batch_decompress, (xs, odd, n, o, ok))
 }
 int ecref_field_op(int curve, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
-    DISPATCH(curve, ecref_k256_field_op(op, a, b, out), ecref_p256_field_op(op, a, b, out),
-             ecref_p384_field_op(op, a, b, out))
+    DISPATCH(curve, field_op, (op, a, b, out))
 }
 int ecref_point_op(int curve, int op, const uint8_t *p, int pi, const uint8_t *q, int qi,
                    uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_point_op(op, p, pi, q, qi, o, oi), ecref_p256_point_op(op, p, pi, q, qi, o, oi),
-             ecref_p384_point_op(op, p, pi, q, qi, o, oi))
+    DISPATCH(curve, point_op, (op, p, pi, q, qi, o, oi))
 }
 int ecref_batch_normalize(int curve, const uint8_t *xyz, size_t n, uint8_t *o, uint8_t *oi) {
-    DISPATCH(curve, ecref_k256_batch_normalize(xyz, n, o, oi), ecref_p256_batch_normalize(xyz, n, o, oi),
-             ecref_p384_batch_normalize(xyz, n, o, oi))
+    DISPATCH(curve, batch_normalize, (xyz, n, o, oi))
 }
 int ecref_validate_points(int curve, const uint8_t *p, const uint8_t *pi, size_t n, size_t *bad) {
-    DISPATCH(curve, ecref_k256_validate_points(p, pi, n, bad), ecref_p256_validate_points(p, pi, n, bad),
-             ecref_p384_validate_points(p, pi, n, bad))
+    DISPATCH(curve, validate_points, (p, pi, n, bad))
 }
 int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
     switch (curve) {
     case ECREF_K256: ecref_k256_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P256: ecref_p256_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P384: ecref_p384_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_SM2: ecref_sm2_scalar_reduce(s, n); return ECREF_OK;
     default: return ECREF_ERR_CURVE;
     }
 }

@@ -106,5 +106,6 @@ static inline void ecref_mp_mul(uint64_t *r, const uint64_t *a, const uint64_t *
 ECREF_DECL_CURVE(k256)
 ECREF_DECL_CURVE(p256)
 ECREF_DECL_CURVE(p384)
+ECREF_DECL_CURVE(sm2)
 
 #endif

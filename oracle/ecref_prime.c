@@ -366,3 +366,111 @@ static int p384_fe_sqrt(fe384 *out, const fe384 *a) {
 #define PO_GX P384_GX
 #define PO_GY P384_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * SM2 field (generic Montgomery, crypto-bigint ConstMontyForm semantics: sm2/src/arithmetic/field.rs:30-60 ->
+ * primefield::MontyFieldElement, like p384) — SURVEY.md 8(f) rank 4
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe_sm2;
+
+static const uint64_t SM2_P[4] = {                      /* sm2/src/arithmetic/field.rs:34 */
+    0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFF00000000ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFEFFFFFFFFULL};
+static const uint64_t SM2_N[4] = {                      /* sm2/src/lib.rs:86 */
+    0x53BBF40939D54123ULL, 0x7203DF6B21C6052BULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFEFFFFFFFFULL};
+static const uint8_t SM2_B_BYTES[32] = {                /* sm2/src/arithmetic.rs:57-59 */
+    0x28, 0xe9, 0xfa, 0x9e, 0x9d, 0x9f, 0x5e, 0x34, 0x4d, 0x5a, 0x9e, 0x4b, 0xcf, 0x65, 0x09, 0xa7,
+    0xf3, 0x97, 0x89, 0xf5, 0x15, 0xab, 0x8f, 0x92, 0xdd, 0xbc, 0xbd, 0x41, 0x4d, 0x94, 0x0e, 0x93};
+static const uint8_t SM2_GX[32] = {                     /* sm2/src/arithmetic.rs:67-74 */
+    0x32, 0xc4, 0xae, 0x2c, 0x1f, 0x19, 0x81, 0x19, 0x5f, 0x99, 0x04, 0x46, 0x6a, 0x39, 0xc9, 0x94,
+    0x8f, 0xe3, 0x0b, 0xbf, 0xf2, 0x66, 0x0b, 0xe1, 0x71, 0x5a, 0x45, 0x89, 0x33, 0x4c, 0x74, 0xc7};
+static const uint8_t SM2_GY[32] = {
+    0xbc, 0x37, 0x36, 0xa2, 0xf4, 0xf6, 0x77, 0x9c, 0x59, 0xbd, 0xce, 0xe3, 0x6b, 0x69, 0x21, 0x53,
+    0xd0, 0xa9, 0x87, 0x7c, 0xc6, 0x2a, 0x47, 0x40, 0x02, 0xdf, 0x32, 0xe5, 0x21, 0x39, 0xf0, 0xa0};
+
+static fe_sm2 SM2_R, SM2_R2, SM2_B_MONT;
+static uint64_t SM2_MINV;
+static int sm2_ready;
+
+static fe_sm2 sm2_fe_mul(const fe_sm2 *a, const fe_sm2 *b) {       /* monty.rs:346-350 */
+    uint64_t t[8];
+    fe_sm2 r;
+    ecref_mp_mul(t, a->w, b->w, 4);
+    mont_reduce(r.w, t, SM2_P, SM2_MINV, 4);
+    return r;
+}
+static fe_sm2 sm2_fe_sqr(const fe_sm2 *a) { return sm2_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_sm2 sm2_fe_add(const fe_sm2 *a, const fe_sm2 *b) { fe_sm2 r; mont_add(r.w, a->w, b->w, SM2_P, 4); return r; }   /* :316-320 */
+static fe_sm2 sm2_fe_sub(const fe_sm2 *a, const fe_sm2 *b) { fe_sm2 r; mont_sub(r.w, a->w, b->w, SM2_P, 4); return r; }   /* :331-335 */
+static fe_sm2 sm2_fe_zero(void) { fe_sm2 z; memset(&z, 0, sizeof z); return z; }
+static fe_sm2 sm2_fe_neg(const fe_sm2 *a) { fe_sm2 z = sm2_fe_zero(); return sm2_fe_sub(&z, a); }                         /* :353-357 */
+static fe_sm2 sm2_fe_dbl(const fe_sm2 *a) { return sm2_fe_add(a, a); }                                                     /* :323-327 */
+static int sm2_fe_is_zero(const fe_sm2 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void sm2_init(void) {
+    if (sm2_ready) return;
+    SM2_MINV = mont_neg_inv64(SM2_P[0]);
+    mont_pow2_mod(SM2_R.w, SM2_P, 4, 256);
+    mont_pow2_mod(SM2_R2.w, SM2_P, 4, 512);
+    fe_sm2 b;
+    ecref_be_to_words(SM2_B_BYTES, 32, b.w);
+    SM2_B_MONT = sm2_fe_mul(&b, &SM2_R2);
+    sm2_ready = 1;
+}
+static fe_sm2 sm2_fe_one(void) { sm2_init(); return SM2_R; }
+static fe_sm2 sm2_fe_b(void) { sm2_init(); return SM2_B_MONT; }
+
+static int sm2_fe_from_bytes(fe_sm2 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    sm2_init();
+    fe_sm2 t;
+    ecref_be_to_words(b, 32, t.w);
+    if (ecref_mp_cmp(t.w, SM2_P, 4) >= 0) return 0;
+    *r = sm2_fe_mul(&t, &SM2_R2);
+    return 1;
+}
+static void sm2_fe_to_bytes(uint8_t *out, const fe_sm2 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[8];
+    fe_sm2 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 32);
+    mont_reduce(c.w, t, SM2_P, SM2_MINV, 4);
+    ecref_words_to_be(c.w, 4, out);
+}
+static int sm2_fe_invert(fe_sm2 *out, const fe_sm2 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (sm2_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, SM2_P, two, 4);
+    fe_sm2 r = sm2_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = sm2_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = sm2_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int sm2_fe_sqrt(fe_sm2 *out, const fe_sm2 *a) {
+    uint64_t e[4], one[4] = {1, 0, 0, 0};
+    ecref_mp_add(e, SM2_P, one, 4);                         /* p + 1 < 2^256 */
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i + 1 < 4 ? e[i + 1] << 62 : 0);
+    fe_sm2 r = sm2_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = sm2_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = sm2_fe_mul(&r, a);
+    }
+    fe_sm2 sq = sm2_fe_sqr(&r);
+    fe_sm2 d = sm2_fe_sub(&sq, a);
+    *out = r;
+    return sm2_fe_is_zero(&d);
+}
+
+#define PO_PFX sm2
+#define PO_NL 4
+#define PO_FE fe_sm2
+#define PO_F(name) sm2_fe_##name
+#define PO_ORDER SM2_N
+#define PO_GX SM2_GX
+#define PO_GY SM2_GY
+#include "ecref_prime.inc"

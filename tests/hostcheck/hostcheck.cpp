@@ -455,49 +455,42 @@ int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
     return inf;
 }
 
-#define DISPATCH(curve, expr_k, expr_p256, expr_p384) \
-    switch (curve) { case 0: return expr_k; case 1: return expr_p256; case 2: return expr_p384; default: return -1; }
+#define DISPATCH(curve, fn, args)                                                                                   \
+    switch (curve) { case 0: return fn<K256Params> args; case 1: return fn<P256Params> args; case 2: return fn<P384Params> args; \
+                     case 3: return fn<Sm2Params> args; default: return -1; }
 
 }  // namespace
 
 extern "C" {
 
 int hc_field_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    DISPATCH(curve, field_op<K256Params>(op, a, b, out), field_op<P256Params>(op, a, b, out),
-             field_op<P384Params>(op, a, b, out))
+    DISPATCH(curve, field_op, (op, a, b, out))
 }
 int hc_scalar_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
-    DISPATCH(curve, scalar_op<K256Params>(op, a, b, out), scalar_op<P256Params>(op, a, b, out),
-             scalar_op<P384Params>(op, a, b, out))
+    DISPATCH(curve, scalar_op, (op, a, b, out))
 }
 int hc_field_chain(int curve, const uint8_t* a, const uint8_t* b, int steps, uint8_t* out) {
-    DISPATCH(curve, field_chain<K256Params>(a, b, steps, out), field_chain<P256Params>(a, b, steps, out),
-             field_chain<P384Params>(a, b, steps, out))
+    DISPATCH(curve, field_chain, (a, b, steps, out))
 }
 int hc_point_op(int curve, int op, const uint8_t* p, int pi, const uint8_t* q, int qi, uint8_t* out, uint8_t* oi) {
-    DISPATCH(curve, point_op<K256Params>(op, p, pi, q, qi, out, oi), point_op<P256Params>(op, p, pi, q, qi, out, oi),
-             point_op<P384Params>(op, p, pi, q, qi, out, oi))
+    DISPATCH(curve, point_op, (op, p, pi, q, qi, out, oi))
 }
 int hc_on_curve(int curve, const uint8_t* xy) {
-    DISPATCH(curve, on_curve<K256Params>(xy), on_curve<P256Params>(xy), on_curve<P384Params>(xy))
+    DISPATCH(curve, on_curve, (xy))
 }
 int hc_batch_mul_base(int curve, int w, const uint8_t* s, size_t n, size_t nthreads, uint8_t* o, uint8_t* oi) {
-    DISPATCH(curve, batch_mul_base<K256Params>(w, s, n, nthreads, o, oi), batch_mul_base<P256Params>(w, s, n, nthreads, o, oi),
-             batch_mul_base<P384Params>(w, s, n, nthreads, o, oi))
+    DISPATCH(curve, batch_mul_base, (w, s, n, nthreads, o, oi))
 }
 int hc_batch_mul(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, size_t nthreads, uint8_t* o,
                  uint8_t* oi) {
-    DISPATCH(curve, batch_mul<K256Params>(s, p, pi, n, nthreads, o, oi), batch_mul<P256Params>(s, p, pi, n, nthreads, o, oi),
-             batch_mul<P384Params>(s, p, pi, n, nthreads, o, oi))
+    DISPATCH(curve, batch_mul, (s, p, pi, n, nthreads, o, oi))
 }
 int hc_msm(int curve, int c, size_t chunk, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o,
            uint8_t* oi) {
-    DISPATCH(curve, msm<K256Params>(c, chunk, s, p, pi, n, o, oi), msm<P256Params>(c, chunk, s, p, pi, n, o, oi),
-             msm<P384Params>(c, chunk, s, p, pi, n, o, oi))
+    DISPATCH(curve, msm, (c, chunk, s, p, pi, n, o, oi))
 }
 int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {
-    DISPATCH(curve, table_rule_check<K256Params>(w, j, e, out_xy), table_rule_check<P256Params>(w, j, e, out_xy),
-             table_rule_check<P384Params>(w, j, e, out_xy))
+    DISPATCH(curve, table_rule_check, (w, j, e, out_xy))
 }
 // Radix16Msb digits of a big-endian scalar (nl limbs), ndigits = 8*nl + 1, least significant first
 int hc_radix16(const uint8_t* be, int nl, int8_t* digits) {

@@ -45,7 +45,15 @@ P384 = Curve(
     0xAA87CA22BE8B05378EB1C71EF320AD746E1D3B628BA79B9859F741E082542A385502F25DBF55296C3A545E3872760AB7,
     0x3617DE4A96262C6F5D9E98BF9292DC29F8F41DBD289A147CE9DA3113B5F0B8C00A60B1CE1D7E819D7A431D7C90EA0E5F,
 )
-CURVES = {"k256": K256, "p256": P256, "p384": P384}
+SM2 = Curve(                                                   # sm2/src/arithmetic.rs:53-74, field.rs:34, lib.rs:86
+    "sm2", 3, 32,
+    0xFFFFFFFEFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF00000000FFFFFFFFFFFFFFFF,
+    0xFFFFFFFEFFFFFFFFFFFFFFFFFFFFFFFF7203DF6B21C6052B53BBF40939D54123,
+    -3, 0x28E9FA9E9D9F5E344D5A9E4BCF6509A7F39789F515AB8F92DDBCBD414D940E93,
+    0x32C4AE2C1F1981195F9904466A39C9948FE30BBFF2660BE1715A4589334C74C7,
+    0xBC3736A2F4F6779C59BDCEE36B692153D0A9877CC62A474002DF32E52139F0A0,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2}
 
 # secp256k1 endomorphism constants (k256/src/arithmetic/mul.rs:4-5, projective.rs:31-37)
 K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72

@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 import pyec
-from gpu_common import (CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, schnorr_inputs, edge_scalars, ladder_edge_scalars, load_golden,
+from gpu_common import (ALL_CURVES, CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, schnorr_inputs, edge_scalars, ladder_edge_scalars, load_golden,
                         rand_scalars, scalars_to_int_sum)
 
 pytestmark = pytest.mark.gpu
@@ -52,7 +52,7 @@ def test_golden_group_vectors(eng, curve):
         assert bytes(o) == want[2 * c.L * i: 2 * c.L * (i + 1)] and f == 0
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_var_base_ladder_corner_cases(eng, oracle, curve):
     """Scalars that put the incomplete Jacobian ladder at its limits (ecgpu_varmul.h): accumulator equal to
     +-(table operand) at the last digit, late start, digit -8 runs, carry into the top digit."""
@@ -111,7 +111,7 @@ def test_golden_ecdsa_vectors(eng, curve):
 # oracle parity on seeded inputs
 # ---------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 @pytest.mark.parametrize("window", [24, 16, 13, 4])
 def test_fixed_base_vs_oracle(eng, curve, window):
     c = pyec.CURVES[curve]
@@ -124,10 +124,10 @@ def test_fixed_base_vs_oracle(eng, curve, window):
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
-    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20}[curve])        # back to the defaults
+    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24}[curve])        # back to the defaults
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_variable_base_vs_oracle(eng, curve):
     c = pyec.CURVES[curve]
     n = 600
@@ -157,7 +157,7 @@ def test_variable_base_vs_oracle(eng, curve):
     assert bytes(out3) == bytes(want[slot * 2 * c.L:])
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 257, 4000])
 def test_msm_vs_oracle(eng, curve, n):
     c = pyec.CURVES[curve]
@@ -189,7 +189,7 @@ def test_msm_vs_oracle(eng, curve, n):
         assert bytes(want_ct) == bytes(want) and wf == winf
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
     """The accumulation lanes own fixed-size chunks of the sorted run, not buckets.  Sweep the chunk size (1 entry
     per lane .. everything in one lane) against the oracle, then feed scalar sets that put every term of a window
@@ -222,7 +222,7 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
         assert dt < 5.0, "skewed MSM took %.1f s: one lane is walking a whole bucket" % dt
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_msm_cancels_to_identity(eng, curve):
     c = pyec.CURVES[curve]
     n = 64
@@ -233,7 +233,7 @@ def test_msm_cancels_to_identity(eng, curve):
     assert f == 1 and not o.any()
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_batch_normalize_and_point_sum_vs_oracle(eng, curve):
     c = pyec.CURVES[curve]
     rng = np.random.default_rng(5 + c.cid)
@@ -269,7 +269,7 @@ def test_k256_glv_decompose_vs_oracle(eng):
         assert bytes(r1[32 * i: 32 * i + 32]) == w1 and bytes(r2[32 * i: 32 * i + 32]) == w2
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_error_behaviour(eng, curve):
     """Decoding errors mirror the reference: scalar >= n and off-curve / out-of-range points are refused."""
     ecgpu = ecgpu_module()
@@ -497,7 +497,7 @@ def test_schnorr_bip340_vectors(eng):
     assert one.size == 64
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_decompress_vs_oracle(eng, curve):
     """DecompressPoint::decompress on a batch: residues and non-residues, both parities, x >= p, the generator; then
     compress(k*G) -> decompress round trip over 4096 random points."""
@@ -520,7 +520,7 @@ def test_decompress_vs_oracle(eng, curve):
     assert ok.all() and bytes(back) == bytes(pts)
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_ecdh_vs_node_openssl_and_oracle(eng, curve):
     """Batch ECDH (x of k*P) against shared secrets computed by Node's crypto / OpenSSL (tests/golden/ecdh_node.json, an
     implementation independent of the reference and of this repository) and against the oracle's variable-base path."""
@@ -533,6 +533,8 @@ def test_ecdh_vs_node_openssl_and_oracle(eng, curve):
     p = b"".join(bytes.fromhex(r["qx"]) + bytes.fromhex(r["qy"]) for r in rows)
     x, ok = eng.ecdh(c.cid, k, p)
     assert ok.all() and bytes(x) == b"".join(bytes.fromhex(r["z"]) for r in rows)
+    pub, pinf = eng.mul_by_generator(c.cid, k)                      # OpenSSL's d * G
+    assert not pinf.any() and bytes(pub) == b"".join(bytes.fromhex(r["px"]) + bytes.fromhex(r["py"]) for r in rows)
     n = 500
     pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xECD0 + c.cid))
     ks = rand_scalars(c.cid, n, 0xECD1 + c.cid).copy()

@@ -11,7 +11,8 @@ import pytest
 import pyec
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CURVES = ["k256", "p256", "p384"]
+CURVES = ["k256", "p256", "p384"]          # curves with reference KATs (tests/golden/<curve>.json)
+ALL_CURVES = CURVES + ["sm2"]               # + the SURVEY 8(f) rank-4 parameter set: big-int model and OpenSSL only
 
 
 def load(curve):
@@ -130,7 +131,7 @@ def test_schnorr_bip340_vectors(oracle):
     assert list(got) == list(exp)
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_decompress_vs_model(oracle, curve):
     """DecompressPoint::decompress: generator round trip (p256/tests/affine.rs:12-28 compressed basepoint), random x
     with and without a root, both parities, x >= p."""
@@ -159,7 +160,7 @@ def test_decompress_vs_model(oracle, curve):
     assert bytes(out[: 2 * c.L]) == pyec.enc_point(c, g if g[1] % 2 == 0 else pyec.neg(c, g))[0]
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_variable_base_vs_node_openssl_ecdh(oracle, curve):
     """The oracle's `P * k` against ECDH shared secrets from Node's crypto / OpenSSL (tests/golden/ecdh_node.json,
     generated by tests/golden/gen_ecdh_node.js): the third opinion SURVEY.md §8c asks for where the reference has no
@@ -168,6 +169,8 @@ def test_variable_base_vs_node_openssl_ecdh(oracle, curve):
     rows = json.load(open(os.path.join(GOLDEN, "ecdh_node.json")))[curve]
     k = b"".join(bytes.fromhex(r["d"]) for r in rows)
     p = b"".join(bytes.fromhex(r["qx"]) + bytes.fromhex(r["qy"]) for r in rows)
+    pub, pinf = oracle.batch_mul_base(c.cid, k)                      # OpenSSL's d * G
+    assert not pinf.any() and bytes(pub) == b"".join(bytes.fromhex(r["px"]) + bytes.fromhex(r["py"]) for r in rows)
     for vt in (False, True):
         out, inf = oracle.batch_mul(c.cid, k, p, vartime=vt)
         got = np.asarray(out).reshape(len(rows), 2 * c.L)[:, : c.L]
@@ -185,7 +188,7 @@ def test_field_doubling_vectors(oracle, curve):
         cur = oracle.field_op(c.cid, 0, cur, cur)
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_field_ops_vs_bigint(oracle, curve):
     """k256 field.rs:586-597 style differential against integers mod p."""
     c = pyec.CURVES[curve]
@@ -271,7 +274,7 @@ def _rand_points(c, rng, n):
     return pts
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_variable_base_vs_bigint(oracle, curve):
     """No reference KAT exists for P != G (SURVEY.md §8c 'Gaps'): differential of both variable-base
     drivers against the independent affine model, including the edge scalars/points of §8d."""
@@ -296,7 +299,7 @@ def test_variable_base_vs_bigint(oracle, curve):
             assert got == pyec.mul(c, k, P), (curve, vt, i)
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_lincomb_vs_bigint_and_identities(oracle, curve):
     """k256/tests/projective.rs:75-140, p256/tests/projective.rs:83-148: lincomb == sum of
     products, lincomb_vartime == lincomb, chunking does not matter; n == 0 gives the identity."""
@@ -327,7 +330,7 @@ def test_lincomb_vs_bigint_and_identities(oracle, curve):
         assert pyec.dec_point(c, bytes(out), inf) == pyec.msm(c, [ks[i] for i in sub], [pts[i] for i in sub])
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_mul_by_generator_matches_variable_base(oracle, curve):
     """p256/src/arithmetic/tables.rs:64-80, k256/tests/projective.rs mul_by_generator == G * s,
     scalars drawn like the reference generators (32/48 random bytes -> Scalar::reduce)."""
@@ -348,7 +351,7 @@ def test_mul_by_generator_matches_variable_base(oracle, curve):
     assert pyec.dec_point(c, bytes(a[: 2 * c.L]), ai[0]) == pyec.mul(c, k0, pyec.G(c))
 
 
-@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_batch_normalize_and_validation(oracle, curve):
     """k256/tests/projective.rs batch_normalize == to_affine; identity handling; decode errors."""
     c = pyec.CURVES[curve]

@@ -316,6 +316,16 @@ def selftest(trials=300, seed=1):
         assert r == umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
         assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
         assert from_limbs(r, Q_B) < 2 * Q_P
+    # sm2 (dense rows, product limit 24) through the generic routine
+    s_p = 2 ** 256 - 2 ** 224 - 2 ** 96 + 2 ** 64 - 1
+    s_limbs = to_limbs(s_p, 10, 28)
+    sinv = pow(P_R, -1, s_p)
+    for ma, mb in ((15, 1), (4, 6), (3, 8), (12, 2), (1, 1)):
+        a = [ma * P_LB - 1] * 9 + [32 * ma - 1]
+        b = [mb * P_LB - 1] * 9 + [32 * mb - 1]
+        r = umont_mul(a, b, 10, 28, s_limbs)
+        assert from_limbs(r, 28) % s_p == from_limbs(a, 28) * from_limbs(b, 28) * sinv % s_p
+        assert from_limbs(r, 28) < 2 * s_p and all(x < (1 << 28) for x in r[:9]) and r[9] < 32
     # the generic routine agrees with the p256-specific model
     for _ in range(20):
         a = [rng.randrange(P_LB) for _ in range(9)] + [rng.randrange(32)]
