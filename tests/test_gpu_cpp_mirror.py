@@ -30,3 +30,20 @@ def test_cpp_mirror_proptests(tmp_path):
                          env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all ok" in out.stdout
+
+
+def test_c_example_builds():
+    """CPU: the plain-C client of the ABI (examples/) compiles and links."""
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    assert os.path.exists(os.path.join(ex, "batch_pubkeys"))
+
+
+@pytest.mark.gpu
+def test_c_example_runs():
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    out = subprocess.run([os.path.join(ex, "batch_pubkeys")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798" in out.stdout      # x(G)
+    assert "shared(1,7) == shared(7,1): yes" in out.stdout
