@@ -46,6 +46,9 @@ WORKLOADS = {
                      imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
     "var_k256": dict(curve="k256", kind="var", n=1 << 20, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=1984 * 136, bytes_per_unit=160, kernel="k_var_base<K256Params>", scaling="weak"),
+    "msm_p256": dict(curve="p256", kind="msm", n=1 << 24, metric="p256 MSM terms/sec", unit="terms/s",
+                     imad_per_unit=int(16.06 * 11 * 136), bytes_per_unit=96 + 16 * 64, kernel="k_msm_accumulate<P256Params>",
+                     scaling="strong"),
     # batch ECDSA verification: u1 G + u2 Q per signature = fixed-base + variable-base + 1 addition
     "ecdsa_p256": dict(curve="p256", kind="ecdsa", n=1 << 20, metric="p256 ECDSA verifications/sec", unit="verifications/s",
                        imad_per_unit=(962 + 4336 + 14) * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
@@ -178,7 +181,7 @@ def main():
             eng.set_base_window(cid, args.window)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
-    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7}[args.workload] + 1000 * rank
+    seed = 0xEC000000 + {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8}[args.workload] + 1000 * rank
     d_scal = device_random_scalars(torch, n, L, seed, device)
     d_pts = d_out = None
     if kind in ("var", "msm"):
