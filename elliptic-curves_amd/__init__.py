@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
     "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
     "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
+    "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev",
 ]
 
 
@@ -219,6 +220,19 @@ class Engine:
     def ecdh_dev(self, curve, d_scalars, d_points_xy, n, d_out_x, d_ok):
         self._chk(self._lib.ecgpu_batch_ecdh_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), ctypes.c_size_t(n),
                                                  _dp(d_out_x), _dp(d_ok)))
+
+    def schnorr_verify_raw(self, pk_x, msgs, msg_len, sigs):
+        """BIP340 verification from wire bytes: x-only keys (n*32), messages (n*msg_len), signatures (n*64)."""
+        pk, mm, sg = _host(pk_x), _host(msgs), _host(sigs)
+        n = pk.size // 32
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_schnorr_verify_raw_batch(self._ctx, _hp(pk), _hp(mm) if msg_len else None,
+                                                           ctypes.c_size_t(msg_len), _hp(sg), ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
+    def schnorr_verify_raw_dev(self, d_pk_x, d_msgs, msg_len, d_sigs, n, d_ok):
+        self._chk(self._lib.ecgpu_schnorr_verify_raw_batch_dev(self._ctx, _dp(d_pk_x), _dp(d_msgs) if msg_len else None,
+                                                               ctypes.c_size_t(msg_len), _dp(d_sigs), ctypes.c_size_t(n), _dp(d_ok)))
 
     def decompress(self, curve, xs, y_is_odd):
         """DecompressPoint::decompress for a batch: returns (xy uint8[n*2L], ok uint8[n])."""

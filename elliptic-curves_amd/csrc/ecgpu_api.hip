@@ -44,7 +44,7 @@ struct ecgpu_ctx {
     int want_w[4] = {26, 24, 20, 24};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
-    DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf;   // ECDSA verification scratch
+    DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r;   // signature verification scratch
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
 };
@@ -306,9 +306,12 @@ bool check_ctx(ecgpu_ctx* ctx) {
 
 namespace {
 // shared driver of the two verification shapes: prepare -> a*G + b*Q -> normalise -> compare
+enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2 };
+// mode VERIFY_SCHNORR_RAW: d_h = messages (msg_len bytes each), d_s = 64-byte signatures, d_q_xy = 32-byte x-only keys
 template <class C>
-int verify_dev(ecgpu_ctx* ctx, bool schnorr, const void* d_h, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
-               int reject_high_s, void* d_ok) {
+int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
+               int reject_high_s, void* d_ok, size_t msg_len = 0) {
+    const bool schnorr = mode != VERIFY_ECDSA;
     constexpr int NS = Field<C>::NS;
     const size_t L = 4 * C::N;
     int rc;
@@ -323,6 +326,7 @@ int verify_dev(ecgpu_ctx* ctx, bool schnorr, const void* d_h, const void* d_r, c
     if ((rc = ensure(ctx, ctx->ec_valid, n + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
+    if (mode == VERIFY_SCHNORR_RAW && (rc = ensure(ctx, ctx->ec_r, n * L)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     const Table& t = ctx->table[C::ID];
     uint32_t* pa = (uint32_t*)ctx->proj.p;
@@ -330,7 +334,11 @@ int verify_dev(ecgpu_ctx* ctx, bool schnorr, const void* d_h, const void* d_r, c
     uint8_t *u1 = (uint8_t*)ctx->ec_u1.p, *u2 = (uint8_t*)ctx->ec_u2.p, *q = (uint8_t*)ctx->ec_q.p;
     uint8_t* valid = (uint8_t*)ctx->ec_valid.p;
     record(ctx, 0);
-    if (schnorr)
+    if (mode == VERIFY_SCHNORR_RAW) {
+        launch_schnorr_prepare_raw(ctx->stream, (const uint8_t*)d_q_xy, (const uint8_t*)d_h, msg_len, (const uint8_t*)d_s, n, u1,
+                                   u2, q, (uint8_t*)ctx->ec_r.p, valid);
+        d_r = ctx->ec_r.p;
+    } else if (schnorr)
         launch_schnorr_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
                                   (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else
@@ -402,7 +410,7 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3,
                       &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
-                      &ctx->ec_inf})
+                      &ctx->ec_inf, &ctx->ec_r})
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->table)
         if (t.d) (void)hipFree(t.d);
@@ -537,7 +545,7 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
         return ECGPU_ERR_ARG;
     if (curve == ECGPU_SM2) return ECGPU_ERR_CURVE;          // sm2 signatures are SM2DSA (sm2/src/dsa.rs), not ECDSA
     return dispatch(curve, [&](auto c) {
-        return verify_dev<decltype(c)>(ctx, false, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
+        return verify_dev<decltype(c)>(ctx, VERIFY_ECDSA, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
     });
 }
 
@@ -548,7 +556,15 @@ int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* 
     if (n && (!d_e || !d_r || !d_s || !d_p_xy || !d_ok || !aligned16(d_e) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_p_xy)))
         return ECGPU_ERR_ARG;
-    return verify_dev<K256Params>(ctx, true, d_e, d_r, d_s, d_p_xy, n, 0, d_ok);
+    return verify_dev<K256Params>(ctx, VERIFY_SCHNORR, d_e, d_r, d_s, d_p_xy, n, 0, d_ok);
+}
+
+int ecgpu_schnorr_verify_raw_batch_dev(ecgpu_ctx* ctx, const void* d_pk_x, const void* d_msgs, size_t msg_len, const void* d_sigs,
+                                       size_t n, void* d_ok) {
+    // VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig) from wire bytes: lift_x, challenge hash, s G - e P.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_pk_x || !d_sigs || !d_ok || (msg_len && !d_msgs) || !aligned16(d_pk_x) || !aligned16(d_sigs))) return ECGPU_ERR_ARG;
+    return verify_dev<K256Params>(ctx, VERIFY_SCHNORR_RAW, d_msgs, nullptr, d_sigs, d_pk_x, n, 0, d_ok, msg_len);
 }
 
 int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x,
@@ -699,6 +715,20 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
     if ((rc = upload(ctx, ctx->in1, p_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
     if ((rc = ecgpu_schnorr_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
+                                   size_t n, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return ECGPU_ERR_ARG;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, pk_x, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, msgs, n * msg_len)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, sigs, n * 64)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_schnorr_verify_raw_batch_dev(ctx, ctx->in0.p, ctx->in1.p, msg_len, ctx->in3.p, n, ctx->out1.p)) != ECGPU_OK)
         return rc;
     return download(ctx, ok, ctx->out1, n);
 }

@@ -13,6 +13,7 @@
 
 #include "ecgpu_kernels.h"
 #include "ecgpu_scalar.h"
+#include "ecgpu_sha256.h"
 
 namespace ecgpu {
 
@@ -133,6 +134,65 @@ k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, 
     store_be_vec<N>(b_out + i * (4 * N), ne);
     store_be_vec<N>(q_out + i * (8 * N), cx);
     store_be_vec<N>(q_out + i * (8 * N) + 4 * N, cy);
+    valid[i] = ok ? 1 : 0;
+}
+
+// The whole of `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` (k256/src/schnorr/verifying.rs:76-99,149-160) from
+// wire bytes: lift_x of the 32-byte key (even y; fails for x >= p or a non-residue), signature parsing, the challenge
+// hash e = tagged_hash("BIP0340/challenge", r || pk || msg) on the device, then the same a = s, b = -e as above.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_schnorr_prepare_raw(const uint8_t* __restrict__ pk_x, const uint8_t* __restrict__ msgs, size_t msg_len,
+                      const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out,
+                      uint8_t* __restrict__ q_out, uint8_t* __restrict__ r_out, uint8_t* __restrict__ valid) {
+    using S = ScalarN<C>;
+    using F = Field<C>;
+    using G = Group<C>;
+    constexpr int N = C::N;
+    static_assert(N == 8 && C::A_IS_ZERO, "BIP340 is defined over secp256k1");
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[N], sw[N], cx[N], cy[N];
+    load_be_vec<N>(cx, pk_x + i * 32);
+    load_be_vec<N>(rw, sigs + i * 64);
+    load_be_vec<N>(sw, sigs + i * 64 + 32);
+    bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw) && !mp_geq<N>(cx, C::P);
+    {   // lift_x: y = sqrt(x^3 + 7), the even root
+        auto x = F::from_canonical(cx);
+        auto alpha = F::norm(F::add(F::mul(F::sqr(x), x), G::m(G::curve_b())));
+        bool root;
+        auto beta = F::sqrt(alpha, &root);
+        ok = ok && root;
+        F::to_canonical(cy, beta);
+        if (cy[0] & 1u) {
+            uint32_t d[N];
+            mp_sub<N>(d, C::P, cy);
+#pragma unroll
+            for (int j = 0; j < N; j++) cy[j] = d[j];
+        }
+    }
+    uint32_t ew[N], er[N], ne[N];
+    Sha256::bip340_challenge(ew, sigs + i * 64, pk_x + i * 32, msgs + i * msg_len, msg_len);
+    S::reduce_once(er, ew);
+    {
+        uint32_t d[N];
+        bool z = S::is_zero(er);
+        mp_sub<N>(d, C::ORDER, er);
+#pragma unroll
+        for (int j = 0; j < N; j++) ne[j] = z ? 0u : d[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        sw[j] = ok ? sw[j] : 0u;
+        ne[j] = ok ? ne[j] : 0u;
+        cx[j] = ok ? cx[j] : C::GX[j];
+        cy[j] = ok ? cy[j] : C::GY[j];
+    }
+    store_be_vec<N>(a_out + i * 32, sw);
+    store_be_vec<N>(b_out + i * 32, ne);
+    store_be_vec<N>(q_out + i * 64, cx);
+    store_be_vec<N>(q_out + i * 64 + 32, cy);
+    store_be_vec<N>(r_out + i * 32, rw);
     valid[i] = ok ? 1 : 0;
 }
 

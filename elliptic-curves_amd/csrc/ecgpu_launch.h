@@ -59,6 +59,8 @@ template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_
                                    hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
 
 // ---- curve-independent ----
+void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
+                                size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* r_out, uint8_t* valid);
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status);
 void launch_valu_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
 void launch_isa_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);

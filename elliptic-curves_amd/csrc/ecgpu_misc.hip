@@ -1,6 +1,7 @@
 // ecgpu_misc.hip — curve-independent kernels: k256 GLV split (parity probe) and VALU roof probes.
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_ecdsa.h"
 
 namespace ecgpu {
 
@@ -184,6 +185,12 @@ __global__ void __launch_bounds__(BLOCK) k_gather_probe(const uint32_t* __restri
 }
 void launch_gather_probe(hipStream_t s, const uint32_t* table, size_t entries, int per_lane, uint32_t* out, int blocks) {
     hipLaunchKernelGGL(k_gather_probe, dim3(blocks), dim3(BLOCK), 0, s, table, entries, per_lane, out);
+}
+
+void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
+                                size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* r_out, uint8_t* valid) {
+    hipLaunchKernelGGL(k_schnorr_prepare_raw<K256Params>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, pk_x, msgs,
+                       msg_len, sigs, n, a, b, q_out, r_out, valid);
 }
 
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status) {

@@ -54,6 +54,9 @@ unsafe extern "C" {
     /// Batch form of `schnorr::VerifyingKey::verify_raw` (k256); `e` is the BIP340 challenge hash.
     pub fn ecgpu_schnorr_verify_batch(ctx: *mut EcgpuCtx, e: *const u8, r: *const u8, s: *const u8, p_xy: *const u8,
                                       n: usize, ok: *mut u8) -> c_int;
+    /// `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` for a batch of equally long messages.
+    pub fn ecgpu_schnorr_verify_raw_batch(ctx: *mut EcgpuCtx, pk_x: *const u8, msgs: *const u8, msg_len: usize,
+                                          sigs: *const u8, n: usize, ok: *mut u8) -> c_int;
     /// Batch form of `elliptic_curve::ecdh::diffie_hellman`: x-coordinates of k_i * P_i.
     pub fn ecgpu_batch_ecdh(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8, n: usize,
                             out_x: *mut u8, ok: *mut u8) -> c_int;

@@ -189,6 +189,16 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s,
                                    const void *d_p_xy, size_t n, void *d_ok);
 
+/* The same verification from wire bytes — `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)`
+ * (k256/src/schnorr/verifying.rs:76-99,149-160): pk_x n*32 bytes (x-only keys, lifted on the device with even y),
+ * msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*64 bytes (r || s).  The challenge
+ * e = tagged_hash("BIP0340/challenge", r || pk || msg) is computed on the device (SHA-256).  ok[i] = 0 for keys that do
+ * not lift, out-of-range signature halves, and signatures that do not verify. */
+int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx *ctx, const uint8_t *pk_x, const uint8_t *msgs, size_t msg_len,
+                                   const uint8_t *sigs, size_t n, uint8_t *ok);
+int ecgpu_schnorr_verify_raw_batch_dev(ecgpu_ctx *ctx, const void *d_pk_x, const void *d_msgs,
+                                       size_t msg_len, const void *d_sigs, size_t n, void *d_ok);
+
 /* Batch ECDH — `elliptic_curve::ecdh::diffie_hellman(secret, public)` (elliptic-curve 0.14.1, un-vendored; the
  * curves re-export it: k256/src/ecdh.rs, p256/src/ecdh.rs, p384/src/ecdh.rs): out_x[i] = the x-coordinate of
  * k_i * P_i as L big-endian bytes (`SharedSecret::raw_secret_bytes`), ok[i] = 1 unless the product is the identity

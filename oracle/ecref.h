@@ -93,6 +93,11 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
 int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *p_xy,
                                size_t n, uint8_t *ok);
 
+/* The same from wire bytes: x-only keys (lifted with even y), messages of one length, 64-byte signatures; the challenge
+ * hash is computed here (SHA-256).  See ecref_ecdsa.c. */
+int ecref_schnorr_verify_raw_batch(const uint8_t *pk_x, const uint8_t *msgs, size_t msg_len,
+                                   const uint8_t *sigs, size_t n, uint8_t *ok);
+
 /* out[i] = (x_i, y_i) with y_i the square root of x^3 + a x + b of the requested parity —
  * `DecompressPoint::decompress(x_bytes, y_is_odd)` (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280).
  * xs n*L bytes big-endian, y_is_odd n bytes; ok[i] = 0 and a zero record when x >= p or no root exists. */

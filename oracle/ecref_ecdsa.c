@@ -17,6 +17,7 @@
  *
  * Scalar arithmetic mod n: Montgomery multiplication on 64-bit words, inversion as a^(n-2).  (The reference inverts
  * with safegcd; the value is the same.) */
+#include <stdlib.h>
 #include <string.h>
 
 #include "ecref.h"
@@ -204,5 +205,72 @@ int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t
         if (inf || (xy[63] & 1)) continue;
         ok[i] = memcmp(xy, r + 32 * i, 32) == 0;
     }
+    return ECREF_OK;
+}
+
+/* ---- SHA-256 (FIPS 180-4) and the BIP340 tagged hash: k256/src/schnorr.rs `tagged_hash` = SHA256(SHA256(tag) ||
+ * SHA256(tag) || ...), used by verify_raw (verifying.rs:79-85) with tag "BIP0340/challenge" ---------------------------- */
+static const uint32_t SHA_K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+static uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+static void sha256_block(uint32_t h[8], const uint8_t b[64]) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = ((uint32_t)b[4 * i] << 24) | ((uint32_t)b[4 * i + 1] << 16) | ((uint32_t)b[4 * i + 2] << 8) | b[4 * i + 3];
+    for (int i = 16; i < 64; i++)
+        w[i] = w[i - 16] + (ror32(w[i - 15], 7) ^ ror32(w[i - 15], 18) ^ (w[i - 15] >> 3)) + w[i - 7] +
+               (ror32(w[i - 2], 17) ^ ror32(w[i - 2], 19) ^ (w[i - 2] >> 10));
+    uint32_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+        uint32_t t1 = hh + (ror32(e, 6) ^ ror32(e, 11) ^ ror32(e, 25)) + ((e & f) ^ (~e & g)) + SHA_K[i] + w[i];
+        uint32_t t2 = (ror32(a, 2) ^ ror32(a, 13) ^ ror32(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+static void sha256(uint8_t out[32], const uint8_t *msg, size_t len) {
+    uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    size_t full = len / 64;
+    for (size_t i = 0; i < full; i++) sha256_block(h, msg + 64 * i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - 64 * full;
+    memcpy(tail, msg + 64 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_block(h, tail);
+    if (tl == 128) sha256_block(h, tail + 64);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+
+/* `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` for a batch of equally long messages — verifying.rs:76-99 (verify_raw),
+ * :149-160 (from_bytes: lift_x through `AffinePoint::decompact` = decompress with even y), schnorr.rs:132-150 (signature
+ * parsing).  pk_x n*32, msgs n*msg_len, sigs n*64 (r || s). */
+int ecref_schnorr_verify_raw_batch(const uint8_t *pk_x, const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n,
+                                   uint8_t *ok) {
+    static const char TAG[] = "BIP0340/challenge";
+    uint8_t th[32];
+    sha256(th, (const uint8_t *)TAG, sizeof TAG - 1);
+    uint8_t *buf = (uint8_t *)malloc(128 + msg_len);
+    if (!buf) return ECREF_ERR_CURVE;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t pxy[64], lifted, zero = 0, e[32];
+        ok[i] = 0;
+        if (ecref_batch_decompress(ECREF_K256, pk_x + 32 * i, &zero, 1, pxy, &lifted) != ECREF_OK || !lifted) continue;
+        memcpy(buf, th, 32);
+        memcpy(buf + 32, th, 32);
+        memcpy(buf + 64, sigs + 64 * i, 32);
+        memcpy(buf + 96, pk_x + 32 * i, 32);
+        if (msg_len) memcpy(buf + 128, msgs + msg_len * i, msg_len);
+        sha256(e, buf, 128 + msg_len);
+        ecref_schnorr_verify_batch(e, sigs + 64 * i, sigs + 64 * i + 32, pxy, 1, ok + i);
+    }
+    free(buf);
     return ECREF_OK;
 }

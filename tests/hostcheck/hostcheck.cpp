@@ -12,6 +12,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_scalar.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_sha256.h"
 
 using namespace ecgpu;
 
@@ -465,6 +466,13 @@ extern "C" {
 
 int hc_field_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     DISPATCH(curve, field_op, (op, a, b, out))
+}
+// BIP340 challenge hash of r || pk || m -> 32 bytes big-endian
+int hc_bip340_challenge(const uint8_t* r, const uint8_t* pk, const uint8_t* m, size_t msg_len, uint8_t* out) {
+    uint32_t e[8];
+    Sha256::bip340_challenge(e, r, pk, m, msg_len);
+    store_be<8>(out, e);
+    return 0;
 }
 int hc_scalar_op(int curve, int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     DISPATCH(curve, scalar_op, (op, a, b, out))

@@ -16,7 +16,7 @@ _lib = None
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", LIB, SRC])
@@ -50,6 +50,13 @@ def field_op(curve, op, a, b=None):
     A, B = _a(a), _a(b)
     rc = lib().hc_field_op(curve, op, _p(A), _p(B), _p(out))
     assert rc == 0, rc
+    return bytes(out)
+
+
+def bip340_challenge(r, pk, msg):
+    out = np.zeros(32, np.uint8)
+    R, P, M = _a(r), _a(pk), _a(msg if len(msg) else b"\0")
+    assert lib().hc_bip340_challenge(_p(R), _p(P), _p(M), ctypes.c_size_t(len(msg)), _p(out)) == 0
     return bytes(out)
 
 

@@ -119,6 +119,15 @@ def schnorr_verify(e, r, s, p_xy):
     return ok
 
 
+def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
+    pk, sg = _arr(pk_x), _arr(sigs)
+    mm = _arr(msgs) if msg_len else None
+    n = pk.size // 32
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_schnorr_verify_raw_batch(_buf(pk), _buf(mm), ctypes.c_size_t(msg_len), _buf(sg), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
 def batch_decompress(curve, xs, y_is_odd):
     L = FIELD_BYTES[curve]
     x, odd = _arr(xs), _arr(y_is_odd)

@@ -543,3 +543,28 @@ def test_ecdh_vs_node_openssl_and_oracle(eng, curve):
     want, winf = oracle_lib.batch_mul(c.cid, ks, pts)
     assert bytes(x) == bytes(want.reshape(n, 2 * c.L)[:, : c.L].copy().reshape(-1))
     assert list(ok) == [0 if f else 1 for f in winf] and ok[0] == 0 and ok[1:].all()
+
+
+def test_schnorr_bip340_vectors_from_wire_bytes(eng):
+    """`VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` entirely on the device (lift_x, SHA-256 tagged hash, s G - e P):
+    the 19 BIP340 vectors of k256/src/schnorr.rs, the 32-byte-message ones as one batch, plus random batches against the
+    oracle for message lengths on both sides of the SHA-256 block boundaries."""
+    c = pyec.CURVES["k256"]
+    vec = load_golden("k256")["schnorr"]
+    pk_of = lambda v: bytes.fromhex(v["public_key"]) if "public_key" in v else bytes(eng.mul_by_generator(c.cid, bytes.fromhex(v["secret_key"]))[0][:32])
+    v32 = [v for v in vec if len(v["message"]) == 64]
+    got = eng.schnorr_verify_raw(b"".join(pk_of(v) for v in v32), b"".join(bytes.fromhex(v["message"]) for v in v32), 32,
+                                 b"".join(bytes.fromhex(v["signature"]) for v in v32))
+    assert list(got) == [1 if v["valid"] else 0 for v in v32] and len(v32) == 15
+    for v in vec:
+        msg = bytes.fromhex(v["message"])
+        assert int(eng.schnorr_verify_raw(pk_of(v), msg, len(msg), bytes.fromhex(v["signature"]))[0]) == (1 if v["valid"] else 0), v["index"]
+    rng = np.random.default_rng(0xB1F)
+    valid_sig = bytes.fromhex(vec[1]["signature"]); valid_pk = pk_of(vec[1])
+    for mlen in (0, 31, 55, 56, 64, 119, 120, 300):
+        n = 64
+        pk = rng.integers(0, 256, n * 32, dtype=np.uint8); msgs = rng.integers(0, 256, max(1, n * mlen), dtype=np.uint8)
+        sigs = rng.integers(0, 256, n * 64, dtype=np.uint8)
+        pk[:32] = np.frombuffer(valid_pk, np.uint8); sigs[:64] = np.frombuffer(valid_sig, np.uint8)
+        got = eng.schnorr_verify_raw(pk, msgs, mlen, sigs)
+        assert bytes(got) == bytes(oracle_lib.schnorr_verify_raw(pk, msgs, mlen, sigs)), mlen

@@ -59,6 +59,16 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
             assert got == 0
 
 
+def test_bip340_challenge_hash():
+    """Sha256::bip340_challenge (midstate + padding logic) against hashlib for message lengths across block edges."""
+    import hashlib
+    rng = random.Random(0xB1F340)
+    tag = hashlib.sha256(b"BIP0340/challenge").digest()
+    for mlen in [0, 1, 17, 32, 54, 55, 56, 57, 63, 64, 65, 100, 119, 120, 121, 200, 1000]:
+        r, pk, m = (bytes(rng.randrange(256) for _ in range(k)) for k in (32, 32, mlen))
+        assert hc.bip340_challenge(r, pk, m) == hashlib.sha256(tag + tag + r + pk + m).digest(), mlen
+
+
 @pytest.mark.parametrize("curve", CURVES)
 def test_scalar_field_ops(curve):
     """ScalarN (ecgpu_scalar.h): the mod-n arithmetic of the ECDSA verification path."""

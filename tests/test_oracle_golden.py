@@ -131,6 +131,20 @@ def test_schnorr_bip340_vectors(oracle):
     assert list(got) == list(exp)
 
 
+def test_schnorr_bip340_vectors_from_wire_bytes(oracle):
+    """The same 19 vectors through the all-in-one entry (x-only key, message, 64-byte signature): lift_x, the tagged
+    challenge hash and the verification all inside the oracle."""
+    c = pyec.CURVES["k256"]
+    for v in load("k256")["schnorr"]:
+        if "public_key" in v:
+            pk = bytes.fromhex(v["public_key"])
+        else:
+            pk = bytes(oracle.batch_mul_base(c.cid, bytes.fromhex(v["secret_key"]))[0][:32])
+        msg = bytes.fromhex(v["message"])
+        got = oracle.schnorr_verify_raw(pk, msg, len(msg), bytes.fromhex(v["signature"]))
+        assert int(got[0]) == (1 if v["valid"] else 0), v["index"]
+
+
 @pytest.mark.parametrize("curve", ALL_CURVES)
 def test_decompress_vs_model(oracle, curve):
     """DecompressPoint::decompress: generator round trip (p256/tests/affine.rs:12-28 compressed basepoint), random x
