@@ -4,9 +4,20 @@
 // Drop-in for `mul_by_generator` (k256/src/arithmetic/mul.rs:180-197; primeorder/src/tables/basepoint.rs:82-99).
 // The reference walks 65 signed nibbles over a 33x8 projective table with full additions; here the scalar is
 // folded to bits-1 bits (k G = -((n - k) G)), cut into nwin = (bits-1)/W + 1 signed W-bit windows, and window j
-// selects entry |d_j| * 2^(W j) * G of an affine table: nwin - 1 complete *mixed* additions (RCB Alg 8 / Alg 5),
-// no doublings, no exceptional cases.  The first window initialises the accumulator (an addition to the identity
-// would be a 2000-instruction copy), the sign of a digit is folded into the addition formula.
+// selects entry |d_j| * 2^(W j) * G of an affine table: no doublings, nwin - 1 additions of affine points.  The sum is
+// kept in XYZZ coordinates (first addition affine + affine, 4M + 2S; the others 8M + 2S, against 11M + constants for
+// the complete mixed addition), the sign of a digit is folded into the addition formula.
+//
+// The XYZZ additions are incomplete (accumulator = +-entry is not handled); that case cannot occur.  With signed
+// digits |d_i| <= 2^(W-1) the partial sum S_j = sum_{i<j} d_i 2^(W i) satisfies |S_j| < 2^(W j) (geometric sum), the
+// entry added next is e_j = d_j 2^(W j) with |e_j| >= 2^(W j), so S_j != +-e_j as integers; as group elements they
+// coincide only if S_j -+ e_j = 0 (mod n).  For j < nwin - 1: |S_j| + |e_j| <= 2^(W (j+1)) <= 2^(bits-1) < n.
+// For the top window S_j + e_j = k (folded, 0 < k < n/2), so S_j = -e_j is impossible, and S_j = e_j (mod n) means
+// 2 S_j - k = -n (the only multiple of n in range), i.e. |S_j| > n/4: that needs W (nwin - 1) = bits - 1, where the
+// top digit is the carry alone (e_j = 2^(bits-1), S_j = k - 2^(bits-1)) and the condition reads k = 2^bits - n —
+// a value < 2^(bits - 31) for every curve here (k256: 2^129, p256 / sm2: 2^225, p384: 2^190), so with W <= 26 the
+// window below the top one is zero and hands no carry up.  Contradiction.
+// tests: comb_corner_scalars (tests/gpu_common.py) at W = 5 and 15 (top window at bit 255) and at the default widths.
 #pragma once
 
 #include "ecgpu_point.h"
@@ -39,24 +50,40 @@ ECGPU_HD Proj<C> fixed_base_mul(const uint32_t* k_in, const Table& table, int w,
     for (int i = 0; i < N; i++) k[i] = k_in[i];
     const bool flip = fold_scalar<N>(k, C::ORDER);
     uint32_t carry = 0;
-    Proj<C> acc = G::identity();
-    {
-        int d = signed_window_step(get_bits<N>(k, 0, w), w, &carry);
-        if (d != 0) {
-            Affine<C> q = load_entry<C>(table, 0, (uint32_t)(d < 0 ? -d : d) - 1);
-            if ((d < 0) != flip) q.y = G::neg_coord(q.y);
-            acc = G::from_affine(q);
-        }
-    }
+    // state 0: nothing added yet; 1: acc = (x, y) affine (one entry); 2: acc in XYZZ coordinates
+    int state = 0;
+    Xyzz<C> acc;
+    acc.x = acc.y = acc.zz = acc.zzz = Field<C>::one().e;
 #pragma unroll 1
-    for (int j = 1; j < nwin; j++) {
+    for (int j = 0; j < nwin; j++) {
         int d = signed_window_step(get_bits<N>(k, j * w, w), w, &carry);
         if (d != 0) {
             Affine<C> q = load_entry<C>(table, j, (uint32_t)(d < 0 ? -d : d) - 1);
-            acc = G::add_mixed(acc, q, b, (d < 0) != flip);
+            const bool neg = (d < 0) != flip;
+            if (state == 2) {
+                acc = G::xyzz_madd(acc, q, neg);
+            } else if (state == 1) {
+                Affine<C> a;
+                a.x = acc.x;
+                a.y = acc.y;
+                acc = G::xyzz_mmadd(a, q, neg);
+                state = 2;
+            } else {
+                if (neg) q.y = G::neg_coord(q.y);
+                acc.x = q.x;
+                acc.y = q.y;
+                state = 1;
+            }
         }
     }
-    return acc;
+    if (state == 0) return G::identity();
+    if (state == 1) {
+        Affine<C> a;
+        a.x = acc.x;
+        a.y = acc.y;
+        return G::from_affine(a);
+    }
+    return G::xyzz_to_proj(acc);
 }
 
 

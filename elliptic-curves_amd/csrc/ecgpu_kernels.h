@@ -277,7 +277,7 @@ struct BaseTableHbm {
     }
 };
 template <class C>
-__global__ void __launch_bounds__(BLOCK, C::A_IS_ZERO ? 4 : 1)      // k256 fits 4 waves per SIMD (128 VGPRs)
+__global__ void __launch_bounds__(BLOCK, C::A_IS_ZERO ? 3 : 1)
 k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __restrict__ table, int w, int nwin,
              uint32_t* __restrict__ proj_out, int* status) {
     using G = Group<C>;

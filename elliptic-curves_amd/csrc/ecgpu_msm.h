@@ -171,7 +171,7 @@ struct MsmPartialsHbm {
 
 // one lane per (window, chunk)
 template <class C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : 2)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
                  int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials) {

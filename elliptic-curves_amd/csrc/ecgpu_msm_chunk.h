@@ -12,6 +12,12 @@
 // Buckets and chunks both advance monotonically along the run, so distinct (b, q) stretches get distinct
 // slots, nb + nchunks slots suffice, and the stretches of one bucket occupy consecutive slots
 // b + q_first .. b + q_last, which msm_bucket_finish adds up.
+//
+// A stretch is summed in XYZZ coordinates with the incomplete mixed addition (8M + 2S against 11M for the complete
+// one), which is wrong exactly when some step adds +-(the running sum) — duplicates of a point in one bucket, or
+// P + Q and (P + Q) handed in as a third term.  Every such step has U2 - X1 = 0 and multiplies ZZ by zero, and ZZ,
+// a product of the steps' (U2 - X1)^2, cannot become zero in any other way: ZZ == 0 at the end of the stretch is the
+// exact test, and a stretch that fails it is summed again with the complete formulas.
 #pragma once
 
 #include "ecgpu_point.h"
@@ -39,7 +45,10 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
     }
     uint32_t b = lo;
     uint32_t bend = b + 1 < nb ? ow[b + 1] : total;
-    Proj<C> acc = G::identity();
+    Xyzz<C> acc;
+    acc.x = acc.y = acc.zz = acc.zzz = F::one().e;
+    bool fresh = true;                               // no term of the current stretch taken yet
+    uint32_t sstart = start;                         // first entry of the current stretch
     PackedPoint<2 * N> pw;
     uint32_t e = run[start];
     points.load(pw, e & 0x7FFFFFFFu);
@@ -48,17 +57,39 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
         Affine<C> cur;
         cur.x = F::unpack(pw.w).e;
         cur.y = F::unpack(pw.w + N).e;
-        const uint32_t ecur = e;
+        const bool neg = (e >> 31) != 0;
         pos++;
         if (pos < end) {                             // fetch the next point under the current addition
             e = run[pos];
             points.load(pw, e & 0x7FFFFFFFu);
         }
-        acc = G::add_mixed(acc, cur, curve_b, (ecur >> 31) != 0);
+        if (fresh) {
+            acc = G::xyzz_from_affine(cur, neg);
+            fresh = false;
+        } else {
+            acc = G::xyzz_madd(acc, cur, neg);
+        }
         if (pos == bend || pos == end) {             // leaving the bucket, or the chunk ends inside it
-            sink.put((size_t)b + q, acc);
+            Proj<C> sum;
+            if (F::is_zero(G::mj(acc.zz))) {         // an exceptional addition happened: redo the stretch, complete
+                sum = G::identity();
+#pragma unroll 1
+                for (uint32_t r = sstart; r < pos; r++) {
+                    const uint32_t er = run[r];
+                    PackedPoint<2 * N> pr;
+                    points.load(pr, er & 0x7FFFFFFFu);
+                    Affine<C> a;
+                    a.x = F::unpack(pr.w).e;
+                    a.y = F::unpack(pr.w + N).e;
+                    sum = G::add_mixed(sum, a, curve_b, (er >> 31) != 0);
+                }
+            } else {
+                sum = G::xyzz_to_proj(acc);
+            }
+            sink.put((size_t)b + q, sum);
+            fresh = true;
+            sstart = pos;
             if (pos == bend && pos < end) {
-                acc = G::identity();
                 do {
                     b++;
                     bend = b + 1 < nb ? ow[b + 1] : total;

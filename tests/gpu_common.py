@@ -56,6 +56,64 @@ def ladder_edge_scalars(c):
     return ks
 
 
+def comb_corner_scalars(c, w):
+    """Scalars whose signed w-bit digit strings drive the comb's incomplete (Jacobian) additions towards their
+    preconditions (accumulator != +-entry): extreme partial sums, one / two non-zero windows only, carries into the
+    top window, 2^bits - n (the one value for which acc - entry = -n would need a carry that cannot happen)."""
+    bits = 8 * c.L
+    nwin = (bits - 1) // w + 1
+    half = 1 << (w - 1)
+    ks = [(1 << bits) - c.n, ((1 << bits) - c.n) // 2, (1 << (bits - 1)) - 1, (1 << (bits - 2)), 3 << (bits - 3)]
+    pats = [[-half] * (nwin - 1) + [1], [half] * (nwin - 1) + [0], [half - 1] * (nwin - 1) + [1],
+            [(-half if j % 2 else half) for j in range(nwin - 1)] + [1], [-1] * (nwin - 1) + [1], [1] * nwin]
+    for j in (0, 1, nwin - 2):
+        for i in (j + 1, nwin - 1):
+            if i <= j or i >= nwin:
+                continue
+            for dj in (1, -1, half, -half):
+                for di in (1, 2):
+                    d = [0] * nwin
+                    d[j], d[i] = dj, di
+                    pats.append(d)
+        d = [0] * nwin
+        d[j] = half
+        pats.append(d)
+    for d in pats:
+        k = sum(x << (w * j) for j, x in enumerate(d))
+        if 0 < k < c.n:
+            ks += [k, c.n - k]
+    return [k % c.n for k in ks]
+
+
+def msm_exceptional_terms(c, rng, filler=40):
+    """(scalars, points) whose sorted bucket runs contain every way the bucket accumulation's incomplete additions
+    can meet +-(their running sum): repeated terms, P, Q, P + Q with one scalar (the third doubles the sum), P, Q,
+    -(P + Q) (the sum cancels and more terms follow), P, -P, P, and +k / -k of one point.  rng: random.Random."""
+    G = pyec.G(c)
+    rp = lambda: pyec.mul(c, rng.randrange(1, c.n), G)
+    ks, pts = [], []
+    def put(k, P):
+        ks.append(k % c.n); pts.append(P)
+    k = rng.randrange(1, c.n); P = rp()
+    for _ in range(5):
+        put(k, P)
+    k = rng.randrange(1, c.n); P, Q = rp(), rp()
+    put(k, P); put(k, Q); put(k, pyec.add(c, P, Q)); put(k, rp())
+    k = rng.randrange(1, c.n); P, Q = rp(), rp()
+    put(k, P); put(k, Q); put(k, pyec.neg(c, pyec.add(c, P, Q))); put(k, rp()); put(k, rp())
+    k = rng.randrange(1, c.n); P = rp()
+    put(k, P); put(k, pyec.neg(c, P)); put(k, P)
+    k = rng.randrange(1, c.n); P = rp()
+    put(k, P); put(-k, P); put(k, P); put(k, P)
+    k = 1; P = rp()                                  # small scalars: upper windows empty, window 0 crowded
+    put(1, P); put(1, P); put(2, P); put(c.n - 1, P)
+    for _ in range(filler):
+        put(rng.randrange(c.n), rp())
+    order = list(range(len(ks)))
+    rng.shuffle(order)
+    return [ks[i] for i in order], [pts[i] for i in order]
+
+
 def scalars_to_int_sum(scalars, L, n_mod):
     """sum of n big-endian L-byte integers mod n_mod, via 32-bit limb column sums (cheap for 2^24 terms)."""
     a = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, L // 4, 4)

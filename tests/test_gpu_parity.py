@@ -6,7 +6,7 @@ import pytest
 
 import oracle_lib
 import pyec
-from gpu_common import (ALL_CURVES, CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, schnorr_inputs, edge_scalars, ladder_edge_scalars, load_golden,
+from gpu_common import (ALL_CURVES, comb_corner_scalars, msm_exceptional_terms, CURVES, ecdsa_cases, ecdsa_pack, ecgpu_module, schnorr_inputs, edge_scalars, ladder_edge_scalars, load_golden,
                         rand_scalars, scalars_to_int_sum)
 
 pytestmark = pytest.mark.gpu
@@ -112,19 +112,30 @@ def test_golden_ecdsa_vectors(eng, curve):
 # ---------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
-@pytest.mark.parametrize("window", [24, 16, 13, 4])
+@pytest.mark.parametrize("window", [24, 16, 15, 13, 5, 4])
 def test_fixed_base_vs_oracle(eng, curve, window):
     c = pyec.CURVES[curve]
     eng.set_base_window(c.cid, window)
     n = 3000 if window >= 16 else 700
     scal = rand_scalars(c.cid, n, 0xEC000002 + c.cid)
-    edge = b"".join(pyec.enc_scalar(c, k) for k in edge_scalars(c))
+    # the comb's Jacobian additions are incomplete: corner scalars drive them towards accumulator = +-entry
+    edge = b"".join(pyec.enc_scalar(c, k) for k in edge_scalars(c) + comb_corner_scalars(c, window))
     scal = np.concatenate([np.frombuffer(edge, np.uint8), scal])
     out, inf = eng.mul_by_generator(c.cid, scal)
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
     eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24}[curve])        # back to the defaults
+
+
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_fixed_base_default_window_corner_scalars(eng, curve):
+    c = pyec.CURVES[curve]
+    w = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24}[curve]
+    scal = b"".join(pyec.enc_scalar(c, k) for k in comb_corner_scalars(c, w) + edge_scalars(c))
+    out, inf = eng.mul_by_generator(c.cid, scal)
+    want, winf = oracle_lib.batch_mul_base(c.cid, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
@@ -220,6 +231,34 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
         w, wf = eng.mul(c.cid, k, total)
         assert bytes(o) == bytes(w) and f == int(wf[0])
         assert dt < 5.0, "skewed MSM took %.1f s: one lane is walking a whole bucket" % dt
+
+
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_msm_exceptional_additions(eng, curve, monkeypatch):
+    """Bucket runs with duplicates, P + Q next to P and Q, cancelling sums: the stretches whose incomplete XYZZ sum
+    fails the exactness test are redone with the complete formulas (ecgpu_msm_chunk.h)."""
+    import random
+    c = pyec.CURVES[curve]
+    ks, pts = msm_exceptional_terms(c, random.Random(0xE8CF + c.cid), filler=300)
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    pxy = b"".join(pyec.enc_point(c, P)[0] for P in pts)
+    want, winf = oracle_lib.msm(c.cid, scal, pxy, None, vartime=True)
+    for chunk in (None, "1", "2", "3", "40"):
+        if chunk is None:
+            monkeypatch.delenv("ECGPU_MSM_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("ECGPU_MSM_CHUNK", chunk)
+        for cbits in (0, 4, 9):
+            eng.set_msm_window(cbits)
+            o, f = eng.lincomb(c.cid, scal, pxy)
+            assert bytes(o) == bytes(want) and f == winf, (chunk, cbits)
+    monkeypatch.delenv("ECGPU_MSM_CHUNK", raising=False)
+    eng.set_msm_window(0)
+    # a whole run of one repeated term: every stretch takes the complete path
+    n = 5000
+    o, f = eng.lincomb(c.cid, scal[: c.L] * n, pxy[: 2 * c.L] * n)
+    w, wf = eng.mul(c.cid, pyec.enc_scalar(c, ks[0] * n % c.n), pxy[: 2 * c.L])
+    assert bytes(o) == bytes(w) and f == int(wf[0])
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)

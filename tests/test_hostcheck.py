@@ -205,6 +205,20 @@ def test_fixed_base_algorithm(oracle, curve, w):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("w", [5, 15])
+def test_fixed_base_comb_corner_cases(oracle, curve, w):
+    """w = 5 and 15 put the top window at bit 255 = bits - 1 of the 256-bit curves (its digit is the carry alone)."""
+    c = pyec.CURVES[curve]
+    from gpu_common import comb_corner_scalars
+    ks = comb_corner_scalars(c, w)
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    rc, out, inf = hc.batch_mul_base(c.cid, w, scal, 3)
+    assert rc == 0
+    want, winf = oracle.batch_mul_base(c.cid, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_var_base_algorithm(oracle, curve):
     c = pyec.CURVES[curve]
     rng = random.Random(0xAB + c.cid)
@@ -294,3 +308,22 @@ def test_pippenger_algorithm(oracle, curve, cbits):
     # all-zero scalars and the empty sum give the identity
     rc, out, inf = hc.msm(c.cid, cbits, bytes(c.L * 4), pxy[: 8 * c.L], None)
     assert rc == 0 and inf == 1 and out == bytes(2 * c.L)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+def test_pippenger_exceptional_additions(oracle, curve):
+    """The bucket accumulation sums a stretch with incomplete XYZZ additions and redoes it with the complete formulas
+    when the exactness test (ZZ == 0) fires: runs that contain duplicates, P + Q next to P and Q, cancelling sums."""
+    from gpu_common import msm_exceptional_terms
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xE8CE + c.cid)
+    ks, pts = msm_exceptional_terms(c, rng, filler=20)
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    enc = [pyec.enc_point(c, P) for P in pts]
+    pxy = b"".join(e[0] for e in enc)
+    want, winf = oracle.msm(c.cid, scal, pxy, None)
+    assert pyec.dec_point(c, bytes(want), winf) == pyec.msm(c, ks, pts)
+    for cbits, chunks in ((4, (1, 2, 3, 7, 1000)), (9, (2, 5)), (16, (3,))):
+        for chunk in chunks:
+            rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, None, chunk=chunk)
+            assert rc == 0 and out == bytes(want) and inf == winf, (cbits, chunk)
