@@ -19,6 +19,11 @@ struct MsmPlan {
     size_t chunk = 0, nchunks = 0; // accumulation: sorted entries per lane, lanes per window
     size_t off_points = 0, off_digits = 0, off_vmask = 0, off_tilehist = 0, off_sorted = 0, off_count = 0, off_offset = 0,
            off_partials = 0, off_buckets = 0, off_segs = 0, off_wins = 0, off_biglist = 0;
+    // two-level sort (large MSMs): level A partitions a window's entries by the top 8 bits of the bucket, level B sorts
+    // by the remaining sort_bits_b bits inside the partitions.  sort_bits_b = 0: single-level sort.
+    int sort_bits_b = 0;
+    size_t npart = 0, ntiles2 = 0;
+    size_t off_tmpidx = 0, off_tmpkey = 0, off_count_a = 0, off_offset_a = 0, off_cursor = 0;
     size_t max_big = 0;            // upper bound on the number of buckets that have more than MSM_BIG_PARTIALS partial sums
     size_t workspace_bytes = 0;
 };

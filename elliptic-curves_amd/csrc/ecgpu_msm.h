@@ -154,6 +154,119 @@ k_msm_scatter(const uint16_t* __restrict__ digits, const unsigned long long* __r
     }
 }
 
+// ---- two-level sort for large MSMs ------------------------------------------------------------------------------------
+// The single-level scatter above issues one 4-byte store per entry to an address that is random within the window's
+// 64 MiB run: 2.7x10^8 separate L2 write requests at 2^24 terms, 4 of the kernel's 4.7 ms (measured: the same kernel
+// without its stores takes 0.76 ms).  Here a workgroup takes a tile of 8192 entries, ranks them by key with LDS
+// atomics, lays them out key-sorted in LDS and writes the runs of equal keys as consecutive addresses, so that a wave's
+// store covers a few cache lines instead of 64.  That needs runs much longer than the 8 entries per (tile, bucket) a
+// 2^15-bucket sort produces, hence two levels: A partitions by the top 8 bits of the bucket (256 keys: 32 entries per
+// run), B sorts by the remaining bits inside each partition — a tile of the partitioned array touches one or two
+// partitions, which it handles one after the other (one round per partition present, <= 128 keys each).
+// Where a run starts comes from a global cursor per key, advanced by one atomicAdd per (tile, key): the order of the
+// entries inside a bucket depends on the scheduling of the workgroups, which bucket sums do not care about.
+constexpr int MSM_SORT2_TILE = 8192;          // entries per workgroup
+constexpr int MSM_SORT2_PER_LANE = MSM_SORT2_TILE / 1024;
+constexpr int MSM_SORT2_BITS_A = 8;
+
+struct MsmSort2Src {
+    const uint16_t* codes;                  // [nwin][n] digit codes (bucket | sign << 15): term order (level A) / partitioned (B)
+    const unsigned long long* vmask;        // level A: validity bits [nwin][ceil(n/64)]
+    const uint32_t* idx;                    // level B: term index of entry j
+    const uint32_t* part_offsets;           // level B: [nwin][npart]; the window holds last offset + last count entries
+    const uint32_t* part_counts;
+    size_t npart;
+};
+
+// LEVEL_B = false: key = bucket >> bits_b (one round).  LEVEL_B = true: one round per partition (bucket >> bits_b) present
+// in the tile, key = bucket & (2^bits_b - 1).  Counter / cursor index: level A the key, level B the bucket.
+// COUNT_ONLY: gcnt[w][index] += number of entries (histogram pass).  Otherwise gcnt holds the cursors (initialised to the
+// run starts) and the entries are written: level A out_idx = term, out_key = code; level B out_idx = term | sign << 31.
+template <bool LEVEL_B, bool COUNT_ONLY>
+static __global__ void __launch_bounds__(1024)
+k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __restrict__ gcnt, uint32_t* __restrict__ out_idx,
+            uint16_t* __restrict__ out_key) {
+    __shared__ uint32_t cnt[256], loc[256], gbase[256];
+    __shared__ uint32_t stage[COUNT_ONLY ? 1 : MSM_SORT2_TILE];
+    __shared__ uint16_t stage_k[COUNT_ONLY ? 1 : MSM_SORT2_TILE];
+    const size_t w = blockIdx.y;
+    const uint32_t tid = threadIdx.x;
+    size_t tot = n;
+    if (LEVEL_B) tot = src.part_offsets[w * src.npart + src.npart - 1] + src.part_counts[w * src.npart + src.npart - 1];
+    const size_t lo = (size_t)blockIdx.x * MSM_SORT2_TILE;
+    if (lo >= tot) return;
+    const size_t hi = lo + MSM_SORT2_TILE < tot ? lo + MSM_SORT2_TILE : tot;
+    const uint16_t* cw = src.codes + w * n;
+    const uint32_t nkeys = LEVEL_B ? 1u << bits_b : (uint32_t)nindex;
+    const uint32_t mask_b = (1u << bits_b) - 1;
+    uint32_t code[MSM_SORT2_PER_LANE], term[MSM_SORT2_PER_LANE], rank[MSM_SORT2_PER_LANE];   // code 0xFFFFFFFF: no entry
+#pragma unroll
+    for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+        const size_t i = lo + (size_t)u * 1024 + tid;                 // tiles start at multiples of 64
+        bool ok = i < hi;
+        if (!LEVEL_B && ok) ok = (src.vmask[w * ((n + 63) / 64) + (i >> 6)] >> (i & 63)) & 1;
+        code[u] = ok ? (uint32_t)cw[i] : 0xFFFFFFFFu;
+        term[u] = LEVEL_B ? (ok ? src.idx[w * n + i] : 0u) : (uint32_t)i;
+        rank[u] = 0;
+    }
+    uint32_t r_lo = 0, r_hi = 0;
+    if (LEVEL_B) {                                                      // the tile is sorted by partition
+        r_lo = (uint32_t)(cw[lo] & 0x7FFFu) >> bits_b;
+        r_hi = (uint32_t)(cw[hi - 1] & 0x7FFFu) >> bits_b;
+    }
+    for (uint32_t r = r_lo; r <= r_hi; r++) {
+        if (tid < 256) cnt[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            if (code[u] == 0xFFFFFFFFu) continue;
+            const uint32_t b = code[u] & 0x7FFFu;
+            if (LEVEL_B && (b >> bits_b) != r) continue;
+            rank[u] = atomicAdd(&cnt[LEVEL_B ? b & mask_b : b >> bits_b], 1u);
+        }
+        __syncthreads();
+        const uint32_t mine = tid < nkeys ? cnt[tid] : 0;
+        const size_t gi = w * nindex + (LEVEL_B ? ((size_t)r << bits_b) + tid : (size_t)tid);
+        if (COUNT_ONLY) {
+            if (mine) atomicAdd(&gcnt[gi], mine);
+            __syncthreads();
+            continue;
+        }
+        if (mine) gbase[tid] = atomicAdd(&gcnt[gi], mine);
+        if (tid < 256) loc[tid] = mine;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                              // inclusive scan of the (<= 256) counts
+            uint32_t v = tid < 256 && (int)tid >= d ? loc[tid - d] : 0;
+            __syncthreads();
+            if (tid < 256) loc[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t total_r = loc[255];
+        const uint32_t excl = tid < 256 ? loc[tid] - mine : 0;          // -> exclusive
+        __syncthreads();
+        if (tid < 256) loc[tid] = excl;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            if (code[u] == 0xFFFFFFFFu) continue;
+            const uint32_t b = code[u] & 0x7FFFu;
+            if (LEVEL_B && (b >> bits_b) != r) continue;
+            const uint32_t slot = loc[LEVEL_B ? b & mask_b : b >> bits_b] + rank[u];
+            stage[slot] = LEVEL_B ? term[u] | ((code[u] >> 15) << 31) : term[u];
+            stage_k[slot] = (uint16_t)code[u];
+        }
+        __syncthreads();
+        for (uint32_t slot = tid; slot < total_r; slot += 1024) {
+            const uint32_t c16 = stage_k[slot];
+            const uint32_t k = LEVEL_B ? c16 & mask_b : (c16 & 0x7FFFu) >> bits_b;
+            const size_t dst = w * n + gbase[k] + (slot - loc[k]);
+            out_idx[dst] = stage[slot];
+            if (!LEVEL_B) out_key[dst] = (uint16_t)c16;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- accumulate: the hot loop --------------------------------------------------------------------------------------
 template <class C>
 struct MsmPointsHbm {
@@ -391,6 +504,20 @@ MsmPlan msm_plan(size_t n, int force_c) {
         p.nchunks = (n + p.chunk - 1) / p.chunk;
         if (p.nchunks == 0) p.nchunks = 1;
     }
+    {
+        bool two = n >= ((size_t)1 << 20);
+        if (const char* e = getenv("ECGPU_MSM_SORT2")) two = atoi(e) != 0;
+        if (two && p.c - 1 > MSM_SORT2_BITS_A) {
+            p.sort_bits_b = p.c - 1 - MSM_SORT2_BITS_A;
+            p.npart = p.nb >> p.sort_bits_b;
+            p.ntiles2 = (n + MSM_SORT2_TILE - 1) / MSM_SORT2_TILE;
+            p.off_tmpidx = o;  o = align(o + (size_t)p.nwin * n * 4);
+            p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * n * 2);
+            p.off_count_a = o;  o = align(o + (size_t)p.nwin * p.npart * 4);
+            p.off_offset_a = o; o = align(o + (size_t)p.nwin * p.npart * 4);
+            p.off_cursor = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
+        }
+    }
     p.off_points = o;  o = align(o + n * 2 * N * 4);
     p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
     p.off_vmask = o;   o = align(o + (size_t)p.nwin * ((n + 63) / 64) * 8);
@@ -442,15 +569,40 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     }
     hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.c, p.nwin, pts,
                        digits, vmask, d_status);
-    hipLaunchKernelGGL(k_msm_hist, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                       (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb, tile_hist);
-    size_t nbk0 = p.nb * p.nwin;
-    hipLaunchKernelGGL(k_msm_tile_scan, dim3((unsigned)((nbk0 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, tile_hist,
-                       p.ntiles, p.nb, p.nwin, counts);
-    hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
-    hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                       (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb,
-                       (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
+    if (p.sort_bits_b) {
+        uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
+        uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);
+        uint32_t* counts_a = (uint32_t*)(ws + p.off_count_a);
+        uint32_t* offsets_a = (uint32_t*)(ws + p.off_offset_a);
+        uint32_t* cursor = (uint32_t*)(ws + p.off_cursor);
+        const dim3 grid2((unsigned)p.ntiles2, (unsigned)p.nwin);
+        MsmSort2Src sa{digits, vmask, nullptr, nullptr, nullptr, 0};
+        (void)hipMemsetAsync(counts_a, 0, (size_t)p.nwin * p.npart * 4, stream);
+        (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
+        hipLaunchKernelGGL((k_msm_sort2<false, true>), grid2, dim3(1024), 0, stream, sa, n, p.sort_bits_b, p.npart, counts_a,
+                           (uint32_t*)nullptr, (uint16_t*)nullptr);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart);
+        (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
+        hipLaunchKernelGGL((k_msm_sort2<false, false>), grid2, dim3(1024), 0, stream, sa, n, p.sort_bits_b, p.npart, cursor,
+                           tmp_idx, tmp_key);
+        MsmSort2Src sb{tmp_key, nullptr, tmp_idx, offsets_a, counts_a, p.npart};
+        hipLaunchKernelGGL((k_msm_sort2<true, true>), grid2, dim3(1024), 0, stream, sb, n, p.sort_bits_b, p.nb, counts,
+                           (uint32_t*)nullptr, (uint16_t*)nullptr);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
+        (void)hipMemcpyAsync(cursor, offsets, (size_t)p.nwin * p.nb * 4, hipMemcpyDeviceToDevice, stream);
+        hipLaunchKernelGGL((k_msm_sort2<true, false>), grid2, dim3(1024), 0, stream, sb, n, p.sort_bits_b, p.nb, cursor,
+                           sorted, (uint16_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_msm_hist, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
+                           (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb, tile_hist);
+        size_t nbk0 = p.nb * p.nwin;
+        hipLaunchKernelGGL(k_msm_tile_scan, dim3((unsigned)((nbk0 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, tile_hist,
+                           p.ntiles, p.nb, p.nwin, counts);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
+        hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
+                           (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb,
+                           (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
+    }
     (void)hipEventRecord(ev_sorted, stream);
     size_t nbk = p.nb * p.nwin, nlanes = p.nchunks * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,

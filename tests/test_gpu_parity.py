@@ -170,7 +170,7 @@ def test_variable_base_vs_oracle(eng, curve):
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 257, 4000])
-def test_msm_vs_oracle(eng, curve, n):
+def test_msm_vs_oracle(eng, curve, n, monkeypatch):
     c = pyec.CURVES[curve]
     if n == 0:
         o, f = eng.lincomb(c.cid, b"", b"")
@@ -190,10 +190,13 @@ def test_msm_vs_oracle(eng, curve, n):
         pts[15 * 2 * c.L: 16 * 2 * c.L] = np.frombuffer(pyec.enc_point(c, neg)[0], np.uint8)
         scal[15 * c.L: 16 * c.L] = scal[14 * c.L: 15 * c.L]
     want, winf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=True)
-    for cbits in ((0,) if n < 257 else (0, 4, 9, 16)):
-        eng.set_msm_window(cbits)
-        o, f = eng.lincomb(c.cid, scal, pts, inf)
-        assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits)
+    for sort2 in ("0", "1"):                  # single-level / two-level (partition, then buckets) counting sort
+        monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)
+        for cbits in ((0,) if n < 257 else (0, 4, 9, 12, 16)):
+            eng.set_msm_window(cbits)
+            o, f = eng.lincomb(c.cid, scal, pts, inf)
+            assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits, sort2)
+    monkeypatch.delenv("ECGPU_MSM_SORT2")
     eng.set_msm_window(0)
     if n == 17:
         want_ct, wf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=False)
@@ -224,13 +227,15 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
     total, tf = eng.point_sum(c.cid, pts)
     assert tf == 0
     k0 = bytes(rand_scalars(c.cid, 1, 0xEC000017 + c.cid))
-    for k in (k0, pyec.enc_scalar(c, 1), pyec.enc_scalar(c, c.n - 1)):
+    for k, sort2 in ((k0, "0"), (k0, "1"), (pyec.enc_scalar(c, 1), "1"), (pyec.enc_scalar(c, c.n - 1), "0")):
+        monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)          # "1": the two-level sort, whatever n is
         t0 = time.time()
         o, f = eng.lincomb(c.cid, np.tile(np.frombuffer(k, np.uint8), n), pts)
         dt = time.time() - t0
         w, wf = eng.mul(c.cid, k, total)
         assert bytes(o) == bytes(w) and f == int(wf[0])
         assert dt < 5.0, "skewed MSM took %.1f s: one lane is walking a whole bucket" % dt
+    monkeypatch.delenv("ECGPU_MSM_SORT2")
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
@@ -379,7 +384,7 @@ def test_full_size_variable_base_p256_sample(eng):
 
 
 @pytest.mark.parametrize("curve", ["k256", "p256"])
-def test_msm_multi_tile_ragged(eng, curve):
+def test_msm_multi_tile_ragged(eng, curve, monkeypatch):
     """More than one counting-sort tile with a ragged tail (n = 2^19 + 12345), identities sprinkled in, both
     the automatic window and c = 16: split linearity + all-G checksum."""
     c = pyec.CURVES[curve]
@@ -392,7 +397,8 @@ def test_msm_multi_tile_ragged(eng, curve):
     inf[::1001] = 1
     pts.reshape(n, 2 * c.L)[::1001] = 0
     h = (1 << 19) - 7
-    for cbits in (0, 16):
+    for cbits, sort2 in ((0, "0"), (16, "0"), (16, "1"), (11, "1")):
+        monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)
         eng.set_msm_window(cbits)
         full, ff = eng.lincomb(c.cid, k, pts, inf)
         a, af = eng.lincomb(c.cid, k[: c.L * h], pts[: 2 * c.L * h], inf[:h])
@@ -403,6 +409,7 @@ def test_msm_multi_tile_ragged(eng, curve):
         o, f = eng.lincomb(c.cid, k, np.tile(gxy, n))
         w, wf = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, scalars_to_int_sum(k, c.L, c.n)))
         assert bytes(o) == bytes(w) and f == int(wf[0])
+    monkeypatch.delenv("ECGPU_MSM_SORT2")
     eng.set_msm_window(0)
     # oracle on a sample of the same data
     m = 3000
