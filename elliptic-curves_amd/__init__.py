@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
     "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
     "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
-    "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev",
+    "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
 ]
 
 
@@ -73,6 +73,10 @@ def load_library():
     lib.ecgpu_last_error.restype = ctypes.c_char_p
     lib.ecgpu_version.restype = ctypes.c_char_p
     lib.ecgpu_field_bytes.restype = ctypes.c_size_t
+    lib.ecgpu_host_alloc.restype = ctypes.c_void_p
+    lib.ecgpu_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.ecgpu_host_free.restype = None
+    lib.ecgpu_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     _lib = lib
     return lib
 
@@ -109,6 +113,7 @@ class Engine:
 
     def __init__(self, device=0):
         self._lib = load_library()
+        self._pinned = {}
         self._ctx = ctypes.c_void_p()
         rc = self._lib.ecgpu_init(ctypes.byref(self._ctx), int(device))
         if rc != OK:
@@ -135,6 +140,21 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._chk(self._lib.ecgpu_set_stream(self._ctx, ctypes.c_void_p(stream_ptr or 0)))
 
+    def host_alloc(self, nbytes):
+        """uint8 numpy array over page-locked host memory (ecgpu_host_alloc): buffers of the host-pointer calls that live
+        here are transferred at PCIe DMA speed instead of through the driver's bounce buffers.  Free with host_free."""
+        p = self._lib.ecgpu_host_alloc(self._ctx, ctypes.c_size_t(nbytes))
+        if not p:
+            raise EcgpuError(-1, "ecgpu_host_alloc(%d) failed" % nbytes)
+        arr = np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p))
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = self._pinned.pop(arr.ctypes.data, None)
+        if p:
+            self._lib.ecgpu_host_free(self._ctx, ctypes.c_void_p(p))
+
     def set_base_window(self, curve, bits):
         self._chk(self._lib.ecgpu_set_base_window(self._ctx, curve, bits))
 
@@ -152,12 +172,14 @@ class Engine:
         return v.value
 
     # ---- host-buffer operations (numpy uint8 / bytes in, numpy out) ----
-    def mul_by_generator(self, curve, scalars):
+    def mul_by_generator(self, curve, scalars, out=None, inf=None):
+        """out / inf: optional preallocated uint8 arrays (n*2L, n), e.g. from host_alloc."""
         L = _field_bytes(curve)
         s = _host(scalars)
         n = s.size // L
-        out = np.zeros(n * 2 * L, np.uint8)
-        inf = np.zeros(n, np.uint8)
+        out = np.zeros(n * 2 * L, np.uint8) if out is None else out
+        inf = np.zeros(n, np.uint8) if inf is None else inf
+        assert out.dtype == np.uint8 and out.size >= n * 2 * L and inf.size >= n and out.flags.c_contiguous
         self._chk(self._lib.ecgpu_batch_mul_base(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
 

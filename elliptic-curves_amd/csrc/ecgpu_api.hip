@@ -424,6 +424,20 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
 
 const char* ecgpu_last_error(const ecgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+void* ecgpu_host_alloc(ecgpu_ctx* ctx, size_t bytes) {
+    if (!check_ctx(ctx) || bytes == 0) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        ctx->err = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void ecgpu_host_free(ecgpu_ctx* ctx, void* p) {
+    if (p && check_ctx(ctx)) (void)hipHostFree(p);
+}
+
 int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
     if (!ctx) return ECGPU_ERR_ARG;
     ctx->stream = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own_stream;

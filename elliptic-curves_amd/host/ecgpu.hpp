@@ -61,6 +61,25 @@ class Engine {
     ecgpu_ctx* ctx_ = nullptr;
 };
 
+// Page-locked host bytes (ecgpu_host_alloc): batches kept here reach the GPU at PCIe DMA speed.
+class PinnedBytes {
+  public:
+    PinnedBytes(Engine& e, size_t n) : e_(&e), n_(n), p_((uint8_t*)ecgpu_host_alloc(e.ctx(), n)) {
+        if (!p_) throw Error(ECGPU_ERR_OOM, "ecgpu_host_alloc failed");
+    }
+    ~PinnedBytes() { ecgpu_host_free(e_->ctx(), p_); }
+    PinnedBytes(const PinnedBytes&) = delete;
+    PinnedBytes& operator=(const PinnedBytes&) = delete;
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    size_t size() const { return n_; }
+
+  private:
+    Engine* e_;
+    size_t n_;
+    uint8_t* p_;
+};
+
 template <int CURVE, size_t L>
 struct Curve {
     static constexpr int ID = CURVE;

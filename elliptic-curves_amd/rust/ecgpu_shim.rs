@@ -33,6 +33,8 @@ unsafe extern "C" {
     pub fn ecgpu_last_error(ctx: *const EcgpuCtx) -> *const c_char;
     pub fn ecgpu_field_bytes(curve: c_int) -> usize;
     pub fn ecgpu_set_stream(ctx: *mut EcgpuCtx, stream: *mut c_void) -> c_int;
+    pub fn ecgpu_host_alloc(ctx: *mut EcgpuCtx, bytes: usize) -> *mut c_void;
+    pub fn ecgpu_host_free(ctx: *mut EcgpuCtx, p: *mut c_void);
     pub fn ecgpu_set_base_window(ctx: *mut EcgpuCtx, curve: c_int, window_bits: c_int) -> c_int;
     pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
     pub fn ecgpu_batch_mul_base(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, n: usize,

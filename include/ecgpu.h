@@ -74,6 +74,13 @@ size_t ecgpu_field_bytes(int curve);
  * context; NULL restores the context's own stream.  `stream` is a hipStream_t. */
 int ecgpu_set_stream(ecgpu_ctx *ctx, void *stream);
 
+/* Page-locked host memory for the buffers of the host-pointer entry points.  Any host pointer works there, but
+ * transfers from ordinary (pageable) memory go through the driver's bounce buffers at ~8 GB/s, which is 20x the
+ * compute time of a fixed-base batch; from memory allocated here they run at PCIe DMA speed (DESIGN.md section 7 has
+ * both numbers).  Returns NULL on failure.  ecgpu_host_free(NULL) is a no-op. */
+void *ecgpu_host_alloc(ecgpu_ctx *ctx, size_t bytes);
+void ecgpu_host_free(ecgpu_ctx *ctx, void *p);
+
 /* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..26; defaults: k256 26 —
  * 9 additions per scalar over a 21.5 GB table —, p256 24 — 10 additions, 5.9 GB —, p384 20 — 1.0 GB; the table takes
  * ceil(bits/w) * 2^(w-1) * 2L bytes — 21.5 GB at 26 — plus at most 2 GB of scratch while it is built).

@@ -614,3 +614,18 @@ def test_schnorr_bip340_vectors_from_wire_bytes(eng):
         pk[:32] = np.frombuffer(valid_pk, np.uint8); sigs[:64] = np.frombuffer(valid_sig, np.uint8)
         got = eng.schnorr_verify_raw(pk, msgs, mlen, sigs)
         assert bytes(got) == bytes(oracle_lib.schnorr_verify_raw(pk, msgs, mlen, sigs)), mlen
+
+
+def test_pinned_host_buffers(eng):
+    """ecgpu_host_alloc / ecgpu_host_free: the host-pointer entry points on page-locked buffers give the same bytes."""
+    c = pyec.CURVES["k256"]
+    n = 5000
+    scal = rand_scalars(c.cid, n, 0xEC0000F1)
+    want, winf = eng.mul_by_generator(c.cid, scal)
+    pin_s, pin_o, pin_i = eng.host_alloc(n * c.L), eng.host_alloc(n * 2 * c.L), eng.host_alloc(n)
+    pin_s[:] = scal
+    out, inf = eng.mul_by_generator(c.cid, pin_s, out=pin_o, inf=pin_i)
+    assert out.ctypes.data == pin_o.ctypes.data
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    for a in (pin_s, pin_o, pin_i):
+        eng.host_free(a)
