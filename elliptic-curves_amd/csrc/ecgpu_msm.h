@@ -276,10 +276,26 @@ struct MsmPointsHbm {
     }
 };
 template <class C>
-struct MsmPartialsHbm {
+struct MsmPartialsHbm {       // [slot][4] raw elements: X, Y, ZZ, ZZZ
     uint32_t* base;
-    __device__ void put(size_t slot, const Proj<C>& p) { store_proj<C>(base, slot, p); }
-    __device__ Proj<C> get(size_t slot) const { return load_proj<C>(base, slot); }
+    __device__ void put(size_t slot, const Xyzz<C>& p) {
+        constexpr int NS = Field<C>::NS;
+        uint32_t* d = base + slot * (4 * NS);
+        store_raw<C>(d, p.x);
+        store_raw<C>(d + NS, p.y);
+        store_raw<C>(d + 2 * NS, p.zz);
+        store_raw<C>(d + 3 * NS, p.zzz);
+    }
+    __device__ Xyzz<C> get(size_t slot) const {
+        constexpr int NS = Field<C>::NS;
+        const uint32_t* s = base + slot * (4 * NS);
+        Xyzz<C> p;
+        p.x = load_raw<C>(s);
+        p.y = load_raw<C>(s + NS);
+        p.zz = load_raw<C>(s + 2 * NS);
+        p.zzz = load_raw<C>(s + 3 * NS);
+        return p;
+    }
 };
 
 // one lane per (window, chunk)
@@ -295,7 +311,7 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
     const uint32_t* ow = offsets + w * nb;
     const uint32_t total = ow[nb - 1] + counts[w * nb + nb - 1];
     MsmPointsHbm<C> points{pts};
-    MsmPartialsHbm<C> sink{partials + w * (nb + nchunks) * (3 * Field<C>::NS)};
+    MsmPartialsHbm<C> sink{partials + w * (nb + nchunks) * (4 * Field<C>::NS)};
     msm_chunk_accumulate<C>(sorted + w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, G::curve_b(), points, sink);
 }
 
@@ -308,7 +324,8 @@ constexpr uint32_t MSM_BIG_PARTIALS = 32;
 template <class C>
 __global__ void __launch_bounds__(64)
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
-                    const uint32_t* __restrict__ offsets, size_t nb, int nwin, size_t chunk, size_t nchunks,
+                    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
+                    const uint32_t* __restrict__ sorted, size_t n, size_t nb, int nwin, size_t chunk, size_t nchunks,
                     uint32_t* __restrict__ buckets, uint32_t* __restrict__ big_list, uint32_t max_big) {
     using G = Group<C>;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,15 +339,17 @@ k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __res
             return;
         }
     }
-    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (3 * Field<C>::NS)};
-    store_proj<C>(buckets, gid, msm_bucket_finish<C>((uint32_t)b, first, cnt, (uint32_t)chunk, G::curve_b(), src));
+    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (4 * Field<C>::NS)};
+    MsmPointsHbm<C> points{pts};
+    store_proj<C>(buckets, gid, msm_bucket_finish<C>((uint32_t)b, first, cnt, (uint32_t)chunk, G::curve_b(), src, sorted + w * n, points));
 }
 
 // one workgroup per deferred bucket: strided sums of its partials + an LDS tree
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
-                  const uint32_t* __restrict__ offsets, size_t nb, size_t chunk, size_t nchunks,
+                  const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
+                  const uint32_t* __restrict__ sorted, size_t n, size_t nb, size_t chunk, size_t nchunks,
                   uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_list) {
     using G = Group<C>;
     __shared__ uint32_t lds[BLOCK * 3 * C::NL];
@@ -339,10 +358,12 @@ k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restr
     const size_t w = gid / nb, b = gid % nb;
     const uint32_t first = offsets[gid], cnt = counts[gid];
     const uint32_t q0 = first / (uint32_t)chunk, q1 = (first + cnt - 1) / (uint32_t)chunk;
-    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (3 * Field<C>::NS)};
+    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (4 * Field<C>::NS)};
+    MsmPointsHbm<C> points{pts};
     const Fe<C::NL> cb = G::curve_b();
     Proj<C> acc = G::identity();
-    for (uint32_t q = q0 + threadIdx.x; q <= q1; q += BLOCK) acc = G::add(acc, src.get(b + q), cb);
+    for (uint32_t q = q0 + threadIdx.x; q <= q1; q += BLOCK)
+        acc = G::add(acc, msm_stretch_of<C>((uint32_t)b, q, first, cnt, (uint32_t)chunk, cb, src, sorted + w * n, points), cb);
     acc = block_sum<C>(acc, lds, cb);
     if (threadIdx.x == 0) store_proj<C>(buckets, gid, acc);
 }
@@ -525,7 +546,7 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
     p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
-    p.off_partials = o; o = align(o + (size_t)p.nwin * (p.nb + p.nchunks) * 3 * NS * 4);
+    p.off_partials = o; o = align(o + (size_t)p.nwin * (p.nb + p.nchunks) * 4 * NS * 4);
     p.off_buckets = o; o = align(o + (size_t)p.nwin * p.nb * 3 * NS * 4);
     p.max_big = (size_t)p.nwin * (p.nchunks / (MSM_BIG_PARTIALS - 1) + 1);   // a big bucket covers >= 31 whole chunks
     p.off_biglist = o; o = align(o + (p.max_big + 1) * 4);
@@ -610,11 +631,11 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
                        (const uint32_t*)offsets, n, p.nb, p.nwin, p.chunk, p.nchunks, partials);
     (void)hipMemsetAsync(big_list, 0, 4, stream);
     hipLaunchKernelGGL(k_msm_bucket_finish<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, p.nb, p.nwin, p.chunk,
-                       p.nchunks, buckets, big_list, (uint32_t)p.max_big);
+                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
+                       (const uint32_t*)sorted, n, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
     hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
-                       (const uint32_t*)counts, (const uint32_t*)offsets, p.nb, p.chunk, p.nchunks, buckets,
-                       (const uint32_t*)big_list);
+                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, n, p.nb,
+                       p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,

@@ -17,14 +17,16 @@
 // one), which is wrong exactly when some step adds +-(the running sum) — duplicates of a point in one bucket, or
 // P + Q and (P + Q) handed in as a third term.  Every such step has U2 - X1 = 0 and multiplies ZZ by zero, and ZZ,
 // a product of the steps' (U2 - X1)^2, cannot become zero in any other way: ZZ == 0 at the end of the stretch is the
-// exact test, and a stretch that fails it is summed again with the complete formulas.
+// exact test, and a stretch that fails it is summed again with the complete formulas.  Both happen where the partial
+// sums are consumed (msm_stretch_sum, called by the bucket finish), not in the accumulation loop: there, a lane that
+// leaves a bucket makes its whole wave walk the exit path, so that path is four stores and nothing else.
 #pragma once
 
 #include "ecgpu_point.h"
 
 namespace ecgpu {
 
-// Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Proj<C>&).
+// Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Xyzz<C>&).
 // `ow` = bucket start offsets of this window (nb entries), `total` = length of the window's run.
 template <class C, class Points, class Sink>
 ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint32_t* __restrict__ ow, uint32_t total,
@@ -48,7 +50,6 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
     Xyzz<C> acc;
     acc.x = acc.y = acc.zz = acc.zzz = F::one().e;
     bool fresh = true;                               // no term of the current stretch taken yet
-    uint32_t sstart = start;                         // first entry of the current stretch
     PackedPoint<2 * N> pw;
     uint32_t e = run[start];
     points.load(pw, e & 0x7FFFFFFFu);
@@ -70,25 +71,8 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
             acc = G::xyzz_madd(acc, cur, neg);
         }
         if (pos == bend || pos == end) {             // leaving the bucket, or the chunk ends inside it
-            Proj<C> sum;
-            if (F::is_zero(G::mj(acc.zz))) {         // an exceptional addition happened: redo the stretch, complete
-                sum = G::identity();
-#pragma unroll 1
-                for (uint32_t r = sstart; r < pos; r++) {
-                    const uint32_t er = run[r];
-                    PackedPoint<2 * N> pr;
-                    points.load(pr, er & 0x7FFFFFFFu);
-                    Affine<C> a;
-                    a.x = F::unpack(pr.w).e;
-                    a.y = F::unpack(pr.w + N).e;
-                    sum = G::add_mixed(sum, a, curve_b, (er >> 31) != 0);
-                }
-            } else {
-                sum = G::xyzz_to_proj(acc);
-            }
-            sink.put((size_t)b + q, sum);
+            sink.put((size_t)b + q, acc);            // as it is: the exactness test and the conversion happen in the finish
             fresh = true;
-            sstart = pos;
             if (pos == bend && pos < end) {
                 do {
                     b++;
@@ -99,16 +83,48 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
     }
 }
 
-// sum of the stretches of bucket b: slots b + first/chunk .. b + (first + count - 1)/chunk
-template <class C, class Source>
+// The sum of one stretch from its stored XYZZ partial: converted if the exactness test passes, otherwise recomputed
+// from the entries run[lo, hi) with the complete formulas.
+template <class C, class Points>
+ECGPU_HD Proj<C> msm_stretch_sum(const Xyzz<C>& part, const uint32_t* __restrict__ run, uint32_t lo, uint32_t hi,
+                                 const Fe<C::NL>& curve_b, const Points& points) {
+    using G = Group<C>;
+    using F = Field<C>;
+    constexpr int N = C::N;
+    if (!F::is_zero(G::mj(part.zz))) return G::xyzz_to_proj(part);
+    Proj<C> sum = G::identity();
+#pragma unroll 1
+    for (uint32_t r = lo; r < hi; r++) {
+        const uint32_t er = run[r];
+        PackedPoint<2 * N> pr;
+        points.load(pr, er & 0x7FFFFFFFu);
+        Affine<C> a;
+        a.x = F::unpack(pr.w).e;
+        a.y = F::unpack(pr.w + N).e;
+        sum = G::add_mixed(sum, a, curve_b, (er >> 31) != 0);
+    }
+    return sum;
+}
+
+// sum of the stretches of bucket b: slots b + first/chunk .. b + (first + count - 1)/chunk; stretch q holds the entries
+// [max(first, q chunk), min(first + count, (q + 1) chunk)) of the window's run
+template <class C, class Source, class Points>
+ECGPU_HD Proj<C> msm_stretch_of(uint32_t b, uint32_t q, uint32_t first, uint32_t count, uint32_t chunk, const Fe<C::NL>& curve_b,
+                                const Source& partial, const uint32_t* __restrict__ run, const Points& points) {
+    const uint32_t c0 = q * chunk, c1 = c0 + chunk;
+    const uint32_t lo = first > c0 ? first : c0, hi = first + count < c1 ? first + count : c1;
+    return msm_stretch_sum<C>(partial.get((size_t)b + q), run, lo, hi, curve_b, points);
+}
+template <class C, class Source, class Points>
 ECGPU_HD Proj<C> msm_bucket_finish(uint32_t b, uint32_t first, uint32_t count, uint32_t chunk, const Fe<C::NL>& curve_b,
-                                   const Source& partial) {
+                                   const Source& partial, const uint32_t* __restrict__ run, const Points& points) {
     using G = Group<C>;
     if (count == 0) return G::identity();
     const uint32_t q0 = first / chunk, q1 = (first + count - 1) / chunk;
-    Proj<C> acc = partial.get((size_t)b + q0);
+    Proj<C> acc = msm_stretch_of<C>(b, q0, first, count, chunk, curve_b, partial, run, points);
 #pragma unroll 1
-    for (uint32_t q = q0 + 1; q <= q1; q++) acc = G::add(acc, partial.get((size_t)b + q), curve_b);
+    for (uint32_t q = q0 + 1; q <= q1; q++)
+        acc = G::add(acc, msm_stretch_of<C>(b, q, first, count, chunk, curve_b, partial, run, points), curve_b);
     return acc;
 }
 

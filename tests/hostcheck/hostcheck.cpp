@@ -359,20 +359,20 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
         }
     };
     struct Partials {
-        std::vector<Proj<C>>* v;
+        std::vector<Xyzz<C>>* v;
         std::vector<uint8_t>* written;
         size_t base;
-        void put(size_t slot, const Proj<C>& p) {
+        void put(size_t slot, const Xyzz<C>& p) {
             if ((*written)[base + slot]) __builtin_trap();          // slots must be unique
             (*written)[base + slot] = 1;
             (*v)[base + slot] = p;
         }
-        Proj<C> get(size_t slot) const {
+        Xyzz<C> get(size_t slot) const {
             if (!(*written)[base + slot]) __builtin_trap();         // and every slot read must have been written
             return (*v)[base + slot];
         }
     };
-    std::vector<Proj<C>> partials((size_t)nwin * (nb + nchunks));
+    std::vector<Xyzz<C>> partials((size_t)nwin * (nb + nchunks));
     std::vector<uint8_t> written(partials.size(), 0);
     std::vector<Proj<C>> buckets((size_t)nwin * nb);
     for (int w = 0; w < nwin; w++) {
@@ -384,7 +384,8 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
             msm_chunk_accumulate<C>(sorted.data() + (size_t)w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, b,
                                     points, sink);
         for (size_t j = 0; j < nb; j++)
-            buckets[(size_t)w * nb + j] = msm_bucket_finish<C>((uint32_t)j, ow[j], counts[(size_t)w * nb + j], (uint32_t)chunk, b, sink);
+            buckets[(size_t)w * nb + j] = msm_bucket_finish<C>((uint32_t)j, ow[j], counts[(size_t)w * nb + j], (uint32_t)chunk, b, sink,
+                                                               sorted.data() + (size_t)w * n, points);
     }
     std::vector<Proj<C>> wins(nwin);
     for (int w = 0; w < nwin; w++) {                                    // reduce
