@@ -60,10 +60,10 @@ WORKLOADS = {
                      scaling="strong"),
 }
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01/pmc_traffic_v9.json: rocprofv3
+    """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/r01/pmc_traffic_v10.json: rocprofv3
     --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same command).  PMC counters cannot be collected
     from inside the timed process, so the figure is the committed measurement, valid for the default sizes."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_v9.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic_v10.json")
     try:
         with open(path) as f:
             rec = json.load(f).get(kernel)
@@ -71,7 +71,7 @@ def pmc_traffic(kernel):
         return None, None, None
     if not rec:
         return None, None, None
-    return (rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01/pmc_traffic_v9.json (%s)" % rec["workload"],
+    return (rec["fetch_bytes"] + rec["write_bytes"], "profiles/r01/pmc_traffic_v10.json (%s)" % rec["workload"],
             rec.get("valu_busy"))
 
 
