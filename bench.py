@@ -282,7 +282,7 @@ def main():
                                  "frac": hbm_gbps / HBM_PEAK_GBPS if hbm_gbps else None,
                                  "algorithmic_bytes_per_unit": wl["bytes_per_unit"]}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is timed at N = 1 only
             ns = min(n, 1 << 17 if kind == "fixed" else (1 << 14 if kind == "var" else 1 << 15))
             s_host = d_scal[:ns].cpu().numpy().reshape(-1)
             p_host = d_pts[:ns].cpu().numpy().reshape(-1) if d_pts is not None else None

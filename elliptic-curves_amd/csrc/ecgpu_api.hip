@@ -5,8 +5,12 @@
 
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "../../include/ecgpu.h"
 #include "ecgpu_launch.h"
@@ -34,6 +38,7 @@ struct Table {
 struct ecgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t up_stream = nullptr, down_stream = nullptr;   // host <-> device legs of the pipelined host-pointer calls
     std::string err;
     int* d_status = nullptr;
     int* h_status = nullptr;
@@ -293,6 +298,99 @@ int download(ecgpu_ctx* ctx, void* host, const DevBuf& b, size_t bytes) {
     return ECGPU_OK;
 }
 
+// ---- pipelined host-pointer calls --------------------------------------------------------------------------------------
+// A batch of independent units handed over in host memory is cut into chunks of PIPE_CHUNK units: an upload thread and a
+// download thread move chunk i + 1 in and chunk i - 1 out (each on its own stream, PCIe is full duplex) while the calling
+// thread runs the ordinary device-pointer entry point on chunk i.  Serially the transfers of a 2^20-scalar fixed-base
+// batch take five times its compute time.
+constexpr size_t PIPE_CHUNK = (size_t)1 << 18;
+constexpr size_t PIPE_MIN = (size_t)1 << 19;
+
+struct PipeIn { const uint8_t* host; DevBuf* dev; size_t unit; };
+struct PipeOut { uint8_t* host; DevBuf* dev; size_t unit; };
+
+template <class F>
+int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const std::vector<PipeOut>& outs, F&& compute) {
+    if (!ctx->up_stream && hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
+    if (!ctx->down_stream && hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
+    int rc;
+    for (auto& a : ins) if (a.host && (rc = ensure(ctx, *a.dev, n * a.unit + 16)) != ECGPU_OK) return rc;
+    for (auto& o : outs) if ((rc = ensure(ctx, *o.dev, n * o.unit + 16)) != ECGPU_OK) return rc;
+    const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t uploaded = 0, computed = 0;
+    bool failed = false;
+    const int device = ctx->device;
+    auto span = [&](size_t i, size_t* off, size_t* m) { *off = i * PIPE_CHUNK; *m = n - *off < PIPE_CHUNK ? n - *off : PIPE_CHUNK; };
+    std::thread up([&] {
+        bool ok = hipSetDevice(device) == hipSuccess;
+        for (size_t i = 0; i < nchunks; i++) {
+            size_t off, m;
+            span(i, &off, &m);
+            for (auto& a : ins)
+                if (ok && a.host)
+                    ok = hipMemcpyAsync((uint8_t*)a.dev->p + off * a.unit, a.host + off * a.unit, m * a.unit, hipMemcpyHostToDevice,
+                                        ctx->up_stream) == hipSuccess;
+            ok = ok && hipStreamSynchronize(ctx->up_stream) == hipSuccess;
+            std::lock_guard<std::mutex> g(mu);
+            if (!ok) failed = true;
+            uploaded = i + 1;
+            cv.notify_all();
+            if (failed) return;
+        }
+    });
+    std::thread down([&] {
+        bool ok = hipSetDevice(device) == hipSuccess;
+        for (size_t i = 0; i < nchunks; i++) {
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&] { return computed > i || failed; });
+                if (failed) return;
+            }
+            size_t off, m;
+            span(i, &off, &m);
+            for (auto& o : outs)
+                if (ok && o.host)
+                    ok = hipMemcpyAsync(o.host + off * o.unit, (const uint8_t*)o.dev->p + off * o.unit, m * o.unit, hipMemcpyDeviceToHost,
+                                        ctx->down_stream) == hipSuccess;
+            ok = ok && hipStreamSynchronize(ctx->down_stream) == hipSuccess;
+            if (!ok) {
+                std::lock_guard<std::mutex> g(mu);
+                failed = true;
+                cv.notify_all();
+                return;
+            }
+        }
+    });
+    rc = ECGPU_OK;
+    for (size_t i = 0; i < nchunks; i++) {
+        {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return uploaded > i || failed; });
+            if (failed) break;
+        }
+        size_t off, m;
+        span(i, &off, &m);
+        int r = compute(off, m);
+        std::lock_guard<std::mutex> g(mu);
+        if (r != ECGPU_OK) {
+            rc = r;
+            failed = true;
+        }
+        computed = i + 1;
+        cv.notify_all();
+        if (failed) break;
+    }
+    up.join();
+    down.join();
+    if (rc == ECGPU_OK && failed) {
+        ctx->err = "host <-> device transfer failed";
+        rc = ECGPU_ERR_HIP;
+    }
+    return rc;
+}
+
 bool check_ctx(ecgpu_ctx* ctx) {
     if (!ctx) return false;
     return hipSetDevice(ctx->device) == hipSuccess;
@@ -419,6 +517,8 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+    if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     delete ctx;
 }
 
@@ -631,6 +731,12 @@ int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!scalars || !out_xy)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_batch_mul_base_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, m,
+                                                             (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
@@ -646,6 +752,13 @@ int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
+                         {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_batch_mul_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
+                                                        points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m,
+                                                        (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;

@@ -629,3 +629,37 @@ def test_pinned_host_buffers(eng):
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     for a in (pin_s, pin_o, pin_i):
         eng.host_free(a)
+
+
+@pytest.mark.parametrize("curve", ["k256", "p384"])
+def test_pipelined_host_pointer_calls(eng, curve):
+    """From 2^19 units on, the host-pointer batch calls run as a three-stage pipeline over chunks of 2^18 units (upload
+    thread / device-pointer entry point / download thread): ragged last chunk, identity points, NULL flags, and the
+    scalar-range error of a late chunk must come through."""
+    c = pyec.CURVES[curve]
+    n = (1 << 19) + 4321
+    scal = rand_scalars(c.cid, n, 0xEC0000C1 + c.cid).copy()
+    scal[: c.L] = 0                                                        # k = 0 -> identity in chunk 0
+    scal[(n - 1) * c.L: n * c.L] = np.frombuffer(pyec.enc_scalar(c, c.n - 1), np.uint8)
+    out, inf = eng.mul_by_generator(c.cid, scal)
+    assert inf[0] == 1 and inf[1:].sum() == 0
+    idx = np.concatenate([np.arange(0, 300), np.arange((1 << 18) - 150, (1 << 18) + 150), np.arange(n - 300, n)])
+    pick = lambda a, w: np.ascontiguousarray(a.reshape(n, w)[idx]).reshape(-1)
+    want, winf = oracle_lib.batch_mul_base(c.cid, pick(scal, c.L))
+    assert bytes(pick(out, 2 * c.L)) == bytes(want) and bytes(inf[idx]) == bytes(winf)
+    # variable base on the points just computed, a few of them replaced by the identity
+    pinf = np.zeros(n, np.uint8)
+    pinf[[0, 5, (1 << 18) + 7, n - 2]] = 1
+    pts = out.copy()
+    pts.reshape(n, 2 * c.L)[pinf == 1] = 0
+    k2 = rand_scalars(c.cid, n, 0xEC0000D1 + c.cid)
+    o2, i2 = eng.mul(c.cid, k2, pts, pinf)
+    w2, wi2 = oracle_lib.batch_mul(c.cid, pick(k2, c.L), pick(pts, 2 * c.L), pinf[idx])
+    assert bytes(pick(o2, 2 * c.L)) == bytes(w2) and bytes(i2[idx]) == bytes(wi2)
+    assert i2[5] == 1 and i2[(1 << 18) + 7] == 1
+    ecgpu = ecgpu_module()
+    bad = scal.copy()
+    bad[(n - 5) * c.L: (n - 4) * c.L] = 0xFF                                # >= n, in the last chunk
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.mul_by_generator(c.cid, bad)
+    assert e.value.code == ecgpu.ERR_SCALAR_RANGE
