@@ -372,6 +372,28 @@ struct Group {
         return o;
     }
 
+    // madd-2004-hmv (Z2 = 1): 8M + 3S.  Requires p finite, p != +-q.  Z3 = Z1 * H; H is handed back for the callers
+    // that track Z ratios (the shared-Z table of the k256 ladder).
+    static ECGPU_HD J jac_madd(const J& p, const A& q, bool negq, E* h_out = nullptr) {
+        auto X1 = mj(p.x), Y1 = mj(p.y), Z1 = mj(p.z);
+        auto zz1 = F::sqr(Z1);
+        auto Hn = F::norm(F::sub(F::mul(m(q.x), zz1), X1));
+        if (h_out) *h_out = Hn.e;
+        auto H = F::template fit<F::SQLIM>(Hn);
+        auto t = F::mul(Z1, zz1);
+        J o;
+        o.z = jstore(F::mul(Z1, H));
+        auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));
+        auto r = F::template fit<F::SQLIM>(F::sub(F::mul(Y2, t), Y1));
+        auto HH = F::sqr(H);
+        auto V = F::mul(X1, HH);
+        auto HHH = F::mul(H, HH);
+        auto X3 = F::norm(F::sub(F::sqr(r), F::add(HHH, F::dbl(V))));
+        o.x = jstore(X3);
+        o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(Y1), HHH));
+        return o;
+    }
+
     // ---- XYZZ accumulator for sums of affine points (incomplete; preconditions in ecgpu_fixedmul.h) -------------
     using XZ = Xyzz<C>;
     static ECGPU_HD XZ xyzz_from_affine(const A& a, bool negate) {

@@ -9,7 +9,7 @@ namespace ecgpu {
 // ---- variable base: out[i] = k[i] * P[i] -------------------------------------------------------------
 // One lane per scalar multiplication (ecgpu_varmul.h has the algorithm and the reference citations).  The
 // 8-entry table lives in HBM scratch instead of the CPU stack.
-constexpr int VAR_TAB_ELEMS = 5;   // X, Y, Z, Z^2, Z^3 per entry
+constexpr int VAR_TAB_ELEMS = 3;   // x, y of the affine entry + the Z ratio while the table is being built
 
 template <class C>
 struct VarTabHbm {
@@ -18,29 +18,17 @@ struct VarTabHbm {
     uint32_t* base;     // wave block + lane
     static constexpr int NL = C::NL;
     static constexpr int ROWS = VAR_TAB_ELEMS * NL;
-    __device__ void put(int e, const JacTab<C>& t) {
-        uint32_t* row = base + (size_t)e * (ROWS * 64);
+    __device__ void put_el(int e, int k, const Fe<NL>& v) {
+        uint32_t* row = base + (size_t)e * (ROWS * 64) + (size_t)k * (NL * 64);
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-            row[l * 64] = t.x.v[l];
-            row[(NL + l) * 64] = t.y.v[l];
-            row[(2 * NL + l) * 64] = t.z.v[l];
-            row[(3 * NL + l) * 64] = t.zz.v[l];
-            row[(4 * NL + l) * 64] = t.zzz.v[l];
-        }
+        for (int l = 0; l < NL; l++) row[l * 64] = v.v[l];
     }
-    __device__ JacTab<C> get(int e) const {
-        const uint32_t* row = base + (size_t)e * (ROWS * 64);
-        JacTab<C> t;
+    __device__ Fe<NL> get_el(int e, int k) const {
+        const uint32_t* row = base + (size_t)e * (ROWS * 64) + (size_t)k * (NL * 64);
+        Fe<NL> v;
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-            t.x.v[l] = row[l * 64];
-            t.y.v[l] = row[(NL + l) * 64];
-            t.z.v[l] = row[(2 * NL + l) * 64];
-            t.zz.v[l] = row[(3 * NL + l) * 64];
-            t.zzz.v[l] = row[(4 * NL + l) * 64];
-        }
-        return t;
+        for (int l = 0; l < NL; l++) v.v[l] = row[l * 64];
+        return v;
     }
 };
 

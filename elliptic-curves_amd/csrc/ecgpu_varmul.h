@@ -7,7 +7,8 @@
 // addition per digit.
 //
 // Where the reference spends complete projective formulas on all of it, this ladder runs in Jacobian
-// coordinates with incomplete formulas and switches to the complete addition for the last digit only.
+// coordinates with incomplete formulas over an affine table and switches to the complete (mixed) addition for the
+// last digit only.
 // Why that is exact for every scalar 0 <= k < n and every finite P (all three groups have prime order n):
 //   * let A_j = sum_{i >= j} d_i 16^(i-j) be the prefix value after digit j.  |sum_{i<j} d_i 16^i| < 16^j, so
 //     A_j >= 0, A_j = 0 iff all digits processed so far are zero (the `started` flag), and
@@ -17,7 +18,7 @@
 //     is +-d*P with 1 <= d <= 8.  m = +-d (mod n) would need m = d or m = n - d; both are out of range.
 //     So acc != +-operand and neither is the identity: the incomplete addition is exact.
 //   * digit 0: m can reach n - d (e.g. k = n - 2 on a curve with n = 1 mod 16 gives acc = -P, operand -P).
-//     This one addition converts both operands to homogeneous coordinates and uses the complete formula.
+//     This one addition converts the accumulator to homogeneous coordinates and uses the complete formula.
 //   * table: e*P = (e-1)*P + P for e = 3..8 never has (e-1)*P = +-P; 2P is a doubling.
 #pragma once
 
@@ -26,26 +27,51 @@
 
 namespace ecgpu {
 
-// TabIO: void put(int e, const JacTab<C>&);  JacTab<C> get(int e) const;   e = 0..7 holds (e+1)*P
+// Table chain shared by both ladders: entry e (0..7) = (e + 1) P.  2P is a doubling, (e + 1) P = e P + P a mixed addition
+// whose result has Z_(e+1) = Z_e * H_e, so the ratio between the Z of consecutive entries comes for free.  Stores
+// (X_e, Y_e, Z_e / Z_(e-1)) in elements 0..2 of entry e and returns Z_8.
+// TabIO: put_el(entry, k, element) / get_el(entry, k), entries 0..7, k = 0..2.
 template <class C, class TabIO>
-ECGPU_HD void var_build_table(const Affine<C>& a, TabIO& tab) {
+ECGPU_HD Fe<C::NL> var_table_chain(const Affine<C>& a, TabIO& tab) {
     using G = Group<C>;
     Jac<C> t = G::jac_from_affine(a);
-    const JacTab<C> t1 = G::jac_tab(t);
-    tab.put(0, t1);
+    tab.put_el(0, 0, a.x);
+    tab.put_el(0, 1, a.y);
+    t = G::jac_dbl(t);                          // Z_2 / Z_1 = Z_2
+    tab.put_el(1, 0, t.x);
+    tab.put_el(1, 1, t.y);
+    tab.put_el(1, 2, t.z);
 #pragma unroll 1
-    for (int e = 1; e < 8; e++) {
-        if (e == 1) t = G::jac_dbl(t);
-        else t = G::jac_add(t, t1, false);
-        tab.put(e, G::jac_tab(t));
+    for (int e = 2; e < 8; e++) {
+        Fe<C::NL> h;
+        t = G::jac_madd(t, a, false, &h);
+        tab.put_el(e, 0, t.x);
+        tab.put_el(e, 1, t.y);
+        tab.put_el(e, 2, h);
     }
+    return t.z;
 }
 
+// Affine table: one field inversion per lane (Z_8, by division steps: about seven additions' worth of work) and a
+// backward pass over the Z ratios (r = r * ratio, x = X r^2, y = Y r^3) turn the chain into [P..8P] in affine
+// coordinates.  Every ladder addition is then a mixed one (8M + 3S instead of 11M + 3S with cached Z^2, Z^3), an entry
+// is 2 elements instead of 5 to store and to fetch back 64 (96) times, and the last, complete addition is a mixed one too.
 template <class C, class TabIO>
 ECGPU_HD Proj<C> var_base_mul_plain(const Affine<C>& a, const uint32_t* k, const Fe<C::NL>& b, TabIO& tab) {
     using G = Group<C>;
+    using F = Field<C>;
     constexpr int N = C::N;
-    var_build_table<C>(a, tab);
+    {
+        const Fe<C::NL> zg = var_table_chain<C>(a, tab);
+        typename F::M1 r = F::inv(G::m(zg));          // Z_8 is a product: magnitude 1
+#pragma unroll 1
+        for (int e = 7; e >= 1; e--) {          // entry 0 is P itself
+            if (e < 7) r = F::mul(r, G::mj(tab.get_el(e + 1, 2)));
+            auto r2 = F::sqr(r);
+            tab.put_el(e, 0, F::mul(G::mj(tab.get_el(e, 0)), r2).e);
+            tab.put_el(e, 1, F::mul(G::mj(tab.get_el(e, 1)), F::mul(r2, r)).e);
+        }
+    }
     Radix16Msb<N> digits;
     digits.init(k);
     Jac<C> acc = G::jac_from_affine(a);   // placeholder until the first non-zero digit
@@ -60,42 +86,69 @@ ECGPU_HD Proj<C> var_base_mul_plain(const Affine<C>& a, const uint32_t* k, const
         d = digits.digit(di);
         if (di == 0) break;
         if (d != 0) {
-            JacTab<C> q = tab.get((d < 0 ? -d : d) - 1);
+            const int idx = (d < 0 ? -d : d) - 1;
+            Affine<C> q;
+            q.x = tab.get_el(idx, 0);
+            q.y = tab.get_el(idx, 1);
             if (started) {
-                acc = G::jac_add(acc, q, d < 0);
+                acc = G::jac_madd(acc, q, d < 0);
             } else {
-                acc = G::jac_from_tab(q, d < 0);
+                if (d < 0) q.y = G::neg_coord(q.y);
+                acc = G::jac_from_affine(q);
                 started = true;
             }
         }
     }
     Proj<C> r = started ? G::jac_to_proj(acc) : G::identity();
     if (d != 0) {
-        JacTab<C> q = tab.get((d < 0 ? -d : d) - 1);
-        r = G::add(r, G::jac_tab_to_proj(q), b, d < 0);
+        const int idx = (d < 0 ? -d : d) - 1;
+        Affine<C> q;
+        q.x = tab.get_el(idx, 0);
+        q.y = tab.get_el(idx, 1);
+        r = G::add_mixed(r, q, b, d < 0);
     }
     return r;
 }
 
-// ---- k256: the same ladder on the GLV halves ---------------------------------------------------------------
+// ---- k256: the same ladder on the GLV halves, over a shared-Z table ------------------------------------------------
 // k256/src/arithmetic/mul.rs:112-163 (`lincomb` with one term), mul/glv.rs:149-156: k = r1 + r2*lambda (mod n) with
 // |r1|, |r2| < 2^128 after folding the signs into the points, lambda*(x, y) = (beta*x, y).  Two 33-digit
-// recodings share ONE chain of 128 doublings; the table of lambda*P is the table of P with X multiplied by beta on
-// the fly (in Jacobian coordinates too: (X : Y : Z) -> (beta X : Y : Z), Z^2 and Z^3 unchanged).
+// recodings share ONE chain of 128 doublings.
+//
+// Shared-Z table.  e*P = (e-1)*P + P is a mixed addition whose result has Z_e = Z_(e-1) * H_e, so the ratios between
+// the Z of consecutive entries come for free; one backward pass (r = r * H, x' = X r^2, y' = Y r^3: 5M per entry)
+// rewrites every entry over the Z of the last one, Zg = Z_8.  (x'_e, y'_e) is then e*P's image under the isomorphism
+// (x, y) -> (x Zg^2, y Zg^3) onto y^2 = x^3 + 7 Zg^6, an a = 0 curve again: the doublings do not see the difference, the
+// table is AFFINE there, and every ladder addition is a mixed one (8M + 3S instead of 11M + 3S with cached Z^2, Z^3).
+// beta*x' is still the x of lambda*(e*P).  Mapping back multiplies the accumulator's Z by Zg.  The table costs what the
+// Jacobian one did (six mixed instead of full additions pay for the backward pass) and holds 2 instead of 5 elements
+// per entry.
 //
 // Exactness of the incomplete additions: after the doublings of digit j the accumulator is m*P with
 // m = a + b*lambda, a = 16*A1, b = 16*A2 the prefixes of the two recodings (|a|, |b| <= 2^128 / 16^j + 16), and the
 // operand is d*P or d*lambda*P, |d| <= 8.  acc = +-operand would make (a -+ d, b) resp. (a, b -+ d) a non-zero
 // vector of the lattice {(x, y) : x + y*lambda = 0 mod n}, whose shortest vector has length 2^127.8 — impossible
 // while both coordinates are below 2^125, i.e. for every digit j >= 1.  (The same argument gives acc != identity
-// once a non-zero digit has been seen.)  Digit 0 uses the complete formula for both additions.
+// once a non-zero digit has been seen.)  Digit 0 uses the complete formula for both additions, on the original curve.
 template <class TabIO>
 ECGPU_HD Proj<K256Params> var_base_mul_glv(const Affine<K256Params>& a, const uint32_t* k,
                                            const Fe<K256Params::NL>& b, TabIO& tab) {
     using C = K256Params;
     using G = Group<C>;
     using F = Field<C>;
-    var_build_table<C>(a, tab);
+    using E = Fe<C::NL>;
+    {
+        const E zg = var_table_chain<C>(a, tab);
+        typename F::M1 r = F::one();
+#pragma unroll 1
+        for (int e = 6; e >= 0; e--) {
+            r = F::mul(r, G::mj(tab.get_el(e + 1, 2)));
+            auto r2 = F::sqr(r);
+            tab.put_el(e, 0, F::mul(G::mj(tab.get_el(e, 0)), r2).e);
+            tab.put_el(e, 1, F::mul(G::mj(tab.get_el(e, 1)), F::mul(r2, r)).e);
+        }
+        tab.put_el(7, 2, zg);                   // kept for the way back
+    }
     uint32_t r1[8], r2[8];
     K256Scalar::decompose(r1, r2, k);
     const bool s1 = K256Scalar::is_high(r1), s2 = K256Scalar::is_high(r2);
@@ -121,25 +174,40 @@ ECGPU_HD Proj<K256Params> var_base_mul_glv(const Affine<K256Params>& a, const ui
         for (int half = 0; half < 2; half++) {  // one copy of the addition code for both halves
             const int e = half ? e2 : e1;
             if (e == 0) continue;
-            JacTab<C> q = tab.get((e < 0 ? -e : e) - 1);
-            if (half) q.x = F::mul(G::mt(q.x), beta).e;
+            const int idx = (e < 0 ? -e : e) - 1;
+            Affine<C> q;
+            q.x = tab.get_el(idx, 0);
+            q.y = tab.get_el(idx, 1);
+            if (half) q.x = F::mul(G::mj(q.x), beta).e;
             const bool neg = (e < 0) != (half ? s2 : s1);
             if (started) {
-                acc = G::jac_add(acc, q, neg);
+                acc = G::jac_madd(acc, q, neg);
             } else {
-                acc = G::jac_from_tab(q, neg);
+                if (neg) q.y = G::neg_coord(q.y);
+                acc = G::jac_from_affine(q);
                 started = true;
             }
         }
     }
-    Proj<C> r = started ? G::jac_to_proj(acc) : G::identity();
+    // back to the original curve: Z * Zg; the table entries are (x' : y' : Zg) there
+    const auto zg = G::mj(tab.get_el(7, 2));
+    Proj<C> r = G::identity();
+    if (started) {
+        acc.z = F::mul(G::mj(acc.z), zg).e;
+        r = G::jac_to_proj(acc);
+    }
+    const auto zg3 = F::mul(F::sqr(zg), zg);
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
         const int e = half ? e2 : e1;
         if (e == 0) continue;
-        JacTab<C> q = tab.get((e < 0 ? -e : e) - 1);
-        if (half) q.x = F::mul(G::mt(q.x), beta).e;
-        r = G::add(r, G::jac_tab_to_proj(q), b, (e < 0) != (half ? s2 : s1));
+        const int idx = (e < 0 ? -e : e) - 1;
+        auto x = G::mj(tab.get_el(idx, 0));
+        Proj<C> q;
+        q.x = (half ? F::mul(F::mul(x, beta), zg) : F::mul(x, zg)).e;
+        q.y = tab.get_el(idx, 1);
+        q.z = zg3.e;
+        r = G::add(r, q, b, (e < 0) != (half ? s2 : s1));
     }
     return r;
 }

@@ -216,9 +216,9 @@ Proj<C> fixed_base_one(const BaseTable<C>& t, const uint32_t* k_in) {
 // k_var_base: the shared per-lane body with a stack table
 template <class C>
 struct VarTabLocal {
-    JacTab<C> t[8];
-    void put(int e, const JacTab<C>& v) { t[e] = v; }
-    JacTab<C> get(int e) const { return t[e]; }
+    Fe<C::NL> t[8][3];
+    void put_el(int e, int k, const Fe<C::NL>& v) { t[e][k] = v; }
+    Fe<C::NL> get_el(int e, int k) const { return t[e][k]; }
 };
 template <class C>
 Proj<C> var_base_one(const Affine<C>& a, const uint32_t* k) {
