@@ -266,6 +266,10 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     constexpr int N = C::N, NS = Field<C>::NS;
     (void)N;
     int rc;
+    if (n >= ((size_t)1 << 31)) {           // sorted entries are term index | sign << 31
+        ctx->err = "MSM of 2^31 or more terms: split it and add the partial sums (ecgpu_point_sum)";
+        return ECGPU_ERR_ARG;
+    }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     MsmPlan plan = msm_plan<C>(n, ctx->msm_c);
@@ -323,7 +327,7 @@ int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const st
     bool failed = false;
     const int device = ctx->device;
     auto span = [&](size_t i, size_t* off, size_t* m) { *off = i * PIPE_CHUNK; *m = n - *off < PIPE_CHUNK ? n - *off : PIPE_CHUNK; };
-    std::thread up([&] {
+    auto up_body = [&] {
         bool ok = hipSetDevice(device) == hipSuccess;
         for (size_t i = 0; i < nchunks; i++) {
             size_t off, m;
@@ -339,8 +343,8 @@ int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const st
             cv.notify_all();
             if (failed) return;
         }
-    });
-    std::thread down([&] {
+    };
+    auto down_body = [&] {
         bool ok = hipSetDevice(device) == hipSuccess;
         for (size_t i = 0; i < nchunks; i++) {
             {
@@ -362,7 +366,21 @@ int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const st
                 return;
             }
         }
-    });
+    };
+    std::thread up, down;
+    try {                                                   // no C++ exception may cross the C ABI
+        up = std::thread(up_body);
+        down = std::thread(down_body);
+    } catch (...) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            failed = true;
+            cv.notify_all();
+        }
+        if (up.joinable()) up.join();
+        ctx->err = "could not start the transfer threads";
+        return ECGPU_ERR_HIP;
+    }
     rc = ECGPU_OK;
     for (size_t i = 0; i < nchunks; i++) {
         {
