@@ -109,7 +109,12 @@ def _dp(t):
 
 
 class Engine:
-    """One context = one GPU, one stream, device-resident basepoint tables."""
+    """One context = one GPU, one stream, device-resident basepoint tables.
+
+    The *_dev methods enqueue on the context's own non-blocking stream: tensors produced on torch's current stream are
+    not ordered before them unless that stream is handed over first,
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    (bench.py does) or synchronised."""
 
     def __init__(self, device=0):
         self._lib = load_library()

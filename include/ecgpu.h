@@ -134,7 +134,9 @@ int ecgpu_batch_normalize(ecgpu_ctx *ctx, int curve, const uint8_t *points_xyz, 
  * Same semantics, all buffers already resident in this context's device memory (e.g. torch CUDA
  * tensors' data_ptr()).  Work is enqueued on the context stream; the call returns after the
  * status word has been read back (one small D2H copy + stream sync), so errors are reported
- * synchronously exactly like the host-pointer forms. */
+ * synchronously exactly like the host-pointer forms.  The context stream is a non-blocking stream of its own: inputs
+ * written by work on another stream (torch's current stream, the legacy default stream) are NOT ordered before these
+ * calls — either make that stream the context's with ecgpu_set_stream, or synchronise it first. */
 
 int ecgpu_batch_mul_base_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, size_t n,
                              void *d_out_xy, void *d_out_inf);
