@@ -464,13 +464,18 @@ __global__ void k_store_identity(uint32_t* out) {
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
-// Window width from the term count, from a sweep on MI355X (tools/gpu_msm_window_sweep.sh, k256): 2^12 / 2^14 / 2^16 /
-// 2^18 / 2^20 / 2^22 terms are fastest at c = 5-7 / 8-10 / 11 / 11-15 / 16 / 16 (the curve is flat below 2^18, where the
-// 255-doubling Horner chain of the combine step, 0.76 ms, dominates whatever c is).
+// Window width from the term count, from a sweep on MI355X (tools/gpu_msm_window_sweep.sh, k256, v11 kernels): fastest c
+// at 2^12 / 2^14 / 2^16 / 2^17 / 2^18 / 2^19 / 2^20 / 2^21 / 2^22 terms = 9 / 11 / 12 / 13 / 13 / 13 / 14 / 16 / 16 (1.20 / 1.19 /
+// 1.28 / 1.46 / 1.56 / 1.95 / 2.70 / 3.97 / 6.38 ms).  Below 2^17 the curve is flat: the 240-doubling Horner chain of the
+// combine step and the running sums, 1.2 ms together, dominate whatever c is.
 inline int msm_window_bits(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = lg >= 17 ? lg - 4 : lg - 5;
+    int c;
+    if (lg <= 16) c = lg - 3;
+    else if (lg <= 19) c = 13;
+    else if (lg == 20) c = 14;
+    else c = 16;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;

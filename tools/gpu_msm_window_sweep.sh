@@ -5,14 +5,14 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 python - <<'PY'
 import importlib, time, numpy as np, torch
 ec = importlib.import_module("elliptic-curves_amd")
-e = ec.Engine(0)
+e = ec.Engine(0); e.set_stream(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator(device="cuda"); g.manual_seed(11)
 nmax = 1 << 22
 k = torch.randint(0, 256, (nmax, 32), dtype=torch.uint8, device="cuda", generator=g); k[:, 0] &= 0x7f
 pts = torch.empty((nmax, 64), dtype=torch.uint8, device="cuda")
 e.mul_by_generator_dev(0, k, nmax, pts, None)
 r = torch.empty((1, 64), dtype=torch.uint8, device="cuda"); ri = torch.empty((16,), dtype=torch.uint8, device="cuda")
-for lg in (12, 14, 16, 18, 20, 22):
+for lg in (12, 14, 16, 17, 18, 19, 20, 21, 22):
     n = 1 << lg
     row = []
     for c in range(max(4, lg - 10), min(16, lg - 3) + 1):
