@@ -816,6 +816,13 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{a_scalars, &ctx->in0, L}, {b_scalars, &ctx->in3, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
+                         {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_batch_mul_base_and_mul_add_dev(
+                                 ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in3.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
+                                 points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m, (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, a_scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in3, b_scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
@@ -837,6 +844,13 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!z || !r || !s || !q_xy || !ok)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{z, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in2, L}, {q_xy, &ctx->in1, 2 * L}}, {{ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_ecdsa_verify_batch_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in3.p + off * L,
+                                                                 (uint8_t*)ctx->in2.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
+                                                                 reject_high_s, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, z, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in2, s, n * L)) != ECGPU_OK) return rc;
@@ -854,6 +868,13 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
     const size_t L = 32;
     if (n && (!e || !r || !s || !p_xy || !ok)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{e, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in2, L}, {p_xy, &ctx->in1, 2 * L}}, {{ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_schnorr_verify_batch_dev(ctx, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in3.p + off * L,
+                                                                   (uint8_t*)ctx->in2.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
+                                                                   (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, e, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in2, s, n * L)) != ECGPU_OK) return rc;
@@ -869,6 +890,13 @@ int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const ui
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{pk_x, &ctx->in0, 32}, {msg_len ? msgs : nullptr, &ctx->in1, msg_len}, {sigs, &ctx->in3, 64}},
+                         {{ok, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_schnorr_verify_raw_batch_dev(ctx, (uint8_t*)ctx->in0.p + off * 32,
+                                                                       msg_len ? (uint8_t*)ctx->in1.p + off * msg_len : nullptr, msg_len,
+                                                                       (uint8_t*)ctx->in3.p + off * 64, m, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, pk_x, n * 32)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, msgs, n * msg_len)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in3, sigs, n * 64)) != ECGPU_OK) return rc;
@@ -885,6 +913,12 @@ int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const ui
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!scalars || !points_xy || !out_x || !ok)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}}, {{out_x, &ctx->out0, L}, {ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_batch_ecdh_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
+                                                         (uint8_t*)ctx->out0.p + off * L, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * L + 16)) != ECGPU_OK) return rc;
@@ -901,6 +935,12 @@ int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const u
     if (!L) return ECGPU_ERR_CURVE;
     if (n && (!xs || !y_is_odd || !out_xy || !ok)) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{xs, &ctx->in0, L}, {y_is_odd, &ctx->in2, 1}}, {{out_xy, &ctx->out0, 2 * L}, {ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_batch_decompress_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in2.p + off, m,
+                                                               (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
     if ((rc = upload(ctx, ctx->in0, xs, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in2, y_is_odd, n)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;

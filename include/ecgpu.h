@@ -29,9 +29,10 @@
  * ecgpu_init fails with ECGPU_ERR_NO_DEVICE.
  *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
- * create one context per thread / per GPU for concurrency.  The host-pointer forms of ecgpu_batch_mul_base and
- * ecgpu_batch_mul run batches of 2^19 units and more as a pipeline over chunks of 2^18 units: two helper threads,
- * alive for the duration of the call, move the next chunk in and the previous one out on their own streams.
+ * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
+ * (everything except ecgpu_msm, ecgpu_point_sum and ecgpu_batch_normalize) run batches of 2^19 units and more as a
+ * pipeline over chunks of 2^18 units: two helper threads, alive for the duration of the call, move the next chunk in and
+ * the previous one out on their own streams.
  */
 #ifndef ECGPU_H
 #define ECGPU_H

@@ -663,3 +663,51 @@ def test_pipelined_host_pointer_calls(eng, curve):
     with pytest.raises(ecgpu.EcgpuError) as e:
         eng.mul_by_generator(c.cid, bad)
     assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+
+
+def test_pipelined_host_pointer_calls_other_entry_points(eng):
+    """ECDSA / Schnorr verification, ECDH, decompression and a*G + b*P above the pipeline threshold: the big call must
+    return exactly what two calls on the halves (both below the threshold, i.e. the serial path) return, and the known
+    verdicts of the reference's vectors, tiled across all chunks, must come out."""
+    c = pyec.CURVES["k256"]
+    L = c.L
+    n = (1 << 19) + 1500
+    h = n // 2
+    cat = lambda a, b: np.concatenate([np.asarray(a), np.asarray(b)])
+    def tile(b, unit):
+        a = np.frombuffer(b, np.uint8).reshape(-1, unit)
+        return np.ascontiguousarray(np.tile(a, ((n + a.shape[0] - 1) // a.shape[0], 1))[:n]).reshape(-1)
+    # ECDSA: the corner-case set (valid and broken signatures), tiled
+    z, r, s_, q, exp = ecdsa_pack(ecdsa_cases(c, 0xE1))
+    Z, R, S, Q = tile(z, L), tile(r, L), tile(s_, L), tile(q, 2 * L)
+    got = eng.ecdsa_verify(c.cid, Z, R, S, Q)
+    assert bytes(got) == bytes(np.tile(exp, (n + len(exp) - 1) // len(exp))[:n])
+    assert bytes(got) == bytes(cat(eng.ecdsa_verify(c.cid, Z[: h * L], R[: h * L], S[: h * L], Q[: h * 2 * L]),
+                                   eng.ecdsa_verify(c.cid, Z[h * L:], R[h * L:], S[h * L:], Q[h * 2 * L:])))
+    # BIP340 from wire bytes: the 15 vectors with 32-byte messages, tiled
+    vec = [v for v in load_golden("k256")["schnorr"] if len(v["message"]) == 64]
+    pk_of = lambda v: bytes.fromhex(v["public_key"]) if "public_key" in v else bytes(eng.mul_by_generator(c.cid, bytes.fromhex(v["secret_key"]))[0][:32])
+    PK = tile(b"".join(pk_of(v) for v in vec), 32)
+    MS = tile(b"".join(bytes.fromhex(v["message"]) for v in vec), 32)
+    SG = tile(b"".join(bytes.fromhex(v["signature"]) for v in vec), 64)
+    got = eng.schnorr_verify_raw(PK, MS, 32, SG)
+    want = np.array([1 if v["valid"] else 0 for v in vec], np.uint8)
+    assert bytes(got) == bytes(np.tile(want, (n + len(vec) - 1) // len(vec))[:n])
+    # ECDH, decompression, a*G + b*P: big call == two serial calls
+    k = rand_scalars(c.cid, n, 0xEC0000E1)
+    pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xEC0000E2))
+    x, ok = eng.ecdh(c.cid, k, pts)
+    x1, ok1 = eng.ecdh(c.cid, k[: h * L], pts[: h * 2 * L]); x2, ok2 = eng.ecdh(c.cid, k[h * L:], pts[h * 2 * L:])
+    assert bytes(x) == bytes(cat(x1, x2)) and bytes(ok) == bytes(cat(ok1, ok2)) and ok.all()
+    xs = np.ascontiguousarray(pts.reshape(n, 2 * L)[:, :L]).reshape(-1).copy()
+    xs[5 * L: 6 * L] = 0xFF                                                    # not a field element
+    odd = (pts.reshape(n, 2 * L)[:, 2 * L - 1] & 1).astype(np.uint8)
+    d, dok = eng.decompress(c.cid, xs, odd)
+    assert dok[5] == 0 and dok.sum() == n - 1
+    keep = np.ones(n, bool); keep[5] = False
+    assert bytes(d.reshape(n, 2 * L)[keep]) == bytes(pts.reshape(n, 2 * L)[keep])
+    a = rand_scalars(c.cid, n, 0xEC0000E3)
+    o, oi = eng.mul_by_generator_and_mul_add(c.cid, a, k, pts)
+    o1, oi1 = eng.mul_by_generator_and_mul_add(c.cid, a[: h * L], k[: h * L], pts[: h * 2 * L])
+    o2, oi2 = eng.mul_by_generator_and_mul_add(c.cid, a[h * L:], k[h * L:], pts[h * 2 * L:])
+    assert bytes(o) == bytes(cat(o1, o2)) and bytes(oi) == bytes(cat(oi1, oi2))
