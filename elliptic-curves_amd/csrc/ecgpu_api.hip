@@ -309,24 +309,26 @@ int download(ecgpu_ctx* ctx, void* host, const DevBuf& b, size_t bytes) {
 // batch take five times its compute time.
 constexpr size_t PIPE_CHUNK = (size_t)1 << 18;
 constexpr size_t PIPE_MIN = (size_t)1 << 19;
+constexpr size_t MSM_PIPE_CHUNK = (size_t)1 << 22;   // terms per partial MSM of the host-pointer ecgpu_msm
 
 struct PipeIn { const uint8_t* host; DevBuf* dev; size_t unit; };
 struct PipeOut { uint8_t* host; DevBuf* dev; size_t unit; };
 
 template <class F>
-int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const std::vector<PipeOut>& outs, F&& compute) {
+int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const std::vector<PipeOut>& outs, F&& compute,
+              const size_t chunk = PIPE_CHUNK) {
     if (!ctx->up_stream && hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
     if (!ctx->down_stream && hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
     int rc;
     for (auto& a : ins) if (a.host && (rc = ensure(ctx, *a.dev, n * a.unit + 16)) != ECGPU_OK) return rc;
     for (auto& o : outs) if ((rc = ensure(ctx, *o.dev, n * o.unit + 16)) != ECGPU_OK) return rc;
-    const size_t nchunks = (n + PIPE_CHUNK - 1) / PIPE_CHUNK;
+    const size_t nchunks = (n + chunk - 1) / chunk;
     std::mutex mu;
     std::condition_variable cv;
     size_t uploaded = 0, computed = 0;
     bool failed = false;
     const int device = ctx->device;
-    auto span = [&](size_t i, size_t* off, size_t* m) { *off = i * PIPE_CHUNK; *m = n - *off < PIPE_CHUNK ? n - *off : PIPE_CHUNK; };
+    auto span = [&](size_t i, size_t* off, size_t* m) { *off = i * chunk; *m = n - *off < chunk ? n - *off : chunk; };
     auto up_body = [&] {
         bool ok = hipSetDevice(device) == hipSuccess;
         for (size_t i = 0; i < nchunks; i++) {
@@ -796,6 +798,27 @@ int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* 
     if (!L) return ECGPU_ERR_CURVE;
     if (!out_xy || (n && (!scalars || !points_xy))) return ECGPU_ERR_ARG;
     int rc;
+    if (n >= 2 * MSM_PIPE_CHUNK) {
+        // An MSM needs all of its terms before its sort can start, and 96 (144) bytes per term take longer to upload than
+        // the MSM takes to compute: sum_i k_i P_i is computed as one MSM per chunk of 2^22 terms, each under the upload of
+        // the next chunk, and the partial sums are added at the end.
+        const size_t nparts = (n + MSM_PIPE_CHUNK - 1) / MSM_PIPE_CHUNK;
+        if ((rc = ensure(ctx, ctx->out0, (nparts + 1) * 2 * L + 16)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->out1, nparts + 32)) != ECGPU_OK) return rc;
+        uint8_t* part_xy = (uint8_t*)ctx->out0.p + 2 * L;          // [0] is the final result
+        uint8_t* part_inf = (uint8_t*)ctx->out1.p + 16;
+        rc = pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}}, {},
+                       [&](size_t off, size_t m) {
+                           const size_t j = off / MSM_PIPE_CHUNK;
+                           return ecgpu_msm_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
+                                                points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m, part_xy + j * 2 * L, part_inf + j);
+                       },
+                       MSM_PIPE_CHUNK);
+        if (rc != ECGPU_OK) return rc;
+        if ((rc = ecgpu_point_sum_dev(ctx, curve, part_xy, part_inf, nparts, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+        if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
+        return download(ctx, out_inf, ctx->out1, 1);
+    }
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;

@@ -30,8 +30,8 @@
  *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
  * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
- * (everything except ecgpu_msm, ecgpu_point_sum and ecgpu_batch_normalize) run batches of 2^19 units and more as a
- * pipeline over chunks of 2^18 units: two helper threads, alive for the duration of the call, move the next chunk in and
+ * (everything except ecgpu_point_sum and ecgpu_batch_normalize) run batches of 2^19 units and more as a
+ * pipeline over chunks of 2^18 units (ecgpu_msm: from 2^23 terms, as partial MSMs over chunks of 2^22 terms): two helper threads, alive for the duration of the call, move the next chunk in and
  * the previous one out on their own streams.
  */
 #ifndef ECGPU_H

@@ -711,3 +711,24 @@ def test_pipelined_host_pointer_calls_other_entry_points(eng):
     o1, oi1 = eng.mul_by_generator_and_mul_add(c.cid, a[: h * L], k[: h * L], pts[: h * 2 * L])
     o2, oi2 = eng.mul_by_generator_and_mul_add(c.cid, a[h * L:], k[h * L:], pts[h * 2 * L:])
     assert bytes(o) == bytes(cat(o1, o2)) and bytes(oi) == bytes(cat(oi1, oi2))
+
+
+def test_host_pointer_msm_in_chunks(eng):
+    """ecgpu_msm on host buffers of 2^23 terms and more: one MSM per chunk of 2^22 terms under the upload of the next
+    chunk, partial sums added at the end.  All points = G: the result must be (sum k_i) G; and with a few terms switched
+    to the identity, the sum without them."""
+    c = pyec.K256
+    n = (1 << 23) + 999
+    k = rand_scalars(c.cid, n, 0xEC0000F7)
+    gxy = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+    pts = np.tile(gxy, n)
+    o, f = eng.lincomb(c.cid, k, pts)
+    w, wf = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, scalars_to_int_sum(k, c.L, c.n)))
+    assert bytes(o) == bytes(w) and f == int(wf[0])
+    inf = np.zeros(n, np.uint8)
+    drop = [0, 1, (1 << 22) - 1, 1 << 22, (1 << 23) + 500, n - 1]
+    inf[drop] = 1
+    o2, f2 = eng.lincomb(c.cid, k, pts, inf)
+    rest = (scalars_to_int_sum(k, c.L, c.n) - sum(int.from_bytes(bytes(k[i * c.L: (i + 1) * c.L]), "big") for i in drop)) % c.n
+    w2, wf2 = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, rest))
+    assert bytes(o2) == bytes(w2) and f2 == int(wf2[0])
