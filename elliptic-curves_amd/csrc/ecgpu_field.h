@@ -49,15 +49,6 @@ static ECGPU_HD uint32_t opaque_const(uint32_t x) {
     return x;
 }
 
-// Scheduling fence (device only): the instruction scheduler does not move anything across it.  Between the field
-// multiplications of a long formula it stops the compiler from interleaving independent products, whose column
-// accumulators (36 VGPRs each) otherwise push a kernel over its occupancy target and into scratch spills.
-static ECGPU_HD void sched_fence() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-}
-
 template <class C>
 struct Field {
     ECGPU_CONST int N = C::N;     // canonical 32-bit words

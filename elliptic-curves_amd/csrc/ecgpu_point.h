@@ -46,10 +46,6 @@ template <class C>
 struct Jac {
     Fe<C::NL> x, y, z;
 };
-template <class C>
-struct JacTab {  // table entry: the point plus Z^2 and Z^3, which every addition with it needs
-    Fe<C::NL> x, y, z, zz, zzz;
-};
 
 // Extended Jacobian ("XYZZ") coordinates: x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2.  The accumulator of sums of affine
 // points (fixed-base comb): a mixed addition is 8M + 2S with nine reductions, against 8M + 3S / ten for Jacobian and
@@ -262,7 +258,6 @@ struct Group {
     ECGPU_CONST int JTV = C::REPR == REPR_U28_MONT ? 10 : 1;
     ECGPU_CONST int JV = C::REPR == REPR_U28_MONT ? JTV + 1 : 1;
     using J = Jac<C>;
-    using JT = JacTab<C>;
     static ECGPU_HD Mag<C, 1, JV> mj(const E& e) { return F::template wrap<1, JV>(e); }
     static ECGPU_HD Mag<C, 1, JTV> mt(const E& e) { return F::template wrap<1, JTV>(e); }
     template <int L, int V>
@@ -277,30 +272,10 @@ struct Group {
         r.z = F::one().e;
         return r;
     }
-    static ECGPU_HD JT jac_tab(const J& p) {
-        JT t;
-        auto Z = mj(p.z);
-        auto zz = F::sqr(Z);
-        t.x = p.x;
-        t.y = p.y;
-        t.z = p.z;
-        t.zz = zz.e;
-        t.zzz = F::mul(Z, zz).e;
-        return t;
-    }
     // value-magnitude-1 copy of a Jacobian coordinate (a no-op where JV = 1)
     static ECGPU_HD E j_unit(const E& c) {
         if constexpr (JV == 1) return c;
         else return F::mul(mj(c), F::one()).e;
-    }
-    static ECGPU_HD J jac_from_tab(const JT& t, bool negate) {
-        auto yn = F::norm(F::neg(mt(t.y)));
-        static_assert(decltype(magv(yn))::value <= JV, "negated table coordinate");
-        J r;
-        r.x = t.x;
-        r.y = F::sel(negate, yn, mt(t.y)).e;
-        r.z = t.z;
-        return r;
     }
     // (X : Y : Z) Jacobian -> (X Z : Y : Z^3) homogeneous
     static ECGPU_HD P jac_to_proj(const J& p) {
@@ -309,13 +284,6 @@ struct Group {
         r.x = F::mul(X, Z).e;
         r.y = j_unit(p.y);
         r.z = F::mul(Z, F::sqr(Z)).e;
-        return r;
-    }
-    static ECGPU_HD P jac_tab_to_proj(const JT& t) {
-        P r;
-        r.x = F::mul(mt(t.x), mt(t.z)).e;
-        r.y = j_unit(t.y);
-        r.z = t.zzz;
         return r;
     }
     // dbl-2001-b (a = -3) / dbl-2009-l (a = 0); valid for every finite point of odd order
@@ -347,31 +315,6 @@ struct Group {
         }
         return o;
     }
-    // add-1998-cmo-2 with the table entry's Z^2, Z^3 cached (10M + 3S + one fused pair).  Requires p != +-q and
-    // both finite.  negq adds -q.
-    static ECGPU_HD J jac_add(const J& p, const JT& q, bool negq) {
-        auto X1 = mj(p.x), Y1 = mj(p.y), Z1 = mj(p.z);
-        auto X2 = mt(q.x), Z2 = mt(q.z);
-        auto ZZ2 = m(q.zz), ZZZ2 = m(q.zzz);
-        auto Y2 = F::sel(negq, F::neg(mt(q.y)), mt(q.y));
-        auto zz1 = F::sqr(Z1);
-        auto U1 = F::mul(X1, ZZ2);
-        auto U2 = F::mul(X2, zz1);
-        auto S1 = F::mul(Y1, ZZZ2);
-        auto S2 = F::mul(Y2, F::mul(Z1, zz1));
-        auto H = F::template fit<F::SQLIM>(F::sub(U2, U1));                               // 3
-        auto r = F::template fit<F::SQLIM>(F::sub(S2, S1));                               // 3
-        auto HH = F::sqr(H);
-        auto HHH = F::mul(H, HH);
-        auto V = F::mul(U1, HH);
-        auto X3 = F::norm(F::sub(F::sqr(r), F::add(HHH, F::dbl(V))));                     // 5 -> 1
-        J o;
-        o.x = jstore(X3);
-        o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(S1), HHH));                         // 3*3 + 2*1
-        o.z = jstore(F::mul(F::mul(Z1, Z2), H));
-        return o;
-    }
-
     // madd-2004-hmv (Z2 = 1): 8M + 3S.  Requires p finite, p != +-q.  Z3 = Z1 * H; H is handed back for the callers
     // that track Z ratios (the shared-Z table of the k256 ladder).
     static ECGPU_HD J jac_madd(const J& p, const A& q, bool negq, E* h_out = nullptr) {
