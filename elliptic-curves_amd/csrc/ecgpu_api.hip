@@ -260,6 +260,17 @@ int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n,
     return rc;
 }
 
+// largest term count for which the per-term multiplication + tree sum replaces the bucket method (0: never);
+// ECGPU_MSM_SMALL_LOG2 overrides the measured default (tuning knob, -1 disables)
+template <class C>
+size_t msm_small_max() {
+    // measured (tools/gpu_run51.sh): k256 0.75-0.91 ms against 1.21-1.36 ms up to 2^16 terms (1.51 against 1.39 at 2^17),
+    // p256 1.23-1.44 against 1.39-1.59 ms, p384 3.3-3.4 against 3.7-4.1 ms up to 2^10 and level beyond
+    int lg = C::N > 8 ? 10 : 16;
+    if (const char* e = getenv("ECGPU_MSM_SMALL_LOG2")) lg = atoi(e);
+    return lg <= 0 ? 0 : (size_t)1 << (lg > 24 ? 24 : lg);
+}
+
 template <class C>
 int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy,
             void* d_out_inf) {
@@ -269,6 +280,29 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     if (n >= ((size_t)1 << 31)) {           // sorted entries are term index | sign << 31
         ctx->err = "MSM of 2^31 or more terms: split it and add the partial sums (ecgpu_point_sum)";
         return ECGPU_ERR_ARG;
+    }
+    if (n >= 1 && n <= msm_small_max<C>() && ctx->msm_c == 0) {
+        // Small MSM: the bucket method has a floor of ~1.2 ms of serial work that does not depend on n (running sums, the
+        // 240-doubling combine chain).  Below ~2^17 terms one variable-base multiplication per term (all lanes in
+        // parallel, ~0.5 ms of latency) and a tree sum of the products are faster.
+        size_t tstride = var_base_slots<C>(n);
+        if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->prefix, ((n + BLOCK - 1) / BLOCK + 1) * 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+        record(ctx, 0);
+        launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
+                           (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, ctx->d_status);
+        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        launch_proj_sum<C>(ctx->stream, (uint32_t*)ctx->proj.p, n, (uint32_t*)ctx->prefix.p);
+        (void)hipEventRecord(ctx->ev[4], ctx->stream);
+        record(ctx, 1);
+        if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+        record(ctx, 2);
+        rc = finish(ctx);
+        collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
+                             {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
+        return rc;
     }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;

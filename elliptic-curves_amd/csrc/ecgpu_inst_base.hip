@@ -51,6 +51,17 @@ template <> void launch_point_sum<CurveT>(hipStream_t s, const uint8_t* xy, cons
                                           int* status) {
     hipLaunchKernelGGL(k_point_sum<CurveT>, dim3(1), dim3(BLOCK), 0, s, xy, inf, n, proj_out, status);
 }
+template <> void launch_proj_sum<CurveT>(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp) {
+    uint32_t *src = a, *dst = tmp;
+    size_t m = n;
+    while (m > 1) {
+        const size_t g = (m + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(k_proj_sum_level<CurveT>, dim3((unsigned)g), dim3(BLOCK), 0, s, (const uint32_t*)src, m, dst);
+        m = g;
+        uint32_t* t = src; src = dst; dst = t;
+    }
+    if (src != a) (void)hipMemcpyAsync(a, src, 3 * Field<CurveT>::NS * 4, hipMemcpyDeviceToDevice, s);
+}
 template <> void launch_proj_add_pairs<CurveT>(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n) {
     hipLaunchKernelGGL(k_proj_add_pairs<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, pa, pb, n);
 }

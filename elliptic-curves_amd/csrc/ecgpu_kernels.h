@@ -347,6 +347,18 @@ k_point_sum(const uint8_t* points_xy, const uint8_t* points_inf, size_t n, uint3
     if (threadIdx.x == 0) store_proj<C>(proj_out, 0, acc);
 }
 
+// out[g] = sum of in[g * BLOCK .. g * BLOCK + BLOCK) (the identity past n): one level of a reduction tree over
+// projective points, one workgroup per output
+template <class C>
+__global__ void __launch_bounds__(BLOCK) k_proj_sum_level(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ out) {
+    using G = Group<C>;
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    Proj<C> acc = i < n ? load_proj<C>(in, i) : G::identity();
+    acc = block_sum<C>(acc, lds, G::curve_b());
+    if (threadIdx.x == 0) store_proj<C>(out, blockIdx.x, acc);
+}
+
 // pa[i] = pa[i] + pb[i]
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_proj_add_pairs(uint32_t* pa, const uint32_t* pb, size_t n) {

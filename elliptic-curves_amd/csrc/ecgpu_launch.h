@@ -39,6 +39,8 @@ template <class C> void launch_load_proj(hipStream_t s, const uint8_t* xyz, size
 template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
                                          int* status);
 template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n);
+// a[0] = sum of the n projective points a[0..n) (a is clobbered; tmp holds ceil(n / 256) points)
+template <class C> void launch_proj_sum(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp);
 template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
                                              size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid);
 template <class C> void launch_schnorr_prepare(hipStream_t s, const uint8_t* e, const uint8_t* r, const uint8_t* sig_s, const uint8_t* p_xy,

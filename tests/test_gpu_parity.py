@@ -192,7 +192,7 @@ def test_msm_vs_oracle(eng, curve, n, monkeypatch):
     want, winf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=True)
     for sort2 in ("0", "1"):                  # single-level / two-level (partition, then buckets) counting sort
         monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)
-        for cbits in ((0,) if n < 257 else (0, 4, 9, 12, 16)):
+        for cbits in ((0, 5) if n < 257 else (0, 4, 9, 12, 16)):       # 0: automatic (small n: per-term products + tree sum)
             eng.set_msm_window(cbits)
             o, f = eng.lincomb(c.cid, scal, pts, inf)
             assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits, sort2)
