@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
     "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
     "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
+    "ecgpu_batch_mul_base_compressed", "ecgpu_batch_mul_base_compressed_dev",
 ]
 
 
@@ -187,6 +188,20 @@ class Engine:
         assert out.dtype == np.uint8 and out.size >= n * 2 * L and inf.size >= n and out.flags.c_contiguous
         self._chk(self._lib.ecgpu_batch_mul_base(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
+
+    def mul_by_generator_compressed(self, curve, scalars, out_x=None, out_tag=None):
+        """k_i * G in SEC1-compressed form: (x uint8[n*L], tag uint8[n] = 2 / 3, 0 for the identity)."""
+        L = _field_bytes(curve)
+        s = _host(scalars)
+        n = s.size // L
+        out_x = np.zeros(n * L, np.uint8) if out_x is None else out_x
+        out_tag = np.zeros(n, np.uint8) if out_tag is None else out_tag
+        self._chk(self._lib.ecgpu_batch_mul_base_compressed(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out_x), _hp(out_tag)))
+        return out_x, out_tag
+
+    def mul_by_generator_compressed_dev(self, curve, d_scalars, n, d_out_x, d_out_tag):
+        self._chk(self._lib.ecgpu_batch_mul_base_compressed_dev(self._ctx, curve, _dp(d_scalars), ctypes.c_size_t(n), _dp(d_out_x),
+                                                                _dp(d_out_tag)))
 
     def mul(self, curve, scalars, points_xy, points_inf=None):
         L = _field_bytes(curve)

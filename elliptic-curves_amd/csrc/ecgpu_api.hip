@@ -183,7 +183,7 @@ int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
 // ---- device-pointer implementations --------------------------------------------------------------------
 
 template <class C>
-int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf) {
+int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf, bool compressed = false) {
     constexpr int N = C::N, NS = Field<C>::NS;
     (void)N;
     int rc;
@@ -196,7 +196,13 @@ int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy
     launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_scalars, n, (const uint32_t*)t.d, t.w, t.nwin, (uint32_t*)ctx->proj.p,
                          ctx->d_status);
     record(ctx, 1);
-    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    if (compressed) {
+        if ((rc = ensure(ctx, ctx->prefix, n * NS * 4)) != ECGPU_OK) return rc;
+        launch_normalize_compressed<C>(ctx->stream, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, n, (uint8_t*)d_out_xy,
+                                       (uint8_t*)d_out_inf);
+    } else if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) {
+        return rc;
+    }
     record(ctx, 2);
     rc = finish(ctx);
     collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
@@ -629,6 +635,13 @@ int ecgpu_batch_mul_base_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, s
     return dispatch(curve, [&](auto c) { return mul_base_dev<decltype(c)>(ctx, d_scalars, n, d_out_xy, d_out_inf); });
 }
 
+int ecgpu_batch_mul_base_compressed_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, size_t n, void* d_out_x,
+                                        void* d_out_tag) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_out_x || !d_out_tag || !aligned16(d_scalars) || !aligned16(d_out_x))) return ECGPU_ERR_ARG;
+    return dispatch(curve, [&](auto c) { return mul_base_dev<decltype(c)>(ctx, d_scalars, n, d_out_x, d_out_tag, true); });
+}
+
 int ecgpu_batch_mul_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy,
                         const void* d_points_inf, size_t n, void* d_out_xy, void* d_out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
@@ -797,6 +810,26 @@ int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size
     if ((rc = ecgpu_batch_mul_base_dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
     if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_x,
+                                    uint8_t* out_tag) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return ECGPU_ERR_CURVE;
+    if (n && (!scalars || !out_x || !out_tag)) return ECGPU_ERR_ARG;
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_x, &ctx->out0, L}, {out_tag, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+            return ecgpu_batch_mul_base_compressed_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, m, (uint8_t*)ctx->out0.p + off * L,
+                                                       (uint8_t*)ctx->out1.p + off);
+        });
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_base_compressed_dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_x, ctx->out0, n * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_tag, ctx->out1, n);
 }
 
 int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy,

@@ -34,11 +34,20 @@ template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, cons
     }
     size_t nthreads = (n + k - 1) / k;
     if (out_internal)
-        hipLaunchKernelGGL((k_normalize<CurveT, true>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+        hipLaunchKernelGGL((k_normalize<CurveT, NORM_PACKED>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
                            out_xy, out_inf, out_limbs);
     else
-        hipLaunchKernelGGL((k_normalize<CurveT, false>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+        hipLaunchKernelGGL((k_normalize<CurveT, NORM_WIRE>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
                            out_xy, out_inf, out_limbs);
+}
+template <> void launch_normalize_compressed<CurveT>(hipStream_t s, const uint32_t* proj, uint32_t* prefix, size_t n,
+                                                     uint8_t* out_x, uint8_t* out_tag) {
+    if (n == 0) return;
+    size_t k = (n + 65535) / 65536;
+    if (k > 64) k = 64;
+    size_t nthreads = (n + k - 1) / k;
+    hipLaunchKernelGGL((k_normalize<CurveT, NORM_COMPRESSED>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                       out_x, out_tag, (uint32_t*)nullptr);
 }
 template <> void launch_fixed_base<CurveT>(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
                                            int nwin, uint32_t* proj_out, int* status) {

@@ -204,9 +204,13 @@ __global__ void __launch_bounds__(BLOCK) k_table_entries(const uint32_t* bases, 
 // `BatchNormalize::batch_normalize` (k256 projective.rs:367-391 + field.rs:244-265; primeorder
 // projective.rs:452-478).  Lane t owns points t, t+T, t+2T, ... so that a wave always touches
 // consecutive records; one field inversion per lane amortised over its K = n/T points.
-// OUT_PACKED = false: big-endian canonical x||y records + identity flags (wire format)
-// OUT_PACKED = true : [n][2] packed elements (table entries; identities not expected)
-template <class C, bool OUT_PACKED>
+// MODE NORM_WIRE      : big-endian canonical x||y records + identity flags (wire format)
+// MODE NORM_PACKED    : [n][2] packed elements (table entries; identities not expected)
+// MODE NORM_COMPRESSED: SEC1 compressed form split in two arrays: x (L bytes, to out_xy) and the tag byte 0x02 / 0x03
+//                       (y even / odd), 0x00 for the identity (to out_inf) — `ToSec1Point::to_sec1_point(true)`,
+//                       primeorder/src/affine.rs:387-401
+enum : int { NORM_WIRE = 0, NORM_PACKED = 1, NORM_COMPRESSED = 2 };
+template <class C, int MODE>
 __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint32_t* prefix, size_t n, size_t nthreads,
                                                      uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_packed) {
     using F = Field<C>;
@@ -236,12 +240,18 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
         uint32_t pw[NS];
         load_words_vec<NS>(pw, prefix + j * NS);
         if (pw[NS - 1]) {
-            if constexpr (!OUT_PACKED) {
+            if constexpr (MODE == NORM_WIRE) {
                 uint32_t zero[2 * N];
 #pragma unroll
                 for (int i = 0; i < 2 * N; i++) zero[i] = 0;
                 store_words_vec<2 * N>(reinterpret_cast<uint32_t*>(out_xy + j * (8 * N)), zero);
                 if (out_inf) out_inf[j] = 1;
+            } else if constexpr (MODE == NORM_COMPRESSED) {
+                uint32_t zero[N];
+#pragma unroll
+                for (int i = 0; i < N; i++) zero[i] = 0;
+                store_words_vec<N>(reinterpret_cast<uint32_t*>(out_xy + j * (4 * N)), zero);
+                out_inf[j] = 0;
             }
         } else {
             Fe<C::NL> pre_e;
@@ -251,8 +261,14 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
             typename F::M1 zinv = F::mul(pre, inv);
             inv = F::mul(inv, G::m(p.z));
             typename F::M1 x = F::mul(G::m(p.x), zinv), y = F::mul(G::m(p.y), zinv);
-            if constexpr (OUT_PACKED) {
+            if constexpr (MODE == NORM_PACKED) {
                 store_packed_affine<C>(out_packed + j * (2 * N), x.e, y.e);
+            } else if constexpr (MODE == NORM_COMPRESSED) {
+                uint32_t w[N];
+                F::to_canonical(w, x);
+                store_be_vec<N>(out_xy + j * (4 * N), w);
+                F::to_canonical(w, y);
+                out_inf[j] = (uint8_t)(2u + (w[0] & 1u));
             } else {
                 uint32_t w[N];
                 F::to_canonical(w, x);

@@ -39,6 +39,10 @@ unsafe extern "C" {
     pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
     pub fn ecgpu_batch_mul_base(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, n: usize,
                                 out_xy: *mut u8, out_inf: *mut u8) -> c_int;
+    pub fn ecgpu_batch_mul_base_compressed(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, n: usize,
+                                           out_x: *mut u8, out_tag: *mut u8) -> c_int;
+    pub fn ecgpu_batch_mul_base_compressed_dev(ctx: *mut EcgpuCtx, curve: c_int, d_scalars: *const c_void, n: usize,
+                                               d_out_x: *mut c_void, d_out_tag: *mut c_void) -> c_int;
     pub fn ecgpu_batch_mul(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8,
                            points_inf: *const u8, n: usize, out_xy: *mut u8, out_inf: *mut u8) -> c_int;
     pub fn ecgpu_msm(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8,

@@ -103,6 +103,13 @@ int ecgpu_set_msm_window(ecgpu_ctx *ctx, int window_bits);
 int ecgpu_batch_mul_base(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, size_t n,
                          uint8_t *out_xy, uint8_t *out_inf);
 
+/* The same with SEC1-compressed output, split in two arrays: out_x[i] = x of k[i] * G (L bytes), out_tag[i] = 0x02 / 0x03
+ * (y even / odd), 0x00 with x = 0 for the identity — tag || x is `to_sec1_point(true)` (primeorder/src/affine.rs:387-401,
+ * k256/src/arithmetic/affine.rs:341), what `PublicKey::to_sec1_bytes` ships.  Half the bytes of the x || y form come
+ * back over PCIe, which is what bounds the host-pointer rate. */
+int ecgpu_batch_mul_base_compressed(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, size_t n, uint8_t *out_x,
+                                    uint8_t *out_tag);
+
 /* out[i] = k[i] * P[i].
  * Batch form of `impl Mul<Scalar> for ProjectivePoint` (k256/src/arithmetic/mul.rs:249-274,
  * primeorder/src/projective.rs:847-886) / `MulVartime` (:888-921), followed by `to_affine`. */
@@ -141,6 +148,8 @@ int ecgpu_batch_normalize(ecgpu_ctx *ctx, int curve, const uint8_t *points_xyz, 
 
 int ecgpu_batch_mul_base_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, size_t n,
                              void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_mul_base_compressed_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, size_t n, void *d_out_x,
+                                        void *d_out_tag);
 int ecgpu_batch_mul_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,
                         const void *d_points_inf, size_t n, void *d_out_xy, void *d_out_inf);
 int ecgpu_msm_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,

@@ -732,3 +732,25 @@ def test_host_pointer_msm_in_chunks(eng):
     rest = (scalars_to_int_sum(k, c.L, c.n) - sum(int.from_bytes(bytes(k[i * c.L: (i + 1) * c.L]), "big") for i in drop)) % c.n
     w2, wf2 = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, rest))
     assert bytes(o2) == bytes(w2) and f2 == int(wf2[0])
+
+
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_fixed_base_compressed_output(eng, curve):
+    """tag || x of ecgpu_batch_mul_base_compressed is the SEC1 compressed encoding of the x || y result: 02 / 03 by the
+    parity of y, 00 and x = 0 for the identity; also through the pipelined host path (n >= 2^19)."""
+    c = pyec.CURVES[curve]
+    for n in (700, (1 << 19) + 77):
+        scal = rand_scalars(c.cid, n, 0xEC0000C7 + c.cid).copy()
+        scal[: c.L] = 0
+        scal[3 * c.L: 4 * c.L] = np.frombuffer(pyec.enc_scalar(c, c.n - 1), np.uint8)
+        xy, inf = eng.mul_by_generator(c.cid, scal)
+        x, tag = eng.mul_by_generator_compressed(c.cid, scal)
+        xy = xy.reshape(n, 2 * c.L)
+        assert bytes(x) == bytes(np.ascontiguousarray(xy[:, : c.L]))
+        want_tag = np.where(inf == 1, 0, 2 + (xy[:, 2 * c.L - 1] & 1)).astype(np.uint8)
+        assert bytes(tag) == bytes(want_tag) and tag[0] == 0 and not x[: c.L].any()
+    # against the big-int model's encoding of a few points
+    for i in (1, 2, 3):
+        k = int.from_bytes(bytes(scal[i * c.L: (i + 1) * c.L]), "big")
+        P = pyec.mul(c, k, pyec.G(c))
+        assert bytes(x[i * c.L: (i + 1) * c.L]) == P[0].to_bytes(c.L, "big") and tag[i] == 2 + (P[1] & 1)
