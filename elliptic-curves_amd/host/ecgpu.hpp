@@ -195,6 +195,22 @@ struct Curve {
         e.check(ecgpu_batch_mul_base(e.ctx(), ID, s.data(), n, xy.data(), inf.data()));
         return unpack(xy, inf);
     }
+    // k_i * G as SEC1 compressed points (tag || x, tag = 02 / 03, a single 00 byte's worth of zeros for the identity):
+    // `(ProjectivePoint::mul_by_generator(k)).to_affine().to_sec1_point(true)` for a batch
+    using CompressedPoint = std::array<uint8_t, L + 1>;
+    static std::vector<CompressedPoint> batch_mul_by_generator_compressed(const std::vector<Scalar>& ks) {
+        size_t n = ks.size();
+        std::vector<uint8_t> s(n * L), x(n * L), tag(n);
+        for (size_t i = 0; i < n; i++) std::memcpy(&s[i * L], ks[i].repr.data(), L);
+        Engine& e = Engine::global();
+        e.check(ecgpu_batch_mul_base_compressed(e.ctx(), ID, s.data(), n, x.data(), tag.data()));
+        std::vector<CompressedPoint> out(n);
+        for (size_t i = 0; i < n; i++) {
+            out[i][0] = tag[i];
+            std::memcpy(&out[i][1], &x[i * L], L);
+        }
+        return out;
+    }
     static std::vector<ProjectivePoint> batch_mul(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks) {
         size_t n = ks.size();
         if (ps.size() != n) throw Error(ECGPU_ERR_ARG, "batch_mul: length mismatch");
