@@ -42,11 +42,11 @@ struct ecgpu_ctx {
     std::string err;
     int* d_status = nullptr;
     int* h_status = nullptr;
-    Table table[4];
+    Table table[5];
     // fixed-base comb width: every addition removed is worth 8 % and HBM keeps up with the gathers, so the tables are
     // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
     // p256 and sm2: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
-    int want_w[4] = {26, 24, 20, 24};
+    int want_w[5] = {26, 24, 20, 24, 24};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r;   // signature verification scratch
@@ -86,6 +86,7 @@ int dispatch(int curve, F&& f) {
     case ECGPU_P256: return f(P256Params{});
     case ECGPU_P384: return f(P384Params{});
     case ECGPU_SM2: return f(Sm2Params{});
+    case ECGPU_P224: return f(P224Params{});
     default: return ECGPU_ERR_CURVE;
     }
 }
@@ -530,6 +531,7 @@ size_t ecgpu_field_bytes(int curve) {
     case ECGPU_K256: case ECGPU_P256: return 32;
     case ECGPU_P384: return 48;
     case ECGPU_SM2: return 32;
+    case ECGPU_P224: return 28;
     default: return 0;
     }
 }
@@ -605,7 +607,7 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 }
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
-    if (!ctx || curve < 0 || curve > 3) return ECGPU_ERR_CURVE;
+    if (!ctx || curve < 0 || curve > 4) return ECGPU_ERR_CURVE;
     if (window_bits < 4 || window_bits > 26) return ECGPU_ERR_ARG;
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
@@ -775,6 +777,10 @@ int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, cons
                                void* d_ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_xs || !d_y_is_odd || !d_out_xy || !d_ok || !aligned16(d_xs) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    if (curve == ECGPU_P224) {              // p = 1 (mod 4): no square root by one exponentiation
+        ctx->err = "point decompression is not available for p224";
+        return ECGPU_ERR_CURVE;
+    }
     return dispatch(curve, [&](auto c) {
         using C = decltype(c);
         if (n == 0) return (int)ECGPU_OK;

@@ -295,6 +295,29 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
+        if constexpr (!PC::P0_IS_MINUS_ONE) {
+            // p = 1 (mod 2^B), as for p224: -p^-1 = -1, u = -c_i mod 2^B, and u * p0 = u clears the low bits of c_i
+            // (model: tools/field_model.py umont_mul_general)
+            static_assert(PC::P[0] == 1, "generic Montgomery rows: p0 must be 2^B - 1 or 1");
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                uint32_t u = (0u - (uint32_t)c[i]) & PMASK;
+                c[i + 1] += (c[i] + u) >> UB;
+#pragma unroll
+                for (int j = 1; j < UN; j++) {
+                    if (PC::P[j] != 0) c[i + j] += (uint64_t)u * opaque_const(PC::P[j]);
+                }
+            }
+            E r;
+            uint64_t v = c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
 #pragma unroll
         for (int i = 0; i < UN; i++) {
             uint32_t u = (uint32_t)c[i] & PMASK;
@@ -686,7 +709,15 @@ struct Field {
             uint32_t e[N];
 #pragma unroll
             for (int i = 0; i < N; i++) e[i] = C::P[i];
-            e[0] -= 2;   // p is odd and its low word is >= 2
+            {            // e = p - 2 (the low word of p224's p is 1: the borrow runs up)
+                uint32_t borrow = 2;
+#pragma unroll
+                for (int i = 0; i < N; i++) {
+                    const uint32_t v = e[i];
+                    e[i] = v - borrow;
+                    borrow = v < borrow ? 1u : 0u;
+                }
+            }
             M1 r = one();
 #pragma unroll 1
             for (int i = 8 * N - 1; i >= 0; i--) {

@@ -28,20 +28,31 @@ constexpr int BLOCK = 256;
 
 // ---- 16-byte vector access helpers ---------------------------------------------------------------
 
+// (NW a multiple of 4: 16-byte accesses; otherwise — the 28-byte records and 56-byte packed points of p224 — 32-bit ones)
 template <int NW>
 __device__ __forceinline__ void load_words_vec(uint32_t* dst, const uint32_t* src) {
-    const uint4* s = reinterpret_cast<const uint4*>(src);
+    if constexpr (NW % 4 == 0) {
+        const uint4* s = reinterpret_cast<const uint4*>(src);
 #pragma unroll
-    for (int i = 0; i < NW / 4; i++) {
-        uint4 v = s[i];
-        dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        for (int i = 0; i < NW / 4; i++) {
+            uint4 v = s[i];
+            dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) dst[i] = src[i];
     }
 }
 template <int NW>
 __device__ __forceinline__ void store_words_vec(uint32_t* dst, const uint32_t* src) {
-    uint4* d = reinterpret_cast<uint4*>(dst);
+    if constexpr (NW % 4 == 0) {
+        uint4* d = reinterpret_cast<uint4*>(dst);
 #pragma unroll
-    for (int i = 0; i < NW / 4; i++) d[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+        for (int i = 0; i < NW / 4; i++) d[i] = make_uint4(src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NW; i++) dst[i] = src[i];
+    }
 }
 // big-endian record of NW words -> little-endian words
 template <int NW>

@@ -13,7 +13,7 @@
 //   * (f, g) <- t (f, g) / 2^30 exactly, and (d, e) <- t (d, e) / 2^30 mod p, made exact by adding the multiple of p
 //     that clears the low 30 bits;
 //   * after enough steps g = 0, f = +-1 and d = +-x^-1.
-// Division-step counts: 590 suffice for 256-bit inputs (20 batches), 886 for 384-bit inputs (31 batches = 930 here,
+// Division-step counts: 518 suffice for 224-bit inputs (18 batches), 590 for 256-bit inputs (20 batches), 886 for 384-bit inputs (31 batches = 930 here,
 // extra steps are harmless once g = 0).
 #pragma once
 
@@ -23,11 +23,11 @@
 
 namespace ecgpu {
 
-template <int NW>          // modulus size in 32-bit words: 8 or 12
+template <int NW>          // modulus size in 32-bit words: 7, 8 or 12
 struct ModInv {
-    static_assert(NW == 8 || NW == 12, "256- or 384-bit moduli");
-    ECGPU_CONST int NL = NW == 8 ? 9 : 13;          // signed 30-bit limbs (2 spare bits above the modulus)
-    ECGPU_CONST int BATCHES = NW == 8 ? 20 : 31;
+    static_assert(NW == 7 || NW == 8 || NW == 12, "224-, 256- or 384-bit moduli");
+    ECGPU_CONST int NL = NW == 7 ? 8 : NW == 8 ? 9 : 13;          // signed 30-bit limbs (2 spare bits above the modulus)
+    ECGPU_CONST int BATCHES = NW == 7 ? 18 : NW == 8 ? 20 : 31;   // (45907 bits + 26313) / 19929 steps: 518 / 591 / 886
     ECGPU_CONST int32_t M30 = (int32_t)((1u << 30) - 1);
 
     struct S30 {

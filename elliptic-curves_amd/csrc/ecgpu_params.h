@@ -17,7 +17,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -246,6 +246,30 @@ struct Sm2Params {
                                     0x6A39C994u, 0x5F990446u, 0x1F198119u, 0x32C4AE2Cu};
     ECGPU_CONST uint32_t GY[8] = {0x2139F0A0u, 0x02DF32E5u, 0xC62A4740u, 0xD0A9877Cu,
                                     0x6B692153u, 0x59BDCEE3u, 0xF4F6779Cu, 0xBC3736A2u};
+};
+
+// NIST P-224: 7 canonical words (28-byte wire records: 4-byte aligned only), 9 limbs x 27 bits.  p = 1 (mod 4): no
+// square root by a single exponentiation, so point decompression is not offered for this curve.
+struct P224Params {
+    ECGPU_CONST int ID = CURVE_P224;
+    ECGPU_CONST int N = 7;
+    ECGPU_CONST int NL = 9;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::P224U;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p224/src/arithmetic.rs:41-45
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^224 - 2^96 + 1                          p224/src/arithmetic/field.rs:54-61
+    ECGPU_CONST uint32_t P[7] = {0x00000001u, 0x00000000u, 0x00000000u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // n                                            p224/src/lib.rs:50-55
+    ECGPU_CONST uint32_t ORDER[7] = {0x5C5C2A3Du, 0x13DD2945u, 0xE0B8F03Eu, 0xFFFF16A2u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^224): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[7] = {0x3AD01289u, 0x6BDAAE6Cu, 0x97A54552u, 0x6AD09D91u, 0xB1E97961u, 0x1822BC47u, 0xD4BAA4CFu};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x6A1FC2EBu;
+    // curve b, canonical                           p224/src/arithmetic.rs:47-50
+    ECGPU_CONST uint32_t B[7] = {0x2355FFB4u, 0x270B3943u, 0xD7BFD8BAu, 0x5044B0B7u, 0xF5413256u, 0x0C04B3ABu, 0xB4050A85u};
+    // generator, canonical                         p224/src/arithmetic.rs:52-62
+    ECGPU_CONST uint32_t GX[7] = {0x115C1D21u, 0x343280D6u, 0x56C21122u, 0x4A03C1D3u, 0x321390B9u, 0x6BB4BF7Fu, 0xB70E0CBDu};
+    ECGPU_CONST uint32_t GY[7] = {0x85007E34u, 0x44D58199u, 0x5A074764u, 0xCD4375A0u, 0x4C22DFE6u, 0xB5F723FBu, 0xBD376388u};
 };
 
 }  // namespace ecgpu

@@ -324,5 +324,6 @@ using k256 = Curve<ECGPU_K256, 32>;
 using p256 = Curve<ECGPU_P256, 32>;
 using p384 = Curve<ECGPU_P384, 48>;
 using sm2 = Curve<ECGPU_SM2, 32>;
+using p224 = Curve<ECGPU_P224, 28>;   // no point decompression (p = 1 mod 4)
 
 }  // namespace ecgpu_host

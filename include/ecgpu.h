@@ -46,7 +46,7 @@ extern "C" {
 
 typedef struct ecgpu_ctx ecgpu_ctx;
 
-enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3 };
+enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3, ECGPU_P224 = 4 };
 
 enum {
     ECGPU_OK = 0,

@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "ecref.h"
+#include "ecref_internal.h"
 
 typedef unsigned __int128 u128;
 
@@ -31,6 +32,9 @@ static const uint64_t ORDER_P256[6] = {0xF3B9CAC2FC632551ull, 0xBCE6FAADA7179E84
                                        0xFFFFFFFF00000000ull, 0, 0};
 static const uint64_t ORDER_P384[6] = {0xECEC196ACCC52973ull, 0x581A0DB248B0A77Aull, 0xC7634D81F4372DDFull,
                                        0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull};
+
+static const uint64_t ORDER_P224[4] = {0x13DD29455C5C2A3Dull, 0xFFFF16A2E0B8F03Eull, 0xFFFFFFFFFFFFFFFFull,
+                                       0x00000000FFFFFFFFull};       /* p224/src/lib.rs:50-55 */
 
 typedef struct {
     int nl;               /* 64-bit words */
@@ -70,7 +74,7 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
 }
 static void modn_init(modn_t *m, int curve) {
     m->nl = curve == ECREF_P384 ? 6 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : (curve == ECREF_P256 ? ORDER_P256 : ORDER_P384);
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -124,31 +128,25 @@ static void inv_mod(uint64_t *r, const uint64_t *a, const modn_t *m) {
     }
     memcpy(r, acc, 8 * m->nl);
 }
-static void from_be(uint64_t *w, const uint8_t *b, int nl) {
-    for (int i = 0; i < nl; i++) {
-        uint64_t v = 0;
-        for (int j = 0; j < 8; j++) v = (v << 8) | b[8 * (nl - 1 - i) + j];
-        w[i] = v;
-    }
-}
-static void to_be(uint8_t *b, const uint64_t *w, int nl) {
-    for (int i = 0; i < nl; i++)
-        for (int j = 0; j < 8; j++) b[8 * (nl - 1 - i) + j] = (uint8_t)(w[i] >> (56 - 8 * j));
-}
+static void from_be(uint64_t *w, const uint8_t *b, int nl) { ecref_be_to_words_n(b, 8 * (size_t)nl, w, (size_t)nl); }
+static void to_be(uint8_t *b, const uint64_t *w, int nl) { ecref_words_to_be_n(w, b, 8 * (size_t)nl); }
+/* L-byte records that need not fill the words (P-224: 28 bytes in 4 words) */
+static void from_be_len(uint64_t *w, const uint8_t *b, size_t len, int nl) { ecref_be_to_words_n(b, len, w, (size_t)nl); }
+static void to_be_len(uint8_t *b, const uint64_t *w, size_t len) { ecref_words_to_be_n(w, b, len); }
 
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
                              size_t n, int reject_high_s, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;
-    const size_t L = 8 * (size_t)nl;
+    const size_t L = curve == ECREF_P224 ? 28 : 8 * (size_t)nl;
     for (size_t i = 0; i < n; i++) {
         uint64_t zw[6], rw[6], sw[6], w[6], u1[6], u2[6];
         ok[i] = 0;
-        from_be(zw, z + L * i, nl);
-        from_be(rw, r + L * i, nl);
-        from_be(sw, s + L * i, nl);
+        from_be_len(zw, z + L * i, L, nl);
+        from_be_len(rw, r + L * i, L, nl);
+        from_be_len(sw, s + L * i, L, nl);
         if (is_zero(rw, nl) || geq(rw, m.n, nl) || is_zero(sw, nl) || geq(sw, m.n, nl)) continue;
         if (reject_high_s) {
             uint64_t twice[6];
@@ -163,12 +161,12 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
         mul_mod(u1, zw, w, &m);
         mul_mod(u2, rw, w, &m);
         uint8_t a[48], b[48], xy[96], inf = 0;
-        to_be(a, u1, nl);
-        to_be(b, u2, nl);
+        to_be_len(a, u1, L);
+        to_be_len(b, u2, L);
         if (ecref_mul_base_and_mul_add_vartime(curve, a, b, q_xy + 2 * L * i, 0, xy, &inf) != ECREF_OK) continue;
         if (inf) continue;
         uint64_t x[6];
-        from_be(x, xy, nl);
+        from_be_len(x, xy, L, nl);
         if (geq(x, m.n, nl)) sub_n(x, m.n, nl);                 /* x < p < 2n */
         ok[i] = memcmp(x, rw, 8 * nl) == 0;
     }

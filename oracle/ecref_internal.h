@@ -35,6 +35,14 @@ static inline void ecref_words_to_be(const uint64_t *w, size_t nw, uint8_t *b) {
         for (int j = 7; j >= 0; j--) { p[j] = (uint8_t)v; v >>= 8; }
     }
 }
+/* the same for byte lengths that are not a multiple of 8 (P-224: 28 bytes in 4 words) */
+static inline void ecref_be_to_words_n(const uint8_t *b, size_t len, uint64_t *w, size_t nw) {
+    for (size_t i = 0; i < nw; i++) w[i] = 0;
+    for (size_t i = 0; i < len && i < 8 * nw; i++) w[i / 8] |= (uint64_t)b[len - 1 - i] << (8 * (i % 8));
+}
+static inline void ecref_words_to_be_n(const uint64_t *w, uint8_t *b, size_t len) {
+    for (size_t i = 0; i < len; i++) b[len - 1 - i] = (uint8_t)(w[i / 8] >> (8 * (i % 8)));
+}
 static inline void ecref_words_to_le(const uint64_t *w, size_t nw, uint8_t *b) {
     for (size_t i = 0; i < nw; i++)
         for (int j = 0; j < 8; j++) b[8 * i + j] = (uint8_t)(w[i] >> (8 * j));
@@ -107,5 +115,6 @@ ECREF_DECL_CURVE(k256)
 ECREF_DECL_CURVE(p256)
 ECREF_DECL_CURVE(p384)
 ECREF_DECL_CURVE(sm2)
+ECREF_DECL_CURVE(p224)
 
 #endif

@@ -474,3 +474,101 @@ static int sm2_fe_sqrt(fe_sm2 *out, const fe_sm2 *a) {
 #define PO_GX SM2_GX
 #define PO_GY SM2_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * P-224 field (generic Montgomery with R = 2^256 on four 64-bit words, crypto-bigint ConstMontyForm semantics:
+ * p224/src/arithmetic/field.rs:54-70 -> primefield::MontyFieldElement, like p384; the reference's default backend is the
+ * fiat-crypto code for the same Montgomery arithmetic) - SURVEY.md 8(f) rank 4.  Wire elements are 28 bytes.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe_p224;
+
+static const uint64_t P224_P[4] = {                     /* p224/src/arithmetic/field.rs:54-61 */
+    0x0000000000000001ULL, 0xFFFFFFFF00000000ULL, 0xFFFFFFFFFFFFFFFFULL, 0x00000000FFFFFFFFULL};
+static const uint64_t P224_N[4] = {                     /* p224/src/lib.rs:50-55 */
+    0x13DD29455C5C2A3DULL, 0xFFFF16A2E0B8F03EULL, 0xFFFFFFFFFFFFFFFFULL, 0x00000000FFFFFFFFULL};
+static const uint8_t P224_B_BYTES[28] = {               /* p224/src/arithmetic.rs:47-50 */
+    0xb4, 0x05, 0x0a, 0x85, 0x0c, 0x04, 0xb3, 0xab, 0xf5, 0x41, 0x32, 0x56, 0x50, 0x44, 0xb0, 0xb7, 0xd7, 0xbf, 0xd8, 0xba, 0x27, 0x0b, 0x39, 0x43, 0x23, 0x55, 0xff, 0xb4};
+static const uint8_t P224_GX[28] = {                    /* p224/src/arithmetic.rs:52-62 */
+    0xb7, 0x0e, 0x0c, 0xbd, 0x6b, 0xb4, 0xbf, 0x7f, 0x32, 0x13, 0x90, 0xb9, 0x4a, 0x03, 0xc1, 0xd3, 0x56, 0xc2, 0x11, 0x22, 0x34, 0x32, 0x80, 0xd6, 0x11, 0x5c, 0x1d, 0x21};
+static const uint8_t P224_GY[28] = {
+    0xbd, 0x37, 0x63, 0x88, 0xb5, 0xf7, 0x23, 0xfb, 0x4c, 0x22, 0xdf, 0xe6, 0xcd, 0x43, 0x75, 0xa0, 0x5a, 0x07, 0x47, 0x64, 0x44, 0xd5, 0x81, 0x99, 0x85, 0x00, 0x7e, 0x34};
+
+static fe_p224 P224_R, P224_R2, P224_B_MONT;
+static uint64_t P224_MINV;
+static int p224_ready;
+
+static fe_p224 p224_fe_mul(const fe_p224 *a, const fe_p224 *b) {       /* monty.rs:346-350 */
+    uint64_t t[8];
+    fe_p224 r;
+    ecref_mp_mul(t, a->w, b->w, 4);
+    mont_reduce(r.w, t, P224_P, P224_MINV, 4);
+    return r;
+}
+static fe_p224 p224_fe_sqr(const fe_p224 *a) { return p224_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_p224 p224_fe_add(const fe_p224 *a, const fe_p224 *b) { fe_p224 r; mont_add(r.w, a->w, b->w, P224_P, 4); return r; }   /* :316-320 */
+static fe_p224 p224_fe_sub(const fe_p224 *a, const fe_p224 *b) { fe_p224 r; mont_sub(r.w, a->w, b->w, P224_P, 4); return r; }   /* :331-335 */
+static fe_p224 p224_fe_zero(void) { fe_p224 z; memset(&z, 0, sizeof z); return z; }
+static fe_p224 p224_fe_neg(const fe_p224 *a) { fe_p224 z = p224_fe_zero(); return p224_fe_sub(&z, a); }                         /* :353-357 */
+static fe_p224 p224_fe_dbl(const fe_p224 *a) { return p224_fe_add(a, a); }                                                     /* :323-327 */
+static int p224_fe_is_zero(const fe_p224 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void p224_init(void) {
+    if (p224_ready) return;
+    P224_MINV = mont_neg_inv64(P224_P[0]);
+    mont_pow2_mod(P224_R.w, P224_P, 4, 256);
+    mont_pow2_mod(P224_R2.w, P224_P, 4, 512);
+    fe_p224 b;
+    ecref_be_to_words_n(P224_B_BYTES, 28, b.w, 4);
+    P224_B_MONT = p224_fe_mul(&b, &P224_R2);
+    p224_ready = 1;
+}
+static fe_p224 p224_fe_one(void) { p224_init(); return P224_R; }
+static fe_p224 p224_fe_b(void) { p224_init(); return P224_B_MONT; }
+
+static int p224_fe_from_bytes(fe_p224 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    p224_init();
+    fe_p224 t;
+    ecref_be_to_words_n(b, 28, t.w, 4);
+    if (ecref_mp_cmp(t.w, P224_P, 4) >= 0) return 0;
+    *r = p224_fe_mul(&t, &P224_R2);
+    return 1;
+}
+static void p224_fe_to_bytes(uint8_t *out, const fe_p224 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[8];
+    fe_p224 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 32);
+    mont_reduce(c.w, t, P224_P, P224_MINV, 4);
+    ecref_words_to_be_n(c.w, out, 28);
+}
+static int p224_fe_invert(fe_p224 *out, const fe_p224 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (p224_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, P224_P, two, 4);
+    fe_p224 r = p224_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = p224_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p224_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* p = 1 (mod 4): no single-exponentiation square root; decompression is not offered for this curve (the device
+ * library returns an error for it as well). */
+static int p224_fe_sqrt(fe_p224 *out, const fe_p224 *a) {
+    (void)a;
+    *out = p224_fe_zero();
+    return 0;
+}
+
+#define PO_PFX p224
+#define PO_NL 4
+#define PO_L 28
+#define PO_FE fe_p224
+#define PO_F(name) p224_fe_##name
+#define PO_ORDER P224_N
+#define PO_GX P224_GX
+#define PO_GY P224_GY
+#include "ecref_prime.inc"

@@ -53,7 +53,15 @@ SM2 = Curve(                                                   # sm2/src/arithme
     0x32C4AE2C1F1981195F9904466A39C9948FE30BBFF2660BE1715A4589334C74C7,
     0xBC3736A2F4F6779C59BDCEE36B692153D0A9877CC62A474002DF32E52139F0A0,
 )
-CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2}
+P224 = Curve(                                                  # p224/src/arithmetic.rs:41-62, field.rs:54-61, lib.rs:50-55
+    "p224", 4, 28,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF000000000000000000000001,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFF16A2E0B8F03E13DD29455C5C2A3D,
+    -3, 0xB4050A850C04B3ABF54132565044B0B7D7BFD8BA270B39432355FFB4,
+    0xB70E0CBD6BB4BF7F321390B94A03C1D356C21122343280D6115C1D21,
+    0xBD376388B5F723FB4C22DFE6CD4375A05A07476444D5819985007E34,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224}
 
 # secp256k1 endomorphism constants (k256/src/arithmetic/mul.rs:4-5, projective.rs:31-37)
 K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72

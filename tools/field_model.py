@@ -211,6 +211,41 @@ def umont_mul(a, b, nl, bits, plimbs):
     return r
 
 
+P224_P = 2 ** 224 - 2 ** 96 + 1                  # p224/src/arithmetic/field.rs:54-61
+
+
+def umont_mul_general(a, b, nl, bits, plimbs, c_extra=None):
+    """unsaturated Montgomery multiplication for any odd p: u = c_i * (-p^-1) mod 2^bits, c += u * p, every accumulator
+    checked.  For p224, p = 1 mod 2^28, so -p^-1 = -1 and u = -c_i mod 2^28."""
+    mask = (1 << bits) - 1
+    pinv = (-pow(from_limbs(plimbs, bits), -1, 1 << bits)) % (1 << bits)
+    c = [0] * (2 * nl + 1)
+    for i in range(nl):
+        for j in range(nl):
+            c[i + j] = chk64(c[i + j] + chk32(a[i]) * chk32(b[j]))
+    if c_extra is not None:
+        for i in range(nl):
+            for j in range(nl):
+                c[i + j] = chk64(c[i + j] + chk32(c_extra[0][i]) * chk32(c_extra[1][j]))
+    for i in range(nl):
+        u = (c[i] * pinv) & mask
+        for j in range(nl):
+            if plimbs[j]:
+                c[i + j] = chk64(c[i + j] + u * plimbs[j])
+        assert c[i] & mask == 0
+        c[i + 1] = chk64(c[i + 1] + (c[i] >> bits))
+    r = [0] * nl
+    carry = 0
+    for k in range(nl):
+        v = chk64(c[nl + k] + carry)
+        if k < nl - 1:
+            r[k] = v & mask
+            carry = v >> bits
+        else:
+            r[k] = chk32(v)
+    return r
+
+
 # ------------------------------------------------------------------------------------------------
 # subtraction constants: a multiple of p whose limbs all dominate a magnitude-M element
 # ------------------------------------------------------------------------------------------------
