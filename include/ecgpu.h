@@ -11,7 +11,8 @@
  * Wire format (identical for host- and device-pointer entry points)
  *   scalars   n * L bytes, big-endian, canonical (< group order n) — `Scalar::to_repr`
  *             (k256/src/arithmetic/scalar.rs:310-316, primefield/src/monty.rs:498-500);
- *             L = 32 (k256, p256) or 48 (p384) = `FieldBytesSize`.
+ *             L = 32 (k256, p256, sm2), 48 (p384) or 28 (p224) = `FieldBytesSize`.  Records are packed without padding
+ *             (p224: 28-byte scalars, 56-byte points); only the base pointers of device buffers must be 16-byte aligned.
  *   points    n * 2L bytes, big-endian affine x || y — `AffinePoint::{x,y}`
  *             (primeorder/src/affine.rs:106-112) + optional n-byte identity flags
  *             (`AffinePoint::infinity`, k256/src/arithmetic/affine.rs:45-49); NULL flags = none.
@@ -70,7 +71,7 @@ void ecgpu_destroy(ecgpu_ctx *ctx);
 /* Human-readable text of the last error on this context (valid until the next call). */
 const char *ecgpu_last_error(const ecgpu_ctx *ctx);
 
-/* Field-byte length L of a curve (32 / 48), 0 for a bad id. */
+/* Field-byte length L of a curve (32 / 48 / 28), 0 for a bad id. */
 size_t ecgpu_field_bytes(int curve);
 
 /* Use an externally owned HIP stream (e.g. torch's current stream) for all later work on this
@@ -233,7 +234,7 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const
  * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;
  * BIP340 `decompact` = y_is_odd 0).  xs n*L bytes big-endian, y_is_odd n bytes.  out_xy[i] = (x, y) with
  * y^2 = x^3 + a x + b and the requested parity and ok[i] = 1, or a zero record and ok[i] = 0 when x >= p or
- * no such y exists (the reference's `CtOption::None`). */
+ * no such y exists (the reference's `CtOption::None`).   ECGPU_ERR_CURVE for p224 (p = 1 mod 4: no square root by a single exponentiation). */
 int ecgpu_batch_decompress(ecgpu_ctx *ctx, int curve, const uint8_t *xs, const uint8_t *y_is_odd,
                            size_t n, uint8_t *out_xy, uint8_t *ok);
 int ecgpu_batch_decompress_dev(ecgpu_ctx *ctx, int curve, const void *d_xs, const void *d_y_is_odd,
