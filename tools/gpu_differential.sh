@@ -20,7 +20,7 @@ def par(fn, n, L, *arrs):
         return fn(lo, hi)
     with ThreadPoolExecutor(T) as ex:
         return [r for r in ex.map(run, range(T)) if r is not None]
-for name in ("k256", "p256", "p384", "sm2"):
+for name in ("k256", "p256", "p384", "sm2", "p224"):
     c = pyec.CURVES[name]; L = c.L
     t0 = time.time()
     n = 1 << 17
@@ -53,7 +53,7 @@ for name in ("k256", "p256", "p384", "sm2"):
     w, wf = pyec.enc_point(c, tot)
     ok5 = bytes(o) == bytes(w) and f == int(wf)
     ok4 = None
-    if name != "sm2":
+    if name != "sm2":   # sm2 signatures are SM2DSA
         # ecdsa random verdicts
         z, r, s_ = (rand_scalars(c.cid, 8192, 0xD3FF + c.cid + i) for i in range(3))
         v = e.ecdsa_verify(c.cid, z, r, s_, got[: 8192 * 2 * L])
