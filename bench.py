@@ -187,6 +187,7 @@ def main():
     if kind in ("var", "msm"):
         d_s2 = device_random_scalars(torch, n, L, seed + 50, device)
         d_pts = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()
         eng.mul_by_generator_dev(cid, d_s2, n, d_pts, None)          # P_i = s_i * G (untimed setup)
         del d_s2
     d_r = d_s = d_ok = None
@@ -197,6 +198,7 @@ def main():
         d_k = device_random_scalars(torch, m, L, seed + 51, device)
         d_Q = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
         d_R = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
+        torch.cuda.synchronize()
         eng.mul_by_generator_dev(cid, d_d, m, d_Q, None)
         eng.mul_by_generator_dev(cid, d_k, m, d_R, None)
         torch.cuda.synchronize()
@@ -219,6 +221,7 @@ def main():
     d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
     d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
     exchange = ecgpu.TensorExchange(torch, dist, L, device) if kind == "msm" and world > 1 else None
+    torch.cuda.synchronize()     # inputs were written on torch's stream; the engine works on its own (non-blocking) stream
 
     main_ms = []
 

@@ -80,4 +80,8 @@ class TensorExchange:
         self.dist.all_gather_into_tensor(self.all.view(-1), self.rec)
         pts = self.all[:, : 2 * L].contiguous()
         flags = self.all[:, 2 * L].contiguous()
+        if pts.is_cuda:
+            # the collective and the slicing run on torch's streams; the engine enqueues on its own stream, which is not
+            # ordered after them (include/ecgpu.h, device-pointer entry points): wait for the gathered bytes first
+            self.torch.cuda.current_stream(pts.device).synchronize()
         point_sum(pts, flags, self.world, out_xy, out_inf)
