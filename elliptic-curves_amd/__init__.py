@@ -8,6 +8,10 @@ it); the product is the shared library.  The directory name contains a hyphen, s
 There is no CPU fallback: `Engine()` raises `EcgpuError` when the HIP extension is missing or no
 gfx950 device is usable.
 
+In a process that also uses torch, import torch FIRST: libecgpu.so then binds to the HIP runtime torch ships.  The
+other order leaves two HIP runtimes in the process and torch reports "No HIP GPUs are available"
+(tests/gpu_dev_pointer_check.py is the working arrangement).
+
 Operation names follow the reference's trait surface (RustCrypto/elliptic-curves):
     mul_by_generator          ProjectivePoint::mul_by_generator / MulBackend::mul_by_generator
     mul                       impl Mul<Scalar> for ProjectivePoint

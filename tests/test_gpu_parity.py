@@ -754,3 +754,13 @@ def test_fixed_base_compressed_output(eng, curve):
         k = int.from_bytes(bytes(scal[i * c.L: (i + 1) * c.L]), "big")
         P = pyec.mul(c, k, pyec.G(c))
         assert bytes(x[i * c.L: (i + 1) * c.L]) == P[0].to_bytes(c.L, "big") and tag[i] == 2 + (P[1] & 1)
+
+
+def test_device_pointer_entry_points():
+    """The *_dev forms on torch tensors (what bench.py and a torch-based caller use) give the same bytes as the
+    host-pointer forms: tests/gpu_dev_pointer_check.py, in a process of its own — torch has to be imported before
+    libecgpu.so so that both use the HIP runtime torch ships."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "gpu_dev_pointer_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "device-pointer entry points: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
