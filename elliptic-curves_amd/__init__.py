@@ -27,9 +27,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libecgpu.so")
 
-K256, P256, P384, SM2, P224 = 0, 1, 2, 3, 4
-CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224}
-FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28}
+K256, P256, P384, SM2, P224, P192 = 0, 1, 2, 3, 4, 5
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24}
 
 OK = 0
 ERR_CURVE, ERR_SCALAR_RANGE, ERR_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_ARG = -1, -2, -3, -4, -5, -6, -7
@@ -55,6 +55,7 @@ GROUP_ORDERS = {   # k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73
     2: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFC7634D81F4372DDF581A0DB248B0A77AECEC196ACCC52973,
     3: 0xFFFFFFFEFFFFFFFFFFFFFFFFFFFFFFFF7203DF6B21C6052B53BBF40939D54123,   # sm2/src/lib.rs:86
     4: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFF16A2E0B8F03E13DD29455C5C2A3D,           # p224/src/lib.rs:50-55
+    5: 0xFFFFFFFFFFFFFFFFFFFFFFFF99DEF836146BC9B1B4D22831,                   # p192/src/lib.rs:41
 }
 
 

@@ -53,7 +53,7 @@ template <class C>
 struct Field {
     ECGPU_CONST int N = C::N;     // canonical 32-bit words
     ECGPU_CONST int NL = C::NL;   // limbs in registers
-    ECGPU_CONST int NS = (C::NL + 3) / 4 * 4;   // words of the raw (lazy) storage form, 16-byte multiple
+    ECGPU_CONST int NS = (C::NL / 4 + 1) * 4;   // words of the raw (lazy) storage form: a 16-byte multiple with at least one spare word
     ECGPU_CONST int REPR = C::REPR;
     using E = Fe<C::NL>;
     using M1 = Mag<C, 1, 1>;

@@ -23,11 +23,11 @@
 
 namespace ecgpu {
 
-template <int NW>          // modulus size in 32-bit words: 7, 8 or 12
+template <int NW>          // modulus size in 32-bit words: 6, 7, 8 or 12
 struct ModInv {
-    static_assert(NW == 7 || NW == 8 || NW == 12, "224-, 256- or 384-bit moduli");
-    ECGPU_CONST int NL = NW == 7 ? 8 : NW == 8 ? 9 : 13;          // signed 30-bit limbs (2 spare bits above the modulus)
-    ECGPU_CONST int BATCHES = NW == 7 ? 18 : NW == 8 ? 20 : 31;   // (45907 bits + 26313) / 19929 steps: 518 / 591 / 886
+    static_assert(NW == 6 || NW == 7 || NW == 8 || NW == 12, "192-, 224-, 256- or 384-bit moduli");
+    ECGPU_CONST int NL = NW == 6 ? 7 : NW == 7 ? 8 : NW == 8 ? 9 : 13;          // signed 30-bit limbs (2 spare bits above the modulus)
+    ECGPU_CONST int BATCHES = NW == 6 ? 15 : NW == 7 ? 18 : NW == 8 ? 20 : 31;  // (45907 bits + 26313) / 19929 steps: 444 / 518 / 591 / 886
     ECGPU_CONST int32_t M30 = (int32_t)((1u << 30) - 1);
 
     struct S30 {

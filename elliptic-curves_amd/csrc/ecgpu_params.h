@@ -17,7 +17,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -270,6 +270,29 @@ struct P224Params {
     // generator, canonical                         p224/src/arithmetic.rs:52-62
     ECGPU_CONST uint32_t GX[7] = {0x115C1D21u, 0x343280D6u, 0x56C21122u, 0x4A03C1D3u, 0x321390B9u, 0x6BB4BF7Fu, 0xB70E0CBDu};
     ECGPU_CONST uint32_t GY[7] = {0x85007E34u, 0x44D58199u, 0x5A074764u, 0xCD4375A0u, 0x4C22DFE6u, 0xB5F723FBu, 0xBD376388u};
+};
+
+// NIST P-192: 6 canonical words (24-byte wire records: 8-byte aligned), 8 limbs x 26 bits.
+struct P192Params {
+    ECGPU_CONST int ID = CURVE_P192;
+    ECGPU_CONST int N = 6;
+    ECGPU_CONST int NL = 8;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::P192U;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p192/src/arithmetic.rs:39-43
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^192 - 2^64 - 1                          p192/src/arithmetic/field.rs:54
+    ECGPU_CONST uint32_t P[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // n                                            p192/src/lib.rs:41
+    ECGPU_CONST uint32_t ORDER[6] = {0xB4D22831u, 0x146BC9B1u, 0x99DEF836u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^192): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[6] = {0xDEB35961u, 0xCE66BACCu, 0xBB3A6BEEu, 0x4696EA5Bu, 0xEA0581A2u, 0x28BE5677u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x0DDBCF2Fu;
+    // curve b, canonical                           p192/src/arithmetic.rs:46-47
+    ECGPU_CONST uint32_t B[6] = {0xC146B9B1u, 0xFEB8DEECu, 0x72243049u, 0x0FA7E9ABu, 0xE59C80E7u, 0x64210519u};
+    // generator, canonical                         p192/src/arithmetic.rs:55-58
+    ECGPU_CONST uint32_t GX[6] = {0x82FF1012u, 0xF4FF0AFDu, 0x43A18800u, 0x7CBF20EBu, 0xB03090F6u, 0x188DA80Eu};
+    ECGPU_CONST uint32_t GY[6] = {0x1E794811u, 0x73F977A1u, 0x6B24CDD5u, 0x631011EDu, 0xFFC8DA78u, 0x07192B95u};
 };
 
 }  // namespace ecgpu

@@ -36,6 +36,8 @@ static const uint64_t ORDER_P384[6] = {0xECEC196ACCC52973ull, 0x581A0DB248B0A77A
 static const uint64_t ORDER_P224[4] = {0x13DD29455C5C2A3Dull, 0xFFFF16A2E0B8F03Eull, 0xFFFFFFFFFFFFFFFFull,
                                        0x00000000FFFFFFFFull};       /* p224/src/lib.rs:50-55 */
 
+static const uint64_t ORDER_P192[3] = {0x146BC9B1B4D22831ull, 0xFFFFFFFF99DEF836ull, 0xFFFFFFFFFFFFFFFFull};   /* p192/src/lib.rs:41 */
+
 typedef struct {
     int nl;               /* 64-bit words */
     const uint64_t *n;
@@ -73,8 +75,8 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
     if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
 }
 static void modn_init(modn_t *m, int curve) {
-    m->nl = curve == ECREF_P384 ? 6 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : ORDER_P384;
+    m->nl = curve == ECREF_P384 ? 6 : curve == ECREF_P192 ? 3 : 4;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -136,7 +138,7 @@ static void to_be_len(uint8_t *b, const uint64_t *w, size_t len) { ecref_words_t
 
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
                              size_t n, int reject_high_s, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;

@@ -116,5 +116,6 @@ ECREF_DECL_CURVE(p256)
 ECREF_DECL_CURVE(p384)
 ECREF_DECL_CURVE(sm2)
 ECREF_DECL_CURVE(p224)
+ECREF_DECL_CURVE(p192)
 
 #endif

@@ -572,3 +572,109 @@ static int p224_fe_sqrt(fe_p224 *out, const fe_p224 *a) {
 #define PO_GX P224_GX
 #define PO_GY P224_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * P-192 field (generic Montgomery with R = 2^192 on three 64-bit words, crypto-bigint ConstMontyForm semantics:
+ * p192/src/arithmetic/field.rs:54-70 -> primefield::MontyFieldElement; the reference's default backend is the
+ * fiat-crypto code for the same Montgomery arithmetic) - a parameter set beyond SURVEY.md 8(f) rank 4's list.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[3]; } fe_p192;
+
+static const uint64_t P192_P[3] = {                     /* p192/src/arithmetic/field.rs:54 */
+    0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFEULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint64_t P192_N[3] = {                     /* p192/src/lib.rs:41 */
+    0x146BC9B1B4D22831ULL, 0xFFFFFFFF99DEF836ULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint8_t P192_B_BYTES[24] = {               /* p192/src/arithmetic.rs:46-47 */
+    0x64, 0x21, 0x05, 0x19, 0xe5, 0x9c, 0x80, 0xe7, 0x0f, 0xa7, 0xe9, 0xab, 0x72, 0x24, 0x30, 0x49, 0xfe, 0xb8, 0xde, 0xec, 0xc1, 0x46, 0xb9, 0xb1};
+static const uint8_t P192_GX[24] = {                    /* p192/src/arithmetic.rs:55-58 */
+    0x18, 0x8d, 0xa8, 0x0e, 0xb0, 0x30, 0x90, 0xf6, 0x7c, 0xbf, 0x20, 0xeb, 0x43, 0xa1, 0x88, 0x00, 0xf4, 0xff, 0x0a, 0xfd, 0x82, 0xff, 0x10, 0x12};
+static const uint8_t P192_GY[24] = {
+    0x07, 0x19, 0x2b, 0x95, 0xff, 0xc8, 0xda, 0x78, 0x63, 0x10, 0x11, 0xed, 0x6b, 0x24, 0xcd, 0xd5, 0x73, 0xf9, 0x77, 0xa1, 0x1e, 0x79, 0x48, 0x11};
+
+static fe_p192 P192_R, P192_R2, P192_B_MONT;
+static uint64_t P192_MINV;
+static int p192_ready;
+
+static fe_p192 p192_fe_mul(const fe_p192 *a, const fe_p192 *b) {       /* monty.rs:346-350 */
+    uint64_t t[6];
+    fe_p192 r;
+    ecref_mp_mul(t, a->w, b->w, 3);
+    mont_reduce(r.w, t, P192_P, P192_MINV, 3);
+    return r;
+}
+static fe_p192 p192_fe_sqr(const fe_p192 *a) { return p192_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_p192 p192_fe_add(const fe_p192 *a, const fe_p192 *b) { fe_p192 r; mont_add(r.w, a->w, b->w, P192_P, 3); return r; }   /* :316-320 */
+static fe_p192 p192_fe_sub(const fe_p192 *a, const fe_p192 *b) { fe_p192 r; mont_sub(r.w, a->w, b->w, P192_P, 3); return r; }   /* :331-335 */
+static fe_p192 p192_fe_zero(void) { fe_p192 z; memset(&z, 0, sizeof z); return z; }
+static fe_p192 p192_fe_neg(const fe_p192 *a) { fe_p192 z = p192_fe_zero(); return p192_fe_sub(&z, a); }                         /* :353-357 */
+static fe_p192 p192_fe_dbl(const fe_p192 *a) { return p192_fe_add(a, a); }                                                     /* :323-327 */
+static int p192_fe_is_zero(const fe_p192 *a) { return ecref_mp_is_zero(a->w, 3); }
+
+static void p192_init(void) {
+    if (p192_ready) return;
+    P192_MINV = mont_neg_inv64(P192_P[0]);
+    mont_pow2_mod(P192_R.w, P192_P, 3, 192);
+    mont_pow2_mod(P192_R2.w, P192_P, 3, 384);
+    fe_p192 b;
+    ecref_be_to_words(P192_B_BYTES, 24, b.w);
+    P192_B_MONT = p192_fe_mul(&b, &P192_R2);
+    p192_ready = 1;
+}
+static fe_p192 p192_fe_one(void) { p192_init(); return P192_R; }
+static fe_p192 p192_fe_b(void) { p192_init(); return P192_B_MONT; }
+
+static int p192_fe_from_bytes(fe_p192 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    p192_init();
+    fe_p192 t;
+    ecref_be_to_words(b, 24, t.w);
+    if (ecref_mp_cmp(t.w, P192_P, 3) >= 0) return 0;
+    *r = p192_fe_mul(&t, &P192_R2);
+    return 1;
+}
+static void p192_fe_to_bytes(uint8_t *out, const fe_p192 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[6];
+    fe_p192 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 24);
+    mont_reduce(c.w, t, P192_P, P192_MINV, 3);
+    ecref_words_to_be(c.w, 3, out);
+}
+static int p192_fe_invert(fe_p192 *out, const fe_p192 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (p192_fe_is_zero(a)) return 0;
+    uint64_t e[3], two[3] = {2, 0, 0};
+    ecref_mp_sub(e, P192_P, two, 3);
+    fe_p192 r = p192_fe_one();
+    for (int i = 191; i >= 0; i--) {
+        r = p192_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p192_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int p192_fe_sqrt(fe_p192 *out, const fe_p192 *a) {
+    uint64_t e[3], one[3] = {1, 0, 0};
+    ecref_mp_add(e, P192_P, one, 3);                         /* p + 1 < 2^192 */
+    for (int i = 0; i < 3; i++) e[i] = (e[i] >> 2) | (i + 1 < 3 ? e[i + 1] << 62 : 0);
+    fe_p192 r = p192_fe_one();
+    for (int i = 191; i >= 0; i--) {
+        r = p192_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p192_fe_mul(&r, a);
+    }
+    fe_p192 sq = p192_fe_sqr(&r);
+    fe_p192 d = p192_fe_sub(&sq, a);
+    *out = r;
+    return p192_fe_is_zero(&d);
+}
+
+#define PO_PFX p192
+#define PO_NL 3
+#define PO_FE fe_p192
+#define PO_F(name) p192_fe_##name
+#define PO_ORDER P192_N
+#define PO_GX P192_GX
+#define PO_GY P192_GY
+#include "ecref_prime.inc"

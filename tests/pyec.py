@@ -61,7 +61,15 @@ P224 = Curve(                                                  # p224/src/arithm
     0xB70E0CBD6BB4BF7F321390B94A03C1D356C21122343280D6115C1D21,
     0xBD376388B5F723FB4C22DFE6CD4375A05A07476444D5819985007E34,
 )
-CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224}
+P192 = Curve(                                                  # p192/src/arithmetic.rs:39-58, field.rs:54, lib.rs:41
+    "p192", 5, 24,
+    0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEFFFFFFFFFFFFFFFF,
+    0xFFFFFFFFFFFFFFFFFFFFFFFF99DEF836146BC9B1B4D22831,
+    -3, 0x64210519E59C80E70FA7E9AB72243049FEB8DEECC146B9B1,
+    0x188DA80EB03090F67CBF20EB43A18800F4FF0AFD82FF1012,
+    0x07192B95FFC8DA78631011ED6B24CDD573F977A11E794811,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192}
 
 # secp256k1 endomorphism constants (k256/src/arithmetic/mul.rs:4-5, projective.rs:31-37)
 K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72

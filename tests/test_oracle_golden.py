@@ -11,7 +11,7 @@ import pytest
 import pyec
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CURVES = ["k256", "p256", "p384", "p224"]          # curves with reference KATs (tests/golden/<curve>.json)
+CURVES = ["k256", "p256", "p384", "p224", "p192"]          # curves with reference KATs (tests/golden/<curve>.json)
 ALL_CURVES = CURVES + ["sm2"]               # + the SURVEY 8(f) rank-4 parameter set: big-int model and OpenSSL only
 
 
