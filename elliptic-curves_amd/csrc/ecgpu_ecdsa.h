@@ -26,15 +26,16 @@ k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, co
                 uint8_t* __restrict__ u2_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
     using S = ScalarN<C>;
     using F = Field<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t zw[N], rw[N], sw[N], cx[N], cy[N];
-    load_be_vec<N>(zw, z + i * (4 * N));
-    load_be_vec<N>(rw, r + i * (4 * N));
-    load_be_vec<N>(sw, s + i * (4 * N));
-    load_be_vec<N>(cx, q_xy + i * (8 * N));
-    load_be_vec<N>(cy, q_xy + i * (8 * N) + 4 * N);
+    load_wire<C>(zw, z + i * WB);
+    load_wire<C>(rw, r + i * WB);
+    load_wire<C>(sw, s + i * WB);
+    load_wire<C>(cx, q_xy + i * (2 * WB));
+    load_wire<C>(cy, q_xy + i * (2 * WB) + WB);
     bool ok = !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
     if (reject_high_s) ok = ok && !S::is_high(sw);
     ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
@@ -59,10 +60,10 @@ k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, co
         cx[j] = ok ? cx[j] : C::GX[j];
         cy[j] = ok ? cy[j] : C::GY[j];
     }
-    store_be_vec<N>(u1_out + i * (4 * N), u1);
-    store_be_vec<N>(u2_out + i * (4 * N), u2);
-    store_be_vec<N>(q_out + i * (8 * N), cx);
-    store_be_vec<N>(q_out + i * (8 * N) + 4 * N, cy);
+    store_wire<C>(u1_out + i * WB, u1);
+    store_wire<C>(u2_out + i * WB, u2);
+    store_wire<C>(q_out + i * (2 * WB), cx);
+    store_wire<C>(q_out + i * (2 * WB) + WB, cy);
     valid[i] = ok ? 1 : 0;
 }
 
@@ -72,12 +73,13 @@ __global__ void __launch_bounds__(BLOCK)
 k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf, const uint8_t* __restrict__ r,
                const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
     using S = ScalarN<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t x[N], xr[N], rw[N];
-    load_be_vec<N>(x, r_xy + i * (8 * N));
-    load_be_vec<N>(rw, r + i * (4 * N));
+    load_wire<C>(x, r_xy + i * (2 * WB));
+    load_wire<C>(rw, r + i * WB);
     S::reduce_once(xr, x);                                // x < p < 2n
     bool eq = true;
 #pragma unroll
@@ -97,15 +99,16 @@ k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, 
                   uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
     using S = ScalarN<C>;
     using F = Field<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t ew[N], rw[N], sw[N], cx[N], cy[N];
-    load_be_vec<N>(ew, e + i * (4 * N));
-    load_be_vec<N>(rw, r + i * (4 * N));
-    load_be_vec<N>(sw, s + i * (4 * N));
-    load_be_vec<N>(cx, p_xy + i * (8 * N));
-    load_be_vec<N>(cy, p_xy + i * (8 * N) + 4 * N);
+    load_wire<C>(ew, e + i * WB);
+    load_wire<C>(rw, r + i * WB);
+    load_wire<C>(sw, s + i * WB);
+    load_wire<C>(cx, p_xy + i * (2 * WB));
+    load_wire<C>(cy, p_xy + i * (2 * WB) + WB);
     bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw);
     ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
     {
@@ -130,10 +133,10 @@ k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, 
         cx[j] = ok ? cx[j] : C::GX[j];
         cy[j] = ok ? cy[j] : C::GY[j];
     }
-    store_be_vec<N>(a_out + i * (4 * N), sw);
-    store_be_vec<N>(b_out + i * (4 * N), ne);
-    store_be_vec<N>(q_out + i * (8 * N), cx);
-    store_be_vec<N>(q_out + i * (8 * N) + 4 * N, cy);
+    store_wire<C>(a_out + i * WB, sw);
+    store_wire<C>(b_out + i * WB, ne);
+    store_wire<C>(q_out + i * (2 * WB), cx);
+    store_wire<C>(q_out + i * (2 * WB) + WB, cy);
     valid[i] = ok ? 1 : 0;
 }
 
@@ -148,7 +151,8 @@ k_schnorr_prepare_raw(const uint8_t* __restrict__ pk_x, const uint8_t* __restric
     using S = ScalarN<C>;
     using F = Field<C>;
     using G = Group<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     static_assert(N == 8 && C::A_IS_ZERO, "BIP340 is defined over secp256k1");
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -200,13 +204,14 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_schnorr_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf, const uint8_t* __restrict__ r,
                  const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t x[N], y[N], rw[N];
-    load_be_vec<N>(x, r_xy + i * (8 * N));
-    load_be_vec<N>(y, r_xy + i * (8 * N) + 4 * N);
-    load_be_vec<N>(rw, r + i * (4 * N));
+    load_wire<C>(x, r_xy + i * (2 * WB));
+    load_wire<C>(y, r_xy + i * (2 * WB) + WB);
+    load_wire<C>(rw, r + i * WB);
     bool eq = true;
 #pragma unroll
     for (int j = 0; j < N; j++) eq = eq && (x[j] == rw[j]);
@@ -222,12 +227,12 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_extract_x(const uint8_t* __restrict__ xy, const uint8_t* __restrict__ inf, size_t n, uint8_t* __restrict__ out_x,
             uint8_t* __restrict__ ok) {
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t x[N];
-    load_words_vec<N>(x, reinterpret_cast<const uint32_t*>(xy + i * (8 * N)));      // bytes stay in wire order
-    store_words_vec<N>(reinterpret_cast<uint32_t*>(out_x + i * (4 * N)), x);
+    copy_wire<C>(out_x + i * WB, xy + i * (2 * WB));
     ok[i] = inf[i] ? 0 : 1;
 }
 
@@ -241,11 +246,12 @@ k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_od
              uint8_t* __restrict__ ok_out) {
     using F = Field<C>;
     using G = Group<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t cx[N], cy[N];
-    load_be_vec<N>(cx, xs + i * (4 * N));
+    load_wire<C>(cx, xs + i * WB);
     bool ok = !mp_geq<N>(cx, C::P);
     auto x = F::from_canonical(cx);
     auto x3 = F::mul(F::sqr(x), x);
@@ -272,8 +278,8 @@ k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_od
         cx[j] = ok ? cx[j] : 0u;
         cy[j] = ok ? cy[j] : 0u;
     }
-    store_be_vec<N>(out_xy + i * (8 * N), cx);
-    store_be_vec<N>(out_xy + i * (8 * N) + 4 * N, cy);
+    store_wire<C>(out_xy + i * (2 * WB), cx);
+    store_wire<C>(out_xy + i * (2 * WB) + WB, cy);
     ok_out[i] = ok ? 1 : 0;
 }
 

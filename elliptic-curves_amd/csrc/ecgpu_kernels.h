@@ -70,6 +70,55 @@ __device__ __forceinline__ void store_be_vec(uint8_t* bytes, const uint32_t* wor
     store_words_vec<NW>(reinterpret_cast<uint32_t*>(bytes), w);
 }
 
+// one wire record (big-endian field element or scalar of WireBytes<C> bytes) <-> N little-endian words.  Records of
+// 4 N bytes go through the vector helpers; others (p521: 66 bytes, 2-byte aligned) byte by byte.
+template <class C>
+__device__ __forceinline__ void load_wire(uint32_t* words, const uint8_t* bytes) {
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        load_be_vec<N>(words, bytes);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; i++) words[i] = 0;
+#pragma unroll
+        for (int j = 0; j < WB; j++) words[(WB - 1 - j) / 4] |= (uint32_t)bytes[j] << (8 * ((WB - 1 - j) % 4));
+    }
+}
+template <class C>
+__device__ __forceinline__ void store_wire(uint8_t* bytes, const uint32_t* words) {
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        store_be_vec<N>(bytes, words);
+    } else {
+#pragma unroll
+        for (int j = 0; j < WB; j++) bytes[j] = (uint8_t)(words[(WB - 1 - j) / 4] >> (8 * ((WB - 1 - j) % 4)));
+    }
+}
+template <class C>
+__device__ __forceinline__ void zero_wire(uint8_t* bytes, int records) {
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        uint32_t zero[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) zero[i] = 0;
+        for (int r = 0; r < records; r++) store_words_vec<N>(reinterpret_cast<uint32_t*>(bytes + r * WB), zero);
+    } else {
+        for (int j = 0; j < records * WB; j++) bytes[j] = 0;
+    }
+}
+template <class C>
+__device__ __forceinline__ void copy_wire(uint8_t* dst, const uint8_t* src) {   // bytes stay in wire order
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        uint32_t x[N];
+        load_words_vec<N>(x, reinterpret_cast<const uint32_t*>(src));
+        store_words_vec<N>(reinterpret_cast<uint32_t*>(dst), x);
+    } else {
+#pragma unroll
+        for (int j = 0; j < WB; j++) dst[j] = src[j];
+    }
+}
+
 // raw element <-> registers
 template <class C>
 __device__ __forceinline__ void store_raw(uint32_t* dst, const Fe<C::NL>& e) {
@@ -132,7 +181,7 @@ __device__ __forceinline__ void store_packed_affine(uint32_t* dst, const Fe<C::N
 // scalar record -> 32-bit words, flags out-of-range scalars (Scalar::from_repr, k256 scalar.rs:310-316)
 template <class C>
 __device__ __forceinline__ void load_scalar(uint32_t* k, const uint8_t* scalars, size_t i, int* status) {
-    load_be_vec<C::N>(k, scalars + i * (4 * C::N));
+    load_wire<C>(k, scalars + i * WireBytes<C>::value);
     if (mp_geq<C::N>(k, C::ORDER)) atomicOr(status, ST_BAD_SCALAR);
 }
 
@@ -144,8 +193,8 @@ __device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, con
     using F = Field<C>;
     if (inf != nullptr && inf[i]) return false;
     uint32_t cx[C::N], cy[C::N];
-    load_be_vec<C::N>(cx, xy + i * (8 * C::N));
-    load_be_vec<C::N>(cy, xy + i * (8 * C::N) + 4 * C::N);
+    load_wire<C>(cx, xy + i * (2 * WireBytes<C>::value));
+    load_wire<C>(cy, xy + i * (2 * WireBytes<C>::value) + WireBytes<C>::value);
     bool ok = !mp_geq<C::N>(cx, C::P) && !mp_geq<C::N>(cy, C::P);
     a->x = F::from_canonical(cx).e;
     a->y = F::from_canonical(cy).e;
@@ -226,7 +275,8 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
                                                      uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_packed) {
     using F = Field<C>;
     using G = Group<C>;
-    constexpr int N = C::N, NS = F::NS;
+    constexpr int N = C::N, NS = F::NS, WB = WireBytes<C>::value;
+    (void)N;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
     typename F::M1 acc = F::one();
@@ -252,16 +302,10 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
         load_words_vec<NS>(pw, prefix + j * NS);
         if (pw[NS - 1]) {
             if constexpr (MODE == NORM_WIRE) {
-                uint32_t zero[2 * N];
-#pragma unroll
-                for (int i = 0; i < 2 * N; i++) zero[i] = 0;
-                store_words_vec<2 * N>(reinterpret_cast<uint32_t*>(out_xy + j * (8 * N)), zero);
+                zero_wire<C>(out_xy + j * (2 * WB), 2);
                 if (out_inf) out_inf[j] = 1;
             } else if constexpr (MODE == NORM_COMPRESSED) {
-                uint32_t zero[N];
-#pragma unroll
-                for (int i = 0; i < N; i++) zero[i] = 0;
-                store_words_vec<N>(reinterpret_cast<uint32_t*>(out_xy + j * (4 * N)), zero);
+                zero_wire<C>(out_xy + j * WB, 1);
                 out_inf[j] = 0;
             }
         } else {
@@ -277,15 +321,15 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
             } else if constexpr (MODE == NORM_COMPRESSED) {
                 uint32_t w[N];
                 F::to_canonical(w, x);
-                store_be_vec<N>(out_xy + j * (4 * N), w);
+                store_wire<C>(out_xy + j * WB, w);
                 F::to_canonical(w, y);
                 out_inf[j] = (uint8_t)(2u + (w[0] & 1u));
             } else {
                 uint32_t w[N];
                 F::to_canonical(w, x);
-                store_be_vec<N>(out_xy + j * (8 * N), w);
+                store_wire<C>(out_xy + j * (2 * WB), w);
                 F::to_canonical(w, y);
-                store_be_vec<N>(out_xy + j * (8 * N) + 4 * N, w);
+                store_wire<C>(out_xy + j * (2 * WB) + WB, w);
                 if (out_inf) out_inf[j] = 0;
             }
         }
@@ -323,15 +367,15 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_load_proj(const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status) {
     using F = Field<C>;
-    constexpr int N = C::N;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Proj<C> p;
     uint32_t c[N];
     bool ok = true;
-    load_be_vec<N>(c, xyz + i * (12 * N));           ok = ok && !mp_geq<N>(c, C::P); p.x = F::from_canonical(c).e;
-    load_be_vec<N>(c, xyz + i * (12 * N) + 4 * N);   ok = ok && !mp_geq<N>(c, C::P); p.y = F::from_canonical(c).e;
-    load_be_vec<N>(c, xyz + i * (12 * N) + 8 * N);   ok = ok && !mp_geq<N>(c, C::P); p.z = F::from_canonical(c).e;
+    load_wire<C>(c, xyz + i * (3 * WB));           ok = ok && !mp_geq<N>(c, C::P); p.x = F::from_canonical(c).e;
+    load_wire<C>(c, xyz + i * (3 * WB) + WB);   ok = ok && !mp_geq<N>(c, C::P); p.y = F::from_canonical(c).e;
+    load_wire<C>(c, xyz + i * (3 * WB) + 2 * WB);   ok = ok && !mp_geq<N>(c, C::P); p.z = F::from_canonical(c).e;
     if (!ok) atomicOr(status, ST_BAD_POINT);
     store_proj<C>(proj_out, i, p);
 }

@@ -1,6 +1,7 @@
 // ecgpu_params.h — limb helpers and curve parameter packs shared by host and device code.
 // (Split out of ecgpu_field.h; constants: SURVEY.md Appendix A, reference lines cited per constant.)
 #pragma once
+#include <type_traits>
 
 #include <stdint.h>
 
@@ -293,6 +294,17 @@ struct P192Params {
     // generator, canonical                         p192/src/arithmetic.rs:55-58
     ECGPU_CONST uint32_t GX[6] = {0x82FF1012u, 0xF4FF0AFDu, 0x43A18800u, 0x7CBF20EBu, 0xB03090F6u, 0x188DA80Eu};
     ECGPU_CONST uint32_t GY[6] = {0x1E794811u, 0x73F977A1u, 0x6B24CDD5u, 0x631011EDu, 0xFFC8DA78u, 0x07192B95u};
+};
+
+// Wire bytes of a field element / scalar (`FieldBytesSize`): 4 N unless the parameter set says otherwise (p521: 66 bytes
+// for 17 words).
+template <class C, class = void>
+struct WireBytes {
+    static constexpr int value = 4 * C::N;
+};
+template <class C>
+struct WireBytes<C, std::void_t<decltype(C::WIRE_BYTES)>> {
+    static constexpr int value = C::WIRE_BYTES;
 };
 
 }  // namespace ecgpu
