@@ -48,7 +48,7 @@ k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, co
     uint32_t u1[N], u2[N];
     {
         uint32_t zr[N], w[N];
-        S::reduce_once(zr, zw);
+        S::reduce_wire(zr, zw);
         S::inv(w, sw);
         S::mul(u1, zr, w);
         S::mul(u2, rw, w);

@@ -295,6 +295,24 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
+        if constexpr (C::ID == CURVE_P521) {
+            // p = 2^521 - 1: u p = u 2^521 - u.  The -u clears the low 27 bits of c[i]; u 2^521 = u 2^8 at limb i + 19.
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                uint32_t u = (uint32_t)c[i] & PMASK;
+                c[i + 1] += (c[i] >> UB);
+                c[i + 19] += (uint64_t)u << 8;
+            }
+            E r;
+            uint64_t v = c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
         if constexpr (!PC::P0_IS_MINUS_ONE) {
             // p = 1 (mod 2^B), as for p224: -p^-1 = -1, u = -c_i mod 2^B, and u * p0 = u clears the low bits of c_i
             // (model: tools/field_model.py umont_mul_general)
@@ -633,7 +651,7 @@ struct Field {
     // big-endian canonical bytes <-> internal; `ok` false if the encoded value is >= p
     static ECGPU_HD M1 from_bytes(const uint8_t* be, bool* ok) {
         uint32_t w[N];
-        load_be<N>(w, be);
+        load_be_wire<C>(w, be);
         *ok = !mp_geq<N>(w, C::P);
         return from_canonical(w);
     }
@@ -641,7 +659,7 @@ struct Field {
     static ECGPU_HD void to_bytes(uint8_t* be, const Mag<C, LA, VA>& a) {
         uint32_t w[N];
         to_canonical(w, a);
-        store_be<N>(be, w);
+        store_be_wire<C>(be, w);
     }
 
     static ECGPU_HD M1 sqr_n(M1 x, int n) {

@@ -23,11 +23,12 @@
 
 namespace ecgpu {
 
-template <int NW>          // modulus size in 32-bit words: 6, 7, 8 or 12
+template <int NW>          // modulus size in 32-bit words: 6, 7, 8, 12 or 17
 struct ModInv {
-    static_assert(NW == 6 || NW == 7 || NW == 8 || NW == 12, "192-, 224-, 256- or 384-bit moduli");
-    ECGPU_CONST int NL = NW == 6 ? 7 : NW == 7 ? 8 : NW == 8 ? 9 : 13;          // signed 30-bit limbs (2 spare bits above the modulus)
-    ECGPU_CONST int BATCHES = NW == 6 ? 15 : NW == 7 ? 18 : NW == 8 ? 20 : 31;  // (45907 bits + 26313) / 19929 steps: 444 / 518 / 591 / 886
+    static_assert(NW == 6 || NW == 7 || NW == 8 || NW == 12 || NW == 17, "192-, 224-, 256-, 384- or 521-bit moduli");
+    ECGPU_CONST int NL = NW == 6 ? 7 : NW == 7 ? 8 : NW == 8 ? 9 : NW == 12 ? 13 : 19;   // signed 30-bit limbs (2 spare bits above the modulus)
+    // (45907 bits + 26313) / 19929 division steps: 444 / 518 / 591 / 886 / 1255 (521-bit moduli counted as 544 bits)
+    ECGPU_CONST int BATCHES = NW == 6 ? 15 : NW == 7 ? 18 : NW == 8 ? 20 : NW == 12 ? 31 : 42;
     ECGPU_CONST int32_t M30 = (int32_t)((1u << 30) - 1);
 
     struct S30 {

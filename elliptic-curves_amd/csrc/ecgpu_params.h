@@ -18,7 +18,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -296,6 +296,42 @@ struct P192Params {
     ECGPU_CONST uint32_t GY[6] = {0x1E794811u, 0x73F977A1u, 0x6B24CDD5u, 0x631011EDu, 0xFFC8DA78u, 0x07192B95u};
 };
 
+// NIST P-521: 17 canonical words, 66-byte wire records (2-byte aligned: byte-wise access, WireBytes), 20 limbs x 27 bits.
+struct P521Params {
+    ECGPU_CONST int ID = CURVE_P521;
+    ECGPU_CONST int N = 17;
+    ECGPU_CONST int NL = 20;
+    ECGPU_CONST int WIRE_BYTES = 66;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::P521U;
+    ECGPU_CONST bool A_IS_ZERO = false;  // a = -3   p521/src/arithmetic.rs:46,57
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p = 2^521 - 1                                 p521/src/arithmetic/field.rs:68-80
+    ECGPU_CONST uint32_t P[17] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                        0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                        0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000001FFu};
+    // n                                            p521/src/lib.rs:51-60
+    ECGPU_CONST uint32_t ORDER[17] = {0x91386409u, 0xBB6FB71Eu, 0x899C47AEu, 0x3BB5C9B8u, 0xF709A5D0u, 0x7FCC0148u,
+                                        0xBF2F966Bu, 0x51868783u, 0xFFFFFFFAu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                        0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0x000001FFu};
+    // group order in Montgomery form (R = 2^544): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[17] = {0x61C64CA7u, 0x1163115Au, 0x4374A642u, 0x18354A56u, 0x0791D9DCu, 0x5D4DD6D3u,
+                                        0xD3402705u, 0x4FB35B72u, 0xB7756E3Au, 0xCFF3D142u, 0xA8E567BCu, 0x5BCC6D61u,
+                                        0x492D0D45u, 0x2D8E03D1u, 0x8C44383Du, 0x5B5A3AFEu, 0x0000019Au};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x79A995C7u;
+    // curve b, canonical                           p521/src/arithmetic.rs:62-64
+    ECGPU_CONST uint32_t B[17] = {0x6B503F00u, 0xEF451FD4u, 0x3D2C34F1u, 0x3573DF88u, 0x3BB1BF07u, 0x1652C0BDu,
+                                        0xEC7E937Bu, 0x56193951u, 0x8EF109E1u, 0xB8B48991u, 0x99B315F3u, 0xA2DA725Bu,
+                                        0xB68540EEu, 0x929A21A0u, 0x8E1C9A1Fu, 0x953EB961u, 0x00000051u};
+    // generator, canonical                         p521/src/arithmetic.rs:76-83
+    ECGPU_CONST uint32_t GX[17] = {0xC2E5BD66u, 0xF97E7E31u, 0x856A429Bu, 0x3348B3C1u, 0xA2FFA8DEu, 0xFE1DC127u,
+                                        0xEFE75928u, 0xA14B5E77u, 0x6B4D3DBAu, 0xF828AF60u, 0x053FB521u, 0x9C648139u,
+                                        0x2395B442u, 0x9E3ECB66u, 0x0404E9CDu, 0x858E06B7u, 0x000000C6u};
+    ECGPU_CONST uint32_t GY[17] = {0x9FD16650u, 0x88BE9476u, 0xA272C240u, 0x353C7086u, 0x3FAD0761u, 0xC550B901u,
+                                        0x5EF42640u, 0x97EE7299u, 0x273E662Cu, 0x17AFBD17u, 0x579B4468u, 0x98F54449u,
+                                        0x2C7D1BD9u, 0x5C8A5FB4u, 0x9A3BC004u, 0x39296A78u, 0x00000118u};
+};
+
 // Wire bytes of a field element / scalar (`FieldBytesSize`): 4 N unless the parameter set says otherwise (p521: 66 bytes
 // for 17 words).
 template <class C, class = void>
@@ -306,5 +342,27 @@ template <class C>
 struct WireBytes<C, std::void_t<decltype(C::WIRE_BYTES)>> {
     static constexpr int value = C::WIRE_BYTES;
 };
+
+// one wire record (WireBytes<C> big-endian bytes) <-> N little-endian words, host or device, any alignment the word
+// accessors above accept for 4 N-byte records, byte by byte otherwise
+template <class C>
+ECGPU_HD void load_be_wire(uint32_t* words, const uint8_t* bytes) {
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        load_be<N>(words, bytes);
+    } else {
+        for (int i = 0; i < N; i++) words[i] = 0;
+        for (int j = 0; j < WB; j++) words[(WB - 1 - j) / 4] |= (uint32_t)bytes[j] << (8 * ((WB - 1 - j) % 4));
+    }
+}
+template <class C>
+ECGPU_HD void store_be_wire(uint8_t* bytes, const uint32_t* words) {
+    constexpr int WB = WireBytes<C>::value, N = C::N;
+    if constexpr (WB == 4 * N) {
+        store_be<N>(bytes, words);
+    } else {
+        for (int j = 0; j < WB; j++) bytes[j] = (uint8_t)(words[(WB - 1 - j) / 4] >> (8 * ((WB - 1 - j) % 4)));
+    }
+}
 
 }  // namespace ecgpu

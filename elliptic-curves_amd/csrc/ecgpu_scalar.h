@@ -24,6 +24,14 @@ struct ScalarN {
 #pragma unroll
         for (int i = 0; i < N; i++) r[i] = borrow ? a[i] : d[i];
     }
+    // a wire-sized value (a message digest, an x coordinate) mod n.  One conditional subtraction where the wire size is
+    // the size of n; a 66-byte p521 value can be 2^7 times n (n = 2^521 - 2^260..): up to 128 subtractions there.
+    static ECGPU_HD void reduce_wire(uint32_t* r, const uint32_t* a) {
+        constexpr int REPS = C::ID == CURVE_P521 ? 128 : 1;
+        reduce_once(r, a);
+#pragma unroll 1
+        for (int i = 1; i < REPS; i++) reduce_once(r, r);
+    }
     // a * b * 2^(-32 N) mod n  (CIOS), inputs < n, output < n
     static ECGPU_HD void mont_mul(uint32_t* r, const uint32_t* a, const uint32_t* b) {
         uint32_t t[N + 2];

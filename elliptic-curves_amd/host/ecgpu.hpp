@@ -326,5 +326,6 @@ using p384 = Curve<ECGPU_P384, 48>;
 using sm2 = Curve<ECGPU_SM2, 32>;
 using p224 = Curve<ECGPU_P224, 28>;   // no point decompression (p = 1 mod 4)
 using p192 = Curve<ECGPU_P192, 24>;
+using p521 = Curve<ECGPU_P521, 66>;
 
 }  // namespace ecgpu_host

@@ -14,6 +14,7 @@ __attribute__((constructor)) static void ecref_init_all(void) {
     ecref_sm2_init();
     ecref_p224_init();
     ecref_p192_init();
+    ecref_p521_init();
 }
 
 size_t ecref_field_bytes(int curve) {
@@ -21,6 +22,7 @@ size_t ecref_field_bytes(int curve) {
     case ECREF_K256: case ECREF_P256: case ECREF_SM2: return 32;
     case ECREF_P224: return 28;
     case ECREF_P192: return 24;
+    case ECREF_P521: return 66;
     case ECREF_P384: return 48;
     default: return 0;
     }
@@ -102,6 +104,7 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     case ECREF_SM2: return ecref_sm2_##fn args;       \
     case ECREF_P224: return ecref_p224_##fn args;     \
     case ECREF_P192: return ecref_p192_##fn args;     \
+    case ECREF_P521: return ecref_p521_##fn args;     \
     default: return ECREF_ERR_CURVE;                  \
     }
 
@@ -148,6 +151,7 @@ int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
     case ECREF_SM2: ecref_sm2_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P224: ecref_p224_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P192: ecref_p192_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_P521: ecref_p521_scalar_reduce(s, n); return ECREF_OK;
     default: return ECREF_ERR_CURVE;
     }
 }

@@ -36,13 +36,14 @@ static const uint64_t ORDER_P384[6] = {0xECEC196ACCC52973ull, 0x581A0DB248B0A77A
 static const uint64_t ORDER_P224[4] = {0x13DD29455C5C2A3Dull, 0xFFFF16A2E0B8F03Eull, 0xFFFFFFFFFFFFFFFFull,
                                        0x00000000FFFFFFFFull};       /* p224/src/lib.rs:50-55 */
 
+static const uint64_t ORDER_P521[9] = {0xBB6FB71E91386409ull, 0x3BB5C9B8899C47AEull, 0x7FCC0148F709A5D0ull, 0x51868783BF2F966Bull, 0xFFFFFFFFFFFFFFFAull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0x00000000000001FFull};   /* p521/src/lib.rs:51-60 */
 static const uint64_t ORDER_P192[3] = {0x146BC9B1B4D22831ull, 0xFFFFFFFF99DEF836ull, 0xFFFFFFFFFFFFFFFFull};   /* p192/src/lib.rs:41 */
 
 typedef struct {
     int nl;               /* 64-bit words */
     const uint64_t *n;
     uint64_t ninv;        /* -n^-1 mod 2^64 */
-    uint64_t r2[6];       /* 2^(128 nl) mod n */
+    uint64_t r2[9];       /* 2^(128 nl) mod n */
 } modn_t;
 
 static int geq(const uint64_t *a, const uint64_t *b, int nl) {
@@ -75,8 +76,8 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
     if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
 }
 static void modn_init(modn_t *m, int curve) {
-    m->nl = curve == ECREF_P384 ? 6 : curve == ECREF_P192 ? 3 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : ORDER_P384;
+    m->nl = curve == ECREF_P384 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -86,7 +87,7 @@ static void modn_init(modn_t *m, int curve) {
 }
 /* r = a*b*2^(-64 nl) mod n */
 static void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const modn_t *m) {
-    uint64_t t[8] = {0};
+    uint64_t t[11] = {0};
     const int nl = m->nl;
     for (int i = 0; i < nl; i++) {
         u128 c = 0;
@@ -114,13 +115,13 @@ static void mont_mul(uint64_t *r, const uint64_t *a, const uint64_t *b, const mo
     memcpy(r, t, 8 * nl);
 }
 static void mul_mod(uint64_t *r, const uint64_t *a, const uint64_t *b, const modn_t *m) {
-    uint64_t t[6];
+    uint64_t t[9];
     mont_mul(t, a, b, m);
     mont_mul(r, t, m->r2, m);
 }
 /* r = a^(n-2) mod n */
 static void inv_mod(uint64_t *r, const uint64_t *a, const modn_t *m) {
-    uint64_t e[6], acc[6] = {1, 0, 0, 0, 0, 0}, base[6];
+    uint64_t e[9], acc[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0}, base[9];
     memcpy(e, m->n, 8 * m->nl);
     e[0] -= 2;                                   /* n is odd and > 2 */
     memcpy(base, a, 8 * m->nl);
@@ -138,20 +139,20 @@ static void to_be_len(uint8_t *b, const uint64_t *w, size_t len) { ecref_words_t
 
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
                              size_t n, int reject_high_s, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;
-    const size_t L = curve == ECREF_P224 ? 28 : 8 * (size_t)nl;
+    const size_t L = curve == ECREF_P224 ? 28 : curve == ECREF_P521 ? 66 : 8 * (size_t)nl;
     for (size_t i = 0; i < n; i++) {
-        uint64_t zw[6], rw[6], sw[6], w[6], u1[6], u2[6];
+        uint64_t zw[9], rw[9], sw[9], w[9], u1[9], u2[9];
         ok[i] = 0;
         from_be_len(zw, z + L * i, L, nl);
         from_be_len(rw, r + L * i, L, nl);
         from_be_len(sw, s + L * i, L, nl);
         if (is_zero(rw, nl) || geq(rw, m.n, nl) || is_zero(sw, nl) || geq(sw, m.n, nl)) continue;
         if (reject_high_s) {
-            uint64_t twice[6];
+            uint64_t twice[9];
             memcpy(twice, sw, 8 * nl);
             uint64_t top = twice[nl - 1] >> 63;
             for (int k = nl - 1; k > 0; k--) twice[k] = (twice[k] << 1) | (twice[k - 1] >> 63);
@@ -162,12 +163,12 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
         inv_mod(w, sw, &m);
         mul_mod(u1, zw, w, &m);
         mul_mod(u2, rw, w, &m);
-        uint8_t a[48], b[48], xy[96], inf = 0;
+        uint8_t a[66], b[66], xy[132], inf = 0;
         to_be_len(a, u1, L);
         to_be_len(b, u2, L);
         if (ecref_mul_base_and_mul_add_vartime(curve, a, b, q_xy + 2 * L * i, 0, xy, &inf) != ECREF_OK) continue;
         if (inf) continue;
-        uint64_t x[6];
+        uint64_t x[9];
         from_be_len(x, xy, L, nl);
         if (geq(x, m.n, nl)) sub_n(x, m.n, nl);                 /* x < p < 2n */
         ok[i] = memcmp(x, rw, 8 * nl) == 0;

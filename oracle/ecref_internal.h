@@ -117,5 +117,6 @@ ECREF_DECL_CURVE(p384)
 ECREF_DECL_CURVE(sm2)
 ECREF_DECL_CURVE(p224)
 ECREF_DECL_CURVE(p192)
+ECREF_DECL_CURVE(p521)
 
 #endif

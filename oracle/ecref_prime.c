@@ -17,13 +17,13 @@
 
 /* add_mod / sub_mod / neg_mod on fully reduced values */
 static void mont_add(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *p, size_t nl) {
-    uint64_t t[8];
+    uint64_t t[9];                                   /* up to nine words (P-521) */
     uint64_t carry = ecref_mp_add(r, a, b, nl);
     uint64_t borrow = ecref_mp_sub(t, r, p, nl);
     if (carry || !borrow) memcpy(r, t, 8 * nl);
 }
 static void mont_sub(uint64_t *r, const uint64_t *a, const uint64_t *b, const uint64_t *p, size_t nl) {
-    uint64_t t[8];
+    uint64_t t[9];
     uint64_t borrow = ecref_mp_sub(r, a, b, nl);
     if (borrow) { ecref_mp_add(t, r, p, nl); memcpy(r, t, 8 * nl); }
 }
@@ -31,7 +31,7 @@ static void mont_sub(uint64_t *r, const uint64_t *a, const uint64_t *b, const ui
 /* Word-by-word Montgomery reduction of a 2*nl-word value t: returns t * R^-1 mod p,
  * m_inv = -p^-1 mod 2^64 (crypto-bigint montgomery_reduction). */
 static void mont_reduce(uint64_t *r, const uint64_t *t_in, const uint64_t *p, uint64_t m_inv, size_t nl) {
-    uint64_t t[17];
+    uint64_t t[19];
     memcpy(t, t_in, 8 * 2 * nl);
     t[2 * nl] = 0;
     for (size_t i = 0; i < nl; i++) {
@@ -48,7 +48,7 @@ static void mont_reduce(uint64_t *r, const uint64_t *t_in, const uint64_t *p, ui
             c >>= 64;
         }
     }
-    uint64_t s[8];
+    uint64_t s[9];
     uint64_t borrow = ecref_mp_sub(s, t + nl, p, nl);
     if (t[2 * nl] || !borrow) memcpy(r, s, 8 * nl);
     else memcpy(r, t + nl, 8 * nl);
@@ -677,4 +677,123 @@ static int p192_fe_sqrt(fe_p192 *out, const fe_p192 *a) {
 #define PO_ORDER P192_N
 #define PO_GX P192_GX
 #define PO_GY P192_GY
+#include "ecref_prime.inc"
+
+/* ======================================================================================
+ * P-521 field (generic Montgomery with R = 2^576 on nine 64-bit words, crypto-bigint ConstMontyForm semantics; the
+ * reference's own p521 field is a hand-written 9-limb unsaturated backend for the same field, p521/src/arithmetic/field.rs)
+ * - SURVEY.md 8(f) rank 4.  Wire elements are 66 bytes.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[9]; } fe_p521;
+
+static const uint64_t P521_P[9] = {                     /* p521/src/arithmetic/field.rs:68-80 */
+    0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x00000000000001FFULL};
+static const uint64_t P521_N[9] = {                     /* p521/src/lib.rs:51-60 */
+    0xBB6FB71E91386409ULL, 0x3BB5C9B8899C47AEULL, 0x7FCC0148F709A5D0ULL, 0x51868783BF2F966BULL, 0xFFFFFFFFFFFFFFFAULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0x00000000000001FFULL};
+static const uint8_t P521_B_BYTES[66] = {               /* p521/src/arithmetic.rs:62-64 */
+    0x00, 0x51, 0x95, 0x3e, 0xb9, 0x61, 0x8e, 0x1c, 0x9a, 0x1f, 0x92, 0x9a, 0x21, 0xa0, 0xb6, 0x85,
+    0x40, 0xee, 0xa2, 0xda, 0x72, 0x5b, 0x99, 0xb3, 0x15, 0xf3, 0xb8, 0xb4, 0x89, 0x91, 0x8e, 0xf1,
+    0x09, 0xe1, 0x56, 0x19, 0x39, 0x51, 0xec, 0x7e, 0x93, 0x7b, 0x16, 0x52, 0xc0, 0xbd, 0x3b, 0xb1,
+    0xbf, 0x07, 0x35, 0x73, 0xdf, 0x88, 0x3d, 0x2c, 0x34, 0xf1, 0xef, 0x45, 0x1f, 0xd4, 0x6b, 0x50,
+    0x3f, 0x00};
+static const uint8_t P521_GX[66] = {                    /* p521/src/arithmetic.rs:76-83 */
+    0x00, 0xc6, 0x85, 0x8e, 0x06, 0xb7, 0x04, 0x04, 0xe9, 0xcd, 0x9e, 0x3e, 0xcb, 0x66, 0x23, 0x95,
+    0xb4, 0x42, 0x9c, 0x64, 0x81, 0x39, 0x05, 0x3f, 0xb5, 0x21, 0xf8, 0x28, 0xaf, 0x60, 0x6b, 0x4d,
+    0x3d, 0xba, 0xa1, 0x4b, 0x5e, 0x77, 0xef, 0xe7, 0x59, 0x28, 0xfe, 0x1d, 0xc1, 0x27, 0xa2, 0xff,
+    0xa8, 0xde, 0x33, 0x48, 0xb3, 0xc1, 0x85, 0x6a, 0x42, 0x9b, 0xf9, 0x7e, 0x7e, 0x31, 0xc2, 0xe5,
+    0xbd, 0x66};
+static const uint8_t P521_GY[66] = {
+    0x01, 0x18, 0x39, 0x29, 0x6a, 0x78, 0x9a, 0x3b, 0xc0, 0x04, 0x5c, 0x8a, 0x5f, 0xb4, 0x2c, 0x7d,
+    0x1b, 0xd9, 0x98, 0xf5, 0x44, 0x49, 0x57, 0x9b, 0x44, 0x68, 0x17, 0xaf, 0xbd, 0x17, 0x27, 0x3e,
+    0x66, 0x2c, 0x97, 0xee, 0x72, 0x99, 0x5e, 0xf4, 0x26, 0x40, 0xc5, 0x50, 0xb9, 0x01, 0x3f, 0xad,
+    0x07, 0x61, 0x35, 0x3c, 0x70, 0x86, 0xa2, 0x72, 0xc2, 0x40, 0x88, 0xbe, 0x94, 0x76, 0x9f, 0xd1,
+    0x66, 0x50};
+
+static fe_p521 P521_R, P521_R2, P521_B_MONT;
+static uint64_t P521_MINV;
+static int p521_ready;
+
+static fe_p521 p521_fe_mul(const fe_p521 *a, const fe_p521 *b) {       /* monty.rs:346-350 */
+    uint64_t t[18];
+    fe_p521 r;
+    ecref_mp_mul(t, a->w, b->w, 9);
+    mont_reduce(r.w, t, P521_P, P521_MINV, 9);
+    return r;
+}
+static fe_p521 p521_fe_sqr(const fe_p521 *a) { return p521_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_p521 p521_fe_add(const fe_p521 *a, const fe_p521 *b) { fe_p521 r; mont_add(r.w, a->w, b->w, P521_P, 9); return r; }   /* :316-320 */
+static fe_p521 p521_fe_sub(const fe_p521 *a, const fe_p521 *b) { fe_p521 r; mont_sub(r.w, a->w, b->w, P521_P, 9); return r; }   /* :331-335 */
+static fe_p521 p521_fe_zero(void) { fe_p521 z; memset(&z, 0, sizeof z); return z; }
+static fe_p521 p521_fe_neg(const fe_p521 *a) { fe_p521 z = p521_fe_zero(); return p521_fe_sub(&z, a); }                         /* :353-357 */
+static fe_p521 p521_fe_dbl(const fe_p521 *a) { return p521_fe_add(a, a); }                                                     /* :323-327 */
+static int p521_fe_is_zero(const fe_p521 *a) { return ecref_mp_is_zero(a->w, 9); }
+
+static void p521_init(void) {
+    if (p521_ready) return;
+    P521_MINV = mont_neg_inv64(P521_P[0]);
+    mont_pow2_mod(P521_R.w, P521_P, 9, 576);
+    mont_pow2_mod(P521_R2.w, P521_P, 9, 1152);
+    fe_p521 b;
+    ecref_be_to_words_n(P521_B_BYTES, 66, b.w, 9);
+    P521_B_MONT = p521_fe_mul(&b, &P521_R2);
+    p521_ready = 1;
+}
+static fe_p521 p521_fe_one(void) { p521_init(); return P521_R; }
+static fe_p521 p521_fe_b(void) { p521_init(); return P521_B_MONT; }
+
+static int p521_fe_from_bytes(fe_p521 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    p521_init();
+    fe_p521 t;
+    ecref_be_to_words_n(b, 66, t.w, 9);
+    if (ecref_mp_cmp(t.w, P521_P, 9) >= 0) return 0;
+    *r = p521_fe_mul(&t, &P521_R2);
+    return 1;
+}
+static void p521_fe_to_bytes(uint8_t *out, const fe_p521 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[18];
+    fe_p521 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 72);
+    mont_reduce(c.w, t, P521_P, P521_MINV, 9);
+    ecref_words_to_be_n(c.w, out, 66);
+}
+static int p521_fe_invert(fe_p521 *out, const fe_p521 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (p521_fe_is_zero(a)) return 0;
+    uint64_t e[9], two[9] = {2, 0, 0, 0, 0, 0, 0, 0, 0};
+    ecref_mp_sub(e, P521_P, two, 9);
+    fe_p521 r = p521_fe_one();
+    for (int i = 575; i >= 0; i--) {
+        r = p521_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p521_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int p521_fe_sqrt(fe_p521 *out, const fe_p521 *a) {
+    uint64_t e[9], one[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+    ecref_mp_add(e, P521_P, one, 9);                         /* p + 1 = 2^521 < 2^576 */
+    for (int i = 0; i < 9; i++) e[i] = (e[i] >> 2) | (i + 1 < 9 ? e[i + 1] << 62 : 0);
+    fe_p521 r = p521_fe_one();
+    for (int i = 575; i >= 0; i--) {
+        r = p521_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = p521_fe_mul(&r, a);
+    }
+    fe_p521 sq = p521_fe_sqr(&r);
+    fe_p521 d = p521_fe_sub(&sq, a);
+    *out = r;
+    return p521_fe_is_zero(&d);
+}
+
+#define PO_PFX p521
+#define PO_NL 9
+#define PO_L 66
+#define PO_FE fe_p521
+#define PO_F(name) p521_fe_##name
+#define PO_ORDER P521_N
+#define PO_GX P521_GX
+#define PO_GY P521_GY
 #include "ecref_prime.inc"

@@ -6,9 +6,9 @@ Run in the build container (needs /root/reference); the GPU box only ever reads 
     python tests/golden/extract_golden.py [/root/reference]
 
 Sources:
-  {k256,p256,p384,p224,p192}/src/test_vectors/group.rs   ADD_TEST_VECTORS (k*G for k = 1..20, affine x,y)
+  {k256,p256,p384,p224,p192,p521}/src/test_vectors/group.rs   ADD_TEST_VECTORS (k*G for k = 1..20, affine x,y)
                                                MUL_TEST_VECTORS ((k, x, y) with k*G = (x, y))
-  {k256,p256,p384,p224,p192}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
+  {k256,p256,p384,p224,p192,p521}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
   {k256,p256}/src/test_vectors/field.rs        DBL_TEST_VECTORS (repeated doubling of 1 mod p)
   k256/src/schnorr.rs                          BIP340_SIGN_VECTORS (index 0-3: public key, message, valid signature),
                                                BIP340_VERIFY_VECTORS (index 4-14: public key, message, signature,
@@ -106,7 +106,7 @@ def schnorr_vectors():
 
 def main():
     summary = {}
-    for curve in ("k256", "p256", "p384", "p224", "p192"):
+    for curve in ("k256", "p256", "p384", "p224", "p192", "p521"):
         data = {
             "source": "RustCrypto/elliptic-curves %s/src/test_vectors/{group,ecdsa,field}.rs" % curve,
             "group": group_vectors(curve),

@@ -24,7 +24,7 @@ bool load_affine(Affine<C>* a, const uint8_t* xy, int inf) {
     if (inf) return false;
     bool ok1, ok2;
     a->x = F::from_bytes(xy, &ok1).e;
-    a->y = F::from_bytes(xy + 4 * C::N, &ok2).e;
+    a->y = F::from_bytes(xy + WireBytes<C>::value, &ok2).e;
     return true;
 }
 
@@ -33,13 +33,13 @@ void store_affine(const Proj<C>& p, uint8_t* xy, uint8_t* inf) {
     using F = Field<C>;
     using G = Group<C>;
     if (F::is_zero(G::m(p.z))) {
-        std::memset(xy, 0, 8 * C::N);
+        std::memset(xy, 0, 2 * WireBytes<C>::value);
         if (inf) *inf = 1;
         return;
     }
     auto zi = F::inv(G::m(p.z));
     F::to_bytes(xy, F::mul(G::m(p.x), zi));
-    F::to_bytes(xy + 4 * C::N, F::mul(G::m(p.y), zi));
+    F::to_bytes(xy + WireBytes<C>::value, F::mul(G::m(p.y), zi));
     if (inf) *inf = 0;
 }
 
@@ -137,7 +137,7 @@ int on_curve(const uint8_t* xy) {
     bool ok1, ok2;
     Affine<C> a;
     a.x = F::from_bytes(xy, &ok1).e;
-    a.y = F::from_bytes(xy + 4 * C::N, &ok2).e;
+    a.y = F::from_bytes(xy + WireBytes<C>::value, &ok2).e;
     return ok1 && ok2 && G::on_curve(a, G::curve_b());
 }
 
@@ -246,13 +246,13 @@ void normalize(const std::vector<Proj<C>>& proj, size_t nthreads, uint8_t* out_x
         for (size_t j = last;; j -= nthreads) {
             const Proj<C>& p = proj[j];
             if (F::is_zero(G::m(p.z))) {
-                std::memset(out_xy + j * 8 * N, 0, 8 * N);
+                std::memset(out_xy + j * 2 * WireBytes<C>::value, 0, 2 * WireBytes<C>::value);
                 out_inf[j] = 1;
             } else {
                 typename F::M1 zinv = F::mul(G::m(prefix[j]), inv);
                 inv = F::mul(inv, G::m(p.z));
-                F::to_bytes(out_xy + j * 8 * N, F::mul(G::m(p.x), zinv));
-                F::to_bytes(out_xy + j * 8 * N + 4 * N, F::mul(G::m(p.y), zinv));
+                F::to_bytes(out_xy + j * 2 * WireBytes<C>::value, F::mul(G::m(p.x), zinv));
+                F::to_bytes(out_xy + j * 2 * WireBytes<C>::value + WireBytes<C>::value, F::mul(G::m(p.y), zinv));
                 out_inf[j] = 0;
             }
             if (j < nthreads) break;
@@ -262,7 +262,7 @@ void normalize(const std::vector<Proj<C>>& proj, size_t nthreads, uint8_t* out_x
 
 template <class C>
 bool load_scalar(uint32_t* k, const uint8_t* be) {
-    load_be<C::N>(k, be);
+    load_be_wire<C>(k, be);
     return !mp_geq<C::N>(k, C::ORDER);
 }
 
@@ -273,7 +273,7 @@ int batch_mul_base(int w, const uint8_t* scalars, size_t n, size_t nthreads, uin
     std::vector<Proj<C>> proj(n);
     for (size_t i = 0; i < n; i++) {
         uint32_t k[C::N];
-        if (!load_scalar<C>(k, scalars + i * 4 * C::N)) return -2;
+        if (!load_scalar<C>(k, scalars + i * WireBytes<C>::value)) return -2;
         proj[i] = fixed_base_one<C>(table, k);
     }
     normalize<C>(proj, nthreads ? nthreads : 1, out_xy, out_inf);
@@ -288,9 +288,9 @@ int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, s
     auto b = G::curve_b();
     for (size_t i = 0; i < n; i++) {
         uint32_t k[C::N];
-        if (!load_scalar<C>(k, scalars + i * 4 * C::N)) return -2;
+        if (!load_scalar<C>(k, scalars + i * WireBytes<C>::value)) return -2;
         Affine<C> a;
-        if (!load_affine<C>(&a, pxy + i * 8 * C::N, pinf ? pinf[i] : 0)) { proj[i] = G::identity(); continue; }
+        if (!load_affine<C>(&a, pxy + i * 2 * WireBytes<C>::value, pinf ? pinf[i] : 0)) { proj[i] = G::identity(); continue; }
         if (!G::on_curve(a, b)) return -3;
         proj[i] = var_base_one<C>(a, k);
     }
@@ -316,8 +316,8 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     std::vector<uint8_t> finite(n, 0), flips(n, 0);
     std::vector<std::vector<uint32_t>> ks(n, std::vector<uint32_t>(N));
     for (size_t i = 0; i < n; i++) {                                    // prepare
-        if (!load_scalar<C>(ks[i].data(), scalars + i * 4 * N)) return -2;
-        if (!load_affine<C>(&pts[i], pxy + i * 8 * N, pinf ? pinf[i] : 0)) continue;
+        if (!load_scalar<C>(ks[i].data(), scalars + i * WireBytes<C>::value)) return -2;
+        if (!load_affine<C>(&pts[i], pxy + i * 2 * WireBytes<C>::value, pinf ? pinf[i] : 0)) continue;
         if (!G::on_curve(pts[i], b)) return -3;
         {
             uint32_t w[N];                                              // packed storage form, as on the GPU
@@ -427,17 +427,17 @@ int scalar_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     using S = ScalarN<C>;
     constexpr int N = C::N;
     uint32_t x[N], y[N], r[N];
-    load_be<N>(x, a);
+    load_be_wire<C>(x, a);
     for (int i = 0; i < N; i++) r[i] = 0;
-    if (b) load_be<N>(y, b);
+    if (b) load_be_wire<C>(y, b);
     switch (op) {
     case 0: S::mul(r, x, y); break;
     case 1: S::inv(r, x); break;
-    case 2: S::reduce_once(r, x); break;
+    case 2: S::reduce_wire(r, x); break;
     case 3: r[0] = S::is_high(x) ? 1u : 0u; break;
     default: return -1;
     }
-    store_be<N>(out, r);
+    store_be_wire<C>(out, r);
     return 0;
 }
 
@@ -459,7 +459,7 @@ int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
 
 #define DISPATCH(curve, fn, args)                                                                                   \
     switch (curve) { case 0: return fn<K256Params> args; case 1: return fn<P256Params> args; case 2: return fn<P384Params> args; \
-                     case 3: return fn<Sm2Params> args; case 4: return fn<P224Params> args; case 5: return fn<P192Params> args; default: return -1; }
+                     case 3: return fn<Sm2Params> args; case 4: return fn<P224Params> args; case 5: return fn<P192Params> args; case 6: return fn<P521Params> args; default: return -1; }
 
 }  // namespace
 

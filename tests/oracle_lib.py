@@ -9,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_ecref.so")
 
-K256, P256, P384, SM2, P224, P192 = 0, 1, 2, 3, 4, 5
-CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192}
-FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24}
+K256, P256, P384, SM2, P224, P192, P521 = 0, 1, 2, 3, 4, 5, 6
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24, P521: 66}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _i8p = ctypes.POINTER(ctypes.c_int8)
@@ -199,5 +199,7 @@ def scalar_reduce(curve, scalars):
     """Scalar::reduce(bytes) of the reference's proptest generators, applied to a uint8 array."""
     L = FIELD_BYTES[curve]
     s = _arr(scalars).copy()
+    if curve == P521:          # 66 bytes hold 528 bits but n < 2^521: keep 521 so that one subtraction of n reduces
+        s.reshape(-1, L)[:, 0] &= 1
     _chk(lib().ecref_scalar_reduce(curve, _buf(s), ctypes.c_size_t(s.size // L)))
     return s

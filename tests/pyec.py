@@ -69,7 +69,15 @@ P192 = Curve(                                                  # p192/src/arithm
     0x188DA80EB03090F67CBF20EB43A18800F4FF0AFD82FF1012,
     0x07192B95FFC8DA78631011ED6B24CDD573F977A11E794811,
 )
-CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192}
+P521 = Curve(                                                  # p521/src/arithmetic.rs:57-83, field.rs:68-80, lib.rs:51-60
+    "p521", 6, 66,
+    0x1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF,
+    0x1FFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFA51868783BF2F966B7FCC0148F709A5D03BB5C9B8899C47AEBB6FB71E91386409,
+    -3, 0x51953EB9618E1C9A1F929A21A0B68540EEA2DA725B99B315F3B8B489918EF109E156193951EC7E937B1652C0BD3BB1BF073573DF883D2C34F1EF451FD46B503F00,
+    0xC6858E06B70404E9CD9E3ECB662395B4429C648139053FB521F828AF606B4D3DBAA14B5E77EFE75928FE1DC127A2FFA8DE3348B3C1856A429BF97E7E31C2E5BD66,
+    0x11839296A789A3BC0045C8A5FB42C7D1BD998F54449579B446817AFBD17273E662C97EE72995EF42640C550B9013FAD0761353C7086A272C24088BE94769FD16650,
+)
+CURVES = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521}
 
 # secp256k1 endomorphism constants (k256/src/arithmetic/mul.rs:4-5, projective.rs:31-37)
 K256_LAMBDA = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72

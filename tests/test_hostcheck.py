@@ -10,7 +10,7 @@ import check_header_constants
 import hostcheck_lib as hc
 import pyec
 
-CURVES = ["k256", "p256", "p384", "sm2", "p224", "p192"]
+CURVES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521"]
 
 
 def test_header_constants():
@@ -178,7 +178,7 @@ def test_table_entry_rule(curve):
 def _scalars(c, rng, n, edge=True):
     ks = []
     if edge:
-        half = 1 << (8 * c.L - 1)
+        half = 1 << (c.n.bit_length() - 1)          # (8 L - 1 except for p521: 66 bytes, 521 bits)
         ks = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, 2 ** 128, half % c.n, int("80" * c.L, 16) % c.n,
               # around the fold threshold 2^(bits-1), and folded values with an all-ones top window
               half - 1, half + 1, c.n - half, c.n - half + 1, c.n - (half - (1 << (8 * c.L - 17))) - 1,
