@@ -116,7 +116,11 @@ def msm_exceptional_terms(c, rng, filler=40):
 
 def scalars_to_int_sum(scalars, L, n_mod):
     """sum of n big-endian L-byte integers mod n_mod, via 32-bit limb column sums (cheap for 2^24 terms)."""
-    a = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, L // 4, 4)
+    a = np.ascontiguousarray(scalars, dtype=np.uint8).reshape(-1, L)
+    if L % 4:                                        # p521: 66 bytes -> two leading zero bytes
+        a = np.concatenate([np.zeros((a.shape[0], 4 - L % 4), np.uint8), a], axis=1)
+        L = a.shape[1]
+    a = a.reshape(-1, L // 4, 4)
     words = (a[:, :, 0].astype(np.uint64) << 24) | (a[:, :, 1].astype(np.uint64) << 16) | (a[:, :, 2].astype(np.uint64) << 8) | a[:, :, 3].astype(np.uint64)
     total = 0
     ncol = L // 4

@@ -23,7 +23,7 @@ def pool(c):
         pools[c.name] = pts.reshape(n, 2 * c.L).copy()
     return pools[c.name]
 while time.time() < t_end:
-    c = pyec.CURVES[rng.choice(["k256", "p256", "p384", "sm2", "p224", "p192"])]
+    c = pyec.CURVES[rng.choice(["k256", "p256", "p384", "sm2", "p224", "p192", "p521"])]
     L = c.L
     kind = rng.choice(["msm", "msm", "msm", "fixed", "var"])
     if kind == "msm":
