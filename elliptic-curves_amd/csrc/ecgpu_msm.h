@@ -300,7 +300,7 @@ struct MsmPartialsHbm {       // [slot][4] raw elements: X, Y, ZZ, ZZZ
 
 // one lane per (window, chunk)
 template <class C>
-__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : 2)
+__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : C::N <= 12 ? 2 : 1)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
                  int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials) {
@@ -322,7 +322,7 @@ constexpr uint32_t MSM_BIG_PARTIALS = 32;
 
 // one lane per (window, bucket); big_list[0] = number of deferred buckets, big_list[1..] their ids
 template <class C>
-__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : 2)     // the redo path may spill; the common path is short
+__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : C::N <= 12 ? 2 : 1)     // the redo path may spill; the common path is short
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
                     const uint32_t* __restrict__ sorted, size_t n, size_t nb, int nwin, size_t chunk, size_t nchunks,
