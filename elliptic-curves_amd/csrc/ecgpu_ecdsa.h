@@ -259,8 +259,12 @@ k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_od
     if constexpr (C::A_IS_ZERO) {
         alpha = F::norm(F::add(x3, G::m(G::curve_b())));
     } else {
-        auto x3x = F::add(F::dbl(x), x);
-        alpha = F::mul(F::add(F::norm(F::sub(x3, x3x)), G::m(G::curve_b())), F::one());   // back to magnitude (1, 1)
+        if constexpr (GenericA<C>::value) {
+            alpha = F::mul(F::norm(F::add(F::add(x3, F::mul(G::curve_a(), x)), G::m(G::curve_b()))), F::one());
+        } else {
+            auto x3x = F::add(F::dbl(x), x);
+            alpha = F::mul(F::add(F::norm(F::sub(x3, x3x)), G::m(G::curve_b())), F::one());   // back to magnitude (1, 1)
+        }
     }
     bool root;
     auto beta = F::sqrt(alpha, &root);

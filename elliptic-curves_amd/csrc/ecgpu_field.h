@@ -313,10 +313,32 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
-        if constexpr (!PC::P0_IS_MINUS_ONE) {
+        if constexpr (!PC::P0_IS_MINUS_ONE && !PC::P0_IS_ONE) {
+            // general p (brainpool): u = c_i * (-p^-1) mod 2^B, then c += u * p over all limbs; the low bits of c_i cancel
+            // (model: tools/field_model.py umont_mul_general)
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                uint32_t u = ((uint32_t)c[i] * PC::PINV) & PMASK;
+#pragma unroll
+                for (int j = 0; j < UN; j++) {
+                    if (PC::P[j] != 0) c[i + j] += (uint64_t)u * opaque_const(PC::P[j]);
+                }
+                c[i + 1] += c[i] >> UB;
+            }
+            E r;
+            uint64_t v = c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
+        if constexpr (PC::P0_IS_ONE) {
             // p = 1 (mod 2^B), as for p224: -p^-1 = -1, u = -c_i mod 2^B, and u * p0 = u clears the low bits of c_i
             // (model: tools/field_model.py umont_mul_general)
-            static_assert(PC::P[0] == 1, "generic Montgomery rows: p0 must be 2^B - 1 or 1");
+            static_assert(PC::P[0] == 1, "p0 = 1 expected");
 #pragma unroll
             for (int i = 0; i < UN; i++) {
                 uint32_t u = (0u - (uint32_t)c[i]) & PMASK;

@@ -42,6 +42,10 @@ ECGPU_HD Affine<C> load_entry(const Table& table, int window, uint32_t index) {
 // entry under the current addition, no staging registers, 3 waves per SIMD) was measured too: 0.644 ms against
 // 0.643 ms — the kernel is not waiting for its gathers.  Repeated with the XYZZ kernel, where the staging registers fit
 // without costing a wave (168 VGPRs, 3 waves per SIMD): 0.545 ms against 0.52 ms.)
+// whether the never-exceptional argument for the comb does not cover the curve: n not within 2^-4 of 2^bits
+template <class C>
+constexpr bool COMB_NEEDS_CHECK = C::ORDER[C::N - 1] < 0xF0000000u;
+
 template <class C, class Table>
 ECGPU_HD Proj<C> fixed_base_mul(const uint32_t* k_in, const Table& table, int w, int nwin, const Fe<C::NL>& b) {
     using G = Group<C>;
@@ -83,6 +87,25 @@ ECGPU_HD Proj<C> fixed_base_mul(const uint32_t* k_in, const Table& table, int w,
         a.x = acc.x;
         a.y = acc.y;
         return G::from_affine(a);
+    }
+    if constexpr (COMB_NEEDS_CHECK<C>) {
+        // the argument above needs n close to 2^bits (2^bits - n small).  For brainpoolP256r1 (n = 0.66 * 2^256) the scalar
+        // k = 2^256 - n is not folded and, at the widths with W (nwin - 1) = 255, meets acc = entry at the top window:
+        // an exceptional addition zeroes ZZ for good, so ZZ == 0 is the exact test; the scalar is then redone with
+        // complete additions.
+        if (Field<C>::is_zero(G::mj(acc.zz))) {
+            uint32_t carry2 = 0;
+            Proj<C> r = G::identity();
+#pragma unroll 1
+            for (int j = 0; j < nwin; j++) {
+                int d = signed_window_step(get_bits<N>(k, j * w, w), w, &carry2);
+                if (d != 0) {
+                    Affine<C> q = load_entry<C>(table, j, (uint32_t)(d < 0 ? -d : d) - 1);
+                    r = G::add_mixed(r, q, b, (d < 0) != flip);
+                }
+            }
+            return r;
+        }
     }
     return G::xyzz_to_proj(acc);
 }

@@ -18,7 +18,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -330,6 +330,40 @@ struct P521Params {
     ECGPU_CONST uint32_t GY[17] = {0x9FD16650u, 0x88BE9476u, 0xA272C240u, 0x353C7086u, 0x3FAD0761u, 0xC550B901u,
                                         0x5EF42640u, 0x97EE7299u, 0x273E662Cu, 0x17AFBD17u, 0x579B4468u, 0x98F54449u,
                                         0x2C7D1BD9u, 0x5C8A5FB4u, 0x9A3BC004u, 0x39296A78u, 0x00000118u};
+};
+
+// brainpoolP256r1: a and b generic (RCB Alg 1-3, generic-a Jacobian doubling), general Montgomery constant.
+struct Bp256Params {
+    ECGPU_CONST int ID = CURVE_BP256;
+    ECGPU_CONST int N = 8;
+    ECGPU_CONST int NL = 10;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::BP256U;
+    ECGPU_CONST bool A_IS_ZERO = false;
+    ECGPU_CONST bool A_GENERIC = true;   // bp256/src/r1/arithmetic.rs:35 (EquationAIsGeneric)
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p                                            bp256/src/arithmetic/field.rs:53
+    ECGPU_CONST uint32_t P[8] = {0x1F6E5377u, 0x2013481Du, 0xD5262028u, 0x6E3BF623u, 0x9D838D72u, 0x3E660A90u, 0xA1EEA9BCu, 0xA9FB57DBu};
+    // n                                            bp256/src/lib.rs:70
+    ECGPU_CONST uint32_t ORDER[8] = {0x974856A7u, 0x901E0E82u, 0xB561A6F7u, 0x8C397AA3u, 0x9D838D71u, 0x3E660A90u, 0xA1EEA9BCu, 0xA9FB57DBu};
+    // group order in Montgomery form (R = 2^256): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[8] = {0x3312FCA6u, 0xE1D8D8DEu, 0x1134E4A0u, 0xF35D176Au, 0x6C815CB0u, 0x9B7F25E7u, 0xC3236762u, 0x0B25F1B9u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0xCBB40EE9u;
+    // curve b, canonical                           bp256/src/r1/arithmetic.rs:41-43
+    ECGPU_CONST uint32_t B[8] = {0xFF8C07B6u, 0x6BCCDC18u, 0x5CF7E1CEu, 0x95841629u, 0xBBD77CBFu, 0xF330B5D9u, 0xE94A4B44u, 0x26DC5C6Cu};
+    // generator, canonical                         bp256/src/r1/arithmetic.rs:44-51
+    ECGPU_CONST uint32_t GX[8] = {0x9ACE3262u, 0x3A4453BDu, 0xE3BD23C2u, 0xB9DE27E1u, 0xFC81B7AFu, 0x2C4B482Fu, 0xCB7E57CBu, 0x8BD2AEB9u};
+    ECGPU_CONST uint32_t GY[8] = {0x2F046997u, 0x5C1D54C7u, 0x2DED8E54u, 0xC2774513u, 0x14611DC9u, 0x97F8461Au, 0xC3DAC4FDu, 0x547EF835u};
+};
+
+// Whether the curve's a is neither 0 nor -3 (the parameter set says A_GENERIC = true)
+template <class C, class = void>
+struct GenericA {
+    static constexpr bool value = false;
+};
+template <class C>
+struct GenericA<C, std::void_t<decltype(C::A_GENERIC)>> {
+    static constexpr bool value = C::A_GENERIC;
 };
 
 // Wire bytes of a field element / scalar (`FieldBytesSize`): 4 N unless the parameter set says otherwise (p521: 66 bytes

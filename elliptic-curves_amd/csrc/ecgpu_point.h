@@ -304,8 +304,16 @@ struct Group {
             auto delta = F::sqr(Z);
             auto gamma = F::sqr(Y);
             auto beta = F::mul(X, gamma);
-            auto alpha = F::mul(F::sub(X, delta), F::add(X, delta));                      // 3 * 2
-            auto alpha3 = F::add(F::dbl(alpha), alpha);                                   // 3
+            // a = -3: 3 (X - delta)(X + delta) = 3 X^2 - 3 delta^2; any a (dbl-2007-bl): 3 X^2 + a delta^2
+            auto alpha3 = [&] {
+                if constexpr (GenericA<C>::value) {
+                    auto xx = F::sqr(X);
+                    return F::norm(F::add(F::add(F::dbl(xx), xx), F::mul(curve_a(), F::sqr(delta))));
+                } else {
+                    auto alpha = F::mul(F::sub(X, delta), F::add(X, delta));              // 3 * 2
+                    return F::add(F::dbl(alpha), alpha);                                  // 3
+                }
+            }();
             auto beta4 = F::dbl(F::dbl(beta));                                            // 4
             auto X3 = F::norm(F::sub(F::sqr(alpha3), F::dbl(beta4)));                     // 10 -> 1
             auto gg8 = F::dbl(F::dbl(F::dbl(F::sqr(gamma))));                             // 8
@@ -391,17 +399,97 @@ struct Group {
         return r;
     }
 
+    // ---- generic a (brainpool): RCB Alg 1-3, primeorder/src/point_arithmetic.rs:56-208 ---------------------------
+    // Written for correctness, not tuned: every sum is normalised before it is multiplied, the pairs of products that
+    // are added go through mul2.  a and 3b are field constants in internal form.
+    static ECGPU_HD M1 curve_a() {
+        if constexpr (GenericA<C>::value) return m(F::p_const(C::UC::AM));
+        else return F::zero();
+    }
+    static ECGPU_HD P add_gen(const P& l, const P& r, const E& be, bool negq) {
+        auto a = curve_a();
+        auto b3 = F::norm(F::add(F::dbl(m(be)), m(be)));
+        auto X1 = m(l.x), Y1 = m(l.y), Z1 = m(l.z), X2 = m(r.x), Z2 = m(r.z);
+        auto Y2 = F::norm(F::sel(negq, F::neg(m(r.y)), F::add(m(r.y), F::zero())));
+        auto t0 = F::mul(X1, X2);                                                             // 1
+        auto t1 = F::mul(Y1, Y2);                                                             // 2
+        auto t2 = F::mul(Z1, Z2);                                                             // 3
+        auto t3 = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(t0, t1)));   // 4-8
+        auto t4 = F::norm(F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(t0, t2)));   // 9-13
+        auto t5 = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(t1, t2)));   // 14-18
+        auto z3 = F::mul2(a, t4, b3, t2);                                                     // 19-21
+        auto x3 = F::norm(F::sub(t1, z3));                                                    // 22
+        auto z3p = F::norm(F::add(t1, z3));                                                   // 23
+        auto at2 = F::mul(a, t2);                                                             // 27
+        auto t1n = F::norm(F::add(F::add(F::dbl(t0), t0), at2));                              // 25, 26, 29
+        auto t2n = F::mul(a, F::norm(F::sub(t0, at2)));                                       // 30, 31
+        auto t4n = F::norm(F::add(F::mul(b3, t4), t2n));                                      // 28, 32
+        P o;
+        o.y = F::mul2(x3, z3p, t1n, t4n).e;                                                   // 24, 33, 34
+        o.x = F::mul2(t3, x3, F::neg(t5), t4n).e;                                             // 35-37
+        o.z = F::mul2(t5, z3p, t3, t1n).e;                                                    // 38-40
+        return o;
+    }
+    static ECGPU_HD P add_mixed_gen(const P& l, const A& r, const E& be, bool negq) {
+        auto a = curve_a();
+        auto b3 = F::norm(F::add(F::dbl(m(be)), m(be)));
+        auto X1 = m(l.x), Y1 = m(l.y), Z1 = m(l.z), X2 = m(r.x);
+        auto Y2 = F::norm(F::sel(negq, F::neg(m(r.y)), F::add(m(r.y), F::zero())));
+        auto t0 = F::mul(X1, X2);                                                             // 1
+        auto t1 = F::mul(Y1, Y2);                                                             // 2
+        auto t3 = F::norm(F::sub(F::mul(F::add(X2, Y2), F::add(X1, Y1)), F::add(t0, t1)));   // 3-7
+        auto t4 = F::norm(F::add(F::mul(X2, Z1), X1));                                        // 8, 9
+        auto t5 = F::norm(F::add(F::mul(Y2, Z1), Y1));                                        // 10, 11
+        auto z3 = F::mul2(a, t4, b3, Z1);                                                     // 12-14
+        auto x3 = F::norm(F::sub(t1, z3));                                                    // 15
+        auto z3p = F::norm(F::add(t1, z3));                                                   // 16
+        auto az = F::mul(a, Z1);                                                              // 20
+        auto t1n = F::norm(F::add(F::add(F::dbl(t0), t0), az));                               // 18, 19, 22
+        auto t2n = F::mul(a, F::norm(F::sub(t0, az)));                                        // 23, 24
+        auto t4n = F::norm(F::add(F::mul(b3, t4), t2n));                                      // 21, 25
+        P o;
+        o.y = F::mul2(x3, z3p, t1n, t4n).e;                                                   // 17, 26, 27
+        o.x = F::mul2(t3, x3, F::neg(t5), t4n).e;                                             // 28-30
+        o.z = F::mul2(t5, z3p, t3, t1n).e;                                                    // 31-33
+        return o;
+    }
+    static ECGPU_HD P dbl_gen(const P& p, const E& be) {
+        auto a = curve_a();
+        auto b3 = F::norm(F::add(F::dbl(m(be)), m(be)));
+        auto X = m(p.x), Y = m(p.y), Z = m(p.z);
+        auto t0 = F::sqr(X);                                                                  // 1
+        auto t1 = F::sqr(Y);                                                                  // 2
+        auto t2 = F::sqr(Z);                                                                  // 3
+        auto t3 = F::norm(F::dbl(F::mul(X, Y)));                                              // 4, 5
+        auto z3 = F::norm(F::dbl(F::mul(X, Z)));                                              // 6, 7
+        auto y3 = F::mul2(a, z3, b3, t2);                                                     // 8-10
+        auto x3 = F::norm(F::sub(t1, y3));                                                    // 11
+        auto y3p = F::norm(F::add(t1, y3));                                                   // 12
+        auto at2 = F::mul(a, t2);                                                             // 16
+        auto t3n = F::norm(F::add(F::mul(a, F::norm(F::sub(t0, at2))), F::mul(b3, z3)));      // 15, 17-19
+        auto t0n = F::norm(F::add(F::add(F::dbl(t0), t0), at2));                              // 20-22
+        auto t2y = F::norm(F::dbl(F::mul(Y, Z)));                                             // 25, 26
+        P o;
+        o.y = F::mul2(x3, y3p, t0n, t3n).e;                                                   // 13, 23, 24
+        o.x = F::mul2(t3, x3, F::neg(t2y), t3n).e;                                            // 14, 27, 28
+        o.z = F::mul(t2y, F::dbl(F::dbl(t1))).e;                                              // 29-31
+        return o;
+    }
+
     // ---- curve-generic entry points (b is ignored for a = 0) -----------------------------------
     static ECGPU_HD P add(const P& p, const P& q, const E& b, bool negq = false) {
         if constexpr (C::A_IS_ZERO) return add_a0(p, q, negq);
+        else if constexpr (GenericA<C>::value) return add_gen(p, q, b, negq);
         else return add_am3(p, q, b, negq);
     }
     static ECGPU_HD P add_mixed(const P& p, const A& q, const E& b, bool negq = false) {
         if constexpr (C::A_IS_ZERO) return add_mixed_a0(p, q, negq);
+        else if constexpr (GenericA<C>::value) return add_mixed_gen(p, q, b, negq);
         else return add_mixed_am3(p, q, b, negq);
     }
     static ECGPU_HD P dbl(const P& p, const E& b) {
         if constexpr (C::A_IS_ZERO) return dbl_a0(p);
+        else if constexpr (GenericA<C>::value) return dbl_gen(p, b);
         else return dbl_am3(p, b);
     }
 
@@ -412,6 +500,8 @@ struct Group {
         auto x3 = F::mul(F::sqr(x), x);
         if constexpr (C::A_IS_ZERO) {
             return F::eq(lhs, F::add(x3, m(be)));
+        } else if constexpr (GenericA<C>::value) {
+            return F::eq(lhs, F::add(F::add(x3, F::mul(curve_a(), x)), m(be)));
         } else {
             auto x3x = F::add(F::dbl(x), x);
             return F::eq(lhs, F::add(F::norm(F::sub(x3, x3x)), m(be)));

@@ -15,11 +15,12 @@ __attribute__((constructor)) static void ecref_init_all(void) {
     ecref_p224_init();
     ecref_p192_init();
     ecref_p521_init();
+    ecref_bp256_init();
 }
 
 size_t ecref_field_bytes(int curve) {
     switch (curve) {
-    case ECREF_K256: case ECREF_P256: case ECREF_SM2: return 32;
+    case ECREF_K256: case ECREF_P256: case ECREF_SM2: case ECREF_BP256: return 32;
     case ECREF_P224: return 28;
     case ECREF_P192: return 24;
     case ECREF_P521: return 66;
@@ -105,6 +106,7 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     case ECREF_P224: return ecref_p224_##fn args;     \
     case ECREF_P192: return ecref_p192_##fn args;     \
     case ECREF_P521: return ecref_p521_##fn args;     \
+    case ECREF_BP256: return ecref_bp256_##fn args;   \
     default: return ECREF_ERR_CURVE;                  \
     }
 
@@ -152,6 +154,7 @@ int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
     case ECREF_P224: ecref_p224_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P192: ecref_p192_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_P521: ecref_p521_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_BP256: ecref_bp256_scalar_reduce(s, n); return ECREF_OK;
     default: return ECREF_ERR_CURVE;
     }
 }

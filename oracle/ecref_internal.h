@@ -118,5 +118,6 @@ ECREF_DECL_CURVE(sm2)
 ECREF_DECL_CURVE(p224)
 ECREF_DECL_CURVE(p192)
 ECREF_DECL_CURVE(p521)
+ECREF_DECL_CURVE(bp256)
 
 #endif

@@ -797,3 +797,120 @@ static int p521_fe_sqrt(fe_p521 *out, const fe_p521 *a) {
 #define PO_GX P521_GX
 #define PO_GY P521_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * brainpoolP256r1 field (generic Montgomery, crypto-bigint ConstMontyForm semantics: bp256/src/arithmetic/field.rs:53-62
+ * -> primefield::MontyFieldElement) and curve with a generic a (bp256/src/r1/arithmetic.rs:34-52, EquationAIsGeneric)
+ * - SURVEY.md 8(f) rank 4.  The reference has no group vectors for this curve: parity rests on the big-int model and on
+ * OpenSSL's brainpoolP256r1.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe_bp256;
+
+static const uint64_t BP256_P[4] = {                    /* bp256/src/arithmetic/field.rs:53 */
+    0x2013481D1F6E5377ULL, 0x6E3BF623D5262028ULL, 0x3E660A909D838D72ULL, 0xA9FB57DBA1EEA9BCULL};
+static const uint64_t BP256_N[4] = {                    /* bp256/src/lib.rs:70 */
+    0x901E0E82974856A7ULL, 0x8C397AA3B561A6F7ULL, 0x3E660A909D838D71ULL, 0xA9FB57DBA1EEA9BCULL};
+static const uint8_t BP256_A_BYTES[32] = {              /* bp256/src/r1/arithmetic.rs:38-40 */
+    0x7d, 0x5a, 0x09, 0x75, 0xfc, 0x2c, 0x30, 0x57, 0xee, 0xf6, 0x75, 0x30, 0x41, 0x7a, 0xff, 0xe7,
+    0xfb, 0x80, 0x55, 0xc1, 0x26, 0xdc, 0x5c, 0x6c, 0xe9, 0x4a, 0x4b, 0x44, 0xf3, 0x30, 0xb5, 0xd9};
+static const uint8_t BP256_B_BYTES[32] = {              /* bp256/src/r1/arithmetic.rs:41-43 */
+    0x26, 0xdc, 0x5c, 0x6c, 0xe9, 0x4a, 0x4b, 0x44, 0xf3, 0x30, 0xb5, 0xd9, 0xbb, 0xd7, 0x7c, 0xbf,
+    0x95, 0x84, 0x16, 0x29, 0x5c, 0xf7, 0xe1, 0xce, 0x6b, 0xcc, 0xdc, 0x18, 0xff, 0x8c, 0x07, 0xb6};
+static const uint8_t BP256_GX[32] = {                   /* bp256/src/r1/arithmetic.rs:44-51 */
+    0x8b, 0xd2, 0xae, 0xb9, 0xcb, 0x7e, 0x57, 0xcb, 0x2c, 0x4b, 0x48, 0x2f, 0xfc, 0x81, 0xb7, 0xaf,
+    0xb9, 0xde, 0x27, 0xe1, 0xe3, 0xbd, 0x23, 0xc2, 0x3a, 0x44, 0x53, 0xbd, 0x9a, 0xce, 0x32, 0x62};
+static const uint8_t BP256_GY[32] = {
+    0x54, 0x7e, 0xf8, 0x35, 0xc3, 0xda, 0xc4, 0xfd, 0x97, 0xf8, 0x46, 0x1a, 0x14, 0x61, 0x1d, 0xc9,
+    0xc2, 0x77, 0x45, 0x13, 0x2d, 0xed, 0x8e, 0x54, 0x5c, 0x1d, 0x54, 0xc7, 0x2f, 0x04, 0x69, 0x97};
+
+static fe_bp256 BP256_R, BP256_R2, BP256_B_MONT, BP256_A_MONT;
+static uint64_t BP256_MINV;
+static int bp256_ready;
+
+static fe_bp256 bp256_fe_mul(const fe_bp256 *a, const fe_bp256 *b) {       /* monty.rs:346-350 */
+    uint64_t t[8];
+    fe_bp256 r;
+    ecref_mp_mul(t, a->w, b->w, 4);
+    mont_reduce(r.w, t, BP256_P, BP256_MINV, 4);
+    return r;
+}
+static fe_bp256 bp256_fe_sqr(const fe_bp256 *a) { return bp256_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_bp256 bp256_fe_add(const fe_bp256 *a, const fe_bp256 *b) { fe_bp256 r; mont_add(r.w, a->w, b->w, BP256_P, 4); return r; }   /* :316-320 */
+static fe_bp256 bp256_fe_sub(const fe_bp256 *a, const fe_bp256 *b) { fe_bp256 r; mont_sub(r.w, a->w, b->w, BP256_P, 4); return r; }   /* :331-335 */
+static fe_bp256 bp256_fe_zero(void) { fe_bp256 z; memset(&z, 0, sizeof z); return z; }
+static fe_bp256 bp256_fe_neg(const fe_bp256 *a) { fe_bp256 z = bp256_fe_zero(); return bp256_fe_sub(&z, a); }                         /* :353-357 */
+static fe_bp256 bp256_fe_dbl(const fe_bp256 *a) { return bp256_fe_add(a, a); }                                                     /* :323-327 */
+static int bp256_fe_is_zero(const fe_bp256 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void bp256_init(void) {
+    if (bp256_ready) return;
+    BP256_MINV = mont_neg_inv64(BP256_P[0]);
+    mont_pow2_mod(BP256_R.w, BP256_P, 4, 256);
+    mont_pow2_mod(BP256_R2.w, BP256_P, 4, 512);
+    fe_bp256 b;
+    ecref_be_to_words(BP256_B_BYTES, 32, b.w);
+    BP256_B_MONT = bp256_fe_mul(&b, &BP256_R2);
+    ecref_be_to_words(BP256_A_BYTES, 32, b.w);
+    BP256_A_MONT = bp256_fe_mul(&b, &BP256_R2);
+    bp256_ready = 1;
+}
+static fe_bp256 bp256_fe_one(void) { bp256_init(); return BP256_R; }
+static fe_bp256 bp256_fe_b(void) { bp256_init(); return BP256_B_MONT; }
+static fe_bp256 bp256_fe_a(void) { bp256_init(); return BP256_A_MONT; }
+
+static int bp256_fe_from_bytes(fe_bp256 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    bp256_init();
+    fe_bp256 t;
+    ecref_be_to_words(b, 32, t.w);
+    if (ecref_mp_cmp(t.w, BP256_P, 4) >= 0) return 0;
+    *r = bp256_fe_mul(&t, &BP256_R2);
+    return 1;
+}
+static void bp256_fe_to_bytes(uint8_t *out, const fe_bp256 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[8];
+    fe_bp256 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 32);
+    mont_reduce(c.w, t, BP256_P, BP256_MINV, 4);
+    ecref_words_to_be(c.w, 4, out);
+}
+static int bp256_fe_invert(fe_bp256 *out, const fe_bp256 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (bp256_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, BP256_P, two, 4);
+    fe_bp256 r = bp256_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bp256_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp256_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int bp256_fe_sqrt(fe_bp256 *out, const fe_bp256 *a) {
+    uint64_t e[4], one[4] = {1, 0, 0, 0};
+    ecref_mp_add(e, BP256_P, one, 4);                         /* p + 1 < 2^256 */
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i + 1 < 4 ? e[i + 1] << 62 : 0);
+    fe_bp256 r = bp256_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bp256_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp256_fe_mul(&r, a);
+    }
+    fe_bp256 sq = bp256_fe_sqr(&r);
+    fe_bp256 d = bp256_fe_sub(&sq, a);
+    *out = r;
+    return bp256_fe_is_zero(&d);
+}
+
+#define PO_PFX bp256
+#define PO_NL 4
+#define PO_A_GENERIC 1
+#define PO_FE fe_bp256
+#define PO_F(name) bp256_fe_##name
+#define PO_ORDER BP256_N
+#define PO_GX BP256_GX
+#define PO_GY BP256_GY
+#include "ecref_prime.inc"
