@@ -15,8 +15,9 @@
 // For the top window S_j + e_j = k (folded, 0 < k < n/2), so S_j = -e_j is impossible, and S_j = e_j (mod n) means
 // 2 S_j - k = -n (the only multiple of n in range), i.e. |S_j| > n/4: that needs W (nwin - 1) = bits - 1, where the
 // top digit is the carry alone (e_j = 2^(bits-1), S_j = k - 2^(bits-1)) and the condition reads k = 2^bits - n —
-// a value < 2^(bits - 31) for every curve here (k256: 2^129, p256 / sm2: 2^225, p384: 2^190), so with W <= 26 the
-// window below the top one is zero and hands no carry up.  Contradiction.
+// a value < 2^(bits - 31) for the curves whose n is within 2^-4 of 2^bits (k256: 2^129, p256 / sm2: 2^225, p384: 2^190,
+// p224: 2^113, p192: 2^96), so with W <= 26 the window below the top one is zero and hands no carry up.  Contradiction.
+// The other curves (brainpoolP256r1: n = 0.66 * 2^256; p521: 521 bits in 544) do not rely on this: COMB_NEEDS_CHECK.
 // tests: comb_corner_scalars (tests/gpu_common.py) at W = 5 and 15 (top window at bit 255) and at the default widths.
 #pragma once
 
