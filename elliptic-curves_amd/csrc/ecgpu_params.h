@@ -18,7 +18,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -354,6 +354,36 @@ struct Bp256Params {
     // generator, canonical                         bp256/src/r1/arithmetic.rs:44-51
     ECGPU_CONST uint32_t GX[8] = {0x9ACE3262u, 0x3A4453BDu, 0xE3BD23C2u, 0xB9DE27E1u, 0xFC81B7AFu, 0x2C4B482Fu, 0xCB7E57CBu, 0x8BD2AEB9u};
     ECGPU_CONST uint32_t GY[8] = {0x2F046997u, 0x5C1D54C7u, 0x2DED8E54u, 0xC2774513u, 0x14611DC9u, 0x97F8461Au, 0xC3DAC4FDu, 0x547EF835u};
+};
+
+// brainpoolP384r1: the same generic-a path on 12 words / 15 x 27-bit limbs.
+struct Bp384Params {
+    ECGPU_CONST int ID = CURVE_BP384;
+    ECGPU_CONST int N = 12;
+    ECGPU_CONST int NL = 15;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::BP384U;
+    ECGPU_CONST bool A_IS_ZERO = false;
+    ECGPU_CONST bool A_GENERIC = true;   // bp384/src/r1/arithmetic.rs:33 (EquationAIsGeneric)
+    ECGPU_CONST bool MONTGOMERY = true;
+    // p                                            bp384/src/arithmetic/field.rs:53
+    ECGPU_CONST uint32_t P[12] = {0x3107EC53u, 0x87470013u, 0x901D1A71u, 0xACD3A729u, 0x7FB71123u, 0x12B1DA19u,
+                                        0xED5456B4u, 0x152F7109u, 0x50E641DFu, 0x0F5D6F7Eu, 0xA3386D28u, 0x8CB91E82u};
+    // n                                            bp384/src/lib.rs:73
+    ECGPU_CONST uint32_t ORDER[12] = {0xE9046565u, 0x3B883202u, 0x6B7FC310u, 0xCF3AB6AFu, 0xAC0425A7u, 0x1F166E6Cu,
+                                        0xED5456B3u, 0x152F7109u, 0x50E641DFu, 0x0F5D6F7Eu, 0xA3386D28u, 0x8CB91E82u};
+    // group order in Montgomery form (R = 2^384): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[12] = {0xDE771C8Eu, 0xAC4ED3A2u, 0x2F2B6B6Eu, 0x37264E20u, 0x9802688Au, 0x2A927E3Bu,
+                                        0x52D748FFu, 0x574A74CBu, 0x65165FDBu, 0x8F886DC9u, 0x614E97C2u, 0x0CE8941Au};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x5CB5BB93u;
+    // curve b, canonical                           bp384/src/r1/arithmetic.rs:39-41
+    ECGPU_CONST uint32_t B[12] = {0xFA504C11u, 0x3AB78696u, 0x95DBC994u, 0x7CB43902u, 0x3EEB62D5u, 0x2E880EA5u,
+                                        0x07DCD2A6u, 0x2FB77DE1u, 0x16F0447Cu, 0x8B39B554u, 0x22CE2826u, 0x04A8C7DDu};
+    // generator, canonical                         bp384/src/r1/arithmetic.rs:42-49
+    ECGPU_CONST uint32_t GX[12] = {0x47D4AF1Eu, 0xEF87B2E2u, 0x36D646AAu, 0xE826E034u, 0x0CBD10E8u, 0xDB7FCAFEu,
+                                        0x7EF14FE3u, 0x8847A3E7u, 0xB7C13F6Bu, 0xA2A63A81u, 0x68CF45FFu, 0x1D1C64F0u};
+    ECGPU_CONST uint32_t GY[12] = {0x263C5315u, 0x42820341u, 0x77918111u, 0x0E464621u, 0xF9912928u, 0xE19C054Fu,
+                                        0xFEEC5864u, 0x62B70B29u, 0x95CFD552u, 0x5CB1EB8Eu, 0x20F9C2A4u, 0x8ABE1D75u};
 };
 
 // Whether the curve's a is neither 0 nor -3 (the parameter set says A_GENERIC = true)

@@ -328,5 +328,6 @@ using p224 = Curve<ECGPU_P224, 28>;   // no point decompression (p = 1 mod 4)
 using p192 = Curve<ECGPU_P192, 24>;
 using p521 = Curve<ECGPU_P521, 66>;
 using bp256r1 = Curve<ECGPU_BP256, 32>;
+using bp384r1 = Curve<ECGPU_BP384, 48>;
 
 }  // namespace ecgpu_host

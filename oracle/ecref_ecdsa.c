@@ -38,6 +38,7 @@ static const uint64_t ORDER_P224[4] = {0x13DD29455C5C2A3Dull, 0xFFFF16A2E0B8F03E
 
 static const uint64_t ORDER_P521[9] = {0xBB6FB71E91386409ull, 0x3BB5C9B8899C47AEull, 0x7FCC0148F709A5D0ull, 0x51868783BF2F966Bull, 0xFFFFFFFFFFFFFFFAull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0x00000000000001FFull};   /* p521/src/lib.rs:51-60 */
 static const uint64_t ORDER_BP256[4] = {0x901E0E82974856A7ull, 0x8C397AA3B561A6F7ull, 0x3E660A909D838D71ull, 0xA9FB57DBA1EEA9BCull};   /* bp256/src/lib.rs:70 */
+static const uint64_t ORDER_BP384[6] = {0x3B883202E9046565ull, 0xCF3AB6AF6B7FC310ull, 0x1F166E6CAC0425A7ull, 0x152F7109ED5456B3ull, 0x0F5D6F7E50E641DFull, 0x8CB91E82A3386D28ull};   /* bp384/src/lib.rs:73 */
 static const uint64_t ORDER_P192[3] = {0x146BC9B1B4D22831ull, 0xFFFFFFFF99DEF836ull, 0xFFFFFFFFFFFFFFFFull};   /* p192/src/lib.rs:41 */
 
 typedef struct {
@@ -77,8 +78,8 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
     if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
 }
 static void modn_init(modn_t *m, int curve) {
-    m->nl = curve == ECREF_P384 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 ? ORDER_BP256 : ORDER_P384;
+    m->nl = curve == ECREF_P384 || curve == ECREF_BP384 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 ? ORDER_BP256 : curve == ECREF_BP384 ? ORDER_BP384 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -140,7 +141,7 @@ static void to_be_len(uint8_t *b, const uint64_t *w, size_t len) { ecref_words_t
 
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
                              size_t n, int reject_high_s, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;

@@ -119,5 +119,6 @@ ECREF_DECL_CURVE(p224)
 ECREF_DECL_CURVE(p192)
 ECREF_DECL_CURVE(p521)
 ECREF_DECL_CURVE(bp256)
+ECREF_DECL_CURVE(bp384)
 
 #endif

@@ -914,3 +914,123 @@ static int bp256_fe_sqrt(fe_bp256 *out, const fe_bp256 *a) {
 #define PO_GX BP256_GX
 #define PO_GY BP256_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * brainpoolP384r1: generic Montgomery field on six words (bp384/src/arithmetic/field.rs:53-62) and the generic-a curve
+ * (bp384/src/r1/arithmetic.rs:32-50, EquationAIsGeneric).  No group vectors in the reference: parity rests on the big-int
+ * model and on OpenSSL's brainpoolP384r1.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[6]; } fe_bp384;
+
+static const uint64_t BP384_P[6] = {                    /* bp384/src/arithmetic/field.rs:53 */
+    0x874700133107EC53ULL, 0xACD3A729901D1A71ULL, 0x12B1DA197FB71123ULL, 0x152F7109ED5456B4ULL, 0x0F5D6F7E50E641DFULL, 0x8CB91E82A3386D28ULL};
+static const uint64_t BP384_N[6] = {                    /* bp384/src/lib.rs:73 */
+    0x3B883202E9046565ULL, 0xCF3AB6AF6B7FC310ULL, 0x1F166E6CAC0425A7ULL, 0x152F7109ED5456B3ULL, 0x0F5D6F7E50E641DFULL, 0x8CB91E82A3386D28ULL};
+static const uint8_t BP384_A_BYTES[48] = {              /* bp384/src/r1/arithmetic.rs:36-38 */
+    0x7b, 0xc3, 0x82, 0xc6, 0x3d, 0x8c, 0x15, 0x0c, 0x3c, 0x72, 0x08, 0x0a, 0xce, 0x05, 0xaf, 0xa0,
+    0xc2, 0xbe, 0xa2, 0x8e, 0x4f, 0xb2, 0x27, 0x87, 0x13, 0x91, 0x65, 0xef, 0xba, 0x91, 0xf9, 0x0f,
+    0x8a, 0xa5, 0x81, 0x4a, 0x50, 0x3a, 0xd4, 0xeb, 0x04, 0xa8, 0xc7, 0xdd, 0x22, 0xce, 0x28, 0x26};
+static const uint8_t BP384_B_BYTES[48] = {              /* bp384/src/r1/arithmetic.rs:39-41 */
+    0x04, 0xa8, 0xc7, 0xdd, 0x22, 0xce, 0x28, 0x26, 0x8b, 0x39, 0xb5, 0x54, 0x16, 0xf0, 0x44, 0x7c,
+    0x2f, 0xb7, 0x7d, 0xe1, 0x07, 0xdc, 0xd2, 0xa6, 0x2e, 0x88, 0x0e, 0xa5, 0x3e, 0xeb, 0x62, 0xd5,
+    0x7c, 0xb4, 0x39, 0x02, 0x95, 0xdb, 0xc9, 0x94, 0x3a, 0xb7, 0x86, 0x96, 0xfa, 0x50, 0x4c, 0x11};
+static const uint8_t BP384_GX[48] = {                   /* bp384/src/r1/arithmetic.rs:42-49 */
+    0x1d, 0x1c, 0x64, 0xf0, 0x68, 0xcf, 0x45, 0xff, 0xa2, 0xa6, 0x3a, 0x81, 0xb7, 0xc1, 0x3f, 0x6b,
+    0x88, 0x47, 0xa3, 0xe7, 0x7e, 0xf1, 0x4f, 0xe3, 0xdb, 0x7f, 0xca, 0xfe, 0x0c, 0xbd, 0x10, 0xe8,
+    0xe8, 0x26, 0xe0, 0x34, 0x36, 0xd6, 0x46, 0xaa, 0xef, 0x87, 0xb2, 0xe2, 0x47, 0xd4, 0xaf, 0x1e};
+static const uint8_t BP384_GY[48] = {
+    0x8a, 0xbe, 0x1d, 0x75, 0x20, 0xf9, 0xc2, 0xa4, 0x5c, 0xb1, 0xeb, 0x8e, 0x95, 0xcf, 0xd5, 0x52,
+    0x62, 0xb7, 0x0b, 0x29, 0xfe, 0xec, 0x58, 0x64, 0xe1, 0x9c, 0x05, 0x4f, 0xf9, 0x91, 0x29, 0x28,
+    0x0e, 0x46, 0x46, 0x21, 0x77, 0x91, 0x81, 0x11, 0x42, 0x82, 0x03, 0x41, 0x26, 0x3c, 0x53, 0x15};
+
+static fe_bp384 BP384_R, BP384_R2, BP384_B_MONT, BP384_A_MONT;
+static uint64_t BP384_MINV;
+static int bp384_ready;
+
+static fe_bp384 bp384_fe_mul(const fe_bp384 *a, const fe_bp384 *b) {       /* monty.rs:346-350 */
+    uint64_t t[12];
+    fe_bp384 r;
+    ecref_mp_mul(t, a->w, b->w, 6);
+    mont_reduce(r.w, t, BP384_P, BP384_MINV, 6);
+    return r;
+}
+static fe_bp384 bp384_fe_sqr(const fe_bp384 *a) { return bp384_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_bp384 bp384_fe_add(const fe_bp384 *a, const fe_bp384 *b) { fe_bp384 r; mont_add(r.w, a->w, b->w, BP384_P, 6); return r; }   /* :316-320 */
+static fe_bp384 bp384_fe_sub(const fe_bp384 *a, const fe_bp384 *b) { fe_bp384 r; mont_sub(r.w, a->w, b->w, BP384_P, 6); return r; }   /* :331-335 */
+static fe_bp384 bp384_fe_zero(void) { fe_bp384 z; memset(&z, 0, sizeof z); return z; }
+static fe_bp384 bp384_fe_neg(const fe_bp384 *a) { fe_bp384 z = bp384_fe_zero(); return bp384_fe_sub(&z, a); }                         /* :353-357 */
+static fe_bp384 bp384_fe_dbl(const fe_bp384 *a) { return bp384_fe_add(a, a); }                                                     /* :323-327 */
+static int bp384_fe_is_zero(const fe_bp384 *a) { return ecref_mp_is_zero(a->w, 6); }
+
+static void bp384_init(void) {
+    if (bp384_ready) return;
+    BP384_MINV = mont_neg_inv64(BP384_P[0]);
+    mont_pow2_mod(BP384_R.w, BP384_P, 6, 384);
+    mont_pow2_mod(BP384_R2.w, BP384_P, 6, 768);
+    fe_bp384 b;
+    ecref_be_to_words(BP384_B_BYTES, 48, b.w);
+    BP384_B_MONT = bp384_fe_mul(&b, &BP384_R2);
+    ecref_be_to_words(BP384_A_BYTES, 48, b.w);
+    BP384_A_MONT = bp384_fe_mul(&b, &BP384_R2);
+    bp384_ready = 1;
+}
+static fe_bp384 bp384_fe_one(void) { bp384_init(); return BP384_R; }
+static fe_bp384 bp384_fe_b(void) { bp384_init(); return BP384_B_MONT; }
+static fe_bp384 bp384_fe_a(void) { bp384_init(); return BP384_A_MONT; }
+
+static int bp384_fe_from_bytes(fe_bp384 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    bp384_init();
+    fe_bp384 t;
+    ecref_be_to_words(b, 48, t.w);
+    if (ecref_mp_cmp(t.w, BP384_P, 6) >= 0) return 0;
+    *r = bp384_fe_mul(&t, &BP384_R2);
+    return 1;
+}
+static void bp384_fe_to_bytes(uint8_t *out, const fe_bp384 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[12];
+    fe_bp384 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 48);
+    mont_reduce(c.w, t, BP384_P, BP384_MINV, 6);
+    ecref_words_to_be(c.w, 6, out);
+}
+static int bp384_fe_invert(fe_bp384 *out, const fe_bp384 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (bp384_fe_is_zero(a)) return 0;
+    uint64_t e[6], two[6] = {2, 0, 0, 0, 0, 0};
+    ecref_mp_sub(e, BP384_P, two, 6);
+    fe_bp384 r = bp384_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = bp384_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp384_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int bp384_fe_sqrt(fe_bp384 *out, const fe_bp384 *a) {
+    uint64_t e[6], one[6] = {1, 0, 0, 0, 0, 0};
+    ecref_mp_add(e, BP384_P, one, 6);                         /* p + 1 < 2^384 */
+    for (int i = 0; i < 6; i++) e[i] = (e[i] >> 2) | (i + 1 < 6 ? e[i + 1] << 62 : 0);
+    fe_bp384 r = bp384_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = bp384_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp384_fe_mul(&r, a);
+    }
+    fe_bp384 sq = bp384_fe_sqr(&r);
+    fe_bp384 d = bp384_fe_sub(&sq, a);
+    *out = r;
+    return bp384_fe_is_zero(&d);
+}
+
+#define PO_PFX bp384
+#define PO_NL 6
+#define PO_A_GENERIC 1
+#define PO_FE fe_bp384
+#define PO_F(name) bp384_fe_##name
+#define PO_ORDER BP384_N
+#define PO_GX BP384_GX
+#define PO_GY BP384_GY
+#include "ecref_prime.inc"
