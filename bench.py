@@ -281,6 +281,9 @@ def main():
                          "traffic_source": traffic_src, "valu_busy_pmc": valu_busy,
                          "algorithmic_imad32_per_unit": wl["imad_per_unit"], "units_per_launch": units_per_launch,
                          "peak_source": "ecgpu_valu_probe(v_mad_u64_u32) measured in this run",
+                         "frac_note": "numerator = the reference algorithm's IMAD32 count (SURVEY.md 8d); above 1 means the "
+                                      "GPU algorithm does less arithmetic per unit; utilisation of the VALU issue roof is "
+                                      "valu_busy_pmc (DESIGN.md 6)",
                          "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                  "frac": hbm_gbps / HBM_PEAK_GBPS if hbm_gbps else None,
                                  "algorithmic_bytes_per_unit": wl["bytes_per_unit"]}},
