@@ -18,7 +18,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8, CURVE_BP256T1 = 9, CURVE_BP384T1 = 10 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -384,6 +384,29 @@ struct Bp384Params {
                                         0x7EF14FE3u, 0x8847A3E7u, 0xB7C13F6Bu, 0xA2A63A81u, 0x68CF45FFu, 0x1D1C64F0u};
     ECGPU_CONST uint32_t GY[12] = {0x263C5315u, 0x42820341u, 0x77918111u, 0x0E464621u, 0xF9912928u, 0xE19C054Fu,
                                         0xFEEC5864u, 0x62B70B29u, 0x95CFD552u, 0x5CB1EB8Eu, 0x20F9C2A4u, 0x8ABE1D75u};
+};
+
+// The brainpool t1 twists: the r1 fields and group orders, their own b and generator, a = -3
+// (bp256/src/t1/arithmetic.rs:35, bp384/src/t1/arithmetic.rs:35: EquationAIsMinusThree).  They stay on the any-a code path
+// with a = p - 3: the a = -3 formulas need a larger product budget (MAXPROD) than a general p leaves on these limb counts.
+// Affine results are the same.
+struct Bp256t1Params : Bp256Params {
+    ECGPU_CONST int ID = CURVE_BP256T1;
+    using UC = consts::BP256T1U;
+    // curve b, canonical                           bp256/src/t1/arithmetic.rs:39-41
+    ECGPU_CONST uint32_t B[8] = {0xFEE92B04u, 0x6AE58101u, 0xAF2F4925u, 0xBF93EBC4u, 0x3D0B76B7u, 0xFE66A773u, 0x30D84EA4u, 0x662C61C4u};
+    // generator, canonical                         bp256/src/t1/arithmetic.rs:42-49
+    ECGPU_CONST uint32_t GX[8] = {0x2E1305F4u, 0x79A19156u, 0x7AAFBC2Bu, 0xAFA142C4u, 0x3A656149u, 0x732213B2u, 0xC1CFE7B7u, 0xA3E8EB3Cu};
+    ECGPU_CONST uint32_t GY[8] = {0x5B25C9BEu, 0x1DABE8F3u, 0x39D02700u, 0x69BCB6DEu, 0x4644417Eu, 0x7F7B22E1u, 0x3439C56Du, 0x2D996C82u};
+};
+struct Bp384t1Params : Bp384Params {
+    ECGPU_CONST int ID = CURVE_BP384T1;
+    using UC = consts::BP384T1U;
+    // curve b, canonical                           bp384/src/t1/arithmetic.rs:38-40
+    ECGPU_CONST uint32_t B[12] = {0x33B471EEu, 0xED70355Au, 0x3B88805Cu, 0x2074AA26u, 0x756DCE1Du, 0x4B1ABD11u, 0x8CCDC64Eu, 0x4B9346EDu, 0x47910F8Cu, 0xD826DBA6u, 0xA7BDA81Bu, 0x7F519EADu};
+    // generator, canonical                         bp384/src/t1/arithmetic.rs:41-48
+    ECGPU_CONST uint32_t GX[12] = {0x418808CCu, 0xD8D0AA2Fu, 0x946A5F54u, 0xC4FF191Bu, 0x462AABFFu, 0x2476FECDu, 0xEBD65317u, 0x9B80AB12u, 0x35F72A81u, 0xF2AFCD72u, 0x2DB9A306u, 0x18DE98B0u};
+    ECGPU_CONST uint32_t GY[12] = {0x9E582928u, 0x2675BF5Bu, 0x4DC2B291u, 0x46940858u, 0xA208CCFEu, 0x3B88F2B6u, 0x5B7A1FCAu, 0x747F9347u, 0x755AD336u, 0xA114AFD2u, 0x62D30651u, 0x25AB0569u};
 };
 
 // Whether the curve's a is neither 0 nor -3 (the parameter set says A_GENERIC = true)

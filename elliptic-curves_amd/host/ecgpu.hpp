@@ -329,5 +329,7 @@ using p192 = Curve<ECGPU_P192, 24>;
 using p521 = Curve<ECGPU_P521, 66>;
 using bp256r1 = Curve<ECGPU_BP256, 32>;
 using bp384r1 = Curve<ECGPU_BP384, 48>;
+using bp256t1 = Curve<ECGPU_BP256T1, 32>;
+using bp384t1 = Curve<ECGPU_BP384T1, 48>;
 
 }  // namespace ecgpu_host

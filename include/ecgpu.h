@@ -11,7 +11,7 @@
  * Wire format (identical for host- and device-pointer entry points)
  *   scalars   n * L bytes, big-endian, canonical (< group order n) — `Scalar::to_repr`
  *             (k256/src/arithmetic/scalar.rs:310-316, primefield/src/monty.rs:498-500);
- *             L = 32 (k256, p256, sm2, bp256 = brainpoolP256r1), 48 (p384, bp384 = brainpoolP384r1), 28 (p224), 24 (p192) or 66 (p521) = `FieldBytesSize`.  Records are packed without
+ *             L = 32 (k256, p256, sm2, bp256 = brainpoolP256r1, bp256t1), 48 (p384, bp384 = brainpoolP384r1, bp384t1), 28 (p224), 24 (p192) or 66 (p521) = `FieldBytesSize`.  Records are packed without
  *             padding (p224: 28-byte scalars, 56-byte points); only the base pointers of device buffers must be 16-byte aligned.
  *   points    n * 2L bytes, big-endian affine x || y — `AffinePoint::{x,y}`
  *             (primeorder/src/affine.rs:106-112) + optional n-byte identity flags
@@ -47,7 +47,7 @@ extern "C" {
 
 typedef struct ecgpu_ctx ecgpu_ctx;
 
-enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3, ECGPU_P224 = 4, ECGPU_P192 = 5, ECGPU_P521 = 6, ECGPU_BP256 = 7, ECGPU_BP384 = 8 };
+enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3, ECGPU_P224 = 4, ECGPU_P192 = 5, ECGPU_P521 = 6, ECGPU_BP256 = 7, ECGPU_BP384 = 8, ECGPU_BP256T1 = 9, ECGPU_BP384T1 = 10 };
 
 enum {
     ECGPU_OK = 0,

@@ -17,15 +17,17 @@ __attribute__((constructor)) static void ecref_init_all(void) {
     ecref_p521_init();
     ecref_bp256_init();
     ecref_bp384_init();
+    ecref_bp256t1_init();
+    ecref_bp384t1_init();
 }
 
 size_t ecref_field_bytes(int curve) {
     switch (curve) {
-    case ECREF_K256: case ECREF_P256: case ECREF_SM2: case ECREF_BP256: return 32;
+    case ECREF_K256: case ECREF_P256: case ECREF_SM2: case ECREF_BP256: case ECREF_BP256T1: return 32;
     case ECREF_P224: return 28;
     case ECREF_P192: return 24;
     case ECREF_P521: return 66;
-    case ECREF_BP384: return 48;
+    case ECREF_BP384: case ECREF_BP384T1: return 48;
     case ECREF_P384: return 48;
     default: return 0;
     }
@@ -110,6 +112,8 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     case ECREF_P521: return ecref_p521_##fn args;     \
     case ECREF_BP256: return ecref_bp256_##fn args;   \
     case ECREF_BP384: return ecref_bp384_##fn args;   \
+    case ECREF_BP256T1: return ecref_bp256t1_##fn args;   \
+    case ECREF_BP384T1: return ecref_bp384t1_##fn args;   \
     default: return ECREF_ERR_CURVE;                  \
     }
 
@@ -159,6 +163,8 @@ int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
     case ECREF_P521: ecref_p521_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_BP256: ecref_bp256_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_BP384: ecref_bp384_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_BP256T1: ecref_bp256t1_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_BP384T1: ecref_bp384t1_scalar_reduce(s, n); return ECREF_OK;
     default: return ECREF_ERR_CURVE;
     }
 }

@@ -78,8 +78,8 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
     if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
 }
 static void modn_init(modn_t *m, int curve) {
-    m->nl = curve == ECREF_P384 || curve == ECREF_BP384 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 ? ORDER_BP256 : curve == ECREF_BP384 ? ORDER_BP384 : ORDER_P384;
+    m->nl = curve == ECREF_P384 || curve == ECREF_BP384 || curve == ECREF_BP384T1 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 || curve == ECREF_BP256T1 ? ORDER_BP256 : curve == ECREF_BP384 || curve == ECREF_BP384T1 ? ORDER_BP384 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -141,7 +141,7 @@ static void to_be_len(uint8_t *b, const uint64_t *w, size_t len) { ecref_words_t
 
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
                              size_t n, int reject_high_s, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384 && curve != ECREF_BP256T1 && curve != ECREF_BP384T1) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;

@@ -120,5 +120,7 @@ ECREF_DECL_CURVE(p192)
 ECREF_DECL_CURVE(p521)
 ECREF_DECL_CURVE(bp256)
 ECREF_DECL_CURVE(bp384)
+ECREF_DECL_CURVE(bp256t1)
+ECREF_DECL_CURVE(bp384t1)
 
 #endif

@@ -1034,3 +1034,239 @@ static int bp384_fe_sqrt(fe_bp384 *out, const fe_bp384 *a) {
 #define PO_GX BP384_GX
 #define PO_GY BP384_GY
 #include "ecref_prime.inc"
+
+/* ======================================================================================
+ * brainpoolP256t1: the twist of brainpoolP256r1 — same field and group order, a = -3 (bp256/src/t1/arithmetic.rs:35,
+ * EquationAIsMinusThree: the a = -3 formulas of ecref_prime.inc), its own b and generator (:38-49).  The field code is repeated
+ * under its own names so that the section stands alone.  No group vectors in the reference: parity rests on the big-int model
+ * and on OpenSSL's brainpoolP256t1.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe_bp256t1;
+
+static const uint64_t BP256T1_P[4] = {                    /* bp256/src/arithmetic/field.rs:53 */
+    0x2013481D1F6E5377ULL, 0x6E3BF623D5262028ULL, 0x3E660A909D838D72ULL, 0xA9FB57DBA1EEA9BCULL};
+static const uint64_t BP256T1_N[4] = {                    /* bp256/src/lib.rs:70 */
+    0x901E0E82974856A7ULL, 0x8C397AA3B561A6F7ULL, 0x3E660A909D838D71ULL, 0xA9FB57DBA1EEA9BCULL};
+static const uint8_t BP256T1_A_BYTES[32] = {
+    0xa9, 0xfb, 0x57, 0xdb, 0xa1, 0xee, 0xa9, 0xbc, 0x3e, 0x66, 0x0a, 0x90, 0x9d, 0x83, 0x8d, 0x72,
+    0x6e, 0x3b, 0xf6, 0x23, 0xd5, 0x26, 0x20, 0x28, 0x20, 0x13, 0x48, 0x1d, 0x1f, 0x6e, 0x53, 0x74};
+static const uint8_t BP256T1_B_BYTES[32] = {
+    0x66, 0x2c, 0x61, 0xc4, 0x30, 0xd8, 0x4e, 0xa4, 0xfe, 0x66, 0xa7, 0x73, 0x3d, 0x0b, 0x76, 0xb7,
+    0xbf, 0x93, 0xeb, 0xc4, 0xaf, 0x2f, 0x49, 0x25, 0x6a, 0xe5, 0x81, 0x01, 0xfe, 0xe9, 0x2b, 0x04};
+static const uint8_t BP256T1_GX[32] = {
+    0xa3, 0xe8, 0xeb, 0x3c, 0xc1, 0xcf, 0xe7, 0xb7, 0x73, 0x22, 0x13, 0xb2, 0x3a, 0x65, 0x61, 0x49,
+    0xaf, 0xa1, 0x42, 0xc4, 0x7a, 0xaf, 0xbc, 0x2b, 0x79, 0xa1, 0x91, 0x56, 0x2e, 0x13, 0x05, 0xf4};
+static const uint8_t BP256T1_GY[32] = {
+    0x2d, 0x99, 0x6c, 0x82, 0x34, 0x39, 0xc5, 0x6d, 0x7f, 0x7b, 0x22, 0xe1, 0x46, 0x44, 0x41, 0x7e,
+    0x69, 0xbc, 0xb6, 0xde, 0x39, 0xd0, 0x27, 0x00, 0x1d, 0xab, 0xe8, 0xf3, 0x5b, 0x25, 0xc9, 0xbe};
+
+static fe_bp256t1 BP256T1_R, BP256T1_R2, BP256T1_B_MONT, BP256T1_A_MONT;
+static uint64_t BP256T1_MINV;
+static int bp256t1_ready;
+
+static fe_bp256t1 bp256t1_fe_mul(const fe_bp256t1 *a, const fe_bp256t1 *b) {       /* monty.rs:346-350 */
+    uint64_t t[8];
+    fe_bp256t1 r;
+    ecref_mp_mul(t, a->w, b->w, 4);
+    mont_reduce(r.w, t, BP256T1_P, BP256T1_MINV, 4);
+    return r;
+}
+static fe_bp256t1 bp256t1_fe_sqr(const fe_bp256t1 *a) { return bp256t1_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_bp256t1 bp256t1_fe_add(const fe_bp256t1 *a, const fe_bp256t1 *b) { fe_bp256t1 r; mont_add(r.w, a->w, b->w, BP256T1_P, 4); return r; }   /* :316-320 */
+static fe_bp256t1 bp256t1_fe_sub(const fe_bp256t1 *a, const fe_bp256t1 *b) { fe_bp256t1 r; mont_sub(r.w, a->w, b->w, BP256T1_P, 4); return r; }   /* :331-335 */
+static fe_bp256t1 bp256t1_fe_zero(void) { fe_bp256t1 z; memset(&z, 0, sizeof z); return z; }
+static fe_bp256t1 bp256t1_fe_neg(const fe_bp256t1 *a) { fe_bp256t1 z = bp256t1_fe_zero(); return bp256t1_fe_sub(&z, a); }                         /* :353-357 */
+static fe_bp256t1 bp256t1_fe_dbl(const fe_bp256t1 *a) { return bp256t1_fe_add(a, a); }                                                     /* :323-327 */
+static int bp256t1_fe_is_zero(const fe_bp256t1 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void bp256t1_init(void) {
+    if (bp256t1_ready) return;
+    BP256T1_MINV = mont_neg_inv64(BP256T1_P[0]);
+    mont_pow2_mod(BP256T1_R.w, BP256T1_P, 4, 256);
+    mont_pow2_mod(BP256T1_R2.w, BP256T1_P, 4, 512);
+    fe_bp256t1 b;
+    ecref_be_to_words(BP256T1_B_BYTES, 32, b.w);
+    BP256T1_B_MONT = bp256t1_fe_mul(&b, &BP256T1_R2);
+    ecref_be_to_words(BP256T1_A_BYTES, 32, b.w);
+    BP256T1_A_MONT = bp256t1_fe_mul(&b, &BP256T1_R2);
+    bp256t1_ready = 1;
+}
+static fe_bp256t1 bp256t1_fe_one(void) { bp256t1_init(); return BP256T1_R; }
+static fe_bp256t1 bp256t1_fe_b(void) { bp256t1_init(); return BP256T1_B_MONT; }
+static fe_bp256t1 bp256t1_fe_a(void) { bp256t1_init(); return BP256T1_A_MONT; }
+
+static int bp256t1_fe_from_bytes(fe_bp256t1 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    bp256t1_init();
+    fe_bp256t1 t;
+    ecref_be_to_words(b, 32, t.w);
+    if (ecref_mp_cmp(t.w, BP256T1_P, 4) >= 0) return 0;
+    *r = bp256t1_fe_mul(&t, &BP256T1_R2);
+    return 1;
+}
+static void bp256t1_fe_to_bytes(uint8_t *out, const fe_bp256t1 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[8];
+    fe_bp256t1 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 32);
+    mont_reduce(c.w, t, BP256T1_P, BP256T1_MINV, 4);
+    ecref_words_to_be(c.w, 4, out);
+}
+static int bp256t1_fe_invert(fe_bp256t1 *out, const fe_bp256t1 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (bp256t1_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, BP256T1_P, two, 4);
+    fe_bp256t1 r = bp256t1_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bp256t1_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp256t1_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int bp256t1_fe_sqrt(fe_bp256t1 *out, const fe_bp256t1 *a) {
+    uint64_t e[4], one[4] = {1, 0, 0, 0};
+    ecref_mp_add(e, BP256T1_P, one, 4);                         /* p + 1 < 2^256 */
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i + 1 < 4 ? e[i + 1] << 62 : 0);
+    fe_bp256t1 r = bp256t1_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bp256t1_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp256t1_fe_mul(&r, a);
+    }
+    fe_bp256t1 sq = bp256t1_fe_sqr(&r);
+    fe_bp256t1 d = bp256t1_fe_sub(&sq, a);
+    *out = r;
+    return bp256t1_fe_is_zero(&d);
+}
+
+#define PO_PFX bp256t1
+#define PO_NL 4
+#define PO_FE fe_bp256t1
+#define PO_F(name) bp256t1_fe_##name
+#define PO_ORDER BP256T1_N
+#define PO_GX BP256T1_GX
+#define PO_GY BP256T1_GY
+#include "ecref_prime.inc"
+
+/* ======================================================================================
+ * brainpoolP384t1: the twist of brainpoolP384r1 — same field and group order, a = -3 (bp384/src/t1/arithmetic.rs:35,
+ * EquationAIsMinusThree: the a = -3 formulas of ecref_prime.inc), its own b and generator (:38-49).  The field code is repeated
+ * under its own names so that the section stands alone.  No group vectors in the reference: parity rests on the big-int model
+ * and on OpenSSL's brainpoolP384t1.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[6]; } fe_bp384t1;
+
+static const uint64_t BP384T1_P[6] = {                    /* bp384/src/arithmetic/field.rs:53 */
+    0x874700133107EC53ULL, 0xACD3A729901D1A71ULL, 0x12B1DA197FB71123ULL, 0x152F7109ED5456B4ULL, 0x0F5D6F7E50E641DFULL, 0x8CB91E82A3386D28ULL};
+static const uint64_t BP384T1_N[6] = {                    /* bp384/src/lib.rs:73 */
+    0x3B883202E9046565ULL, 0xCF3AB6AF6B7FC310ULL, 0x1F166E6CAC0425A7ULL, 0x152F7109ED5456B3ULL, 0x0F5D6F7E50E641DFULL, 0x8CB91E82A3386D28ULL};
+static const uint8_t BP384T1_A_BYTES[48] = {
+    0x8c, 0xb9, 0x1e, 0x82, 0xa3, 0x38, 0x6d, 0x28, 0x0f, 0x5d, 0x6f, 0x7e, 0x50, 0xe6, 0x41, 0xdf,
+    0x15, 0x2f, 0x71, 0x09, 0xed, 0x54, 0x56, 0xb4, 0x12, 0xb1, 0xda, 0x19, 0x7f, 0xb7, 0x11, 0x23,
+    0xac, 0xd3, 0xa7, 0x29, 0x90, 0x1d, 0x1a, 0x71, 0x87, 0x47, 0x00, 0x13, 0x31, 0x07, 0xec, 0x50};
+static const uint8_t BP384T1_B_BYTES[48] = {
+    0x7f, 0x51, 0x9e, 0xad, 0xa7, 0xbd, 0xa8, 0x1b, 0xd8, 0x26, 0xdb, 0xa6, 0x47, 0x91, 0x0f, 0x8c,
+    0x4b, 0x93, 0x46, 0xed, 0x8c, 0xcd, 0xc6, 0x4e, 0x4b, 0x1a, 0xbd, 0x11, 0x75, 0x6d, 0xce, 0x1d,
+    0x20, 0x74, 0xaa, 0x26, 0x3b, 0x88, 0x80, 0x5c, 0xed, 0x70, 0x35, 0x5a, 0x33, 0xb4, 0x71, 0xee};
+static const uint8_t BP384T1_GX[48] = {
+    0x18, 0xde, 0x98, 0xb0, 0x2d, 0xb9, 0xa3, 0x06, 0xf2, 0xaf, 0xcd, 0x72, 0x35, 0xf7, 0x2a, 0x81,
+    0x9b, 0x80, 0xab, 0x12, 0xeb, 0xd6, 0x53, 0x17, 0x24, 0x76, 0xfe, 0xcd, 0x46, 0x2a, 0xab, 0xff,
+    0xc4, 0xff, 0x19, 0x1b, 0x94, 0x6a, 0x5f, 0x54, 0xd8, 0xd0, 0xaa, 0x2f, 0x41, 0x88, 0x08, 0xcc};
+static const uint8_t BP384T1_GY[48] = {
+    0x25, 0xab, 0x05, 0x69, 0x62, 0xd3, 0x06, 0x51, 0xa1, 0x14, 0xaf, 0xd2, 0x75, 0x5a, 0xd3, 0x36,
+    0x74, 0x7f, 0x93, 0x47, 0x5b, 0x7a, 0x1f, 0xca, 0x3b, 0x88, 0xf2, 0xb6, 0xa2, 0x08, 0xcc, 0xfe,
+    0x46, 0x94, 0x08, 0x58, 0x4d, 0xc2, 0xb2, 0x91, 0x26, 0x75, 0xbf, 0x5b, 0x9e, 0x58, 0x29, 0x28};
+
+static fe_bp384t1 BP384T1_R, BP384T1_R2, BP384T1_B_MONT, BP384T1_A_MONT;
+static uint64_t BP384T1_MINV;
+static int bp384t1_ready;
+
+static fe_bp384t1 bp384t1_fe_mul(const fe_bp384t1 *a, const fe_bp384t1 *b) {       /* monty.rs:346-350 */
+    uint64_t t[12];
+    fe_bp384t1 r;
+    ecref_mp_mul(t, a->w, b->w, 6);
+    mont_reduce(r.w, t, BP384T1_P, BP384T1_MINV, 6);
+    return r;
+}
+static fe_bp384t1 bp384t1_fe_sqr(const fe_bp384t1 *a) { return bp384t1_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_bp384t1 bp384t1_fe_add(const fe_bp384t1 *a, const fe_bp384t1 *b) { fe_bp384t1 r; mont_add(r.w, a->w, b->w, BP384T1_P, 6); return r; }   /* :316-320 */
+static fe_bp384t1 bp384t1_fe_sub(const fe_bp384t1 *a, const fe_bp384t1 *b) { fe_bp384t1 r; mont_sub(r.w, a->w, b->w, BP384T1_P, 6); return r; }   /* :331-335 */
+static fe_bp384t1 bp384t1_fe_zero(void) { fe_bp384t1 z; memset(&z, 0, sizeof z); return z; }
+static fe_bp384t1 bp384t1_fe_neg(const fe_bp384t1 *a) { fe_bp384t1 z = bp384t1_fe_zero(); return bp384t1_fe_sub(&z, a); }                         /* :353-357 */
+static fe_bp384t1 bp384t1_fe_dbl(const fe_bp384t1 *a) { return bp384t1_fe_add(a, a); }                                                     /* :323-327 */
+static int bp384t1_fe_is_zero(const fe_bp384t1 *a) { return ecref_mp_is_zero(a->w, 6); }
+
+static void bp384t1_init(void) {
+    if (bp384t1_ready) return;
+    BP384T1_MINV = mont_neg_inv64(BP384T1_P[0]);
+    mont_pow2_mod(BP384T1_R.w, BP384T1_P, 6, 384);
+    mont_pow2_mod(BP384T1_R2.w, BP384T1_P, 6, 768);
+    fe_bp384t1 b;
+    ecref_be_to_words(BP384T1_B_BYTES, 48, b.w);
+    BP384T1_B_MONT = bp384t1_fe_mul(&b, &BP384T1_R2);
+    ecref_be_to_words(BP384T1_A_BYTES, 48, b.w);
+    BP384T1_A_MONT = bp384t1_fe_mul(&b, &BP384T1_R2);
+    bp384t1_ready = 1;
+}
+static fe_bp384t1 bp384t1_fe_one(void) { bp384t1_init(); return BP384T1_R; }
+static fe_bp384t1 bp384t1_fe_b(void) { bp384t1_init(); return BP384T1_B_MONT; }
+static fe_bp384t1 bp384t1_fe_a(void) { bp384t1_init(); return BP384T1_A_MONT; }
+
+static int bp384t1_fe_from_bytes(fe_bp384t1 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    bp384t1_init();
+    fe_bp384t1 t;
+    ecref_be_to_words(b, 48, t.w);
+    if (ecref_mp_cmp(t.w, BP384T1_P, 6) >= 0) return 0;
+    *r = bp384t1_fe_mul(&t, &BP384T1_R2);
+    return 1;
+}
+static void bp384t1_fe_to_bytes(uint8_t *out, const fe_bp384t1 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[12];
+    fe_bp384t1 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 48);
+    mont_reduce(c.w, t, BP384T1_P, BP384T1_MINV, 6);
+    ecref_words_to_be(c.w, 6, out);
+}
+static int bp384t1_fe_invert(fe_bp384t1 *out, const fe_bp384t1 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (bp384t1_fe_is_zero(a)) return 0;
+    uint64_t e[6], two[6] = {2, 0, 0, 0, 0, 0};
+    ecref_mp_sub(e, BP384T1_P, two, 6);
+    fe_bp384t1 r = bp384t1_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = bp384t1_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp384t1_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int bp384t1_fe_sqrt(fe_bp384t1 *out, const fe_bp384t1 *a) {
+    uint64_t e[6], one[6] = {1, 0, 0, 0, 0, 0};
+    ecref_mp_add(e, BP384T1_P, one, 6);                         /* p + 1 < 2^384 */
+    for (int i = 0; i < 6; i++) e[i] = (e[i] >> 2) | (i + 1 < 6 ? e[i + 1] << 62 : 0);
+    fe_bp384t1 r = bp384t1_fe_one();
+    for (int i = 383; i >= 0; i--) {
+        r = bp384t1_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bp384t1_fe_mul(&r, a);
+    }
+    fe_bp384t1 sq = bp384t1_fe_sqr(&r);
+    fe_bp384t1 d = bp384t1_fe_sub(&sq, a);
+    *out = r;
+    return bp384t1_fe_is_zero(&d);
+}
+
+#define PO_PFX bp384t1
+#define PO_NL 6
+#define PO_FE fe_bp384t1
+#define PO_F(name) bp384t1_fe_##name
+#define PO_ORDER BP384T1_N
+#define PO_GX BP384T1_GX
+#define PO_GY BP384T1_GY
+#include "ecref_prime.inc"

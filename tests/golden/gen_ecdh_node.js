@@ -2,7 +2,7 @@
 // implementation independent of both the reference and this repository (SURVEY.md §8c "third opinion").
 //     node tests/golden/gen_ecdh_node.js > tests/golden/ecdh_node.json
 const crypto = require('crypto');
-const curves = {k256: 'secp256k1', p256: 'prime256v1', p384: 'secp384r1', sm2: 'SM2', p224: 'secp224r1', p192: 'prime192v1', p521: 'secp521r1', bp256: 'brainpoolP256r1', bp384: 'brainpoolP384r1'};
+const curves = {k256: 'secp256k1', p256: 'prime256v1', p384: 'secp384r1', sm2: 'SM2', p224: 'secp224r1', p192: 'prime192v1', p521: 'secp521r1', bp256: 'brainpoolP256r1', bp384: 'brainpoolP384r1', bp256t1: 'brainpoolP256t1', bp384t1: 'brainpoolP384t1'};
 const out = {source: 'node ' + process.version + ' crypto.createECDH (OpenSSL ' + process.versions.openssl + ')'};
 for (const [name, ossl] of Object.entries(curves)) {
   const rows = [];

@@ -10,7 +10,7 @@ import pyec
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CURVES = ["k256", "p256", "p384", "p224", "p192", "p521"]          # curves with reference KATs in tests/golden/<curve>.json
-ALL_CURVES = CURVES + ["sm2", "bp256", "bp384"]               # + SURVEY 8(f) rank 4: checked against the oracle, the big-int model, OpenSSL
+ALL_CURVES = CURVES + ["sm2", "bp256", "bp384", "bp256t1", "bp384t1"]               # + SURVEY 8(f) rank 4: checked against the oracle, the big-int model, OpenSSL
 
 
 def load_golden(curve):

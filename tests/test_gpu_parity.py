@@ -125,13 +125,13 @@ def test_fixed_base_vs_oracle(eng, curve, window):
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
-    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20}[curve])        # back to the defaults
+    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20, "bp256t1": 24, "bp384t1": 20}[curve])        # back to the defaults
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
 def test_fixed_base_default_window_corner_scalars(eng, curve):
     c = pyec.CURVES[curve]
-    w = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20}[curve]
+    w = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20, "bp256t1": 24, "bp384t1": 20}[curve]
     scal = b"".join(pyec.enc_scalar(c, k) for k in comb_corner_scalars(c, w) + edge_scalars(c))
     out, inf = eng.mul_by_generator(c.cid, scal)
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)

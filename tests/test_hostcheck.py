@@ -10,7 +10,7 @@ import check_header_constants
 import hostcheck_lib as hc
 import pyec
 
-CURVES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384"]
+CURVES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1"]
 
 
 def test_header_constants():

@@ -24,14 +24,14 @@ def bounds_lib():
     hc._lib = old
 
 
-@pytest.mark.parametrize("curve", ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384"])
+@pytest.mark.parametrize("curve", ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1"])
 def test_bounds_field_and_points(bounds_lib, oracle, curve):
     T.test_field_ops_vs_oracle_and_bigint(oracle, curve)
     T.test_field_lazy_chain(curve)
     T.test_point_ops_complete_formulas(oracle, curve)
 
 
-@pytest.mark.parametrize("curve", ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384"])
+@pytest.mark.parametrize("curve", ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1"])
 def test_bounds_drivers(bounds_lib, oracle, curve):
     T.test_fixed_base_algorithm(oracle, curve, 8)
     T.test_var_base_algorithm(oracle, curve)

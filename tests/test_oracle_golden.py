@@ -12,7 +12,7 @@ import pyec
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 CURVES = ["k256", "p256", "p384", "p224", "p192", "p521"]          # curves with reference KATs (tests/golden/<curve>.json)
-ALL_CURVES = CURVES + ["sm2", "bp256", "bp384"]               # + the SURVEY 8(f) rank-4 parameter set: big-int model and OpenSSL only
+ALL_CURVES = CURVES + ["sm2", "bp256", "bp384", "bp256t1", "bp384t1"]               # + the SURVEY 8(f) rank-4 parameter set: big-int model and OpenSSL only
 
 
 def load(curve):

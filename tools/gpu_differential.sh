@@ -20,7 +20,7 @@ def par(fn, n, L, *arrs):
         return fn(lo, hi)
     with ThreadPoolExecutor(T) as ex:
         return [r for r in ex.map(run, range(T)) if r is not None]
-for name in ("k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384"):
+for name in ("k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1"):
     c = pyec.CURVES[name]; L = c.L
     t0 = time.time()
     n = 1 << 17

@@ -23,7 +23,7 @@ def pool(c):
         pools[c.name] = pts.reshape(n, 2 * c.L).copy()
     return pools[c.name]
 while time.time() < t_end:
-    c = pyec.CURVES[rng.choice(["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384"])]
+    c = pyec.CURVES[rng.choice(["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1"])]
     L = c.L
     kind = rng.choice(["msm", "msm", "msm", "fixed", "var"])
     if kind == "msm":
@@ -68,7 +68,7 @@ while time.time() < t_end:
         o, f = e.mul_by_generator(c.cid, k)
         w, wf = oracle_lib.batch_mul_base(c.cid, k)
         assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("fixed", c.name, n, wdt)
-        if wdt: e.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20}[c.name])
+        if wdt: e.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20, "bp256t1": 24, "bp384t1": 20}[c.name])
         stats["fixed"] += 1
     else:
         n = rng.randrange(1, 1500)
