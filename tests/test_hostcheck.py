@@ -286,6 +286,8 @@ def test_var_base_ladder_corner_cases(oracle, curve):
 @pytest.mark.parametrize("cbits", [4, 7, 10, 13, 16])
 def test_pippenger_algorithm(oracle, curve, cbits):
     c = pyec.CURVES[curve]
+    if cbits >= 13 and curve.endswith("t1"):
+        pytest.skip("the twists share every line of field and window code with their r1 curves, which run these widths")
     if cbits == 16 and c.L > 32:
         pytest.skip("2^15 buckets x 25-33 windows on the host take half a minute; the window logic does not depend on the "
                     "curve and c = 16 runs on the 32-byte curves here and on every curve in the GPU suite")
@@ -326,7 +328,7 @@ def test_pippenger_exceptional_additions(oracle, curve):
     pxy = b"".join(e[0] for e in enc)
     want, winf = oracle.msm(c.cid, scal, pxy, None)
     assert pyec.dec_point(c, bytes(want), winf) == pyec.msm(c, ks, pts)
-    for cbits, chunks in ((4, (1, 2, 3, 7, 1000)), (9, (2, 5)), (16 if c.L <= 32 else 12, (3,))):   # wide curves: see above
+    for cbits, chunks in ((4, (1, 2, 3, 7, 1000)), (9, (2, 5)), (16 if c.L <= 32 and not curve.endswith("t1") else 12, (3,))):   # wide curves: see above
         for chunk in chunks:
             rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, None, chunk=chunk)
             assert rc == 0 and out == bytes(want) and inf == winf, (cbits, chunk)
