@@ -513,6 +513,21 @@ def test_ecdsa_verify_vs_oracle_and_model(eng, curve):
 # BIP340 Schnorr verification and point decompression
 # ---------------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("name", ["k256_der", "k256_p1363", "p256_der", "p384_der", "p224_der", "p521_der"])
+def test_ecdsa_verify_wycheproof(eng, name):
+    """The reference's Wycheproof ECDSA blobs through ecgpu_ecdsa_verify_batch (harness: k256/src/ecdsa.rs:263-384,
+    ecdsa_core::new_wycheproof_test! for p256 / p384 / p224 / p521): host side = the harness's own key padding, DER /
+    P1363 parsing, digest and bits2field (tests/wycheproof_lib.py); the device verdict must equal the pass flag of
+    every vector that parses, and the oracle's verdict."""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    assert not [i for i, ok in p["unparsed"] if ok]
+    got = eng.ecdsa_verify(c.cid, p["z"], p["r"], p["s"], p["q"], p["reject_high_s"])
+    assert bytes(got) == bytes(p["expect"])
+    assert bytes(got) == bytes(oracle_lib.ecdsa_verify(c.cid, p["z"], p["r"], p["s"], p["q"], p["reject_high_s"]))
+
+
 def test_schnorr_bip340_vectors(eng):
     """All 19 BIP340 vectors of k256/src/schnorr.rs: x-only keys lifted on the device (decompress, even y), challenge
     hashed on the host, verdicts equal to the reference's expectations and to the oracle's."""

@@ -110,6 +110,26 @@ def test_ecdsa_verify_golden_and_model(oracle, curve):
     assert list(got) == want and 0 < sum(want) < int(exp.sum())
 
 
+@pytest.mark.parametrize("name", ["k256_der", "k256_p1363", "p256_der", "p384_der", "p224_der", "p521_der"])
+def test_wycheproof_ecdsa_vectors(oracle, name):
+    """The reference's Wycheproof ECDSA blobs (k256/src/ecdsa.rs:263-384 incl. the P1363 file; new_wycheproof_test! at
+    p256/src/ecdsa.rs:166-168, p384/src/ecdsa.rs:184-186, p224/src/ecdsa.rs:113-115, p521/src/ecdsa.rs:107-109):
+    a signature that does not parse must be a pass = 0 vector, and for every one that parses the oracle's verdict
+    (and the big-int model's) equals the pass flag."""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    assert p["total"] > 200 and len(p["expect"]) + len(p["unparsed"]) == p["total"]
+    assert not [i for i, ok in p["unparsed"] if ok]
+    ok = oracle.ecdsa_verify(c.cid, p["z"], p["r"], p["s"], p["q"], p["reject_high_s"])
+    assert bytes(ok) == bytes(p["expect"])
+    L = c.L
+    for i in range(0, len(p["expect"]), 7):                      # the independent model on a stride (it is slow)
+        z, r, s = (int.from_bytes(bytes(p[k][L * i: L * i + L]), "big") for k in ("z", "r", "s"))
+        Q = pyec.dec_point(c, bytes(p["q"][2 * L * i: 2 * L * i + 2 * L]), 0)
+        assert pyec.ecdsa_verify(c, Q, z, r, s, p["reject_high_s"]) == bool(p["expect"][i])
+
+
 def test_schnorr_bip340_vectors(oracle):
     """The BIP340 vectors of k256/src/schnorr.rs (0-3 signing, 4-14 verification incl. every documented failure
     mode, 15-18 variable-length messages) through decompress (lift_x) + Schnorr verification."""
