@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
     "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
     "ecgpu_batch_mul_base_compressed", "ecgpu_batch_mul_base_compressed_dev",
+    "ecgpu_dev_alloc", "ecgpu_dev_free", "ecgpu_copy_to_device", "ecgpu_copy_to_host",
 ]
 
 
@@ -89,6 +90,12 @@ def load_library():
     lib.ecgpu_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     lib.ecgpu_host_free.restype = None
     lib.ecgpu_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.ecgpu_dev_alloc.restype = ctypes.c_void_p
+    lib.ecgpu_dev_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    lib.ecgpu_dev_free.restype = None
+    lib.ecgpu_dev_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.ecgpu_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.ecgpu_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     _lib = lib
     return lib
 
@@ -112,12 +119,36 @@ def _hp(a):
 
 
 def _dp(t):
-    """device pointer of a torch tensor / int / None"""
+    """device pointer of a torch tensor / DeviceBuffer / int / None"""
     if t is None:
         return None
     if isinstance(t, int):
         return ctypes.c_void_p(t)
     return ctypes.c_void_p(t.data_ptr())
+
+
+class DeviceBuffer:
+    """Device memory from ecgpu_dev_alloc; `buf.at(offset)` is a raw device address usable as any *_dev argument."""
+
+    def __init__(self, eng, ptr, nbytes):
+        self._eng, self.ptr, self.nbytes = eng, ptr, nbytes
+
+    def data_ptr(self):
+        return self.ptr
+
+    def at(self, offset):
+        return self.ptr + offset
+
+    def free(self):
+        if self.ptr and getattr(self._eng, "_ctx", None):
+            self._eng._lib.ecgpu_dev_free(self._eng._ctx, ctypes.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Engine:
@@ -171,6 +202,32 @@ class Engine:
         p = self._pinned.pop(arr.ctypes.data, None)
         if p:
             self._lib.ecgpu_host_free(self._ctx, ctypes.c_void_p(p))
+
+    # ---- device memory without torch (ecgpu_dev_alloc & co): DeviceBuffer objects work wherever a tensor does ----
+    def dev_alloc(self, nbytes):
+        p = self._lib.ecgpu_dev_alloc(self._ctx, ctypes.c_size_t(nbytes))
+        if not p:
+            raise EcgpuError(ERR_OOM, "ecgpu_dev_alloc(%d) failed" % nbytes)
+        return DeviceBuffer(self, p, nbytes)
+
+    def to_device(self, host, buf=None):
+        """numpy uint8 / bytes -> DeviceBuffer (a new one unless `buf` is given)."""
+        h = _host(host)
+        buf = buf if buf is not None else self.dev_alloc(max(h.size, 16))
+        if h.size > buf.nbytes:
+            raise EcgpuError(ERR_ARG, "device buffer too small")
+        self._chk(self._lib.ecgpu_copy_to_device(self._ctx, ctypes.c_void_p(buf.ptr), h.ctypes.data_as(ctypes.c_void_p),
+                                                 ctypes.c_size_t(h.size)))
+        return buf
+
+    def to_host(self, buf, nbytes=None, offset=0):
+        nbytes = buf.nbytes - offset if nbytes is None else nbytes
+        if offset + nbytes > buf.nbytes:
+            raise EcgpuError(ERR_ARG, "read past the end of the device buffer")
+        out = np.empty(nbytes, np.uint8)
+        self._chk(self._lib.ecgpu_copy_to_host(self._ctx, out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(buf.ptr + offset),
+                                               ctypes.c_size_t(nbytes)))
+        return out
 
     def set_base_window(self, curve, bits):
         self._chk(self._lib.ecgpu_set_base_window(self._ctx, curve, bits))

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <condition_variable>
 #include <map>
@@ -357,6 +358,15 @@ int download(ecgpu_ctx* ctx, void* host, const DevBuf& b, size_t bytes) {
 constexpr size_t PIPE_CHUNK = (size_t)1 << 18;
 constexpr size_t PIPE_MIN = (size_t)1 << 19;
 constexpr size_t MSM_PIPE_CHUNK = (size_t)1 << 22;   // terms per partial MSM of the host-pointer ecgpu_msm
+// ECGPU_MSM_PIPE_LOG2 moves that (tuning knob; the tests use it to drive the chunked path with small inputs); the
+// chunked path needs chunk starts that keep p224's 28-byte records 4-byte aligned, which every power of two does
+inline size_t msm_pipe_chunk() {
+    if (const char* e = getenv("ECGPU_MSM_PIPE_LOG2")) {
+        int v = atoi(e);
+        if (v >= 8 && v <= 26) return (size_t)1 << v;
+    }
+    return MSM_PIPE_CHUNK;
+}
 
 struct PipeIn { const uint8_t* host; DevBuf* dev; size_t unit; };
 struct PipeOut { uint8_t* host; DevBuf* dev; size_t unit; };
@@ -364,8 +374,8 @@ struct PipeOut { uint8_t* host; DevBuf* dev; size_t unit; };
 template <class F>
 int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const std::vector<PipeOut>& outs, F&& compute,
               const size_t chunk = PIPE_CHUNK) {
-    if (!ctx->up_stream && hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
-    if (!ctx->down_stream && hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking) != hipSuccess) return ECGPU_ERR_HIP;
+    HIP_TRY(ctx, ctx->up_stream ? hipSuccess : hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+    HIP_TRY(ctx, ctx->down_stream ? hipSuccess : hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
     int rc;
     for (auto& a : ins) if (a.host && (rc = ensure(ctx, *a.dev, n * a.unit + 16)) != ECGPU_OK) return rc;
     for (auto& o : outs) if ((rc = ensure(ctx, *o.dev, n * o.unit + 16)) != ECGPU_OK) return rc;
@@ -460,7 +470,19 @@ int pipelined(ecgpu_ctx* ctx, size_t n, const std::vector<PipeIn>& ins, const st
 
 bool check_ctx(ecgpu_ctx* ctx) {
     if (!ctx) return false;
-    return hipSetDevice(ctx->device) == hipSuccess;
+    if (hipSetDevice(ctx->device) == hipSuccess) return true;
+    ctx->err = "hipSetDevice failed";
+    return false;
+}
+
+// every error return leaves a message for ecgpu_last_error (never a stale one)
+int arg_error(ecgpu_ctx* ctx, const char* fn) {
+    if (ctx) ctx->err = std::string(fn) + ": NULL, misaligned or inconsistent argument";
+    return ECGPU_ERR_ARG;
+}
+int curve_error(ecgpu_ctx* ctx, const char* fn) {
+    if (ctx) ctx->err = std::string(fn) + ": unknown curve id, or the operation does not exist for this curve";
+    return ECGPU_ERR_CURVE;
 }
 
 }  // namespace
@@ -608,22 +630,62 @@ void ecgpu_host_free(ecgpu_ctx* ctx, void* p) {
     if (p && check_ctx(ctx)) (void)hipHostFree(p);
 }
 
+void* ecgpu_dev_alloc(ecgpu_ctx* ctx, size_t bytes) {
+    if (!check_ctx(ctx) || bytes == 0) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void ecgpu_dev_free(ecgpu_ctx* ctx, void* d_ptr) {
+    if (!d_ptr || !check_ctx(ctx)) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_ptr);
+}
+
+int ecgpu_copy_to_device(ecgpu_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (bytes == 0) return ECGPU_OK;
+    if (!d_dst || !h_src) {
+        ctx->err = "ecgpu_copy_to_device: null pointer";
+        return arg_error(ctx, __func__);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ECGPU_OK;
+}
+
+int ecgpu_copy_to_host(ecgpu_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (bytes == 0) return ECGPU_OK;
+    if (!h_dst || !d_src) {
+        ctx->err = "ecgpu_copy_to_host: null pointer";
+        return arg_error(ctx, __func__);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ECGPU_OK;
+}
+
 int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
-    if (!ctx) return ECGPU_ERR_ARG;
+    if (!ctx) return arg_error(ctx, __func__);
     ctx->stream = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own_stream;
     return ECGPU_OK;
 }
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
     if (!ctx || curve < 0 || curve > 10) return ECGPU_ERR_CURVE;
-    if (window_bits < 4 || window_bits > 26) return ECGPU_ERR_ARG;
+    if (window_bits < 4 || window_bits > 26) return arg_error(ctx, __func__);
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
 }
 
 int ecgpu_set_msm_window(ecgpu_ctx* ctx, int window_bits) {
-    if (!ctx) return ECGPU_ERR_ARG;
-    if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return ECGPU_ERR_ARG;
+    if (!ctx) return arg_error(ctx, __func__);
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 16)) return arg_error(ctx, __func__);
     ctx->msm_c = window_bits;
     return ECGPU_OK;
 }
@@ -641,14 +703,14 @@ int ecgpu_last_timing(const ecgpu_ctx* ctx, const char* name, double* ms) {
 int ecgpu_batch_mul_base_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, size_t n, void* d_out_xy,
                              void* d_out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_scalars || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_out_xy))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) { return mul_base_dev<decltype(c)>(ctx, d_scalars, n, d_out_xy, d_out_inf); });
 }
 
 int ecgpu_batch_mul_base_compressed_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, size_t n, void* d_out_x,
                                         void* d_out_tag) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_scalars || !d_out_x || !d_out_tag || !aligned16(d_scalars) || !aligned16(d_out_x))) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_out_x || !d_out_tag || !aligned16(d_scalars) || !aligned16(d_out_x))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) { return mul_base_dev<decltype(c)>(ctx, d_scalars, n, d_out_x, d_out_tag, true); });
 }
 
@@ -657,7 +719,7 @@ int ecgpu_batch_mul_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const 
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_scalars || !d_points_xy || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_points_xy) ||
               !aligned16(d_out_xy)))
-        return ECGPU_ERR_ARG;
+        return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return mul_var_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
     });
@@ -666,8 +728,8 @@ int ecgpu_batch_mul_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const 
 int ecgpu_msm_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
                   size_t n, void* d_out_xy, void* d_out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (!d_out_xy || !aligned16(d_out_xy)) return ECGPU_ERR_ARG;
-    if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy)) return arg_error(ctx, __func__);
+    if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return msm_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
     });
@@ -676,14 +738,14 @@ int ecgpu_msm_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* 
 int ecgpu_batch_normalize_dev(ecgpu_ctx* ctx, int curve, const void* d_points_xyz, size_t n, void* d_out_xy,
                               void* d_out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_points_xyz || !d_out_xy || !aligned16(d_points_xyz) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    if (n && (!d_points_xyz || !d_out_xy || !aligned16(d_points_xyz) || !aligned16(d_out_xy))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) { return normalize_dev<decltype(c)>(ctx, d_points_xyz, n, d_out_xy, d_out_inf); });
 }
 
 int ecgpu_point_sum_dev(ecgpu_ctx* ctx, int curve, const void* d_points_xy, const void* d_points_inf, size_t n,
                         void* d_out_xy, void* d_out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (!d_out_xy || !aligned16(d_out_xy) || (n && (!d_points_xy || !aligned16(d_points_xy)))) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy) || (n && (!d_points_xy || !aligned16(d_points_xy)))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return point_sum_dev<decltype(c)>(ctx, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
     });
@@ -697,7 +759,7 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_a || !d_b || !d_points_xy || !d_out_xy || !aligned16(d_a) || !aligned16(d_b) ||
               !aligned16(d_points_xy) || !aligned16(d_out_xy)))
-        return ECGPU_ERR_ARG;
+        return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         using C = decltype(c);
         constexpr int N = C::N, NS = Field<C>::NS;
@@ -733,7 +795,7 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_z || !d_r || !d_s || !d_q_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_q_xy)))
-        return ECGPU_ERR_ARG;
+        return arg_error(ctx, __func__);
     if (curve == ECGPU_SM2) return ECGPU_ERR_CURVE;          // sm2 signatures are SM2DSA (sm2/src/dsa.rs), not ECDSA
     return dispatch(curve, [&](auto c) {
         return verify_dev<decltype(c)>(ctx, VERIFY_ECDSA, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
@@ -746,7 +808,7 @@ int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* 
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_e || !d_r || !d_s || !d_p_xy || !d_ok || !aligned16(d_e) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_p_xy)))
-        return ECGPU_ERR_ARG;
+        return arg_error(ctx, __func__);
     return verify_dev<K256Params>(ctx, VERIFY_SCHNORR, d_e, d_r, d_s, d_p_xy, n, 0, d_ok);
 }
 
@@ -754,7 +816,7 @@ int ecgpu_schnorr_verify_raw_batch_dev(ecgpu_ctx* ctx, const void* d_pk_x, const
                                        size_t n, void* d_ok) {
     // VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig) from wire bytes: lift_x, challenge hash, s G - e P.  See ecgpu_ecdsa.h.
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_pk_x || !d_sigs || !d_ok || (msg_len && !d_msgs) || !aligned16(d_pk_x) || !aligned16(d_sigs))) return ECGPU_ERR_ARG;
+    if (n && (!d_pk_x || !d_sigs || !d_ok || (msg_len && !d_msgs) || !aligned16(d_pk_x) || !aligned16(d_sigs))) return arg_error(ctx, __func__);
     return verify_dev<K256Params>(ctx, VERIFY_SCHNORR_RAW, d_msgs, nullptr, d_sigs, d_pk_x, n, 0, d_ok, msg_len);
 }
 
@@ -762,9 +824,9 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const
                          void* d_ok) {
     // SharedSecret_i = x(k_i * P_i): the variable-base kernel, normalisation into scratch, x extraction
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_out_x || !d_ok || !aligned16(d_out_x))) return ECGPU_ERR_ARG;
+    if (n && (!d_out_x || !d_ok || !aligned16(d_out_x))) return arg_error(ctx, __func__);
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
+    if (!L) return curve_error(ctx, __func__);
     int rc;
     if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
@@ -784,7 +846,7 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const
 int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, const void* d_y_is_odd, size_t n, void* d_out_xy,
                                void* d_ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!d_xs || !d_y_is_odd || !d_out_xy || !d_ok || !aligned16(d_xs) || !aligned16(d_out_xy))) return ECGPU_ERR_ARG;
+    if (n && (!d_xs || !d_y_is_odd || !d_out_xy || !d_ok || !aligned16(d_xs) || !aligned16(d_out_xy))) return arg_error(ctx, __func__);
     if (curve == ECGPU_P224) {              // p = 1 (mod 4): no square root by one exponentiation
         ctx->err = "point decompression is not available for p224";
         return ECGPU_ERR_CURVE;
@@ -809,8 +871,8 @@ int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size
                          uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!scalars || !out_xy)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!scalars || !out_xy)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}},
@@ -830,8 +892,8 @@ int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* sc
                                     uint8_t* out_tag) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!scalars || !out_x || !out_tag)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!scalars || !out_x || !out_tag)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_x, &ctx->out0, L}, {out_tag, &ctx->out1, 1}}, [&](size_t off, size_t m) {
@@ -850,8 +912,8 @@ int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
                     const uint8_t* points_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
@@ -876,29 +938,35 @@ int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* 
               size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (!out_xy || (n && (!scalars || !points_xy))) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (!out_xy || (n && (!scalars || !points_xy))) return arg_error(ctx, __func__);
     int rc;
-    if (n >= 2 * MSM_PIPE_CHUNK) {
+    const size_t pipe_chunk = msm_pipe_chunk();
+    if (n >= 2 * pipe_chunk) {
         // An MSM needs all of its terms before its sort can start, and 96 (144) bytes per term take longer to upload than
         // the MSM takes to compute: sum_i k_i P_i is computed as one MSM per chunk of 2^22 terms, each under the upload of
-        // the next chunk, and the partial sums are added at the end.
-        const size_t nparts = (n + MSM_PIPE_CHUNK - 1) / MSM_PIPE_CHUNK;
-        if ((rc = ensure(ctx, ctx->out0, (nparts + 1) * 2 * L + 16)) != ECGPU_OK) return rc;
+        // the next chunk, and the partial sums are added at the end.  The partial records sit at a pitch of 2L bytes
+        // (56 for p224, 132 for p521: not 16-byte multiples), so the internal implementations are called directly — the
+        // kernels of those curves use 4-byte / byte accesses; only the public *_dev entry points insist on 16-byte bases.
+        const size_t nparts = (n + pipe_chunk - 1) / pipe_chunk;
+        if ((rc = ensure(ctx, ctx->out0, (nparts + 1) * 2 * L + 64)) != ECGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->out1, nparts + 32)) != ECGPU_OK) return rc;
-        uint8_t* part_xy = (uint8_t*)ctx->out0.p + 2 * L;          // [0] is the final result
+        uint8_t* part_xy = (uint8_t*)ctx->out0.p + (2 * L + 15) / 16 * 16;          // [0] is the final result
         uint8_t* part_inf = (uint8_t*)ctx->out1.p + 16;
-        rc = pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}}, {},
-                       [&](size_t off, size_t m) {
-                           const size_t j = off / MSM_PIPE_CHUNK;
-                           return ecgpu_msm_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
-                                                points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m, part_xy + j * 2 * L, part_inf + j);
-                       },
-                       MSM_PIPE_CHUNK);
-        if (rc != ECGPU_OK) return rc;
-        if ((rc = ecgpu_point_sum_dev(ctx, curve, part_xy, part_inf, nparts, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
-        if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
-        return download(ctx, out_inf, ctx->out1, 1);
+        return dispatch(curve, [&](auto c) -> int {
+            using C = decltype(c);
+            int r = pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}}, {},
+                              [&](size_t off, size_t m) {
+                                  const size_t j = off / pipe_chunk;
+                                  return msm_dev<C>(ctx, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
+                                                    points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m, part_xy + j * 2 * L, part_inf + j);
+                              },
+                              pipe_chunk);
+            if (r != ECGPU_OK) return r;
+            if ((r = point_sum_dev<C>(ctx, part_xy, part_inf, nparts, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return r;
+            if ((r = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return r;
+            return download(ctx, out_inf, ctx->out1, 1);
+        });
     }
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
@@ -917,8 +985,8 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
                                      uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{a_scalars, &ctx->in0, L}, {b_scalars, &ctx->in3, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
@@ -945,8 +1013,8 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
                              const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!z || !r || !s || !q_xy || !ok)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!z || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{z, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in2, L}, {q_xy, &ctx->in1, 2 * L}}, {{ok, &ctx->out1, 1}},
@@ -970,7 +1038,7 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
                                size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     const size_t L = 32;
-    if (n && (!e || !r || !s || !p_xy || !ok)) return ECGPU_ERR_ARG;
+    if (n && (!e || !r || !s || !p_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{e, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in2, L}, {p_xy, &ctx->in1, 2 * L}}, {{ok, &ctx->out1, 1}},
@@ -992,7 +1060,7 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
 int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
                                    size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return ECGPU_ERR_ARG;
+    if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{pk_x, &ctx->in0, 32}, {msg_len ? msgs : nullptr, &ctx->in1, msg_len}, {sigs, &ctx->in3, 64}},
@@ -1014,8 +1082,8 @@ int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const ui
                      uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!scalars || !points_xy || !out_x || !ok)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}}, {{out_x, &ctx->out0, L}, {ok, &ctx->out1, 1}},
@@ -1036,8 +1104,8 @@ int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const u
                            uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!xs || !y_is_odd || !out_xy || !ok)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!xs || !y_is_odd || !out_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{xs, &ctx->in0, L}, {y_is_odd, &ctx->in2, 1}}, {{out_xy, &ctx->out0, 2 * L}, {ok, &ctx->out1, 1}},
@@ -1058,8 +1126,8 @@ int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, 
                           uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (n && (!points_xyz || !out_xy)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!points_xyz || !out_xy)) return arg_error(ctx, __func__);
     int rc;
     if ((rc = upload(ctx, ctx->in0, points_xyz, n * 3 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
@@ -1073,8 +1141,8 @@ int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const u
                     uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return ECGPU_ERR_CURVE;
-    if (!out_xy || (n && !points_xy)) return ECGPU_ERR_ARG;
+    if (!L) return curve_error(ctx, __func__);
+    if (!out_xy || (n && !points_xy)) return arg_error(ctx, __func__);
     int rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
@@ -1089,7 +1157,7 @@ int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const u
 
 int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
-    if (n && (!scalars || !r1 || !r2)) return ECGPU_ERR_ARG;
+    if (n && (!scalars || !r1 || !r2)) return arg_error(ctx, __func__);
     if (n == 0) return ECGPU_OK;
     int rc;
     if ((rc = upload(ctx, ctx->in0, scalars, n * 32)) != ECGPU_OK) return rc;

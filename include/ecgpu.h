@@ -85,6 +85,16 @@ int ecgpu_set_stream(ecgpu_ctx *ctx, void *stream);
 void *ecgpu_host_alloc(ecgpu_ctx *ctx, size_t bytes);
 void ecgpu_host_free(ecgpu_ctx *ctx, void *p);
 
+/* Device memory for the *_dev entry points, for callers that have no HIP binding of their own (a Rust or C host that
+ * wants its inputs to stay resident between calls; torch callers pass tensor data_ptr()s instead).  Allocations are
+ * 256-byte aligned and live on the context's device until ecgpu_dev_free (ecgpu_destroy does not release them: free
+ * them first).  The two copies are synchronous (they return when the bytes have arrived) and ordered after earlier
+ * work on the context stream. */
+void *ecgpu_dev_alloc(ecgpu_ctx *ctx, size_t bytes);
+void ecgpu_dev_free(ecgpu_ctx *ctx, void *d_ptr);
+int ecgpu_copy_to_device(ecgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int ecgpu_copy_to_host(ecgpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
 /* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..26; defaults: k256 26 —
  * 9 additions per scalar over a 21.5 GB table —, p256 24 — 10 additions, 5.9 GB —, p384 20 — 1.0 GB; the table takes
  * ceil(bits/w) * 2^(w-1) * 2L bytes — 21.5 GB at 26 — plus at most 2 GB of scratch while it is built).

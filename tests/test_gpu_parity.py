@@ -753,6 +753,29 @@ def test_host_pointer_msm_in_chunks(eng):
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
+def test_host_pointer_msm_chunked_path_every_curve(eng, curve, monkeypatch):
+    """The chunked host-pointer ecgpu_msm on every parameter set, with the chunk size lowered to 2^10 terms
+    (ECGPU_MSM_PIPE_LOG2) so that 2^11 + 37 terms take it: the partial-sum records sit at a pitch of 2L bytes, which is not a
+    multiple of 16 for p224 (56) and p521 (132).  Result == the unchunked call == the oracle; identities mixed in."""
+    c = pyec.CURVES[curve]
+    n = (1 << 11) + 37
+    k = rand_scalars(c.cid, n, 0xEC0001F7 + c.cid)
+    s = rand_scalars(c.cid, n, 0xEC0002F7 + c.cid)
+    pts, _ = eng.mul_by_generator(c.cid, s)
+    pts = pts.copy()
+    inf = np.zeros(n, np.uint8)
+    inf[[0, 1023, 1024, n - 1]] = 1
+    pts.reshape(n, 2 * c.L)[inf == 1] = 0
+    plain, pf = eng.lincomb(c.cid, k, pts, inf)
+    monkeypatch.setenv("ECGPU_MSM_PIPE_LOG2", "10")
+    o, f = eng.lincomb(c.cid, k, pts, inf)
+    monkeypatch.delenv("ECGPU_MSM_PIPE_LOG2")
+    assert bytes(o) == bytes(plain) and f == pf
+    w, wf = oracle_lib.msm(c.cid, k, pts, inf, vartime=True)
+    assert bytes(o) == bytes(w) and f == wf
+
+
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_fixed_base_compressed_output(eng, curve):
     """tag || x of ecgpu_batch_mul_base_compressed is the SEC1 compressed encoding of the x || y result: 02 / 03 by the
     parity of y, 00 and x = 0 for the identity; also through the pipelined host path (n >= 2^19)."""
