@@ -1,0 +1,55 @@
+#!/bin/bash
+# The one GPU-box script.  `gpurun -- 'bash tools/gpu_run.sh <tag> <recipe> [<recipe> ...]'` runs the recipes in order and
+# leaves everything under gpurun_out/<tag>/ (copy what is to be judged into profiles/rNN/).
+#
+# recipes
+#   smoke                 __graft_entry__.smoke()
+#   pytest[:<expr>]       python -m pytest tests -m gpu [-k <expr>]   (expr with _ for spaces: "wycheproof_or_fullsize")
+#   bench[:<workload>]    python bench.py [--workload W] --check           -> bench_<W>.json
+#   benchall              the default bench line (all four GPU configs as sub-records) with --check
+#   prof:<workload>       rocprofv3 --kernel-trace --stats of bench.py --workload W  -> prof_<W>/ + kernel_stats summary
+#   pmc:<workload>        three rocprofv3 --pmc passes (VALU counters, FETCH_SIZE, WRITE_SIZE) of bench.py --workload W
+#   sweep:<script>        bash tools/<script>.sh
+#   py:<file>             python <file>  (a one-off measurement script under tools/)
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+TAG=${1:?tag}; shift
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+ROOT=$PWD
+STEPS=${STEPS:-5}
+for recipe in "$@"; do
+  name=${recipe%%:*}; arg=""; [[ "$recipe" == *:* ]] && arg=${recipe#*:}
+  echo "=== $recipe"
+  case "$name" in
+    smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.txt" ;;
+    pytest)
+      if [ -n "$arg" ]; then timeout 1700 python -m pytest tests -m gpu -q -x -k "${arg//_/ }" --durations=8 > "$OUT/pytest_${arg}.txt" 2>&1; tail -15 "$OUT/pytest_${arg}.txt"
+      else timeout 1700 python -m pytest tests -m gpu -q -x --durations=12 > "$OUT/pytest_gpu.txt" 2>&1; tail -20 "$OUT/pytest_gpu.txt"; fi ;;
+    bench)
+      w=${arg:-fixed_k256}
+      timeout 900 python bench.py --workload "$w" --steps "$STEPS" --warmup 2 --check > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; tail -c 3000 "$OUT/bench_$w.json"; tail -3 "$OUT/bench_$w.err" ;;
+    benchall)
+      timeout 1200 python bench.py --check > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; tail -c 6000 "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err" ;;
+    prof)
+      w=${arg:-fixed_k256}
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -o "$w" -- python "$ROOT/bench.py" --only "$w" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/prof_$w.log" 2>&1)
+      python tools/pmc_summary.py stats "$OUT/prof_$w" | tee "$OUT/kernel_stats_$w.txt"
+      find "$OUT/prof_$w" -name "*.db" -delete; find "$OUT/prof_$w" -name "*kernel_trace.csv" -size +1M -delete ;;
+    pmc)
+      w=${arg:-fixed_k256}
+      B="python $ROOT/bench.py --only $w --steps 2 --warmup 1 --no-cpu-baseline"
+      i=0
+      for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+        i=$((i + 1))
+        (cd /tmp && timeout 900 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/pmc_${w}_$i" -o pmc -- $B > "$OUT/pmc_${w}_$i.log" 2>&1)
+      done
+      python tools/pmc_summary.py pmc "$OUT" "$w" | tee "$OUT/pmc_summary_$w.txt"
+      find "$OUT" -name "*.db" -delete; find "$OUT" -name "*counter_collection.csv" -size +2M -delete ;;
+    sweep) timeout 1500 bash "tools/$arg.sh" 2>&1 | tee "$OUT/sweep_$arg.txt" | tail -40 ;;
+    py) timeout 1500 python "$arg" 2>&1 | tee "$OUT/py_$(basename "$arg" .py).txt" | tail -60 ;;
+    *) echo "unknown recipe $recipe" ;;
+  esac
+done
+du -sh "$OUT"
