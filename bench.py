@@ -15,8 +15,9 @@ same run, with the same K / W and the same fences, and reported under "configs":
 
 `--only NAME` times a single workload as the top-level record (profiling runs; also var_k256, msm_p256, ecdsa_p256).
 Batch workloads shard embarrassingly (weak scaling, no data-path collective).  The MSM shards its terms (strong
-scaling) and has one exchange step: an RCCL all-gather of one record per rank followed by a device point sum
-(elliptic-curves_amd/sharded.py).
+scaling) and has one exchange step: an RCCL all-gather of each rank's per-window partial sums, after which the window
+sums over all ranks and the one Horner chain run on every rank (ecgpu_msm_parts_dev / ecgpu_msm_finish_dev,
+elliptic-curves_amd/sharded.py).
 
 `roofline` prices the dominant kernel against the integer-VALU issue roof (the path is neither HBM- nor
 MFMA-bound).  The roof is one wave64 instruction slot per SIMD per cycle pair: on gfx950 a VOP3 / 64-bit instruction —
@@ -114,12 +115,15 @@ def device_dot_mod(torch, d_k, d_s, mod):
     return total % mod
 
 
-def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_wall=1.5):
+def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_wall=1.2):
     """Oracle ("port" of the reference's CPU algorithm) on the host cores: a single-thread pilot, then every core busy
     for about `target_wall` seconds (each thread works through a slice of the sample sized from the pilot rate)."""
     import oracle_lib
     oracle_lib.build()
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
     kind = wl["kind"]
 
     def run(lo, hi):
@@ -140,12 +144,20 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
     t0 = time.perf_counter()
     run(0, pilot)
     single = pilot / (time.perf_counter() - t0)
-    per_thread = int(max(16, min(avail, single * target_wall)))
-    starts = [(i * per_thread) % max(1, avail - per_thread + 1) for i in range(cores)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda lo: run(lo, lo + per_thread), starts))
-    dt = time.perf_counter() - t0
+
+    def all_threads(per_thread):
+        per_thread = int(max(8, min(avail, per_thread)))
+        starts = [(i * per_thread) % max(1, avail - per_thread + 1) for i in range(cores)]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda lo: run(lo, lo + per_thread), starts))
+        return per_thread, time.perf_counter() - t0
+
+    # a short all-thread probe measures how many cores the box really gives this process (the container may be limited to
+    # fewer than os.cpu_count()); the timed pass is then sized for about `target_wall` seconds with every thread busy
+    probe_units, probe_dt = all_threads(single * 0.04)
+    rate = probe_units * cores / probe_dt
+    per_thread, dt = all_threads(rate * target_wall / cores)
     total = per_thread * cores
     algo = {"fixed": "mul_by_generator (33/49-LUT basepoint table)", "var": "ProjectivePoint * Scalar (LUT + radix-16)",
             "msm": "lincomb_vartime (GLV + wNAF-5 Straus), one %d-term lincomb per thread" % per_thread,
@@ -247,7 +259,10 @@ class Bench:
         n_out = 1 if kind == "msm" else n
         d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
         d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
-        exchange = ecgpu.TensorExchange(torch, dist, L, device) if kind == "msm" and world > 1 else None
+        exchange = None
+        if kind == "msm" and world > 1:
+            plan_terms = (n_total + world - 1) // world              # the largest shard: every rank plans the same windows
+            exchange = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device)
         torch.cuda.synchronize()     # inputs were written on torch's stream; make sure they are there whatever stream the engine uses
 
         main_ms, stages = [], {}
@@ -259,15 +274,19 @@ class Bench:
                 eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
             elif kind == "ecdsa":
                 eng.ecdsa_verify_dev(cid, d_scal, d_r, d_s, d_pts, n, False, d_ok)
-            else:
+            elif exchange is None:
                 eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
+            else:
+                # sharded MSM: local pipeline down to the per-window partial sums, ONE exchange step (RCCL all-gather of
+                # the parts over xGMI), window sums over all ranks + the Horner chain on every rank
+                eng.msm_parts_dev(cid, d_scal, d_pts, None, n, plan_terms, exchange.mine)
             main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
             for st in ("sort", "accumulate", "reduce", "normalize", "main", "total"):
                 v = eng.last_timing(st)
                 if v is not None:
                     stages.setdefault(st, []).append(v)
-            if exchange is not None:                                       # the one exchange step: all-gather + EC sum
-                exchange.combine(lambda pts, flags, w, oxy, oinf: eng.point_sum_dev(cid, pts, flags, w, oxy, oinf), d_out, d_inf)
+            if exchange is not None:
+                eng.msm_finish_dev(cid, exchange.gather(), world, plan_terms, d_out, d_inf)
 
         for _ in range(args.warmup):
             step()

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
     "ecgpu_batch_mul_base_compressed", "ecgpu_batch_mul_base_compressed_dev",
     "ecgpu_dev_alloc", "ecgpu_dev_free", "ecgpu_copy_to_device", "ecgpu_copy_to_host",
+    "ecgpu_msm_parts_bytes", "ecgpu_msm_parts_dev", "ecgpu_msm_finish_dev",
 ]
 
 
@@ -96,6 +97,8 @@ def load_library():
     lib.ecgpu_dev_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.ecgpu_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ecgpu_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.ecgpu_msm_parts_bytes.restype = ctypes.c_size_t
+    lib.ecgpu_msm_parts_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
     _lib = lib
     return lib
 
@@ -393,6 +396,18 @@ class Engine:
         self._chk(self._lib.ecgpu_msm_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
                                           ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
 
+    # an MSM spread over several GPUs: local half -> all-gather of the parts -> combining half (include/ecgpu.h)
+    def msm_parts_bytes(self, curve, plan_terms):
+        return int(self._lib.ecgpu_msm_parts_bytes(self._ctx, curve, ctypes.c_size_t(plan_terms)))
+
+    def msm_parts_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, plan_terms, d_parts):
+        self._chk(self._lib.ecgpu_msm_parts_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
+                                                ctypes.c_size_t(n), ctypes.c_size_t(plan_terms), _dp(d_parts)))
+
+    def msm_finish_dev(self, curve, d_parts_all, nranks, plan_terms, d_out_xy, d_out_inf):
+        self._chk(self._lib.ecgpu_msm_finish_dev(self._ctx, curve, _dp(d_parts_all), int(nranks), ctypes.c_size_t(plan_terms),
+                                                 _dp(d_out_xy), _dp(d_out_inf)))
+
     def ecdsa_verify_dev(self, curve, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok):
         self._chk(self._lib.ecgpu_ecdsa_verify_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_q_xy),
                                                          ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_ok)))
@@ -406,4 +421,4 @@ def version():
     return load_library().ecgpu_version().decode()
 
 
-from .sharded import TensorExchange, lincomb_sharded, shard_range  # noqa: E402,F401
+from .sharded import RecordExchange, TensorExchange, lincomb_sharded, shard_range  # noqa: E402,F401

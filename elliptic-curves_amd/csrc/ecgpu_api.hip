@@ -291,8 +291,8 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     constexpr int N = C::N, NS = Field<C>::NS;
     (void)N;
     int rc;
-    if (n >= ((size_t)1 << 31)) {           // sorted entries are term index | sign << 31
-        ctx->err = "MSM of 2^31 or more terms: split it and add the partial sums (ecgpu_point_sum)";
+    if (n > msm_max_terms<C>()) {           // sorted entries are sub-term index | sign << 31
+        ctx->err = "MSM of 2^31 (k256: 2^30) or more terms: split it and add the partial sums (ecgpu_point_sum)";
         return ECGPU_ERR_ARG;
     }
     if (n >= 1 && n <= msm_small_max<C>() && ctx->msm_c == 0) {
@@ -332,6 +332,52 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
                          {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
     return rc;
+}
+
+// ---- an MSM whose terms are spread over several GPUs: local half / combining half ------------------------
+template <class C>
+int msm_parts_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void* d_inf, size_t n, size_t plan_terms,
+                  void* d_parts) {
+    int rc;
+    if (n > msm_max_terms<C>() || plan_terms > msm_max_terms<C>()) {
+        ctx->err = "MSM shard of 2^31 (k256: 2^30) or more terms";
+        return ECGPU_ERR_ARG;
+    }
+    const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms > n ? plan_terms : n);
+    MsmPlan plan = msm_plan<C>(n, c);
+    if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_msm_parts<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, ctx->msm_ws.p,
+                        (uint32_t*)d_parts, ctx->d_status, ctx->ev[3], ctx->ev[4]);
+    record(ctx, 1);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"total", {0, 1}}, {"sort", {0, 3}}, {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
+    return rc;
+}
+
+template <class C>
+int msm_finish_dev(ecgpu_ctx* ctx, const void* d_parts_all, int nranks, size_t plan_terms, void* d_out_xy, void* d_out_inf) {
+    constexpr int NS = Field<C>::NS;
+    int rc;
+    const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms);
+    MsmPlan plan = msm_plan<C>(0, c);                       // only c, nwin and nparts matter here
+    if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->bases, (size_t)plan.nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_msm_finish<C>(plan, ctx->stream, (const uint32_t*)d_parts_all, nranks, (uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+size_t msm_parts_bytes(const ecgpu_ctx* ctx, size_t plan_terms) {
+    return msm_plan<C>(0, ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms)).parts_bytes;
 }
 
 // ---- host-pointer plumbing ---------------------------------------------------------------------------------
@@ -732,6 +778,36 @@ int ecgpu_msm_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* 
     if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return msm_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+size_t ecgpu_msm_parts_bytes(ecgpu_ctx* ctx, int curve, size_t plan_terms) {
+    if (!check_ctx(ctx)) return 0;
+    size_t bytes = 0;
+    (void)dispatch(curve, [&](auto c) {
+        bytes = msm_parts_bytes<decltype(c)>(ctx, plan_terms);
+        return (int)ECGPU_OK;
+    });
+    return bytes;
+}
+
+int ecgpu_msm_parts_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
+                        size_t n, size_t plan_terms, void* d_parts) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_parts || !aligned16(d_parts)) return arg_error(ctx, __func__);
+    if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return msm_parts_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, plan_terms, d_parts);
+    });
+}
+
+int ecgpu_msm_finish_dev(ecgpu_ctx* ctx, int curve, const void* d_parts_all, int nranks, size_t plan_terms, void* d_out_xy,
+                         void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_parts_all || !aligned16(d_parts_all) || !d_out_xy || !aligned16(d_out_xy) || nranks < 1 || nranks > 4096)
+        return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return msm_finish_dev<decltype(c)>(ctx, d_parts_all, nranks, plan_terms, d_out_xy, d_out_inf);
     });
 }
 

@@ -25,6 +25,11 @@ struct MsmPlan {
     size_t npart = 0, ntiles2 = 0;
     size_t off_tmpidx = 0, off_tmpkey = 0, off_count_a = 0, off_offset_a = 0, off_cursor = 0;
     size_t max_big = 0;            // upper bound on the number of buckets that have more than MSM_BIG_PARTIALS partial sums
+    // sub-terms: MsmSplit<C>::SUB per term (k256: the two GLV halves), sub-term h of term i at index h * npad + i
+    size_t npad = 0, nsub = 0;     // n rounded up to a multiple of 64; entries per window = SUB * npad
+    int kbits = 0;                 // significant bits of a sub-scalar
+    // per-window partial sums handed from launch_msm_parts to launch_msm_finish (and between GPUs): [nwin][nparts] points
+    size_t nparts = 0, per_part = 0, off_parts = 0, parts_bytes = 0;
     size_t workspace_bytes = 0;
 };
 
@@ -63,9 +68,16 @@ template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, c
 
 // ---- group "msm": Pippenger pipeline ----
 template <class C> MsmPlan msm_plan(size_t n, int force_c);
+template <class C> int msm_choose_window(size_t n);
+template <class C> size_t msm_max_terms();              // sorted entries are sub-term index | sign << 31
 template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,
                                    const uint8_t* inf, size_t n, void* workspace, uint32_t* out, int* status,
                                    hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
+template <class C> void launch_msm_parts(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,
+                                         const uint8_t* inf, size_t n, void* workspace, uint32_t* parts, int* status,
+                                         hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
+template <class C> void launch_msm_finish(const MsmPlan& p, hipStream_t s, const uint32_t* parts_all, int nranks, uint32_t* wins,
+                                          uint32_t* out);
 
 // ---- curve-independent ----
 void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,

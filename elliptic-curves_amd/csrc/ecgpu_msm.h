@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 
 #include "ecgpu_kernels.h"
@@ -39,32 +40,48 @@
 namespace ecgpu {
 
 // ---- prepare ----------------------------------------------------------------------------------------------
-// A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether term i has a digit in
-// window w at all (non-zero digit, finite point) is one bit of vmask[w][i / 64], written with a wave ballot.
+// One lane per term.  The scalar is cut into MsmSplit<C>::SUB sub-scalars (ecgpu_recode.h: the folded scalar; for k256 the
+// two GLV halves, the second one against lambda P = (beta x, y)); sub-term h of term i has index j = h * npad + i
+// (npad = n rounded up to a multiple of 64), so that a wave still writes 64 consecutive digits, points and validity bits
+// per half.  Everything after this kernel sees nsub = SUB * npad independent entries.
+// A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether sub-term j has a digit in
+// window w at all (non-zero digit, finite point) is one bit of vmask[w][j / 64], written with a wave ballot.
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
-              const uint8_t* __restrict__ points_inf, size_t n, int c, int nwin, uint32_t* __restrict__ pts,
+              const uint8_t* __restrict__ points_inf, size_t n, size_t npad, int c, int nwin, uint32_t* __restrict__ pts,
               uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status) {
     using G = Group<C>;
+    using F = Field<C>;
+    using S = MsmSplit<C>;
     constexpr int N = C::N;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
-    const bool flip = fold_scalar<N>(k, C::ORDER);                  // k P = (n - k)(-P)
+    uint32_t sub[S::SUB][S::KW];
+    bool flip[S::SUB];
+    S::split(k, sub, flip);
     Fe<C::NL> b = G::curve_b();
     Affine<C> a;
     bool finite = load_affine<C>(&a, points_xy, points_inf, i, b, status);
-    if (finite) store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
-    uint32_t carry = 0;
-    const size_t nmask = (n + 63) / 64;
+    if (finite) {
+        store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
+        if constexpr (S::SUB == 2)
+            store_packed_affine<C>(pts + (npad + i) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+    }
+    const size_t nsub = S::SUB * npad, nmask = nsub / 64;
+#pragma unroll
+    for (int h = 0; h < S::SUB; h++) {
+        const size_t j = (size_t)h * npad + i;
+        uint32_t carry = 0;
 #pragma unroll 1
-    for (int w = 0; w < nwin; w++) {
-        MsmDigit d = msm_digit<N>(k, w, c, nwin, &carry, (uint32_t)i, flip);
-        digits[(size_t)w * n + i] = (uint16_t)(d.bucket | (d.neg << 15));
-        unsigned long long m = __ballot(finite && d.nonzero);          // lanes past n have already returned
-        if ((threadIdx.x & 63) == 0) vmask[(size_t)w * nmask + (i >> 6)] = m;
+        for (int w = 0; w < nwin; w++) {
+            MsmDigit d = msm_digit<S::KW>(sub[h], w, c, nwin, &carry, (uint32_t)j, flip[h], S::KBITS);
+            digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
+            unsigned long long m = __ballot(finite && d.nonzero);          // lanes past n have already returned
+            if ((threadIdx.x & 63) == 0) vmask[(size_t)w * nmask + (j >> 6)] = m;
+        }
     }
 }
 
@@ -412,16 +429,37 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
     store_proj<C>(segs, gid, local);
 }
 
-// wins[w] = sum_s segs[w][s]
+// parts[w][g] = sum of the segment sums segs[w][g * per .. (g + 1) * per): one workgroup per (g, w), a strided pass
+// and an LDS tree.  With the default plan (4 buckets per segment, 256 segments per workgroup) a lane adds one segment:
+// the depth is the 8 levels of the tree, where one workgroup per window used to walk 32 segments per lane first.
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
-k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, uint32_t* __restrict__ wins) {
+k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per, uint32_t* __restrict__ parts) {
     using G = Group<C>;
     __shared__ uint32_t lds[BLOCK * 3 * C::NL];
     Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
-    for (size_t s = threadIdx.x; s < nseg; s += BLOCK)
-        acc = G::add(acc, load_proj<C>(segs, (size_t)blockIdx.x * nseg + s), b);
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < nseg ? lo + per : nseg;
+    for (size_t s = lo + threadIdx.x; s < hi; s += BLOCK)
+        acc = G::add(acc, load_proj<C>(segs, (size_t)blockIdx.y * nseg + s), b);
+    acc = block_sum<C>(acc, lds, b);
+    if (threadIdx.x == 0) store_proj<C>(parts, (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
+}
+
+// wins[w] = sum over ranks r and workgroups g of parts[r][w][g] — the one place where the partial results of several
+// GPUs meet (nranks = 1: this GPU's own).  One workgroup per window.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int nparts, uint32_t* __restrict__ wins) {
+    using G = Group<C>;
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    Fe<C::NL> b = G::curve_b();
+    Proj<C> acc = G::identity();
+    const int items = nranks * nparts;
+    for (int t = threadIdx.x; t < items; t += BLOCK) {
+        const int r = t / nparts, g = t % nparts;
+        acc = G::add(acc, load_proj<C>(parts, ((size_t)r * nwin + blockIdx.x) * nparts + g), b);
+    }
     acc = block_sum<C>(acc, lds, b);
     if (threadIdx.x == 0) store_proj<C>(wins, blockIdx.x, acc);
 }
@@ -431,7 +469,7 @@ template <class C>
 __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    // Everything here is wave-uniform, and left alone the compiler moves the whole 240-doubling chain to the
+    // Everything here is wave-uniform, and left alone the compiler moves the whole doubling chain to the
     // scalar ALU (no 32x32+64 multiply-add there: 10x the instructions).  An opaque zero in a VGPR makes the
     // addresses, hence the data, formally divergent, which keeps the arithmetic on the vector ALU.
     uint32_t vzero = 0;
@@ -458,19 +496,19 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
     store_proj<C>(out, 0, acc);
 }
 
+// out[0 .. count) = the identity
 template <class C>
-__global__ void k_store_identity(uint32_t* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) store_proj<C>(out, 0, Group<C>::identity());
+__global__ void __launch_bounds__(BLOCK) k_store_identity(uint32_t* out, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) store_proj<C>(out, i, Group<C>::identity());
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
-// Window width from the term count, from a sweep on MI355X (tools/gpu_msm_window_sweep.sh, k256, v11 kernels): fastest c
-// at 2^12 / 2^14 / 2^16 / 2^17 / 2^18 / 2^19 / 2^20 / 2^21 / 2^22 terms = 9 / 11 / 12 / 13 / 13 / 13 / 14 / 16 / 16 (1.20 / 1.19 /
-// 1.28 / 1.46 / 1.56 / 1.95 / 2.70 / 3.97 / 6.38 ms).  Below 2^17 the curve is flat: the 240-doubling Horner chain of the
-// combine step and the running sums, 1.2 ms together, dominate whatever c is.
-inline int msm_window_bits(size_t n) {
+// Window width from the number of entries per window (terms; twice that for k256's GLV halves), from sweeps on MI355X
+// (tools/gpu_msm_window_sweep.sh).  Below 2^17 the curve is flat: the parts that do not depend on n dominate whatever c is.
+inline int msm_window_bits(size_t entries) {
     int lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    while (((size_t)1 << (lg + 1)) <= entries) lg++;
     int c;
     if (lg <= 16) c = lg - 3;
     else if (lg <= 19) c = 13;
@@ -481,12 +519,33 @@ inline int msm_window_bits(size_t n) {
     return c;
 }
 
+// per-device launch facts (a context per GPU may plan concurrently: no unsynchronised function statics)
+struct MsmDeviceFacts {
+    std::atomic<size_t> wave_slots[64];
+    std::atomic<bool> lds_attr[64];
+};
+inline MsmDeviceFacts& msm_device_facts() {
+    static MsmDeviceFacts f{};
+    return f;
+}
+
+// the window width an MSM of n terms gets (0 terms: the narrowest)
+template <class C>
+int msm_choose_window(size_t n) {
+    return msm_window_bits((size_t)MsmSplit<C>::SUB * (n ? n : 1));
+}
+
 template <class C>
 MsmPlan msm_plan(size_t n, int force_c) {
     constexpr int N = C::N, NS = Field<C>::NS;
+    using S = MsmSplit<C>;
     MsmPlan p;
-    p.c = force_c ? force_c : msm_window_bits(n);
-    p.nwin = signed_window_count(32 * N - 1, p.c);          // scalars are folded to 32 N - 1 bits
+    p.npad = (n + 63) / 64 * 64;
+    p.nsub = (size_t)S::SUB * p.npad;
+    p.kbits = S::KBITS;
+    const size_t ne = p.nsub;                               // entries per window the sort and the accumulation see
+    p.c = force_c ? force_c : msm_window_bits((size_t)S::SUB * n);
+    p.nwin = signed_window_count(p.kbits, p.c);
     p.nb = (size_t)1 << (p.c - 1);
     p.seg = 4;                                              // buckets per running-sum lane: 4 ... 8 measured best for
                                                             // small MSMs (more lanes), neutral at 2^24 (tuning knob)
@@ -496,6 +555,9 @@ MsmPlan msm_plan(size_t n, int force_c) {
     }
     if ((size_t)p.seg > p.nb) p.seg = (int)p.nb;
     p.nseg = p.nb / p.seg;
+    p.nparts = (p.nseg + BLOCK - 1) / BLOCK;                // workgroups per window in the tree over the segment sums
+    if (p.nparts > 32) p.nparts = 32;
+    p.per_part = (p.nseg + p.nparts - 1) / p.nparts;
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     int tile_log2 = 18;                                   // terms per counting-sort tile (tuning knob)
@@ -504,51 +566,55 @@ MsmPlan msm_plan(size_t n, int force_c) {
         if (v >= 12 && v <= 24) tile_log2 = v;
     }
     p.tile = (size_t)1 << tile_log2;
-    p.ntiles = (n + p.tile - 1) / p.tile;
+    p.ntiles = (ne + p.tile - 1) / p.tile;
     if (p.ntiles == 0) p.ntiles = 1;
     // Accumulation lanes: about three rounds of the wave slots the kernel can occupy (measured on MI355X: chunks
     // of ~500 entries beat one exactly-filling round of ~1400 by 2%, and anything that leaves slots empty loses
     // badly), but at least 32 entries per lane so that partial sums stay a small overhead.
     {
-        static size_t wave_slots = 0;                       // resident waves of k_msm_accumulate<C> on this device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t>& slots = msm_device_facts().wave_slots[dev & 63];   // resident waves of k_msm_accumulate<C>
+        size_t wave_slots = slots.load();
         if (!wave_slots) {
-            int dev = 0, cus = 256, blocks = 0;
-            (void)hipGetDevice(&dev);
+            int cus = 256, blocks = 0;
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_msm_accumulate<C>, 64, 0) != hipSuccess || blocks < 1)
                 blocks = 8;
             wave_slots = (size_t)cus * blocks;
+            slots.store(wave_slots);
         }
         size_t lanes = wave_slots * 64 * 3;
         size_t per_window = (lanes + p.nwin - 1) / p.nwin;
-        p.chunk = (n + per_window - 1) / per_window;
+        p.chunk = (ne + per_window - 1) / per_window;
         if (p.chunk < 32) p.chunk = 32;
+        p.chunk = (p.chunk + 3) & ~(size_t)3;               // chunks start on 16-byte boundaries of the index stream
         if (const char* e = getenv("ECGPU_MSM_CHUNK")) {
             long v = atol(e);
             if (v >= 1 && v <= (1L << 30)) p.chunk = (size_t)v;
         }
-        p.nchunks = (n + p.chunk - 1) / p.chunk;
+        p.nchunks = (ne + p.chunk - 1) / p.chunk;
         if (p.nchunks == 0) p.nchunks = 1;
     }
     {
-        bool two = n >= ((size_t)1 << 17);      // measured: equal at 2^16, 12 % faster at 2^18, 14 % at 2^24
+        bool two = ne >= ((size_t)1 << 17);      // measured: equal at 2^16, 12 % faster at 2^18, 14 % at 2^24
         if (const char* e = getenv("ECGPU_MSM_SORT2")) two = atoi(e) != 0;
         if (two && p.c - 1 > MSM_SORT2_BITS_A) {
             p.sort_bits_b = p.c - 1 - MSM_SORT2_BITS_A;
             p.npart = p.nb >> p.sort_bits_b;
-            p.ntiles2 = (n + MSM_SORT2_TILE - 1) / MSM_SORT2_TILE;
-            p.off_tmpidx = o;  o = align(o + (size_t)p.nwin * n * 4);
-            p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * n * 2);
+            p.ntiles2 = (ne + MSM_SORT2_TILE - 1) / MSM_SORT2_TILE;
+            p.off_tmpidx = o;  o = align(o + (size_t)p.nwin * ne * 4);
+            p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * ne * 2);
             p.off_count_a = o;  o = align(o + (size_t)p.nwin * p.npart * 4);
             p.off_offset_a = o; o = align(o + (size_t)p.nwin * p.npart * 4);
             p.off_cursor = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
         }
     }
-    p.off_points = o;  o = align(o + n * 2 * N * 4);
-    p.off_digits = o;  o = align(o + (size_t)p.nwin * n * 2);
-    p.off_vmask = o;   o = align(o + (size_t)p.nwin * ((n + 63) / 64) * 8);
+    p.off_points = o;  o = align(o + ne * 2 * N * 4);
+    p.off_digits = o;  o = align(o + (size_t)p.nwin * ne * 2);
+    p.off_vmask = o;   o = align(o + (size_t)p.nwin * (ne / 64) * 8);
     p.off_tilehist = o; o = align(o + (size_t)p.nwin * p.ntiles * p.nb * 4);
-    p.off_sorted = o;  o = align(o + (size_t)p.nwin * n * 4);
+    p.off_sorted = o;  o = align(o + (size_t)p.nwin * ne * 4);
     p.off_count = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_offset = o;  o = align(o + (size_t)p.nwin * p.nb * 4);
     p.off_partials = o; o = align(o + (size_t)p.nwin * (p.nb + p.nchunks) * 4 * NS * 4);
@@ -556,22 +622,28 @@ MsmPlan msm_plan(size_t n, int force_c) {
     p.max_big = (size_t)p.nwin * (p.nchunks / (MSM_BIG_PARTIALS - 1) + 1);   // a big bucket covers >= 31 whole chunks
     p.off_biglist = o; o = align(o + (p.max_big + 1) * 4);
     p.off_segs = o;    o = align(o + (size_t)p.nwin * p.nseg * 3 * NS * 4);
+    p.parts_bytes = (size_t)p.nwin * p.nparts * 3 * NS * 4;
+    p.off_parts = o;   o = align(o + p.parts_bytes);
     p.off_wins = o;    o = align(o + (size_t)p.nwin * 3 * NS * 4);
     p.workspace_bytes = o + 256;
     return p;
 }
 
-// Enqueues the whole pipeline on `stream`; the result (projective, internal form) lands in out[0].
+// First half of the pipeline: everything up to the per-window partial sums parts[nwin][nparts] (projective, internal
+// form, plan.parts_bytes bytes) — what a GPU contributes to an MSM whose terms are spread over several GPUs.
 template <class C>
-void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, const uint8_t* d_xy,
-                const uint8_t* d_inf, size_t n, void* workspace, uint32_t* out, int* d_status, hipEvent_t ev_sorted,
-                hipEvent_t ev_accumulated) {
+void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, const uint8_t* d_xy,
+                      const uint8_t* d_inf, size_t n, void* workspace, uint32_t* parts, int* d_status, hipEvent_t ev_sorted,
+                      hipEvent_t ev_accumulated) {
+    const size_t nparts_total = (size_t)p.nwin * p.nparts;
     if (n == 0) {
-        hipLaunchKernelGGL(k_store_identity<C>, dim3(1), dim3(64), 0, stream, out);
+        hipLaunchKernelGGL(k_store_identity<C>, dim3((unsigned)((nparts_total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, parts,
+                           nparts_total);
         (void)hipEventRecord(ev_sorted, stream);
         (void)hipEventRecord(ev_accumulated, stream);
         return;
     }
+    const size_t ne = p.nsub;
     uint8_t* ws = (uint8_t*)workspace;
     uint32_t* pts = (uint32_t*)(ws + p.off_points);
     uint16_t* digits = (uint16_t*)(ws + p.off_digits);
@@ -584,16 +656,19 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
     uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
     uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
-    uint32_t* wins = (uint32_t*)(ws + p.off_wins);
     unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
     const size_t lds_bytes = p.nb * 4;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // the window histogram may take 128 KiB of the 160 KiB LDS
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_attr_set = true;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<bool>& done = msm_device_facts().lds_attr[dev & 63];
+        if (!done.load()) {   // the window histogram may take 128 KiB of the 160 KiB LDS (an attribute of the function on this device)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            done.store(true);
+        }
     }
-    hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.c, p.nwin, pts,
+    hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin, pts,
                        digits, vmask, d_status);
     if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
@@ -605,48 +680,67 @@ void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, 
         MsmSort2Src sa{digits, vmask, nullptr, nullptr, nullptr, 0};
         (void)hipMemsetAsync(counts_a, 0, (size_t)p.nwin * p.npart * 4, stream);
         (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
-        hipLaunchKernelGGL((k_msm_sort2<false, true>), grid2, dim3(1024), 0, stream, sa, n, p.sort_bits_b, p.npart, counts_a,
+        hipLaunchKernelGGL((k_msm_sort2<false, true>), grid2, dim3(1024), 0, stream, sa, ne, p.sort_bits_b, p.npart, counts_a,
                            (uint32_t*)nullptr, (uint16_t*)nullptr);
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart);
         (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
-        hipLaunchKernelGGL((k_msm_sort2<false, false>), grid2, dim3(1024), 0, stream, sa, n, p.sort_bits_b, p.npart, cursor,
+        hipLaunchKernelGGL((k_msm_sort2<false, false>), grid2, dim3(1024), 0, stream, sa, ne, p.sort_bits_b, p.npart, cursor,
                            tmp_idx, tmp_key);
         MsmSort2Src sb{tmp_key, nullptr, tmp_idx, offsets_a, counts_a, p.npart};
-        hipLaunchKernelGGL((k_msm_sort2<true, true>), grid2, dim3(1024), 0, stream, sb, n, p.sort_bits_b, p.nb, counts,
+        hipLaunchKernelGGL((k_msm_sort2<true, true>), grid2, dim3(1024), 0, stream, sb, ne, p.sort_bits_b, p.nb, counts,
                            (uint32_t*)nullptr, (uint16_t*)nullptr);
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
         (void)hipMemcpyAsync(cursor, offsets, (size_t)p.nwin * p.nb * 4, hipMemcpyDeviceToDevice, stream);
-        hipLaunchKernelGGL((k_msm_sort2<true, false>), grid2, dim3(1024), 0, stream, sb, n, p.sort_bits_b, p.nb, cursor,
+        hipLaunchKernelGGL((k_msm_sort2<true, false>), grid2, dim3(1024), 0, stream, sb, ne, p.sort_bits_b, p.nb, cursor,
                            sorted, (uint16_t*)nullptr);
     } else {
         hipLaunchKernelGGL(k_msm_hist, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                           (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb, tile_hist);
+                           (const uint16_t*)digits, (const unsigned long long*)vmask, ne, p.tile, p.nb, tile_hist);
         size_t nbk0 = p.nb * p.nwin;
         hipLaunchKernelGGL(k_msm_tile_scan, dim3((unsigned)((nbk0 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, tile_hist,
                            p.ntiles, p.nb, p.nwin, counts);
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, p.nb);
         hipLaunchKernelGGL(k_msm_scatter, dim3((unsigned)p.ntiles, (unsigned)p.nwin), dim3(1024), lds_bytes, stream,
-                           (const uint16_t*)digits, (const unsigned long long*)vmask, n, p.tile, p.nb,
+                           (const uint16_t*)digits, (const unsigned long long*)vmask, ne, p.tile, p.nb,
                            (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
     }
     (void)hipEventRecord(ev_sorted, stream);
     size_t nbk = p.nb * p.nwin, nlanes = p.nchunks * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
-                       (const uint32_t*)offsets, n, p.nb, p.nwin, p.chunk, p.nchunks, partials);
+                       (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials);
     (void)hipMemsetAsync(big_list, 0, 4, stream);
     hipLaunchKernelGGL(k_msm_bucket_finish<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
-                       (const uint32_t*)sorted, n, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
+                       (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
     hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
-                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, n, p.nb,
+                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
                        p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
     hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(32 * C::N - 1, p.c), segs);
-    hipLaunchKernelGGL(k_msm_reduce_windows<C>, dim3(p.nwin), dim3(BLOCK), 0, stream, (const uint32_t*)segs, p.nseg, wins);
+                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
+    hipLaunchKernelGGL(k_msm_reduce_windows<C>, dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
+                       (const uint32_t*)segs, p.nseg, p.per_part, parts);
+}
+
+// Second half: the window sums over `nranks` sets of partial sums (laid out [rank][nwin][nparts]) and the Horner chain
+// over the windows; the result (projective, internal form) lands in out[0].  `wins` is nwin points of scratch.
+template <class C>
+void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
+    hipLaunchKernelGGL(k_msm_window_sums<C>, dim3((unsigned)p.nwin), dim3(BLOCK), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
     hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
+}
+
+// The whole pipeline on one GPU.
+template <class C>
+void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, const uint8_t* d_xy,
+                const uint8_t* d_inf, size_t n, void* workspace, uint32_t* out, int* d_status, hipEvent_t ev_sorted,
+                hipEvent_t ev_accumulated) {
+    uint8_t* ws = (uint8_t*)workspace;
+    uint32_t* parts = (uint32_t*)(ws + p.off_parts);
+    launch_msm_parts<C>(p, stream, d_scalars, d_xy, d_inf, n, workspace, parts, d_status, ev_sorted, ev_accumulated);
+    launch_msm_finish<C>(p, stream, parts, 1, (uint32_t*)(ws + p.off_wins), out);
 }
 
 }  // namespace ecgpu

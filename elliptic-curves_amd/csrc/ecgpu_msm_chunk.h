@@ -26,6 +26,39 @@
 
 namespace ecgpu {
 
+// The sorted (sign, index) entries of a lane's chunk, fetched four at a time: one 16-byte load per four additions
+// instead of a 4-byte one per addition (a quarter of the requests, and a lane's 128-byte line is asked for 8 times
+// instead of 32).  `run` must be 16-byte aligned and readable up to the next multiple of four past the last entry taken.
+struct MsmIndexStream {
+    const uint32_t* run;
+    uint32_t b0, b1, b2, b3;
+    ECGPU_HD void fetch(uint32_t pos4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint4 v = *reinterpret_cast<const uint4*>(run + pos4);
+        b0 = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+#else
+        b0 = run[pos4]; b1 = run[pos4 + 1]; b2 = run[pos4 + 2]; b3 = run[pos4 + 3];
+#endif
+    }
+    ECGPU_HD void rotate() { b0 = b1; b1 = b2; b2 = b3; }
+    // positions first, first + 1, ... are then handed out by take()
+    ECGPU_HD void start(const uint32_t* r, uint32_t first) {
+        run = r;
+        fetch(first & ~3u);
+        for (uint32_t s = first & 3u; s != 0; s--) rotate();
+    }
+    // the entry at `pos` (calls must come in position order); `more`: an entry at pos + 1 will be asked for
+    ECGPU_HD uint32_t take(uint32_t pos, bool more) {
+        const uint32_t e = b0;
+        if (((pos + 1) & 3u) == 0) {
+            if (more) fetch(pos + 1);
+        } else {
+            rotate();
+        }
+        return e;
+    }
+};
+
 // Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Xyzz<C>&).
 // `ow` = bucket start offsets of this window (nb entries), `total` = length of the window's run.
 template <class C, class Points, class Sink>
@@ -51,7 +84,9 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
     acc.x = acc.y = acc.zz = acc.zzz = F::one().e;
     bool fresh = true;                               // no term of the current stretch taken yet
     PackedPoint<2 * N> pw;
-    uint32_t e = run[start];
+    MsmIndexStream idx;
+    idx.start(run, start);
+    uint32_t e = idx.take(start, start + 1 < end);
     points.load(pw, e & 0x7FFFFFFFu);
 #pragma unroll 1
     for (uint32_t pos = start; pos < end;) {
@@ -61,7 +96,7 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
         const bool neg = (e >> 31) != 0;
         pos++;
         if (pos < end) {                             // fetch the next point under the current addition
-            e = run[pos];
+            e = idx.take(pos, pos + 1 < end);
             points.load(pw, e & 0x7FFFFFFFu);
         }
         if (fresh) {

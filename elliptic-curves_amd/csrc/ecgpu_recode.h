@@ -75,9 +75,11 @@ struct MsmDigit {
     bool nonzero;
 };
 
-// k: folded scalar (< 2^(32 NL - 1)), flip: its fold flag.  The returned sign already includes the flip.
+// k: sub-scalar of kbits significant bits in NL words (the folded scalar, kbits = 32 NL - 1; a GLV half, kbits = 128),
+// flip: its sign flag.  The returned sign already includes the flip.  nwin = signed_window_count(kbits, c).
 template <int NL>
-ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t* carry, uint32_t term_index, bool flip) {
+ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t* carry, uint32_t term_index, bool flip,
+                            int kbits = 32 * NL - 1) {
     MsmDigit r;
     r.bucket = 0; r.neg = 0; r.nonzero = false;
     if (w < nwin - 1) {
@@ -88,7 +90,6 @@ ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t*
             r.bucket = (uint32_t)(d < 0 ? -d : d) - 1;
         }
     } else {
-        const int kbits = 32 * NL - 1;
         const int rem = kbits % c;
         const int shift = c - 1 - rem;
         uint32_t d = (rem ? get_bits<NL>(k, w * c, rem) : 0u) + *carry;
@@ -257,6 +258,41 @@ struct K256Scalar {
         add(r2, c1, c2);
         mul(t, r2, MINUS_LAMBDA);
         add(r1, k, t);
+    }
+};
+
+// ---- how an MSM term's scalar is cut into sub-scalars before the bucket windows ---------------------------------------
+// Generic curves: one sub-term per term, the folded scalar (k -> n - k when the top bit is set, sign flag): 32 N - 1 bits.
+// k256: the two GLV halves k = r1 + r2 lambda (mod n), |r_i| < 2^128 after folding their signs into flags
+// (k256/src/arithmetic/mul.rs:112-132, mul/glv.rs:149-156), the second one against lambda P = (beta x, y): 2 n sub-terms of
+// 128 bits.  The additions are the same in number (2 n x 8.2 windows against n x 16), but there are 9 windows of buckets to
+// reduce instead of 16 and the Horner chain over the window sums needs 128 doublings instead of 240 — the part of an MSM
+// that does not shrink with n.
+template <class C>
+struct MsmSplit {
+    static constexpr int SUB = 1;
+    static constexpr int KW = C::N;
+    static constexpr int KBITS = 32 * C::N - 1;
+    static ECGPU_HD void split(const uint32_t* k, uint32_t (*sub)[KW], bool* neg) {
+#pragma unroll
+        for (int i = 0; i < KW; i++) sub[0][i] = k[i];
+        neg[0] = fold_scalar<KW>(sub[0], C::ORDER);
+    }
+};
+template <>
+struct MsmSplit<K256Params> {
+    static constexpr int SUB = 2;
+    static constexpr int KW = 4;
+    static constexpr int KBITS = 128;
+    static ECGPU_HD void split(const uint32_t* k, uint32_t (*sub)[KW], bool* neg) {
+        uint32_t r1[8], r2[8];
+        K256Scalar::decompose(r1, r2, k);
+        neg[0] = K256Scalar::is_high(r1);
+        neg[1] = K256Scalar::is_high(r2);
+        if (neg[0]) K256Scalar::neg(r1, r1);
+        if (neg[1]) K256Scalar::neg(r2, r2);
+#pragma unroll
+        for (int i = 0; i < KW; i++) { sub[0][i] = r1[i]; sub[1][i] = r2[i]; }
     }
 };
 

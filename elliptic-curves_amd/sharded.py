@@ -1,11 +1,16 @@
-"""Sharded MSM across the GPUs of one node.
+"""Sharded MSM across the GPUs of one node, one process per GPU over torch.distributed.
 
 sum_i k_i P_i = sum_ranks ( sum_{i in shard(rank)} k_i P_i ): terms are partitioned into contiguous
-slices, every rank runs the full local Pippenger pipeline on its slice, and the only exchange step is
-an all-gather of one affine point per rank (2L + 1 bytes) followed by a point sum on every rank.
+slices, every rank runs the local Pippenger pipeline on its slice, and the only exchange step is
+an all-gather of one fixed-size record per rank followed by a combining step on every rank.
 RCCL's built-in reductions cannot add curve points, so "all-reduce of partial sums" is realised as
-all-gather + a device EC-add (ecgpu_point_sum).  The payload is < 1 KiB for 8 ranks, so the step is
-latency- not bandwidth-bound on xGMI.
+all-gather + a device combine.  Two record kinds:
+  * RecordExchange with ecgpu_msm_parts_dev / ecgpu_msm_finish_dev (bench.py): the record is the GPU's per-window
+    partial sums (41 KiB for k256) and the combine is the window sums over all ranks + ONE Horner chain — the serial
+    tail of the bucket method runs once instead of once per rank plus a point sum;
+  * lincomb_sharded / TensorExchange: the record is one affine point per rank (2L + 1 bytes), the combine a point sum
+    (ecgpu_point_sum) — what a caller without the split entry points does.
+Either way the payload is far below a megabyte: the step is latency- not bandwidth-bound on xGMI.
 
 The compute steps are injected, so the same host logic is exercised on CPU by the gloo tests (with the
 oracle standing in for the GPU) and on the GPU box by bench.py / the -m gpu tests (with Engine methods).
@@ -85,3 +90,26 @@ class TensorExchange:
             # ordered after them (include/ecgpu.h, device-pointer entry points): wait for the gathered bytes first
             self.torch.cuda.current_stream(pts.device).synchronize()
         point_sum(pts, flags, self.world, out_xy, out_inf)
+
+
+class RecordExchange:
+    """The exchange step of a sharded computation on fixed-size opaque records that stay on their device:
+    `mine` (nbytes uint8) is filled by the local half, gather() all-gathers it into `all` (world * nbytes, rank-major), and
+    the combining half reads `all`.  With CUDA tensors the collective is RCCL over xGMI; with CPU tensors (the gloo
+    tests) the same logic runs on the host."""
+
+    def __init__(self, torch, dist, nbytes, device, group=None):
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group)
+        pad = (nbytes + 255) // 256 * 256
+        self.nbytes = nbytes
+        self.mine = torch.zeros((pad,), dtype=torch.uint8, device=device)[:nbytes]
+        self.all = torch.zeros((self.world * nbytes,), dtype=torch.uint8, device=device)
+
+    def gather(self):
+        self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+        if self.all.is_cuda:
+            # a consumer that enqueues on a stream of its own (an Engine without set_stream) is not ordered after the
+            # collective: wait for the gathered bytes
+            self.torch.cuda.current_stream(self.all.device).synchronize()
+        return self.all

@@ -181,6 +181,21 @@ int ecgpu_point_sum(ecgpu_ctx *ctx, int curve, const uint8_t *points_xy, const u
 int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
                         const void *d_points_inf, size_t n, void *d_out_xy, void *d_out_inf);
 
+/* ---- an MSM whose terms are spread over several GPUs ------------------------------------------------ *
+ * sum_i k_i P_i = sum over GPUs of the sum over that GPU's terms, and the bucket method is linear up to its last step:
+ * every GPU runs the pipeline on its own terms down to the per-window partial sums ("parts", ecgpu_msm_parts_bytes bytes of
+ * opaque internal-form points — 41 KiB for k256 at c = 16), the parts are exchanged (one all-gather: RCCL over xGMI in a
+ * torch.distributed job, peer copies inside ecgpu_group_msm), and ONE combining step — window sums over all GPUs, then the
+ * chain of doublings over the windows — produces the result.  The serial tail of the method runs once, not once per GPU
+ * plus a point sum.  `plan_terms` is the term count the window width is chosen from and must be the same on every GPU
+ * (use the largest shard); so must ecgpu_set_msm_window.  `lincomb` semantics as for ecgpu_msm_dev. */
+size_t ecgpu_msm_parts_bytes(ecgpu_ctx *ctx, int curve, size_t plan_terms);
+int ecgpu_msm_parts_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
+                        size_t n, size_t plan_terms, void *d_parts);
+/* d_parts_all: nranks consecutive parts records (the all-gather's output). */
+int ecgpu_msm_finish_dev(ecgpu_ctx *ctx, int curve, const void *d_parts_all, int nranks, size_t plan_terms, void *d_out_xy,
+                         void *d_out_inf);
+
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 
 /* k256 GLV split on the device: k -> (r1, r2) with r1 + r2*lambda = k (mod n), canonical scalars

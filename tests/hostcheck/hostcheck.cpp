@@ -4,6 +4,7 @@
 // flow (k_fixed_base, k_var_base, k_normalize, the Pippenger pipeline) on one CPU thread.  Nothing here
 // is linked into libecgpu.so.
 #include <cstring>
+#include <array>
 #include <vector>
 
 #include "../../elliptic-curves_amd/csrc/ecgpu_point.h"
@@ -306,30 +307,52 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     using F = Field<C>;
     constexpr int N = C::N;
     auto b = G::curve_b();
-    int nwin = signed_window_count(32 * N - 1, c);
+    using S = MsmSplit<C>;
+    const size_t npad = (n + 63) / 64 * 64, ne = (size_t)S::SUB * npad;      // sub-term h of term i sits at h * npad + i
+    int nwin = signed_window_count(S::KBITS, c);
     size_t nb = (size_t)1 << (c - 1);
     int seg = nb < 32 ? (int)nb : 32;
     size_t nseg = nb / seg;
-    std::vector<Affine<C>> pts(n);
-    std::vector<uint32_t> ranks((size_t)nwin * n), sorted((size_t)nwin * n), counts((size_t)nwin * nb, 0),
+    std::vector<Affine<C>> pts(ne);
+    std::vector<uint32_t> ranks((size_t)nwin * ne), sorted((size_t)nwin * ne + 4), counts((size_t)nwin * nb, 0),
         offsets((size_t)nwin * nb);
-    std::vector<uint8_t> finite(n, 0), flips(n, 0);
-    std::vector<std::vector<uint32_t>> ks(n, std::vector<uint32_t>(N));
+    std::vector<uint8_t> finite(n, 0);
+    std::vector<std::array<std::array<uint32_t, S::KW>, S::SUB>> subs(n);
+    std::vector<std::array<bool, S::SUB>> flips(n);
+    auto digit_of = [&](size_t i, int h, int w, uint32_t* carry) {
+        return msm_digit<S::KW>(subs[i][h].data(), w, c, nwin, carry, (uint32_t)(h * npad + i), flips[i][h], S::KBITS);
+    };
     for (size_t i = 0; i < n; i++) {                                    // prepare
-        if (!load_scalar<C>(ks[i].data(), scalars + i * WireBytes<C>::value)) return -2;
+        uint32_t k[N];
+        if (!load_scalar<C>(k, scalars + i * WireBytes<C>::value)) return -2;
+        {
+            uint32_t sub[S::SUB][S::KW];
+            bool neg[S::SUB];
+            S::split(k, sub, neg);
+            for (int h = 0; h < S::SUB; h++) {
+                for (int t = 0; t < S::KW; t++) subs[i][h][t] = sub[h][t];
+                flips[i][h] = neg[h];
+            }
+        }
         if (!load_affine<C>(&pts[i], pxy + i * 2 * WireBytes<C>::value, pinf ? pinf[i] : 0)) continue;
         if (!G::on_curve(pts[i], b)) return -3;
         {
             uint32_t w[N];                                              // packed storage form, as on the GPU
+            if constexpr (S::SUB == 2) {
+                F::pack(w, F::mul(G::m(pts[i].x), F::unpack(C::BETA)));
+                pts[npad + i].x = F::unpack(w).e;
+            }
             F::pack(w, G::m(pts[i].x)); pts[i].x = F::unpack(w).e;
             F::pack(w, G::m(pts[i].y)); pts[i].y = F::unpack(w).e;
+            if constexpr (S::SUB == 2) pts[npad + i].y = pts[i].y;
         }
         finite[i] = 1;
-        flips[i] = fold_scalar<N>(ks[i].data(), C::ORDER);
-        uint32_t carry = 0;
-        for (int w = 0; w < nwin; w++) {
-            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i, flips[i]);
-            if (d.nonzero) ranks[(size_t)w * n + i] = counts[(size_t)w * nb + d.bucket]++;
+        for (int h = 0; h < S::SUB; h++) {
+            uint32_t carry = 0;
+            for (int w = 0; w < nwin; w++) {
+                MsmDigit d = digit_of(i, h, w, &carry);
+                if (d.nonzero) ranks[(size_t)w * ne + h * npad + i] = counts[(size_t)w * nb + d.bucket]++;
+            }
         }
     }
     for (int w = 0; w < nwin; w++) {                                    // scan
@@ -338,18 +361,21 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     }
     for (size_t i = 0; i < n; i++) {                                    // scatter
         if (!finite[i]) continue;
-        uint32_t carry = 0;
-        for (int w = 0; w < nwin; w++) {
-            MsmDigit d = msm_digit<N>(ks[i].data(), w, c, nwin, &carry, (uint32_t)i, flips[i]);
-            if (d.nonzero) {
-                uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * n + i];
-                sorted[(size_t)w * n + pos] = (uint32_t)i | (d.neg << 31);
+        for (int h = 0; h < S::SUB; h++) {
+            uint32_t carry = 0;
+            for (int w = 0; w < nwin; w++) {
+                MsmDigit d = digit_of(i, h, w, &carry);
+                if (d.nonzero) {
+                    const size_t j = h * npad + i;
+                    uint32_t pos = offsets[(size_t)w * nb + d.bucket] + ranks[(size_t)w * ne + j];
+                    sorted[(size_t)w * ne + pos] = (uint32_t)j | (d.neg << 31);
+                }
             }
         }
     }
     // accumulate + finish: the lane bodies of k_msm_accumulate / k_msm_bucket_finish (ecgpu_msm_chunk.h)
     if (chunk == 0) chunk = 32;
-    size_t nchunks = (n + chunk - 1) / chunk;
+    size_t nchunks = (ne + chunk - 1) / chunk;
     if (nchunks == 0) nchunks = 1;
     struct Points {
         const std::vector<Affine<C>>* pts;
@@ -381,11 +407,11 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
         Points points{&pts};
         Partials sink{&partials, &written, (size_t)w * (nb + nchunks)};
         for (size_t q = 0; q < nchunks; q++)
-            msm_chunk_accumulate<C>(sorted.data() + (size_t)w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, b,
+            msm_chunk_accumulate<C>(sorted.data() + (size_t)w * ne, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, b,
                                     points, sink);
         for (size_t j = 0; j < nb; j++)
             buckets[(size_t)w * nb + j] = msm_bucket_finish<C>((uint32_t)j, ow[j], counts[(size_t)w * nb + j], (uint32_t)chunk, b, sink,
-                                                               sorted.data() + (size_t)w * n, points);
+                                                               sorted.data() + (size_t)w * ne, points);
     }
     std::vector<Proj<C>> wins(nwin);
     for (int w = 0; w < nwin; w++) {                                    // reduce
@@ -393,7 +419,7 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
         for (size_t s = 0; s < nseg; s++) {
             Proj<C> running = G::identity(), local = G::identity();
             size_t base = s * seg;
-            const int sh = w == nwin - 1 ? msm_top_shift(32 * N - 1, c) : 0;
+            const int sh = w == nwin - 1 ? msm_top_shift(S::KBITS, c) : 0;
             for (int j = seg - 1; j >= 0; j--) {
                 running = G::add(running, buckets[(size_t)w * nb + base + j], b);
                 if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);

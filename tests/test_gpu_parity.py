@@ -752,6 +752,51 @@ def test_host_pointer_msm_in_chunks(eng):
     assert bytes(o2) == bytes(w2) and f2 == int(wf2[0])
 
 
+@pytest.mark.parametrize("curve", ["k256", "p256", "p384", "p224", "bp256"])
+@pytest.mark.parametrize("n,shards", [(5000, 2), ((1 << 17) + 77, 3), (3, 4)])
+def test_msm_parts_and_finish_split(eng, curve, n, shards):
+    """The two halves of a multi-GPU MSM on one GPU: ecgpu_msm_parts_dev on unequal term shards (one of them possibly
+    empty), their parts laid out rank after rank as an all-gather would, ecgpu_msm_finish_dev over all of them == the
+    one-call MSM == the oracle (sample).  Identities mixed in."""
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES[curve]
+    L = c.L
+    k = rand_scalars(c.cid, n, 0xEC0003F7 + c.cid)
+    s = rand_scalars(c.cid, n, 0xEC0004F7 + c.cid)
+    pts, _ = eng.mul_by_generator(c.cid, s)
+    pts = pts.copy()
+    inf = np.zeros(n, np.uint8)
+    inf[::7] = 1
+    pts.reshape(n, 2 * L)[::7] = 0
+    want, wf = eng.lincomb(c.cid, k, pts, inf)
+    if n <= 5000:
+        w, wi = oracle_lib.msm(c.cid, k, pts, inf, vartime=True)
+        assert bytes(want) == bytes(w) and wf == wi
+    bounds = [ecgpu.shard_range(n, r, shards) for r in range(shards)]
+    plan_terms = max(hi - lo for lo, hi in bounds)
+    nbytes = eng.msm_parts_bytes(c.cid, plan_terms)
+    assert nbytes % 16 == 0 and nbytes > 0
+    d_all = eng.dev_alloc(shards * nbytes)
+    d_k, d_p, d_i = eng.to_device(k), eng.to_device(pts), eng.to_device(inf)
+    pad = lambda x: (x + 15) // 16 * 16
+    for r, (lo, hi) in enumerate(bounds):
+        # shard inputs copied to 16-byte aligned device buffers of their own (a rank holds only its slice)
+        m = hi - lo
+        dk = eng.to_device(k[lo * L: hi * L]) if m else None
+        dp = eng.to_device(pts[lo * 2 * L: hi * 2 * L]) if m else None
+        di = eng.to_device(inf[lo:hi]) if m else None
+        eng.msm_parts_dev(c.cid, dk, dp, di, m, plan_terms, d_all.at(r * nbytes))
+        for b in (dk, dp, di):
+            if b is not None:
+                b.free()
+    d_o, d_f = eng.dev_alloc(pad(2 * L)), eng.dev_alloc(16)
+    eng.msm_finish_dev(c.cid, d_all, shards, plan_terms, d_o, d_f)
+    got, gf = eng.to_host(d_o, 2 * L), int(eng.to_host(d_f, 1)[0])
+    assert bytes(got) == bytes(want) and gf == wf
+    for b in (d_all, d_k, d_p, d_i, d_o, d_f):
+        b.free()
+
+
 @pytest.mark.parametrize("curve", ALL_CURVES)
 def test_host_pointer_msm_chunked_path_every_curve(eng, curve, monkeypatch):
     """The chunked host-pointer ecgpu_msm on every parameter set, with the chunk size lowered to 2^10 terms

@@ -114,3 +114,51 @@ def test_tensor_exchange_world2_gloo(oracle, tmp_path, curve, n):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert " ok" in o
+
+
+WORKER_RECORD = r'''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import oracle_lib
+ecgpu = importlib.import_module("elliptic-curves_amd")
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=int(sys.argv[2]))
+curve = int(sys.argv[3]); n = int(sys.argv[4])
+L = oracle_lib.FIELD_BYTES[curve]
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(9876)
+scal = oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8))
+pts, _ = oracle_lib.batch_mul_base(curve, oracle_lib.scalar_reduce(curve, rng.integers(0, 256, n * L, dtype=np.uint8)))
+lo, hi = ecgpu.shard_range(n, rank, world)                      # bench.py's term partition
+# the record stands in for ecgpu_msm_parts_dev's output: here the shard's sum as x || y || flag
+nbytes = 2 * L + 1
+ex = ecgpu.RecordExchange(torch, dist, nbytes, "cpu")
+assert ex.mine.numel() == nbytes and ex.all.numel() == world * nbytes
+for step in range(2):                                          # the buffers are reused every step
+    xy, inf = oracle_lib.msm(curve, scal[lo * L: hi * L], pts[lo * 2 * L: hi * 2 * L])
+    ex.mine[: 2 * L] = torch.from_numpy(np.asarray(xy, np.uint8).copy()); ex.mine[2 * L] = int(inf)
+    rec = ex.gather().numpy().reshape(world, nbytes)           # stands in for ecgpu_msm_finish_dev's input
+    ones = np.tile(np.array([0] * (L - 1) + [1], np.uint8), world)
+    got, gi = oracle_lib.msm(curve, ones, np.ascontiguousarray(rec[:, : 2 * L]).reshape(-1), np.ascontiguousarray(rec[:, 2 * L]))
+    want, wi = oracle_lib.msm(curve, scal, pts)
+    assert bytes(got) == bytes(want) and gi == wi, "rank %d mismatch" % rank
+print("rank", rank, "ok")
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("curve,n", [(0, 41), (1, 2)])
+def test_record_exchange_world2_gloo(oracle, tmp_path, curve, n):
+    """bench.py's sharded-MSM exchange (RecordExchange: all_gather_into_tensor of one opaque fixed-size record per rank) on
+    CPU tensors; the records are the oracle's shard sums where the GPU path exchanges per-window partial sums."""
+    port = 33500 + (os.getpid() + curve * 13 + n) % 2000
+    script = tmp_path / "worker_record.py"
+    script.write_text(WORKER_RECORD.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", str(curve), str(n)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert " ok" in o
