@@ -48,6 +48,9 @@ ABI_SYMBOLS = [
     "ecgpu_batch_mul_base_compressed", "ecgpu_batch_mul_base_compressed_dev",
     "ecgpu_dev_alloc", "ecgpu_dev_free", "ecgpu_copy_to_device", "ecgpu_copy_to_host",
     "ecgpu_msm_parts_bytes", "ecgpu_msm_parts_dev", "ecgpu_msm_finish_dev",
+    "ecgpu_group_init", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_ctx", "ecgpu_group_last_error",
+    "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
+    "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul",
 ]
 
 
@@ -97,6 +100,12 @@ def load_library():
     lib.ecgpu_dev_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.ecgpu_copy_to_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ecgpu_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.ecgpu_group_last_error.restype = ctypes.c_char_p
+    lib.ecgpu_group_exchange.restype = ctypes.c_char_p
+    lib.ecgpu_group_last_error.argtypes = [ctypes.c_void_p]
+    lib.ecgpu_group_exchange.argtypes = [ctypes.c_void_p]
+    lib.ecgpu_group_destroy.restype = None
+    lib.ecgpu_group_destroy.argtypes = [ctypes.c_void_p]
     lib.ecgpu_msm_parts_bytes.restype = ctypes.c_size_t
     lib.ecgpu_msm_parts_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
     _lib = lib
@@ -119,6 +128,12 @@ def _host(a):
 
 def _hp(a):
     return None if a is None else a.ctypes.data_as(_u8p)
+
+
+def _need(what, a, nbytes):
+    """Host buffers are handed to C as bare pointers: a short one would be read or written past its end."""
+    if a is not None and a.size != nbytes:
+        raise EcgpuError(ERR_ARG, "%s holds %d bytes, expected %d" % (what, a.size, nbytes))
 
 
 def _dp(t):
@@ -267,6 +282,9 @@ class Engine:
         n = s.size // L
         out_x = np.zeros(n * L, np.uint8) if out_x is None else out_x
         out_tag = np.zeros(n, np.uint8) if out_tag is None else out_tag
+        for o, need in ((out_x, n * L), (out_tag, n)):
+            if o.dtype != np.uint8 or not o.flags.c_contiguous or o.size < need:
+                raise EcgpuError(ERR_ARG, "output buffer must be contiguous uint8 of at least %d bytes" % need)
         self._chk(self._lib.ecgpu_batch_mul_base_compressed(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out_x), _hp(out_tag)))
         return out_x, out_tag
 
@@ -278,6 +296,7 @@ class Engine:
         L = _field_bytes(curve)
         s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
         n = s.size // L
+        _need("scalars", s, n * L); _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
         out = np.zeros(n * 2 * L, np.uint8)
         inf = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_batch_mul(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
@@ -287,6 +306,7 @@ class Engine:
         L = _field_bytes(curve)
         s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
         n = s.size // L
+        _need("scalars", s, n * L); _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
         out = np.zeros(2 * L, np.uint8)
         inf = np.zeros(1, np.uint8)
         self._chk(self._lib.ecgpu_msm(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
@@ -296,6 +316,7 @@ class Engine:
         L = _field_bytes(curve)
         a, b, p, pi = _host(a_scalars), _host(b_scalars), _host(points_xy), _host(points_inf)
         n = a.size // L
+        _need("a_scalars", a, n * L); _need("b_scalars", b, n * L); _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
         out = np.zeros(n * 2 * L, np.uint8)
         inf = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_batch_mul_base_and_mul_add(self._ctx, curve, _hp(a), _hp(b), _hp(p), _hp(pi),
@@ -307,6 +328,7 @@ class Engine:
         L = _field_bytes(curve)
         zz, rr, ss, qq = _host(z), _host(r), _host(s), _host(q_xy)
         n = zz.size // L
+        _need("z", zz, n * L); _need("r", rr, n * L); _need("s", ss, n * L); _need("q_xy", qq, n * 2 * L)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_ecdsa_verify_batch(self._ctx, curve, _hp(zz), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n),
                                                      int(bool(reject_high_s)), _hp(ok)))
@@ -316,6 +338,7 @@ class Engine:
         """Batch BIP340 verification (k256): e = challenge hash as 32 bytes, (r, s) signature halves, p_xy lifted key."""
         ee, rr, ss, pp = _host(e), _host(r), _host(s), _host(p_xy)
         n = ee.size // 32
+        _need("e", ee, n * 32); _need("r", rr, n * 32); _need("s", ss, n * 32); _need("p_xy", pp, n * 64)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_schnorr_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(pp), ctypes.c_size_t(n), _hp(ok)))
         return ok
@@ -325,6 +348,7 @@ class Engine:
         L = _field_bytes(curve)
         k, p = _host(scalars), _host(points_xy)
         n = k.size // L
+        _need("scalars", k, n * L); _need("points_xy", p, n * 2 * L)
         out = np.zeros(n * L, np.uint8)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_batch_ecdh(self._ctx, curve, _hp(k), _hp(p), ctypes.c_size_t(n), _hp(out), _hp(ok)))
@@ -338,6 +362,9 @@ class Engine:
         """BIP340 verification from wire bytes: x-only keys (n*32), messages (n*msg_len), signatures (n*64)."""
         pk, mm, sg = _host(pk_x), _host(msgs), _host(sigs)
         n = pk.size // 32
+        _need("pk_x", pk, n * 32); _need("sigs", sg, n * 64)
+        if msg_len:
+            _need("msgs", mm, n * msg_len)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_schnorr_verify_raw_batch(self._ctx, _hp(pk), _hp(mm) if msg_len else None,
                                                            ctypes.c_size_t(msg_len), _hp(sg), ctypes.c_size_t(n), _hp(ok)))
@@ -352,6 +379,7 @@ class Engine:
         L = _field_bytes(curve)
         x, odd = _host(xs), _host(y_is_odd)
         n = x.size // L
+        _need("xs", x, n * L); _need("y_is_odd", odd, n)
         out = np.zeros(n * 2 * L, np.uint8)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_batch_decompress(self._ctx, curve, _hp(x), _hp(odd), ctypes.c_size_t(n), _hp(out), _hp(ok)))
@@ -370,6 +398,7 @@ class Engine:
         L = _field_bytes(curve)
         p, pi = _host(points_xy), _host(points_inf)
         n = p.size // (2 * L)
+        _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
         out = np.zeros(2 * L, np.uint8)
         inf = np.zeros(1, np.uint8)
         self._chk(self._lib.ecgpu_point_sum(self._ctx, curve, _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
@@ -415,6 +444,71 @@ class Engine:
     def point_sum_dev(self, curve, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_point_sum_dev(self._ctx, curve, _dp(d_points_xy), _dp(d_points_inf), ctypes.c_size_t(n),
                                                 _dp(d_out_xy), _dp(d_out_inf)))
+
+
+class Group:
+    """All GPUs of a node from one process (ecgpu_group_*): batch calls slice the index range, lincomb shards its terms
+    and exchanges per-window partial sums once."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._g = ctypes.c_void_p()
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.ecgpu_group_init(ctypes.byref(self._g), devs, len(devices))
+        if rc != OK:
+            self._g = None
+            raise EcgpuError(rc, "ecgpu_group_init failed")
+        self.size = int(self._lib.ecgpu_group_size(self._g))
+        self.exchange = self._lib.ecgpu_group_exchange(self._g).decode()
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.ecgpu_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise EcgpuError(rc, (self._lib.ecgpu_group_last_error(self._g) or b"").decode())
+
+    def set_msm_window(self, bits):
+        self._chk(self._lib.ecgpu_group_set_msm_window(self._g, int(bits)))
+
+    def lincomb(self, curve, scalars, points_xy, points_inf=None):
+        L = _field_bytes(curve)
+        s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
+        n = s.size // L
+        if p.size != n * 2 * L or (pi is not None and pi.size != n):
+            raise EcgpuError(ERR_ARG, "lincomb: buffer sizes do not match %d terms" % n)
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_group_msm(self._g, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
+    def mul_by_generator(self, curve, scalars):
+        L = _field_bytes(curve)
+        s = _host(scalars)
+        n = s.size // L
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_group_batch_mul_base(self._g, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def mul(self, curve, scalars, points_xy, points_inf=None):
+        L = _field_bytes(curve)
+        s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
+        n = s.size // L
+        if p.size != n * 2 * L or (pi is not None and pi.size != n):
+            raise EcgpuError(ERR_ARG, "mul: buffer sizes do not match %d units" % n)
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_group_batch_mul(self._g, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
 
 
 def version():

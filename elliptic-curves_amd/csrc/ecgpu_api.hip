@@ -320,7 +320,7 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
-    MsmPlan plan = msm_plan<C>(n, ctx->msm_c);
+    MsmPlan plan = msm_plan<C>(n, ctx->msm_c, msm_use_glv<C>(n));
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_msm<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
@@ -343,8 +343,12 @@ int msm_parts_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const
         ctx->err = "MSM shard of 2^31 (k256: 2^30) or more terms";
         return ECGPU_ERR_ARG;
     }
-    const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms > n ? plan_terms : n);
-    MsmPlan plan = msm_plan<C>(n, c);
+    if (plan_terms < n) {
+        ctx->err = "ecgpu_msm_parts_dev: plan_terms must be at least the shard's term count (and the same on every GPU)";
+        return ECGPU_ERR_ARG;
+    }
+    const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms);
+    MsmPlan plan = msm_plan<C>(n, c, msm_use_glv<C>(plan_terms));
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
@@ -361,7 +365,7 @@ int msm_finish_dev(ecgpu_ctx* ctx, const void* d_parts_all, int nranks, size_t p
     constexpr int NS = Field<C>::NS;
     int rc;
     const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms);
-    MsmPlan plan = msm_plan<C>(0, c);                       // only c, nwin and nparts matter here
+    MsmPlan plan = msm_plan<C>(0, c, msm_use_glv<C>(plan_terms));   // only c, nwin and nparts matter here
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->bases, (size_t)plan.nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
@@ -377,7 +381,7 @@ int msm_finish_dev(ecgpu_ctx* ctx, const void* d_parts_all, int nranks, size_t p
 
 template <class C>
 size_t msm_parts_bytes(const ecgpu_ctx* ctx, size_t plan_terms) {
-    return msm_plan<C>(0, ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms)).parts_bytes;
+    return msm_plan<C>(0, ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms), msm_use_glv<C>(plan_terms)).parts_bytes;
 }
 
 // ---- host-pointer plumbing ---------------------------------------------------------------------------------

@@ -5,9 +5,10 @@ namespace ecgpu {
 
 using CurveT = ECGPU_CURVE;
 
-template MsmPlan msm_plan<CurveT>(size_t n, int force_c);
+template MsmPlan msm_plan<CurveT>(size_t n, int force_c, bool glv);
+template bool msm_use_glv<CurveT>(size_t n);
 template int msm_choose_window<CurveT>(size_t n);
-template <> size_t msm_max_terms<CurveT>() { return (((size_t)1 << 31) - 64) / MsmSplit<CurveT>::SUB; }
+template <> size_t msm_max_terms<CurveT>() { return (((size_t)1 << 31) - 64) / (MsmHasGlv<CurveT>::value ? 2 : 1); }
 template void launch_msm<CurveT>(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf,
                                  size_t n, void* workspace, uint32_t* out, int* status, hipEvent_t ev_sorted,
                                  hipEvent_t ev_accumulated);

@@ -28,6 +28,7 @@ struct MsmPlan {
     // sub-terms: MsmSplit<C>::SUB per term (k256: the two GLV halves), sub-term h of term i at index h * npad + i
     size_t npad = 0, nsub = 0;     // n rounded up to a multiple of 64; entries per window = SUB * npad
     int kbits = 0;                 // significant bits of a sub-scalar
+    bool glv = false;              // k256: sub-terms are the GLV halves
     // per-window partial sums handed from launch_msm_parts to launch_msm_finish (and between GPUs): [nwin][nparts] points
     size_t nparts = 0, per_part = 0, off_parts = 0, parts_bytes = 0;
     size_t workspace_bytes = 0;
@@ -67,7 +68,8 @@ template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, c
                                         size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
 
 // ---- group "msm": Pippenger pipeline ----
-template <class C> MsmPlan msm_plan(size_t n, int force_c);
+template <class C> MsmPlan msm_plan(size_t n, int force_c, bool glv);
+template <class C> bool msm_use_glv(size_t n);          // k256: GLV halves for this term count?
 template <class C> int msm_choose_window(size_t n);
 template <class C> size_t msm_max_terms();              // sorted entries are sub-term index | sign << 31
 template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,

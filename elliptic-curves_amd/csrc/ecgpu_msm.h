@@ -40,20 +40,20 @@
 namespace ecgpu {
 
 // ---- prepare ----------------------------------------------------------------------------------------------
-// One lane per term.  The scalar is cut into MsmSplit<C>::SUB sub-scalars (ecgpu_recode.h: the folded scalar; for k256 the
-// two GLV halves, the second one against lambda P = (beta x, y)); sub-term h of term i has index j = h * npad + i
+// One lane per term.  The scalar is cut into MsmSplit<C, GLV>::SUB sub-scalars (ecgpu_recode.h: the folded scalar; in GLV
+// mode, k256 only, the two halves, the second one against lambda P = (beta x, y)); sub-term h of term i has index j = h * npad + i
 // (npad = n rounded up to a multiple of 64), so that a wave still writes 64 consecutive digits, points and validity bits
 // per half.  Everything after this kernel sees nsub = SUB * npad independent entries.
 // A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether sub-term j has a digit in
 // window w at all (non-zero digit, finite point) is one bit of vmask[w][j / 64], written with a wave ballot.
-template <class C>
+template <class C, bool GLV>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, size_t npad, int c, int nwin, uint32_t* __restrict__ pts,
               uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status) {
     using G = Group<C>;
     using F = Field<C>;
-    using S = MsmSplit<C>;
+    using S = MsmSplit<C, GLV>;
     constexpr int N = C::N;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -504,19 +504,36 @@ __global__ void __launch_bounds__(BLOCK) k_store_identity(uint32_t* out, size_t 
 }
 
 // ---- plan ------------------------------------------------------------------------------------------------------------
-// Window width from the number of entries per window (terms; twice that for k256's GLV halves), from sweeps on MI355X
-// (tools/gpu_msm_window_sweep.sh).  Below 2^17 the curve is flat: the parts that do not depend on n dominate whatever c is.
-inline int msm_window_bits(size_t entries) {
+// Window width from the term count, from sweeps on MI355X (tools/gpu_msm_sweep.py; plain: v11 kernels, GLV: r02b):
+// plain, fastest c at 2^12 / 2^14 / 2^16 / 2^17 ... 2^19 / 2^20 / 2^21 ... = 9 / 11 / 12 / 13 / 14 / 16; GLV (2 n entries of
+// 128 bits: c = 15 gives 9 full windows, c = 16 eight and a carry-only ninth): 13 up to 2^18 terms, 15 from 2^19.
+// Below 2^17 the curve is flat: the parts that do not depend on n dominate whatever c is.
+inline int msm_window_bits(size_t n, bool glv) {
     int lg = 0;
-    while (((size_t)1 << (lg + 1)) <= entries) lg++;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c;
-    if (lg <= 16) c = lg - 3;
+    if (glv) c = lg <= 15 ? lg - 2 : (lg <= 18 ? 13 : 15);
+    else if (lg <= 16) c = lg - 3;
     else if (lg <= 19) c = 13;
     else if (lg == 20) c = 14;
     else c = 16;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;
+}
+
+// GLV halves or the plain folded scalar?  k256 only, up to 2^22 terms by default (see MsmSplit); ECGPU_MSM_GLV = 0 / 1
+// forces it off / on, ECGPU_MSM_GLV_MAX_LOG2 moves the threshold (tuning knobs; results do not depend on them).
+template <class C>
+bool msm_use_glv(size_t n) {
+    if (!MsmHasGlv<C>::value) return false;
+    int max_log2 = 22;
+    if (const char* e = getenv("ECGPU_MSM_GLV")) {
+        if (e[0] == '0') return false;
+        if (e[0] == '1') return true;
+    }
+    if (const char* e = getenv("ECGPU_MSM_GLV_MAX_LOG2")) max_log2 = atoi(e);
+    return max_log2 >= 0 && max_log2 < 40 && n <= ((size_t)1 << max_log2);
 }
 
 // per-device launch facts (a context per GPU may plan concurrently: no unsynchronised function statics)
@@ -532,19 +549,20 @@ inline MsmDeviceFacts& msm_device_facts() {
 // the window width an MSM of n terms gets (0 terms: the narrowest)
 template <class C>
 int msm_choose_window(size_t n) {
-    return msm_window_bits((size_t)MsmSplit<C>::SUB * (n ? n : 1));
+    return msm_window_bits(n ? n : 1, msm_use_glv<C>(n));
 }
 
+// glv: as msm_use_glv<C> decided for the term count the plan is made for (all GPUs of a sharded MSM: the same)
 template <class C>
-MsmPlan msm_plan(size_t n, int force_c) {
+MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     constexpr int N = C::N, NS = Field<C>::NS;
-    using S = MsmSplit<C>;
     MsmPlan p;
+    p.glv = glv;
     p.npad = (n + 63) / 64 * 64;
-    p.nsub = (size_t)S::SUB * p.npad;
-    p.kbits = S::KBITS;
+    p.nsub = (glv ? 2 : 1) * p.npad;
+    p.kbits = glv ? 128 : 32 * N - 1;
     const size_t ne = p.nsub;                               // entries per window the sort and the accumulation see
-    p.c = force_c ? force_c : msm_window_bits((size_t)S::SUB * n);
+    p.c = force_c ? force_c : msm_window_bits(n ? n : 1, glv);
     p.nwin = signed_window_count(p.kbits, p.c);
     p.nb = (size_t)1 << (p.c - 1);
     p.seg = 4;                                              // buckets per running-sum lane: 4 ... 8 measured best for
@@ -668,8 +686,14 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
             done.store(true);
         }
     }
-    hipLaunchKernelGGL(k_msm_prepare<C>, dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin, pts,
-                       digits, vmask, d_status);
+    if constexpr (MsmHasGlv<C>::value) {
+        if (p.glv)
+            hipLaunchKernelGGL((k_msm_prepare<C, true>), dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin,
+                               pts, digits, vmask, d_status);
+    }
+    if (!p.glv)
+        hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin,
+                           pts, digits, vmask, d_status);
     if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
         uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);

@@ -262,14 +262,16 @@ struct K256Scalar {
 };
 
 // ---- how an MSM term's scalar is cut into sub-scalars before the bucket windows ---------------------------------------
-// Generic curves: one sub-term per term, the folded scalar (k -> n - k when the top bit is set, sign flag): 32 N - 1 bits.
-// k256: the two GLV halves k = r1 + r2 lambda (mod n), |r_i| < 2^128 after folding their signs into flags
+// Plain (every curve): one sub-term per term, the folded scalar (k -> n - k when the top bit is set, sign flag): 32 N - 1 bits.
+// GLV (k256 only): the two halves k = r1 + r2 lambda (mod n), |r_i| < 2^128 after folding their signs into flags
 // (k256/src/arithmetic/mul.rs:112-132, mul/glv.rs:149-156), the second one against lambda P = (beta x, y): 2 n sub-terms of
-// 128 bits.  The additions are the same in number (2 n x 8.2 windows against n x 16), but there are 9 windows of buckets to
-// reduce instead of 16 and the Horner chain over the window sums needs 128 doublings instead of 240 — the part of an MSM
-// that does not shrink with n.
-template <class C>
+// 128 bits.  The additions are about the same in number (2 n x 8.5 windows against n x 16), but there are 9 windows of
+// buckets to reduce instead of 16 and the Horner chain over the window sums needs 128 doublings instead of 240 — the part
+// of an MSM that does not shrink with n.  It costs a decomposition per term and doubles the array the point gathers
+// range over, so it pays for MSMs of up to a few million terms (a GPU's share of a sharded 2^24-term MSM), not beyond.
+template <class C, bool GLV>
 struct MsmSplit {
+    static_assert(!GLV, "the GLV split exists for secp256k1 only");
     static constexpr int SUB = 1;
     static constexpr int KW = C::N;
     static constexpr int KBITS = 32 * C::N - 1;
@@ -280,7 +282,7 @@ struct MsmSplit {
     }
 };
 template <>
-struct MsmSplit<K256Params> {
+struct MsmSplit<K256Params, true> {
     static constexpr int SUB = 2;
     static constexpr int KW = 4;
     static constexpr int KBITS = 128;
@@ -295,5 +297,9 @@ struct MsmSplit<K256Params> {
         for (int i = 0; i < KW; i++) { sub[0][i] = r1[i]; sub[1][i] = r2[i]; }
     }
 };
+template <class C>
+struct MsmHasGlv { static constexpr bool value = false; };
+template <>
+struct MsmHasGlv<K256Params> { static constexpr bool value = true; };
 
 }  // namespace ecgpu

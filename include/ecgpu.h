@@ -188,13 +188,44 @@ int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
  * torch.distributed job, peer copies inside ecgpu_group_msm), and ONE combining step — window sums over all GPUs, then the
  * chain of doublings over the windows — produces the result.  The serial tail of the method runs once, not once per GPU
  * plus a point sum.  `plan_terms` is the term count the window width is chosen from and must be the same on every GPU
- * (use the largest shard); so must ecgpu_set_msm_window.  `lincomb` semantics as for ecgpu_msm_dev. */
+ * (at least the largest shard); so must ecgpu_set_msm_window and the ECGPU_MSM_* environment knobs.  `lincomb` semantics as for ecgpu_msm_dev. */
 size_t ecgpu_msm_parts_bytes(ecgpu_ctx *ctx, int curve, size_t plan_terms);
 int ecgpu_msm_parts_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
                         size_t n, size_t plan_terms, void *d_parts);
 /* d_parts_all: nranks consecutive parts records (the all-gather's output). */
 int ecgpu_msm_finish_dev(ecgpu_ctx *ctx, int curve, const void *d_parts_all, int nranks, size_t plan_terms, void *d_out_xy,
                          void *d_out_inf);
+
+/* ---- all GPUs of a node from ONE process (`ecgpu_init(ctx**, devices, ndev)`; 8e) --------------------- *
+ * A group owns one context per listed device and runs one worker thread per device for the duration of a call: what a
+ * single-process caller — the Rust `lincomb` of the reference, which knows nothing about ranks — uses to reach the 8 GPUs
+ * of a node.  (A torch.distributed job with one process per GPU uses ecgpu_msm_parts_dev / ecgpu_msm_finish_dev and its own
+ * collective instead: bench.py.)  A device may be listed more than once (independent contexts; how the exchange is tested
+ * on a one-GPU box).  Batch calls cut the index range into one contiguous slice per GPU and need no exchange; the MSM
+ * cuts the terms the same way, runs ecgpu_msm_parts_dev per GPU and has ONE exchange step: RCCL ncclAllGather of the
+ * per-window partial sums over xGMI when librccl can be dlopen()ed and the devices are distinct, a peer copy into
+ * GPU 0 otherwise or with ECGPU_GROUP_EXCHANGE=peer (=rccl: fail instead of falling back); then ecgpu_msm_finish_dev once.
+ * Results are identical to the single-GPU calls.  Not thread-safe: one call at a time per group. */
+typedef struct ecgpu_group ecgpu_group;
+int ecgpu_group_init(ecgpu_group **group, const int *devices, int ndev);
+void ecgpu_group_destroy(ecgpu_group *group);
+int ecgpu_group_size(const ecgpu_group *group);
+ecgpu_ctx *ecgpu_group_ctx(ecgpu_group *group, int i);              /* borrowed: member i's context */
+const char *ecgpu_group_last_error(const ecgpu_group *group);
+const char *ecgpu_group_exchange(const ecgpu_group *group);         /* "rccl" or "peer" */
+int ecgpu_group_set_msm_window(ecgpu_group *group, int window_bits);
+/* `lincomb` over all GPUs of the group, host buffers (every GPU uploads its own shard over its own PCIe link). */
+int ecgpu_group_msm(ecgpu_group *group, int curve, const uint8_t *scalars, const uint8_t *points_xy,
+                    const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+/* The same with the shards already resident: d_scalars[i] / d_points_xy[i] / d_points_inf[i] (the array or any entry may be
+ * NULL) live on member i's device and hold n_per_device[i] terms; out_xy / out_inf are host buffers. */
+int ecgpu_group_msm_dev(ecgpu_group *group, int curve, const void *const *d_scalars, const void *const *d_points_xy,
+                        const void *const *d_points_inf, const size_t *n_per_device, uint8_t *out_xy, uint8_t *out_inf);
+/* ecgpu_batch_mul_base / ecgpu_batch_mul over all GPUs of the group (index-range slices, no exchange). */
+int ecgpu_group_batch_mul_base(ecgpu_group *group, int curve, const uint8_t *scalars, size_t n, uint8_t *out_xy,
+                               uint8_t *out_inf);
+int ecgpu_group_batch_mul(ecgpu_group *group, int curve, const uint8_t *scalars, const uint8_t *points_xy,
+                          const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
 
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 

@@ -300,14 +300,14 @@ int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, s
 }
 
 // the Pippenger pipeline of ecgpu_msm.h: prepare/scan/scatter/accumulate/reduce/combine, sequentially
-template <class C>
+template <class C, bool GLV>
 int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy,
         uint8_t* out_inf) {
     using G = Group<C>;
     using F = Field<C>;
     constexpr int N = C::N;
     auto b = G::curve_b();
-    using S = MsmSplit<C>;
+    using S = MsmSplit<C, GLV>;
     const size_t npad = (n + 63) / 64 * 64, ne = (size_t)S::SUB * npad;      // sub-term h of term i sits at h * npad + i
     int nwin = signed_window_count(S::KBITS, c);
     size_t nb = (size_t)1 << (c - 1);
@@ -447,6 +447,12 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     return 0;
 }
 
+template <class C>
+int msm_plain(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy,
+              uint8_t* out_inf) {
+    return msm<C, false>(c, chunk, scalars, pxy, pinf, n, out_xy, out_inf);
+}
+
 // ScalarN<C>: op 0 a*b mod n, 1 1/a mod n, 2 a mod n (a < 2^(32N)), 3 is_high(a) -> out[last byte]
 template <class C>
 int scalar_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -520,9 +526,11 @@ int hc_batch_mul(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* p
                  uint8_t* oi) {
     DISPATCH(curve, batch_mul, (s, p, pi, n, nthreads, o, oi))
 }
-int hc_msm(int curve, int c, size_t chunk, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o,
+// glv != 0: k256 on the GLV halves (MsmSplit<K256Params, true>), otherwise the plain folded scalar
+int hc_msm(int curve, int c, size_t chunk, int glv, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o,
            uint8_t* oi) {
-    DISPATCH(curve, msm, (c, chunk, s, p, pi, n, o, oi))
+    if (glv) return curve == 0 ? msm<K256Params, true>(c, chunk, s, p, pi, n, o, oi) : -1;
+    DISPATCH(curve, msm_plain, (c, chunk, s, p, pi, n, o, oi))
 }
 int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {
     DISPATCH(curve, table_rule_check, (w, j, e, out_xy))

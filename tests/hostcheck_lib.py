@@ -105,13 +105,21 @@ def batch_mul(curve, scalars, pxy, pinf=None, nthreads=1):
     return rc, out, inf[:n]
 
 
-def msm(curve, c, scalars, pxy, pinf=None, chunk=32):
+def msm(curve, c, scalars, pxy, pinf=None, chunk=32, glv=None):
+    """The Pippenger pipeline on the CPU.  glv: k256 on the GLV halves (True) or the plain folded scalar (False);
+    None = both for k256 (the two must agree; the GLV result is returned), plain for the other curves."""
     s, p, pi = _a(scalars), _a(pxy), _a(pinf)
     n = s.size // L[curve]
-    out = np.zeros(2 * L[curve], np.uint8)
-    inf = np.zeros(1, np.uint8)
-    rc = lib().hc_msm(curve, c, ctypes.c_size_t(chunk), _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
-    return rc, bytes(out), int(inf[0])
+    res = None
+    for g in ((False, True) if glv is None and curve == 0 else (bool(glv),)):
+        out = np.zeros(2 * L[curve], np.uint8)
+        inf = np.zeros(1, np.uint8)
+        rc = lib().hc_msm(curve, c, ctypes.c_size_t(chunk), int(g), _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
+        cur = (rc, bytes(out), int(inf[0]))
+        if res is not None and cur != res:
+            raise AssertionError("plain and GLV Pippenger disagree: %r vs %r" % (res, cur))
+        res = cur
+    return res
 
 
 def table_rule(curve, w, j, e):

@@ -797,6 +797,52 @@ def test_msm_parts_and_finish_split(eng, curve, n, shards):
         b.free()
 
 
+@pytest.mark.parametrize("devices,mode", [([0, 0], "peer"), ([0, 0, 0], "peer"), ([0], "rccl"), ([0], "peer")])
+def test_group_multi_device_entry_points(eng, devices, mode, monkeypatch):
+    """ecgpu_group_*: the single-process multi-GPU entry (one context + worker thread per member).  On a one-GPU box the
+    members are contexts on the same device: term shards, the parts exchange by peer copy (or RCCL's all-gather in a
+    one-member communicator, which is what can be exercised here), one combining step.  lincomb, mul_by_generator and mul
+    must give the bytes of the single-context calls, for a GLV-sized and a tiny MSM, with identities mixed in."""
+    ecgpu = ecgpu_module()
+    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", mode)
+    try:
+        grp = ecgpu.Group(devices)
+    except ecgpu.EcgpuError:
+        if mode == "rccl":
+            pytest.skip("librccl could not be loaded in this process")
+        raise
+    try:
+        assert grp.size == len(devices) and grp.exchange == mode
+        for curve in ("k256", "p256"):
+            c = pyec.CURVES[curve]
+            for n in ((1 << 15) + 13, 5, 0):
+                k = rand_scalars(c.cid, n, 0xEC0005F7 + c.cid + n)
+                s = rand_scalars(c.cid, n, 0xEC0006F7 + c.cid + n)
+                pts, _ = eng.mul_by_generator(c.cid, s)
+                pts = pts.copy()
+                inf = np.zeros(n, np.uint8)
+                inf[::5] = 1
+                pts.reshape(n, 2 * c.L)[::5] = 0
+                want, wf = eng.lincomb(c.cid, k, pts, inf)
+                got, gf = grp.lincomb(c.cid, k, pts, inf)
+                assert bytes(got) == bytes(want) and gf == wf
+                if n:                                           # without the flags the zeroed records are (0, 0): off the curve
+                    with pytest.raises(ecgpu.EcgpuError) as ei:
+                        grp.lincomb(c.cid, k, pts)
+                    assert ei.value.code == ecgpu.ERR_POINT
+            n = 3000
+            k = rand_scalars(c.cid, n, 0xEC0007F7 + c.cid)
+            a, ai = grp.mul_by_generator(c.cid, k)
+            b, bi = eng.mul_by_generator(c.cid, k)
+            assert bytes(a) == bytes(b) and bytes(ai) == bytes(bi)
+            k2 = rand_scalars(c.cid, n, 0xEC0008F7 + c.cid)
+            a2, ai2 = grp.mul(c.cid, k2, b)
+            b2, bi2 = eng.mul(c.cid, k2, b)
+            assert bytes(a2) == bytes(b2) and bytes(ai2) == bytes(bi2)
+    finally:
+        grp.close()
+
+
 @pytest.mark.parametrize("curve", ALL_CURVES)
 def test_host_pointer_msm_chunked_path_every_curve(eng, curve, monkeypatch):
     """The chunked host-pointer ecgpu_msm on every parameter set, with the chunk size lowered to 2^10 terms

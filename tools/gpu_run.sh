@@ -4,7 +4,7 @@
 #
 # recipes
 #   smoke                 __graft_entry__.smoke()
-#   pytest[:<expr>]       python -m pytest tests -m gpu [-k <expr>]   (expr with _ for spaces: "wycheproof_or_fullsize")
+#   pytest[:<expr>]       python -m pytest tests -m gpu [-k <expr>]   (expr with + for spaces: "wycheproof+or+full_size")
 #   bench[:<workload>]    python bench.py [--workload W] --check           -> bench_<W>.json
 #   benchall              the default bench line (all four GPU configs as sub-records) with --check
 #   prof:<workload>       rocprofv3 --kernel-trace --stats of bench.py --workload W  -> prof_<W>/ + kernel_stats summary
@@ -25,7 +25,7 @@ for recipe in "$@"; do
   case "$name" in
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.txt" ;;
     pytest)
-      if [ -n "$arg" ]; then timeout 1700 python -m pytest tests -m gpu -q -x -k "${arg//_/ }" --durations=8 > "$OUT/pytest_${arg}.txt" 2>&1; tail -15 "$OUT/pytest_${arg}.txt"
+      if [ -n "$arg" ]; then timeout 1700 python -m pytest tests -m gpu -q -x -k "${arg//+/ }" --durations=8 > "$OUT/pytest_${arg}.txt" 2>&1; tail -15 "$OUT/pytest_${arg}.txt"
       else timeout 1700 python -m pytest tests -m gpu -q -x --durations=12 > "$OUT/pytest_gpu.txt" 2>&1; tail -20 "$OUT/pytest_gpu.txt"; fi ;;
     bench)
       w=${arg:-fixed_k256}
