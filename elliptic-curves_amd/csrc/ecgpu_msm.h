@@ -522,12 +522,14 @@ inline int msm_window_bits(size_t n, bool glv) {
     return c;
 }
 
-// GLV halves or the plain folded scalar?  k256 only, up to 2^22 terms by default (see MsmSplit); ECGPU_MSM_GLV = 0 / 1
-// forces it off / on, ECGPU_MSM_GLV_MAX_LOG2 moves the threshold (tuning knobs; results do not depend on them).
+// GLV halves or the plain folded scalar?  k256 only, up to 2^21 terms by default (see MsmSplit; measured, r02c sweep:
+// GLV / plain = 0.88 / 1.22 ms at 2^14 terms, 1.10 / 1.46 at 2^17, 1.56 / 1.93 at 2^19, 3.58 / 3.74 at 2^21, 6.46 / 6.16 at
+// 2^22, 22.8 / 20.1 at 2^24); ECGPU_MSM_GLV = 0 / 1 forces it off / on, ECGPU_MSM_GLV_MAX_LOG2 moves the threshold (tuning
+// knobs; results do not depend on them).
 template <class C>
 bool msm_use_glv(size_t n) {
     if (!MsmHasGlv<C>::value) return false;
-    int max_log2 = 22;
+    int max_log2 = 21;
     if (const char* e = getenv("ECGPU_MSM_GLV")) {
         if (e[0] == '0') return false;
         if (e[0] == '1') return true;

@@ -1,211 +1,324 @@
-//! ecgpu_shim.rs — the reference-side binding a maintainer would add (NOT built in this repo: the
-//! image has no rustc/cargo; kept next to include/ecgpu.h and checked against it by hand).
+//! ecgpu_shim.rs — the reference-side binding a maintainer would add to RustCrypto/elliptic-curves (as a workspace
+//! crate `ecgpu`, enabled by a cargo feature `gpu` in `k256`, `p256`, `p384`, `primeorder`).  NOT built in this repo:
+//! the image has no rustc / cargo.  The raw `extern "C"` block is generated from include/ecgpu.h
+//! (ecgpu_sys.rs, tools/gen_rust_sys.py) and checked against the header by tests/test_abi.py; this file is the safe
+//! layer above it and the text of the patch sites.
 //!
 //! It exposes libecgpu.so behind the reference's own plug-in points:
-//!   * `primeorder::MulBackend<C>`            (primeorder/src/mul_backend.rs:11-40)
-//!   * `elliptic_curve::ops::LinearCombination` (primeorder/src/projective.rs:480-511,
-//!                                               k256/src/arithmetic/mul.rs:84-109)
-//!   * new batch entry points `batch_mul_by_generator`, `batch_mul`
+//!   * `elliptic_curve::ops::LinearCombination::lincomb_vartime`
+//!         primeorder/src/projective.rs:480-511 (generic curves) and k256/src/arithmetic/mul.rs:84-109 (k256)
+//!   * `elliptic_curve::ops::MulByGeneratorVartime::{mul_by_generator_vartime, mul_by_generator_and_mul_add_vartime}`
+//!         primeorder/src/projective.rs:923-940 -> `primeorder::MulBackend<C>` (primeorder/src/mul_backend.rs:11-40);
+//!         k256: inherent fns k256/src/arithmetic/mul.rs:177-233 and the impl at :296-310
+//!   * new batch entry points (a GPU needs batches; the reference's API is one element at a time):
+//!         `batch_mul_by_generator_vartime`, `batch_mul_vartime`, `batch_mul_by_generator_and_mul_add_vartime`,
+//!         `batch_verify_prehashed`
 //!
-//! Build: add `links = "ecgpu"` + a build.rs emitting `cargo:rustc-link-lib=dylib=ecgpu` and
+//! SECRET SCALARS.  Every GPU path is VARIABLE-TIME in its scalars (zero digits are skipped, table entries and buckets
+//! are addressed by scalar bits).  It therefore stands behind the reference's `*_vartime` names ONLY
+//! (`MulVartime` primeorder/src/projective.rs:888-921, `lincomb_vartime`, `mul_by_generator_vartime`): public scalars —
+//! signature verification, MSMs over public data, public-key derivation from non-secret material.  The constant-time
+//! entry points (`Mul`, `mul_by_generator`, `lincomb`: primeorder/src/projective.rs:532-557, tables/lookup.rs:43-65)
+//! are NOT redirected; `ecgpu_batch_ecdh` and `ecgpu_batch_mul_base` take whatever scalars the caller hands them and
+//! the caller owns that decision (see include/ecgpu.h, "Secret scalars").
+//!
+//! Build: `links = "ecgpu"` + a build.rs emitting `cargo:rustc-link-lib=dylib=ecgpu` and
 //! `cargo:rustc-link-search=<repo>/elliptic-curves_amd/lib`.
 
-use core::ffi::{c_char, c_int, c_void};
+#[path = "ecgpu_sys.rs"]
+pub mod sys;
 
-#[repr(C)]
-pub struct EcgpuCtx {
-    _private: [u8; 0],
-}
+use core::ffi::c_int;
+use std::sync::{LazyLock, Mutex};
 
-pub const ECGPU_K256: c_int = 0;
-pub const ECGPU_P256: c_int = 1;
-pub const ECGPU_P384: c_int = 2;
-pub const ECGPU_SM2: c_int = 3;
-pub const ECGPU_P224: c_int = 4;
-pub const ECGPU_P192: c_int = 5;
-pub const ECGPU_P521: c_int = 6;
-pub const ECGPU_BP256: c_int = 7;
-pub const ECGPU_BP384: c_int = 8;
-pub const ECGPU_BP256T1: c_int = 9;
-pub const ECGPU_BP384T1: c_int = 10;
+use elliptic_curve::{
+    point::AffineCoordinates,
+    sec1::{FromSec1Point, ModulusSize, Sec1Point},
+    CurveArithmetic, FieldBytes, PrimeField,
+};
+use sys::*;
 
-pub const ECGPU_OK: c_int = 0;
-pub const ECGPU_ERR_SCALAR_RANGE: c_int = -2;
-pub const ECGPU_ERR_POINT: c_int = -3;
-pub const ECGPU_ERR_NO_DEVICE: c_int = -4;
-
-#[link(name = "ecgpu")]
-unsafe extern "C" {
-    pub fn ecgpu_init(ctx: *mut *mut EcgpuCtx, device: c_int) -> c_int;
-    pub fn ecgpu_destroy(ctx: *mut EcgpuCtx);
-    pub fn ecgpu_last_error(ctx: *const EcgpuCtx) -> *const c_char;
-    pub fn ecgpu_field_bytes(curve: c_int) -> usize;
-    pub fn ecgpu_set_stream(ctx: *mut EcgpuCtx, stream: *mut c_void) -> c_int;
-    pub fn ecgpu_host_alloc(ctx: *mut EcgpuCtx, bytes: usize) -> *mut c_void;
-    pub fn ecgpu_host_free(ctx: *mut EcgpuCtx, p: *mut c_void);
-    pub fn ecgpu_set_base_window(ctx: *mut EcgpuCtx, curve: c_int, window_bits: c_int) -> c_int;
-    pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
-    pub fn ecgpu_batch_mul_base(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, n: usize,
-                                out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    pub fn ecgpu_batch_mul_base_compressed(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, n: usize,
-                                           out_x: *mut u8, out_tag: *mut u8) -> c_int;
-    pub fn ecgpu_batch_mul_base_compressed_dev(ctx: *mut EcgpuCtx, curve: c_int, d_scalars: *const c_void, n: usize,
-                                               d_out_x: *mut c_void, d_out_tag: *mut c_void) -> c_int;
-    pub fn ecgpu_batch_mul(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8,
-                           points_inf: *const u8, n: usize, out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    pub fn ecgpu_msm(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8,
-                     points_inf: *const u8, n: usize, out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    pub fn ecgpu_batch_mul_base_and_mul_add(ctx: *mut EcgpuCtx, curve: c_int, a: *const u8, b: *const u8,
-                                            points_xy: *const u8, points_inf: *const u8, n: usize,
-                                            out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    pub fn ecgpu_batch_normalize(ctx: *mut EcgpuCtx, curve: c_int, points_xyz: *const u8, n: usize,
-                                 out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    pub fn ecgpu_point_sum(ctx: *mut EcgpuCtx, curve: c_int, points_xy: *const u8, points_inf: *const u8,
-                           n: usize, out_xy: *mut u8, out_inf: *mut u8) -> c_int;
-    /// Batch form of `ecdsa::hazmat::verify_prehashed`; `reject_high_s` = `C::NORMALIZE_S`.
-    pub fn ecgpu_ecdsa_verify_batch(ctx: *mut EcgpuCtx, curve: c_int, z: *const u8, r: *const u8, s: *const u8,
-                                    q_xy: *const u8, n: usize, reject_high_s: c_int, ok: *mut u8) -> c_int;
-    /// Batch form of `schnorr::VerifyingKey::verify_raw` (k256); `e` is the BIP340 challenge hash.
-    pub fn ecgpu_schnorr_verify_batch(ctx: *mut EcgpuCtx, e: *const u8, r: *const u8, s: *const u8, p_xy: *const u8,
-                                      n: usize, ok: *mut u8) -> c_int;
-    /// `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` for a batch of equally long messages.
-    pub fn ecgpu_schnorr_verify_raw_batch(ctx: *mut EcgpuCtx, pk_x: *const u8, msgs: *const u8, msg_len: usize,
-                                          sigs: *const u8, n: usize, ok: *mut u8) -> c_int;
-    /// Batch form of `elliptic_curve::ecdh::diffie_hellman`: x-coordinates of k_i * P_i.
-    pub fn ecgpu_batch_ecdh(ctx: *mut EcgpuCtx, curve: c_int, scalars: *const u8, points_xy: *const u8, n: usize,
-                            out_x: *mut u8, ok: *mut u8) -> c_int;
-    /// Batch form of `DecompressPoint::decompress(x_bytes, y_is_odd)`.
-    pub fn ecgpu_batch_decompress(ctx: *mut EcgpuCtx, curve: c_int, xs: *const u8, y_is_odd: *const u8, n: usize,
-                                  out_xy: *mut u8, ok: *mut u8) -> c_int;
-}
-
-/// Process-wide context: the analogue of `static BASEPOINT_TABLE: LazyLock<..>`
-/// (k256/src/arithmetic/tables.rs:18).
+/// One GPU: the analogue of `static BASEPOINT_TABLE: LazyLock<..>` (k256/src/arithmetic/tables.rs:18,
+/// primeorder/src/tables/basepoint.rs:29-31) — created on first use, holds the device-resident comb tables.
 pub struct Engine(*mut EcgpuCtx);
 unsafe impl Send for Engine {}
-unsafe impl Sync for Engine {}
 
-pub static ENGINE: std::sync::LazyLock<std::sync::Mutex<Engine>> = std::sync::LazyLock::new(|| {
+pub static ENGINE: LazyLock<Option<Mutex<Engine>>> = LazyLock::new(|| {
     let mut ctx = core::ptr::null_mut();
-    let rc = unsafe { ecgpu_init(&mut ctx, 0) };
-    assert_eq!(rc, ECGPU_OK, "no gfx950 device: the GPU backend has no CPU fallback");
-    std::sync::Mutex::new(Engine(ctx))
+    // no gfx950 device -> None: every adapter below then reports "not handled" and the CPU code runs
+    (unsafe { ecgpu_init(&mut ctx, 0) } == ECGPU_OK).then(|| Mutex::new(Engine(ctx)))
 });
 
-// ---- p256: a `MulBackend` that a curve crate selects via `PrimeCurveParams::Backend` ----------------
-// (primeorder/src/lib.rs:62; compare p256/src/arithmetic/tables.rs:24-44)
-pub mod p256_backend {
-    use super::*;
-    use elliptic_curve::{
-        ops::LinearCombination,
-        point::AffineCoordinates,
-        sec1::{FromSec1Point, ToSec1Point},
-        PrimeField,
-    };
-    use p256::{AffinePoint, NistP256, ProjectivePoint, Scalar};
-    use primeorder::MulBackend;
+/// All GPUs of the node: used for MSMs of `NODE_MIN_TERMS` terms and more.
+pub struct Node(*mut EcgpuGroup);
+unsafe impl Send for Node {}
 
-    fn to_wire(p: &ProjectivePoint) -> ([u8; 64], u8) {
-        let a = p.to_affine();
-        let mut xy = [0u8; 64];
-        if bool::from(a.is_identity()) {
-            return (xy, 1);
-        }
-        xy[..32].copy_from_slice(&a.x());
-        xy[32..].copy_from_slice(&a.y());
-        (xy, 0)
-    }
+pub static NODE: LazyLock<Option<Mutex<Node>>> = LazyLock::new(|| {
+    let ndev = std::env::var("ECGPU_DEVICES").ok().and_then(|v| v.parse::<usize>().ok()).unwrap_or(8);
+    let devices: Vec<c_int> = (0..ndev as c_int).collect();
+    let mut g = core::ptr::null_mut();
+    (unsafe { ecgpu_group_init(&mut g, devices.as_ptr(), devices.len() as c_int) } == ECGPU_OK).then(|| Mutex::new(Node(g)))
+});
 
-    fn from_wire(xy: &[u8], inf: u8) -> ProjectivePoint {
-        if inf != 0 {
-            return ProjectivePoint::IDENTITY;
-        }
-        let x = p256::FieldBytes::try_from(&xy[..32]).unwrap();
-        let y = p256::FieldBytes::try_from(&xy[32..64]).unwrap();
-        ProjectivePoint::from(AffinePoint::from_coordinates(&x, &y).unwrap())
-    }
+/// Below this many terms a sum stays on the CPU (a launch costs ~1 ms end to end).
+pub const GPU_MIN_TERMS: usize = 1 << 10;
+/// From this many terms on an MSM is spread over all GPUs of the node.
+pub const NODE_MIN_TERMS: usize = 1 << 22;
 
-    /// New API: `k[i] * G` for a whole slice on the GPU.
-    pub fn batch_mul_by_generator(ks: &[Scalar]) -> Vec<ProjectivePoint> {
-        let scalars: Vec<u8> = ks.iter().flat_map(|k| k.to_repr()).collect();
-        let mut xy = vec![0u8; ks.len() * 64];
-        let mut inf = vec![0u8; ks.len()];
-        let eng = ENGINE.lock().unwrap();
-        let rc = unsafe {
-            ecgpu_batch_mul_base(eng.0, ECGPU_P256, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr())
-        };
-        assert_eq!(rc, ECGPU_OK);
-        xy.chunks(64).zip(inf).map(|(c, f)| from_wire(c, f)).collect()
-    }
+/// What the adapters need to know about a curve of the reference.
+pub trait GpuCurve: CurveArithmetic
+where
+    Self::FieldBytesSize: ModulusSize,
+{
+    /// `ECGPU_K256` ... (include/ecgpu.h)
+    const ID: c_int;
+}
+impl GpuCurve for k256::Secp256k1 {
+    const ID: c_int = ECGPU_K256;
+}
+impl GpuCurve for p256::NistP256 {
+    const ID: c_int = ECGPU_P256;
+}
+impl GpuCurve for p384::NistP384 {
+    const ID: c_int = ECGPU_P384;
+}
+// p224 / p192 / p521 / sm2 / bp256 / bp384: the same one-liner with their ids.
 
-    /// New API: `k[i] * P[i]`.
-    pub fn batch_mul(terms: &[(ProjectivePoint, Scalar)]) -> Vec<ProjectivePoint> {
-        let n = terms.len();
-        let scalars: Vec<u8> = terms.iter().flat_map(|(_, k)| k.to_repr()).collect();
-        let (mut pts, mut pinf) = (Vec::with_capacity(n * 64), Vec::with_capacity(n));
-        for (p, _) in terms {
-            let (xy, f) = to_wire(p);
-            pts.extend_from_slice(&xy);
-            pinf.push(f);
-        }
-        let mut xy = vec![0u8; n * 64];
-        let mut inf = vec![0u8; n];
-        let eng = ENGINE.lock().unwrap();
-        let rc = unsafe {
-            ecgpu_batch_mul(eng.0, ECGPU_P256, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(),
-                            inf.as_mut_ptr())
-        };
-        assert_eq!(rc, ECGPU_OK);
-        xy.chunks(64).zip(inf).map(|(c, f)| from_wire(c, f)).collect()
-    }
+type Proj<C> = <C as CurveArithmetic>::ProjectivePoint;
+type Aff<C> = <C as CurveArithmetic>::AffinePoint;
+type Sc<C> = <C as CurveArithmetic>::Scalar;
 
-    /// `LinearCombination::lincomb` on the GPU (Pippenger instead of Straus; same group element).
-    pub fn lincomb(terms: &[(ProjectivePoint, Scalar)]) -> ProjectivePoint {
-        let n = terms.len();
-        let scalars: Vec<u8> = terms.iter().flat_map(|(_, k)| k.to_repr()).collect();
-        let (mut pts, mut pinf) = (Vec::with_capacity(n * 64), Vec::with_capacity(n));
-        for (p, _) in terms {
-            let (xy, f) = to_wire(p);
-            pts.extend_from_slice(&xy);
-            pinf.push(f);
-        }
-        let (mut xy, mut inf) = ([0u8; 64], 0u8);
-        let eng = ENGINE.lock().unwrap();
-        let rc = unsafe {
-            ecgpu_msm(eng.0, ECGPU_P256, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf)
-        };
-        assert_eq!(rc, ECGPU_OK);
-        from_wire(&xy, inf)
-    }
+fn field_len<C: GpuCurve>() -> usize
+where
+    C::FieldBytesSize: ModulusSize,
+{
+    unsafe { ecgpu_field_bytes(C::ID) }
+}
 
-    /// The `MulBackend` plug-in.  Single-element calls keep using the CPU tables (a GPU launch for one
-    /// scalar is pointless); callers with batches use the functions above.  Below `GPU_MIN_TERMS`
-    /// terms `lincomb` also stays on the CPU.
-    #[derive(Clone, Copy, Debug)]
-    pub struct GpuBackend;
-    pub const GPU_MIN_TERMS: usize = 1 << 10;
+/// Wire format of include/ecgpu.h: scalars = `Scalar::to_repr()`, points = affine x || y + identity flag.
+fn scalars_to_wire<C: GpuCurve>(ks: impl Iterator<Item = Sc<C>>) -> Vec<u8>
+where
+    C::FieldBytesSize: ModulusSize,
+{
+    ks.flat_map(|k| k.to_repr().as_ref().to_vec()).collect()
+}
 
-    impl MulBackend<NistP256> for GpuBackend {
-        fn mul_by_generator(k: &Scalar) -> ProjectivePoint {
-            <p256::arithmetic::tables::backend::PrecomputedTables as MulBackend<NistP256>>::mul_by_generator(k)
-        }
-        fn mul_by_generator_vartime(k: &Scalar) -> ProjectivePoint {
-            <p256::arithmetic::tables::backend::PrecomputedTables as MulBackend<NistP256>>::mul_by_generator_vartime(k)
-        }
-        fn mul_by_generator_and_mul_add_vartime(a: &Scalar, b: &Scalar, p: &ProjectivePoint) -> ProjectivePoint {
-            ProjectivePoint::lincomb_vartime(&[(ProjectivePoint::GENERATOR, *a), (*p, *b)])
-        }
-    }
-
-    /// Drop-in for `ProjectivePoint::lincomb(&[(P, k)])` that moves large sums to the GPU.
-    pub fn lincomb_auto(terms: &[(ProjectivePoint, Scalar)]) -> ProjectivePoint {
-        if terms.len() >= GPU_MIN_TERMS {
-            lincomb(terms)
+fn points_to_wire<C: GpuCurve>(ps: impl Iterator<Item = Proj<C>>) -> (Vec<u8>, Vec<u8>)
+where
+    C::FieldBytesSize: ModulusSize,
+    Aff<C>: AffineCoordinates<FieldRepr = FieldBytes<C>>,
+{
+    // to_affine per point (one inversion each on the CPU); a caller holding many projective points ships X || Y || Z
+    // to ecgpu_batch_normalize instead (BatchNormalize::batch_normalize, primeorder/src/projective.rs:452-478)
+    let l = field_len::<C>();
+    let (mut xy, mut inf) = (Vec::new(), Vec::new());
+    for p in ps {
+        let a: Aff<C> = p.into();
+        let ident = bool::from(elliptic_curve::group::Group::is_identity(&p));
+        if ident {
+            xy.extend(core::iter::repeat(0u8).take(2 * l));
         } else {
-            ProjectivePoint::lincomb(terms)
+            xy.extend_from_slice(a.x().as_ref());
+            xy.extend_from_slice(a.y().as_ref());
         }
+        inf.push(ident as u8);
+    }
+    (xy, inf)
+}
+
+fn point_from_wire<C: GpuCurve>(xy: &[u8], inf: u8) -> Proj<C>
+where
+    C::FieldBytesSize: ModulusSize,
+    Aff<C>: FromSec1Point<C>,
+{
+    if inf != 0 {
+        return <Proj<C> as elliptic_curve::group::Group>::identity();
+    }
+    let l = xy.len() / 2;
+    let x = FieldBytes::<C>::try_from(&xy[..l]).expect("field length");
+    let y = FieldBytes::<C>::try_from(&xy[l..]).expect("field length");
+    // the device only returns points of the curve: from_sec1_point cannot fail here
+    let a: Aff<C> = Option::from(Aff::<C>::from_sec1_point(&Sec1Point::<C>::from_affine_coordinates(&x, &y, false))).expect("on curve");
+    a.into()
+}
+
+/// The safe batch layer.  Every function returns `None` when there is no usable GPU (the caller then runs the
+/// reference's CPU code) and panics only on a contract violation (ECGPU_ERR_ARG).
+pub mod gpu {
+    use super::*;
+
+    fn check(rc: c_int) {
+        assert!(rc == ECGPU_OK, "libecgpu: error {rc}");
+    }
+
+    /// `k[i] * G` — batch form of `MulByGeneratorVartime::mul_by_generator_vartime`.
+    pub fn batch_mul_by_generator_vartime<C: GpuCurve>(ks: &[Sc<C>]) -> Option<Vec<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let l = field_len::<C>();
+        let scalars = scalars_to_wire::<C>(ks.iter().copied());
+        let (mut xy, mut inf) = (vec![0u8; ks.len() * 2 * l], vec![0u8; ks.len()]);
+        check(unsafe { ecgpu_batch_mul_base(eng.0, C::ID, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) });
+        Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
+    }
+
+    /// `k[i] * P[i]` — batch form of `MulVartime::mul_vartime` (primeorder/src/projective.rs:888-921).
+    pub fn batch_mul_vartime<C: GpuCurve>(terms: &[(Proj<C>, Sc<C>)]) -> Option<Vec<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (terms.len(), field_len::<C>());
+        let scalars = scalars_to_wire::<C>(terms.iter().map(|t| t.1));
+        let (pts, pinf) = points_to_wire::<C>(terms.iter().map(|t| t.0));
+        let (mut xy, mut inf) = (vec![0u8; n * 2 * l], vec![0u8; n]);
+        check(unsafe {
+            ecgpu_batch_mul(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr())
+        });
+        Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
+    }
+
+    /// `sum_i k[i] * P[i]` — `LinearCombination::lincomb_vartime` (Pippenger instead of Straus; same group element).
+    /// One GPU up to NODE_MIN_TERMS terms, all GPUs of the node beyond (ecgpu_group_msm: term shards, one exchange of
+    /// per-window partial sums over xGMI, one combining step).
+    pub fn lincomb_vartime<C: GpuCurve>(terms: &[(Proj<C>, Sc<C>)]) -> Option<Proj<C>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let (n, l) = (terms.len(), field_len::<C>());
+        let scalars = scalars_to_wire::<C>(terms.iter().map(|t| t.1));
+        let (pts, pinf) = points_to_wire::<C>(terms.iter().map(|t| t.0));
+        let (mut xy, mut inf) = (vec![0u8; 2 * l], 0u8);
+        if n >= NODE_MIN_TERMS {
+            if let Some(node) = NODE.as_ref().and_then(|m| m.lock().ok()) {
+                check(unsafe {
+                    ecgpu_group_msm(node.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf)
+                });
+                return Some(point_from_wire::<C>(&xy, inf));
+            }
+        }
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        check(unsafe { ecgpu_msm(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf) });
+        Some(point_from_wire::<C>(&xy, inf))
+    }
+
+    /// `a[i] * G + b[i] * P[i]` — batch form of `mul_by_generator_and_mul_add_vartime`
+    /// (primeorder/src/mul_backend.rs:29-40, k256/src/arithmetic/mul.rs:303-310).
+    pub fn batch_mul_by_generator_and_mul_add_vartime<C: GpuCurve>(abp: &[(Sc<C>, Sc<C>, Proj<C>)]) -> Option<Vec<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (abp.len(), field_len::<C>());
+        let a = scalars_to_wire::<C>(abp.iter().map(|t| t.0));
+        let b = scalars_to_wire::<C>(abp.iter().map(|t| t.1));
+        let (pts, pinf) = points_to_wire::<C>(abp.iter().map(|t| t.2));
+        let (mut xy, mut inf) = (vec![0u8; n * 2 * l], vec![0u8; n]);
+        check(unsafe {
+            ecgpu_batch_mul_base_and_mul_add(eng.0, C::ID, a.as_ptr(), b.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(),
+                                             inf.as_mut_ptr())
+        });
+        Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
+    }
+
+    /// Batch form of `ecdsa::hazmat::verify_prehashed` (ecdsa 0.17.0; p256/src/ecdsa.rs:69, k256/src/ecdsa.rs:99-106):
+    /// `z` = `bits2field(digest)`, `(r, s)` the signature scalars as bytes, `q` the verifying keys.  One verdict per
+    /// element; a bad element never fails the batch.  `normalize_s` = `C::NORMALIZE_S` (true for k256).
+    pub fn batch_verify_prehashed<C: GpuCurve>(z: &[FieldBytes<C>], r: &[FieldBytes<C>], s: &[FieldBytes<C>], q: &[Aff<C>],
+                                               normalize_s: bool) -> Option<Vec<bool>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let n = z.len();
+        assert!(r.len() == n && s.len() == n && q.len() == n);
+        let cat = |v: &[FieldBytes<C>]| v.iter().flat_map(|b| b.as_ref().to_vec()).collect::<Vec<u8>>();
+        let qxy: Vec<u8> = q.iter().flat_map(|p| [p.x().as_ref(), p.y().as_ref()].concat()).collect();
+        let mut ok = vec![0u8; n];
+        check(unsafe {
+            ecgpu_ecdsa_verify_batch(eng.0, C::ID, cat(z).as_ptr(), cat(r).as_ptr(), cat(s).as_ptr(), qxy.as_ptr(), n,
+                                     normalize_s as c_int, ok.as_mut_ptr())
+        });
+        Some(ok.into_iter().map(|b| b != 0).collect())
     }
 }
-// k256 does not go through MulBackend (inherent fns, k256/src/arithmetic/mul.rs:177-233); the same three
-// wrappers are written against k256::{ProjectivePoint, Scalar} with ECGPU_K256 and hooked at
-// `ProjectivePoint::mul_by_generator`, `Mul<Scalar>` (batch form) and `LinearCombination::lincomb`.
+
+// =====================================================================================================================
+// Patch sites in the reference (what `--features gpu` adds; `ecgpu` = this crate)
+// =====================================================================================================================
+//
+// (1) primeorder/src/projective.rs:498-510 — `impl<C> LinearCombination<[(Self, Scalar<C>)]> for ProjectivePoint<C>`,
+//     at the top of `fn lincomb_vartime` (p256, p384, p224, p521, sm2, bp256, bp384: every primeorder curve):
+//
+//         #[cfg(feature = "gpu")]
+//         if points_and_scalars.len() >= ecgpu::GPU_MIN_TERMS {
+//             if let Some(sum) = ecgpu::gpu::lincomb_vartime::<C>(points_and_scalars) {
+//                 return sum;
+//             }
+//         }
+//
+//     `fn lincomb` (:484-496, constant time) is left alone — see "SECRET SCALARS" above.
+//
+// (2) k256/src/arithmetic/mul.rs:100-108 — the same three lines at the top of k256's own
+//     `LinearCombination<[(ProjectivePoint, Scalar)]>::lincomb_vartime` (k256 does not use primeorder), with
+//     `ecgpu::gpu::lincomb_vartime::<Secp256k1>`; the array form at :75-82 forwards to the slice form above
+//     GPU_MIN_TERMS.
+//
+// (3) k256/src/arithmetic/mul.rs:205-232 (`mul_by_generator_vartime`) and :303-310
+//     (`mul_by_generator_and_mul_add_vartime`) are single-element calls: they stay on the CPU (a launch for one scalar
+//     is pointless).  Their batch forms are new inherent functions next to them:
+//
+//         #[cfg(feature = "gpu")]
+//         impl ProjectivePoint {
+//             /// `ks[i] * G` for a whole slice (GPU; variable time).
+//             pub fn batch_mul_by_generator_vartime(ks: &[Scalar]) -> Vec<ProjectivePoint> {
+//                 ecgpu::gpu::batch_mul_by_generator_vartime::<Secp256k1>(ks)
+//                     .unwrap_or_else(|| ks.iter().map(ProjectivePoint::mul_by_generator_vartime).collect())
+//             }
+//             /// `terms[i].1 * terms[i].0` for a whole slice (GPU; variable time).
+//             pub fn batch_mul_vartime(terms: &[(ProjectivePoint, Scalar)]) -> Vec<ProjectivePoint> {
+//                 ecgpu::gpu::batch_mul_vartime::<Secp256k1>(terms)
+//                     .unwrap_or_else(|| terms.iter().map(|(p, k)| p.mul_vartime(k)).collect())
+//             }
+//         }
+//
+//     and `k256/src/schnorr/verifying.rs:76-99` / `k256/src/ecdsa.rs` gain `verify_batch` functions built on
+//     `ecgpu::gpu::batch_verify_prehashed` resp. `ecgpu_schnorr_verify_raw_batch`.
+//
+// (4) primeorder curves select their generator-multiplication backend through `PrimeCurveParams::Backend`
+//     (primeorder/src/lib.rs:62; p256/src/arithmetic/tables.rs:24-44).  `GpuBackend` below is such a backend: single calls
+//     delegate to the curve's CPU tables, and it is the type the batch functions hang off for primeorder curves.
+
+/// `MulBackend` plug-in for the primeorder curves (primeorder/src/mul_backend.rs:11-40).
+#[derive(Clone, Copy, Debug)]
+pub struct GpuBackend<Cpu>(core::marker::PhantomData<Cpu>);
+
+impl<C, Cpu> primeorder::MulBackend<C> for GpuBackend<Cpu>
+where
+    C: primeorder::PrimeCurveParams + GpuCurve,
+    C::FieldBytesSize: ModulusSize,
+    Cpu: primeorder::MulBackend<C>,
+{
+    // one scalar: the CPU tables (constant time, as the trait promises)
+    fn mul_by_generator(k: &primeorder::Scalar<C>) -> primeorder::ProjectivePoint<C> {
+        Cpu::mul_by_generator(k)
+    }
+    fn mul_by_generator_vartime(k: &primeorder::Scalar<C>) -> primeorder::ProjectivePoint<C> {
+        Cpu::mul_by_generator_vartime(k)
+    }
+    fn mul_by_generator_and_mul_add_vartime(a: &primeorder::Scalar<C>, b: &primeorder::Scalar<C>,
+                                            p: &primeorder::ProjectivePoint<C>) -> primeorder::ProjectivePoint<C> {
+        Cpu::mul_by_generator_and_mul_add_vartime(a, b, p)
+    }
+}
+// p256/src/arithmetic/tables.rs:44 under `--features gpu`:
+//     pub type Backend = ecgpu::GpuBackend<backend::PrecomputedTables>;
+// and the batch functions for p256 callers:
+//     ecgpu::gpu::batch_mul_by_generator_vartime::<NistP256>(&ks), ecgpu::gpu::batch_mul_vartime::<NistP256>(&terms), ...

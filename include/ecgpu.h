@@ -29,6 +29,18 @@
  * itself is total (complete formulas).  There is NO CPU fallback: without a usable gfx950 device
  * ecgpu_init fails with ECGPU_ERR_NO_DEVICE.
  *
+ * Secret scalars: EVERY entry point of this library is VARIABLE-TIME in its scalars (zero digits are skipped; comb-table
+ * entries, per-point table entries and Pippenger buckets are addressed by scalar bits; the kernels' duration and memory
+ * access pattern depend on the scalar).  The library therefore stands behind the reference's `*_vartime` names —
+ * `MulVartime::mul_vartime` (primeorder/src/projective.rs:888-921), `LinearCombination::lincomb_vartime` (:498-510,
+ * k256/src/arithmetic/mul.rs:100-108), `MulByGeneratorVartime::{mul_by_generator_vartime,
+ * mul_by_generator_and_mul_add_vartime}` (:923-940, k256 mul.rs:205-232,296-310) — and is meant for PUBLIC scalars:
+ * signature verification, MSMs over public data, batch derivation of public values.  It is NOT a replacement for the
+ * constant-time `Mul` / `mul_by_generator` / `lincomb` (primeorder/src/projective.rs:532-557, tables/lookup.rs:43-65)
+ * when the scalar is a long-term secret and an attacker can observe the device (timing of a shared GPU, its memory
+ * traffic).  ecgpu_batch_mul_base* and ecgpu_batch_ecdh accept whatever scalars they are given: a caller that passes
+ * private keys there has decided that its threat model allows it; the results are the same group elements either way.
+ *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
  * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
  * (everything except ecgpu_point_sum and ecgpu_batch_normalize) run batches of 2^19 units and more as a

@@ -65,3 +65,44 @@ def test_product_does_not_touch_oracle():
                 assert "ecref" not in text and "oracle_lib" not in text and "liboracle" not in text, os.path.join(dirpath, f)
     out = os.popen("ldd %s" % os.path.join(pkg, "lib", "libecgpu.so")).read()
     assert "oracle" not in out
+
+
+def test_group_entry_refuses_without_gpu(ecgpu):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        ecgpu.Group([0, 1])
+    assert e.value.code == ecgpu.ERR_NO_DEVICE
+
+
+def test_rust_binding_matches_header():
+    """rustc is not in this image, so the reference-side binding is checked mechanically: every function include/ecgpu.h
+    declares appears in elliptic-curves_amd/rust/ecgpu_sys.rs with the same name, arity, argument types and return type
+    (C types mapped by tests/abi_parse.py), nothing else is declared there, and the enum constants agree.  The safe layer
+    (ecgpu_shim.rs) may only call functions that exist."""
+    import abi_parse
+    header = abi_parse.parse_header(os.path.join(ROOT, "include", "ecgpu.h"))
+    assert len(header) >= 50
+    rust = abi_parse.parse_rust_extern(os.path.join(ROOT, "elliptic-curves_amd", "rust", "ecgpu_sys.rs"))
+    assert sorted(rust) == sorted(d[0] for d in header)
+    for d in header:
+        name, ret, args = abi_parse.rust_signature(d)
+        assert rust[name] == (ret, args), "%s: header says %r, ecgpu_sys.rs says %r" % (name, (ret, args), rust[name])
+    sys_src = open(os.path.join(ROOT, "elliptic-curves_amd", "rust", "ecgpu_sys.rs")).read()
+    hdr_src = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "ecgpu.h")).read(), flags=re.S)
+    consts = dict((m.group(1), int(m.group(2))) for m in re.finditer(r"(ECGPU_\w+)\s*=\s*(-?\d+)", hdr_src))
+    assert len(consts) >= 19
+    for k, v in consts.items():
+        assert re.search(r"pub const %s: c_int = %d;" % (k, v), sys_src), k
+    shim = open(os.path.join(ROOT, "elliptic-curves_amd", "rust", "ecgpu_shim.rs")).read()
+    shim_code = re.sub(r"//[^\n]*", "", shim)
+    called = set(re.findall(r"\b(ecgpu_\w+)\s*\(", shim_code))
+    assert called and called <= set(rust), called - set(rust)
+    # and the generator reproduces the committed file (nobody edited it by hand)
+    import subprocess, sys as _sys, tempfile, shutil
+    with tempfile.TemporaryDirectory() as td:
+        keep = os.path.join(td, "ecgpu_sys.rs")
+        shutil.copy(os.path.join(ROOT, "elliptic-curves_amd", "rust", "ecgpu_sys.rs"), keep)
+        subprocess.check_call([_sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py")], stdout=subprocess.DEVNULL)
+        assert open(keep).read() == open(os.path.join(ROOT, "elliptic-curves_amd", "rust", "ecgpu_sys.rs")).read()
