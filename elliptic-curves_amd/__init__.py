@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "ecgpu_msm_parts_bytes", "ecgpu_msm_parts_dev", "ecgpu_msm_finish_dev",
     "ecgpu_group_init", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_ctx", "ecgpu_group_last_error",
     "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
-    "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul",
+    "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",
 ]
 
 
@@ -411,6 +411,27 @@ class Engine:
         r2 = np.zeros(n * 32, np.uint8)
         self._chk(self._lib.ecgpu_k256_glv_decompose(self._ctx, _hp(s), ctypes.c_size_t(n), _hp(r1), _hp(r2)))
         return r1, r2
+
+    # ---- device-side known-answer tests of the field / group arithmetic (ecgpu_selftest_*) ----
+    def selftest_field(self, curve, op, a, b=None):
+        L = _field_bytes(curve)
+        A, B = _host(a), _host(b)
+        n = A.size // L
+        _need("a", A, n * L); _need("b", B, n * L)
+        out = np.zeros(n * L, np.uint8)
+        self._chk(self._lib.ecgpu_selftest_field(self._ctx, curve, int(op), _hp(A), _hp(B), ctypes.c_size_t(n), _hp(out)))
+        return out
+
+    def selftest_point(self, curve, op, p_xy, p_inf=None, q_xy=None, q_inf=None):
+        L = _field_bytes(curve)
+        P, PI, Q, QI = _host(p_xy), _host(p_inf), _host(q_xy), _host(q_inf)
+        n = P.size // (2 * L)
+        _need("p_xy", P, n * 2 * L); _need("p_inf", PI, n); _need("q_xy", Q, n * 2 * L); _need("q_inf", QI, n)
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_selftest_point(self._ctx, curve, int(op), _hp(P), _hp(PI), _hp(Q), _hp(QI), ctypes.c_size_t(n),
+                                                 _hp(out), _hp(inf)))
+        return out, inf
 
     # ---- device-resident operations (torch uint8 CUDA tensors or raw device pointers) ----
     def mul_by_generator_dev(self, curve, d_scalars, n, d_out_xy, d_out_inf=None):

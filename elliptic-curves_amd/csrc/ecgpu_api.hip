@@ -1250,6 +1250,54 @@ int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, u
     return download(ctx, r2, ctx->in1, n * 32);
 }
 
+int ecgpu_selftest_field(ecgpu_ctx* ctx, int curve, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!a || !out)) return arg_error(ctx, __func__);
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, a, n * L)) != ECGPU_OK) return rc;
+    if (b && (rc = upload(ctx, ctx->in1, b, n * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    rc = dispatch(curve, [&](auto c) {
+        launch_selftest_field<decltype(c)>(ctx->stream, op, (const uint8_t*)ctx->in0.p, b ? (const uint8_t*)ctx->in1.p : nullptr, n,
+                                           (uint8_t*)ctx->out0.p, ctx->d_status);
+        return (int)ECGPU_OK;
+    });
+    if (rc != ECGPU_OK) return rc;
+    if ((rc = finish(ctx)) != ECGPU_OK) return rc;
+    return download(ctx, out, ctx->out0, n * L);
+}
+
+int ecgpu_selftest_point(ecgpu_ctx* ctx, int curve, int op, const uint8_t* p_xy, const uint8_t* p_inf, const uint8_t* q_xy,
+                         const uint8_t* q_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!p_xy || !out_xy || !out_inf)) return arg_error(ctx, __func__);
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, p_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (p_inf && (rc = upload(ctx, ctx->in2, p_inf, n)) != ECGPU_OK) return rc;
+    if (q_xy && (rc = upload(ctx, ctx->in1, q_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (q_inf && (rc = upload(ctx, ctx->in3, q_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    rc = dispatch(curve, [&](auto c) {
+        launch_selftest_point<decltype(c)>(ctx->stream, op, (const uint8_t*)ctx->in0.p, p_inf ? (const uint8_t*)ctx->in2.p : nullptr,
+                                           q_xy ? (const uint8_t*)ctx->in1.p : nullptr, q_inf ? (const uint8_t*)ctx->in3.p : nullptr, n,
+                                           (uint8_t*)ctx->out0.p, (uint8_t*)ctx->out1.p, ctx->d_status);
+        return (int)ECGPU_OK;
+    });
+    if (rc != ECGPU_OK) return rc;
+    if ((rc = finish(ctx)) != ECGPU_OK) return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
+}
+
 int ecgpu_valu_probe(ecgpu_ctx* ctx, int which, double* ops_per_sec) {
     if (!check_ctx(ctx) || !ops_per_sec) return ECGPU_ERR_ARG;
     int rc;

@@ -4,6 +4,7 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_ecdsa.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_selftest.h"
 
 namespace ecgpu {
 
@@ -100,6 +101,16 @@ template <> void launch_decompress<CurveT>(hipStream_t s, const uint8_t* xs, con
 template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                              const uint8_t* valid, size_t n, uint8_t* ok) {
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
+}
+
+template <> void launch_selftest_field<CurveT>(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out,
+                                               int* status) {
+    hipLaunchKernelGGL(k_selftest_field<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, op, a, b, n, out, status);
+}
+template <> void launch_selftest_point<CurveT>(hipStream_t s, int op, const uint8_t* pxy, const uint8_t* pinf, const uint8_t* qxy,
+                                               const uint8_t* qinf, size_t n, uint8_t* out_xy, uint8_t* out_inf, int* status) {
+    hipLaunchKernelGGL(k_selftest_point<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, op, pxy, pinf, qxy, qinf, n, out_xy, out_inf,
+                       status);
 }
 
 }  // namespace ecgpu

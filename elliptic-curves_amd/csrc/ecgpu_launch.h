@@ -61,6 +61,10 @@ template <class C> void launch_decompress(hipStream_t s, const uint8_t* xs, cons
 template <class C> void launch_ecdsa_finish(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                             const uint8_t* valid, size_t n, uint8_t* ok);
 
+template <class C> void launch_selftest_field(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, int* status);
+template <class C> void launch_selftest_point(hipStream_t s, int op, const uint8_t* pxy, const uint8_t* pinf, const uint8_t* qxy,
+                                              const uint8_t* qinf, size_t n, uint8_t* out_xy, uint8_t* out_inf, int* status);
+
 // ---- group "var": variable-base kernel ----
 template <class C> size_t var_base_slots(size_t n);     // table slots (threads) the launch will use
 template <class C> size_t var_base_tab_words();         // 32-bit words of table scratch per slot

@@ -1,0 +1,120 @@
+// ecgpu_selftest.h — device-side known-answer kernels for the arithmetic every other kernel is built from.
+//
+// tests/hostcheck runs the same __host__ __device__ field / group code on the CPU (g++ build); these two kernels run it
+// as gfx950 code, one lane per element, so that the -m gpu tests can compare the DEVICE's field and point operations with
+// the oracle and the reference's own field vectors (k256/src/test_vectors/field.rs) directly, not only through
+// scalar-multiplication results.  Operation codes follow tests/hostcheck (field_op / point_op).
+#pragma once
+
+#include "ecgpu_kernels.h"
+
+namespace ecgpu {
+
+// field: 0 a + b, 1 a - b, 2 a * b, 3 a^2, 4 1/a (division steps; 0 -> 0), 5 -a, 7 2a, 8 pack/unpack of the lazy value
+// 2a + b, 9 the fused a*b - (a + b)*b, 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain of lazily reduced
+// operations at the magnitudes the point formulas use.  Inputs must be canonical (< p), else ST_BAD_POINT.
+template <class C>
+__global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
+                                                          uint8_t* __restrict__ out, int* status) {
+    using F = Field<C>;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t wa[N], wb[N], wr[N];
+    load_wire<C>(wa, a + i * WB);
+    if (b) load_wire<C>(wb, b + i * WB);
+    else {
+#pragma unroll
+        for (int t = 0; t < N; t++) wb[t] = 0;
+    }
+    if (mp_geq<N>(wa, C::P) || mp_geq<N>(wb, C::P)) atomicOr(status, ST_BAD_POINT);
+    typename F::M1 x = F::from_canonical(wa), y = F::from_canonical(wb);
+    switch (op) {
+    case 0: F::to_canonical(wr, F::add(x, y)); break;
+    case 1: F::to_canonical(wr, F::norm(F::sub(x, y))); break;
+    case 2: F::to_canonical(wr, F::mul(x, y)); break;
+    case 3: F::to_canonical(wr, F::sqr(x)); break;
+    case 4: F::to_canonical(wr, F::inv(x)); break;
+    case 5: F::to_canonical(wr, F::neg(x)); break;
+    case 7: F::to_canonical(wr, F::dbl(x)); break;
+    case 8: {
+        uint32_t w[N];
+        F::pack(w, F::norm(F::add(F::dbl(x), y)));
+        F::to_canonical(wr, F::unpack(w));
+        break;
+    }
+    case 9: F::to_canonical(wr, F::mul2(x, y, F::add(x, y), F::neg(y))); break;
+    case 10: F::to_canonical(wr, F::inv_fermat(x)); break;
+    case 11: {
+        bool root;
+        auto r = F::sqrt(x, &root);
+        F::to_canonical(wr, root ? r : F::zero());
+        break;
+    }
+    case 12: {
+#pragma unroll 1
+        for (int s = 0; s < 25; s++) {
+            auto t = F::mul(x, y);
+            auto u = F::norm(F::sub(F::add(t, x), F::dbl(y)));
+            auto v = F::norm(F::neg(F::add(t, F::dbl(F::dbl(y)))));
+            x = F::sqr(u);
+            y = F::mul(v, F::one());
+        }
+        F::to_canonical(wr, F::add(x, y));
+        break;
+    }
+    default:
+#pragma unroll
+        for (int t = 0; t < N; t++) wr[t] = 0;
+        atomicOr(status, ST_BAD_SCALAR);
+    }
+    store_wire<C>(out + i * WB, wr);
+}
+
+// point: 0 P + Q (complete), 1 P + Q (complete, mixed), 2 2P, 3 -P, 4 P - Q, 5 P - Q (mixed), and the incomplete
+// formulas of the ladders / the comb / the bucket sums on inputs inside their domain (P, Q finite, P != +-Q; the caller
+// sees the identity otherwise): 6 2P by the Jacobian doubling, 7 P + Q by the Jacobian mixed addition, 8 P + Q by the
+// XYZZ mixed addition, 9 P + Q by the XYZZ affine + affine addition.  Output: affine + identity flag (one inversion per lane).
+template <class C>
+__global__ void __launch_bounds__(BLOCK) k_selftest_point(int op, const uint8_t* __restrict__ pxy, const uint8_t* __restrict__ pinf,
+                                                          const uint8_t* __restrict__ qxy, const uint8_t* __restrict__ qinf, size_t n,
+                                                          uint8_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf, int* status) {
+    using G = Group<C>;
+    using F = Field<C>;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fe<C::NL> b = G::curve_b();
+    Affine<C> pa, qa;
+    const bool pf = load_affine<C>(&pa, pxy, pinf, i, b, status);
+    const bool needs_q = op == 0 || op == 1 || op == 4 || op == 5 || op >= 7;
+    const bool qf = needs_q && qxy ? load_affine<C>(&qa, qxy, qinf, i, b, status) : false;
+    Proj<C> p = pf ? G::from_affine(pa) : G::identity(), r = G::identity();
+    switch (op) {
+    case 0: r = G::add(p, qf ? G::from_affine(qa) : G::identity(), b); break;
+    case 1: r = qf ? G::add_mixed(p, qa, b) : p; break;
+    case 2: r = G::dbl(p, b); break;
+    case 3: r = G::neg(p); break;
+    case 4: r = G::add(p, qf ? G::from_affine(qa) : G::identity(), b, true); break;
+    case 5: r = qf ? G::add_mixed(p, qa, b, true) : p; break;
+    case 6: if (pf) r = G::jac_to_proj(G::jac_dbl(G::jac_from_affine(pa))); break;
+    case 7: if (pf && qf) r = G::jac_to_proj(G::jac_madd(G::jac_dbl(G::jac_from_affine(pa)), qa, false)); break;   // 2P + Q
+    case 8: if (pf && qf) r = G::xyzz_to_proj(G::xyzz_madd(G::xyzz_from_affine(pa, false), qa, false)); break;
+    case 9: if (pf && qf) r = G::xyzz_to_proj(G::xyzz_mmadd(pa, qa, false)); break;
+    default: atomicOr(status, ST_BAD_SCALAR);
+    }
+    if (G::is_identity(r)) {
+        zero_wire<C>(out_xy + i * (2 * WB), 2);
+        out_inf[i] = 1;
+    } else {
+        auto zi = F::inv(G::m(r.z));
+        uint32_t w[N];
+        F::to_canonical(w, F::mul(G::m(r.x), zi));
+        store_wire<C>(out_xy + i * (2 * WB), w);
+        F::to_canonical(w, F::mul(G::m(r.y), zi));
+        store_wire<C>(out_xy + i * (2 * WB) + WB, w);
+        out_inf[i] = 0;
+    }
+}
+
+}  // namespace ecgpu

@@ -345,6 +345,27 @@ unsafe extern "C" {
         d_out_xy: *mut c_void,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_selftest_field(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        op: c_int,
+        a: *const u8,
+        b: *const u8,
+        n: usize,
+        out: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_selftest_point(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        op: c_int,
+        p_xy: *const u8,
+        p_inf: *const u8,
+        q_xy: *const u8,
+        q_inf: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
     pub fn ecgpu_valu_probe(ctx: *mut EcgpuCtx, which: c_int, ops_per_sec: *mut f64) -> c_int;
     pub fn ecgpu_last_timing(ctx: *const EcgpuCtx, name: *const c_char, ms: *mut f64) -> c_int;
     pub fn ecgpu_version() -> *const c_char;

@@ -308,6 +308,21 @@ int ecgpu_batch_decompress(ecgpu_ctx *ctx, int curve, const uint8_t *xs, const u
 int ecgpu_batch_decompress_dev(ecgpu_ctx *ctx, int curve, const void *d_xs, const void *d_y_is_odd,
                                size_t n, void *d_out_xy, void *d_ok);
 
+/* Device-side known-answer tests of the arithmetic the kernels are built from — the same field / group code the CPU
+ * host checks run (tests/hostcheck), here as gfx950 code, one lane per element; host buffers.
+ * ecgpu_selftest_field: out[i] = op(a[i], b[i]) on canonical field elements (L bytes each; b may be NULL for unary ops).
+ *   op 0 a + b, 1 a - b, 2 a * b, 3 a^2, 4 1/a by division steps (0 for 0), 5 -a, 7 2a, 8 pack / unpack round trip of the
+ *   lazily reduced 2a + b, 9 the fused a*b - (a + b)*b, 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain at the
+ *   magnitudes the point formulas use.  The reference's counterparts: `FieldElement::{add, sub, mul, square, invert,
+ *   negate, double, sqrt}` (k256/src/arithmetic/field.rs, p256/src/arithmetic/field.rs, primefield/src/monty.rs).
+ * ecgpu_selftest_point: out[i] = op(P[i], Q[i]); op 0 P + Q (complete), 1 the same mixed, 2 2P, 3 -P, 4 P - Q, 5 the same
+ *   mixed, and the incomplete formulas inside their domain (P, Q finite, P != +-Q): 6 2P (Jacobian), 7 2P + Q (Jacobian
+ *   doubling + mixed addition), 8 P + Q (XYZZ mixed), 9 P + Q (XYZZ affine + affine).
+ * ECGPU_ERR_POINT: an input >= p / off the curve; ECGPU_ERR_SCALAR_RANGE: unknown op. */
+int ecgpu_selftest_field(ecgpu_ctx *ctx, int curve, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
+int ecgpu_selftest_point(ecgpu_ctx *ctx, int curve, int op, const uint8_t *p_xy, const uint8_t *p_inf, const uint8_t *q_xy,
+                         const uint8_t *q_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+
 /* Integer-VALU roof probe: runs a dependency-free v_mad_u64_u32 stream on every CU and returns
  * the measured 32x32->64 multiply-add rate in operations per second (SURVEY.md §8d "peak to
  * divide by").  `which` selects the instruction: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32,
