@@ -115,15 +115,28 @@ def device_dot_mod(torch, d_k, d_s, mod):
     return total % mod
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask, capped by the container's cgroup CPU quota (the GPU box shows
+    256 logical CPUs but grants 16: /sys/fs/cgroup/cpu.max = "1600000 100000")."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_wall=1.2):
     """Oracle ("port" of the reference's CPU algorithm) on the host cores: a single-thread pilot, then every core busy
     for about `target_wall` seconds (each thread works through a slice of the sample sized from the pilot rate)."""
     import oracle_lib
     oracle_lib.build()
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = host_cores()
     kind = wl["kind"]
 
     def run(lo, hi):

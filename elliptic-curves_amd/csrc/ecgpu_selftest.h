@@ -12,7 +12,8 @@ namespace ecgpu {
 
 // field: 0 a + b, 1 a - b, 2 a * b, 3 a^2, 4 1/a (division steps; 0 -> 0), 5 -a, 7 2a, 8 pack/unpack of the lazy value
 // 2a + b, 9 the fused a*b - (a + b)*b, 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain of lazily reduced
-// operations at the magnitudes the point formulas use.  Inputs must be canonical (< p), else ST_BAD_POINT.
+// operations at the magnitudes the point formulas use, 20 a through the wire -> words -> wire conversion only, 21 a through
+// the internal domain and back.  Inputs must be canonical (< p), else ST_BAD_POINT.
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                                                           uint8_t* __restrict__ out, int* status) {
@@ -63,6 +64,11 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
         F::to_canonical(wr, F::add(x, y));
         break;
     }
+    case 20:                                   // wire round trip: bytes -> words -> bytes
+#pragma unroll
+        for (int t = 0; t < N; t++) wr[t] = wa[t];
+        break;
+    case 21: F::to_canonical(wr, x); break;    // internal-domain round trip
     default:
 #pragma unroll
         for (int t = 0; t < N; t++) wr[t] = 0;
