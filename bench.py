@@ -26,8 +26,11 @@ v_mad_u64_u32, the 32x32+64 multiply-add, among them — issues in 4 cycles and 
 (ecgpu_valu_probe: 1024 SIMDs x 16 lanes per cycle); `achieved` is the EXECUTED work of the kernel in the same unit:
 VALU wave-instructions per launch (rocprofv3 SQ_INSTS_VALU, committed under profiles/, constant for the seeded default
 workload) x their mean issue cost in v_mad_u64_u32 slots (static ISA histogram of the kernel) x 64 lanes / the kernel's
-average duration measured live with HIP events on the launch stream.  frac = achieved / peak <= 1 is the utilisation of
-the VALU issue roof; `mad_frac` is the share of it spent on multiply-adds proper.  The reference algorithm's IMAD32
+average duration measured live with HIP events on the launch stream.  frac = achieved / peak is the utilisation of
+the VALU issue roof; `mad_frac` is the share of it spent on multiply-adds proper.  The shader clock floats with the load
+(the probe, every lane multiplying, runs at ~2.1 GHz; the real kernels up to 2.35), so two more views are printed:
+`frac_vs_nominal_2p4ghz` (the same numerator over 256 CUs x 64 lanes/4 cycles x 2.4 GHz) and `frac_cycles_pmc`
+(executed issue cycles / GRBM_GUI_ACTIVE cycles of the committed PMC pass: no clock in it).  The reference algorithm's IMAD32
 count of SURVEY.md §8d divided by the same time and peak is reported separately as `algorithmic_speedup` (it exceeds 1
 when the GPU algorithm does less arithmetic per unit than the reference's).  The HBM view is under "hbm".
 `cpu_baseline` times the oracle (a C restatement of the reference's own CPU algorithm, kind "port") on the host cores.
@@ -71,6 +74,7 @@ WORKLOADS = {
 }
 SEEDS = {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8}
 DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384"]      # BASELINE configs[2], [3], [4] beside the top-level configs[1]
+NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 ROOFLINE_CONSTS = os.path.join(ROOT, "profiles", "roofline_consts.json")
 
@@ -358,13 +362,18 @@ class Bench:
         peak = self.valu_peak()
         ksec = kernel_ms * 1e-3 if kernel_ms else None
         rc = roofline_consts(wl["kernel"])
-        achieved = mad = traffic = None
+        achieved = mad = traffic = frac_cycles = clock_kernel = None
         basis = "no committed PMC constants for this kernel"
         if rc and ksec:
             scale = n / rc["units_per_launch"]
             insts = rc["insts_valu"] * scale
             achieved = insts * rc["slots_per_inst"] * 64 / ksec
             mad = insts * rc["mad_share"] * 64 / ksec
+            if rc.get("gui_cycles"):
+                # clock-independent view: issue cycles executed / cycles the 1024 SIMDs had under the profiler
+                # (GRBM_GUI_ACTIVE sums the 8 XCDs), and the shader clock that cycle count implies for the live duration
+                frac_cycles = rc["insts_valu"] * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * 1024)
+                clock_kernel = rc["gui_cycles"] / 8 * scale / ksec / 1e9
             traffic = (rc["fetch_bytes"] + rc["write_bytes"]) * scale if rc.get("fetch_bytes") is not None else None
             basis = rc["source"] + ("" if scale == 1 and not args.window else " (scaled from %d units per launch)" % rc["units_per_launch"])
         hbm_gbps = wl["bytes_per_unit"] * n / ksec / 1e9 if ksec else None
@@ -378,6 +387,8 @@ class Bench:
                          "achieved": achieved / 1e12 if achieved else None, "peak": peak / 1e12, "unit": "TIMAD32-slots/s",
                          "frac": achieved / peak if achieved else None,
                          "mad_frac": mad / peak if mad else None,
+                         "frac_vs_nominal_2p4ghz": achieved / NOMINAL_PEAK if achieved else None,
+                         "frac_cycles_pmc": frac_cycles, "clock_ghz_kernel": clock_kernel, "clock_ghz_probe": peak / (1024 * 16) / 1e9,
                          "traffic": traffic, "traffic_unit": "bytes/launch", "basis": basis,
                          "algorithmic_imad32_per_unit": wl["imad_per_unit"], "units_per_launch": n,
                          "algorithmic_speedup": wl["imad_per_unit"] * n / ksec / peak if ksec else None,

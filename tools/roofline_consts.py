@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Builds profiles/roofline_consts.json — the executed-work constants bench.py prices its kernels with.
 
-    python tools/roofline_consts.py <pmc json> [<pmc json> ...]        (the pmc_<workload>.json files written by
-                                                                        `tools/gpu_run.sh <tag> pmc:<workload>`)
+    python tools/roofline_consts.py <dir>        (<dir>/pmc_<workload>.json as written by `tools/gpu_run.sh <tag>
+                                                  pmc:<workload>`; a kernel's counters are taken from its OWN workload's file —
+                                                  the same kernel also runs at other sizes in the setup of other workloads)
 
 For every headline kernel:
     insts_valu        VALU wave-instructions per launch                 (rocprofv3 --pmc SQ_INSTS_VALU)
@@ -57,17 +58,17 @@ def isa_histogram(group, curve, substr):
 
 
 def main():
-    pmc = {}
-    for path in sys.argv[1:]:
-        with open(path) as f:
-            for k, v in json.load(f).items():
-                pmc.setdefault(k, {}).update(v)
-                pmc[k]["_source"] = os.path.relpath(os.path.abspath(path), ROOT)
+    d = sys.argv[1]
     out = {}
     for name, (group, curve, substr, units, workload) in KERNELS.items():
-        rec = pmc.get(name)
+        path = os.path.join(d, "pmc_%s.json" % workload)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rec = json.load(f).get(name)
         if not rec or "SQ_INSTS_VALU" not in rec:
             continue
+        rec["_source"] = os.path.relpath(os.path.abspath(path), ROOT)
         h = isa_histogram(group, curve, substr)
         out[name] = {
             "workload": workload, "units_per_launch": units, "insts_valu": rec["SQ_INSTS_VALU"],
