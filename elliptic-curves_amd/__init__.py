@@ -27,9 +27,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libecgpu.so")
 
-K256, P256, P384, SM2, P224, P192, P521, BP256, BP384, BP256T1, BP384T1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521, "bp256": BP256, "bp384": BP384, "bp256t1": BP256T1, "bp384t1": BP384T1}
-FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24, P521: 66, BP256: 32, BP384: 48, BP256T1: 32, BP384T1: 48}
+K256, P256, P384, SM2, P224, P192, P521, BP256, BP384, BP256T1, BP384T1, BIGN256 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521, "bp256": BP256, "bp384": BP384, "bp256t1": BP256T1, "bp384t1": BP384T1, "bign256": BIGN256}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24, P521: 66, BP256: 32, BP384: 48, BP256T1: 32, BP384T1: 48, BIGN256: 32}
 
 OK = 0
 ERR_CURVE, ERR_SCALAR_RANGE, ERR_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_ARG = -1, -2, -3, -4, -5, -6, -7
@@ -66,6 +66,7 @@ GROUP_ORDERS = {   # k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73
     8: 0x8CB91E82A3386D280F5D6F7E50E641DF152F7109ED5456B31F166E6CAC0425A7CF3AB6AF6B7FC3103B883202E9046565,   # bp384/src/lib.rs:73
     9: 0xA9FB57DBA1EEA9BC3E660A909D838D718C397AA3B561A6F7901E0E82974856A7,   # bp256/src/t1.rs:36 (the r1 order)
     10: 0x8CB91E82A3386D280F5D6F7E50E641DF152F7109ED5456B31F166E6CAC0425A7CF3AB6AF6B7FC3103B883202E9046565,   # bp384/src/t1.rs (the r1 order)
+    11: 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFD95C8ED60DFB4DFC7E5ABF99263D6607,   # bignp256/src/lib.rs:74
 }
 
 

@@ -43,11 +43,11 @@ struct ecgpu_ctx {
     std::string err;
     int* d_status = nullptr;
     int* h_status = nullptr;
-    Table table[11];
+    Table table[12];
     // fixed-base comb width: every addition removed is worth 8 % and HBM keeps up with the gathers, so the tables are
     // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
     // p256 and sm2: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
-    int want_w[11] = {26, 24, 20, 24, 24, 24, 20, 24, 20, 24, 20};
+    int want_w[12] = {26, 24, 20, 24, 24, 24, 20, 24, 20, 24, 20, 24};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r;   // signature verification scratch
@@ -94,6 +94,7 @@ int dispatch(int curve, F&& f) {
     case ECGPU_BP384: return f(Bp384Params{});
     case ECGPU_BP256T1: return f(Bp256t1Params{});
     case ECGPU_BP384T1: return f(Bp384t1Params{});
+    case ECGPU_BIGN256: return f(Bign256Params{});
     default: return ECGPU_ERR_CURVE;
     }
 }
@@ -608,7 +609,7 @@ size_t ecgpu_field_bytes(int curve) {
     switch (curve) {
     case ECGPU_K256: case ECGPU_P256: return 32;
     case ECGPU_P384: case ECGPU_BP384: case ECGPU_BP384T1: return 48;
-    case ECGPU_SM2: case ECGPU_BP256: case ECGPU_BP256T1: return 32;
+    case ECGPU_SM2: case ECGPU_BP256: case ECGPU_BP256T1: case ECGPU_BIGN256: return 32;
     case ECGPU_P224: return 28;
     case ECGPU_P192: return 24;
     case ECGPU_P521: return 66;
@@ -727,7 +728,7 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 }
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
-    if (!ctx || curve < 0 || curve > 10) return ECGPU_ERR_CURVE;
+    if (!ctx || curve < 0 || curve > 11) return ECGPU_ERR_CURVE;
     if (window_bits < 4 || window_bits > 26) return arg_error(ctx, __func__);
     ctx->want_w[curve] = window_bits;
     return ECGPU_OK;
@@ -876,7 +877,8 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     if (n && (!d_z || !d_r || !d_s || !d_q_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_q_xy)))
         return arg_error(ctx, __func__);
-    if (curve == ECGPU_SM2) return ECGPU_ERR_CURVE;          // sm2 signatures are SM2DSA (sm2/src/dsa.rs), not ECDSA
+    if (curve == ECGPU_SM2 || curve == ECGPU_BIGN256)          // sm2 signatures are SM2DSA (sm2/src/dsa.rs), bign's its own scheme
+        return curve_error(ctx, __func__);                     // (bignp256/src/ecdsa.rs) — not ECDSA
     return dispatch(curve, [&](auto c) {
         return verify_dev<decltype(c)>(ctx, VERIFY_ECDSA, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok);
     });

@@ -75,7 +75,9 @@ __device__ __forceinline__ void store_be_vec(uint8_t* bytes, const uint32_t* wor
 template <class C>
 __device__ __forceinline__ void load_wire(uint32_t* words, const uint8_t* bytes) {
     constexpr int WB = WireBytes<C>::value, N = C::N;
-    if constexpr (WB == 4 * N) {
+    if constexpr (WireLe<C>::value) {                  // little-endian records (bignp256): the words as they lie
+        load_words_vec<N>(words, reinterpret_cast<const uint32_t*>(bytes));
+    } else if constexpr (WB == 4 * N) {
         load_be_vec<N>(words, bytes);
     } else {
 #pragma unroll
@@ -87,7 +89,9 @@ __device__ __forceinline__ void load_wire(uint32_t* words, const uint8_t* bytes)
 template <class C>
 __device__ __forceinline__ void store_wire(uint8_t* bytes, const uint32_t* words) {
     constexpr int WB = WireBytes<C>::value, N = C::N;
-    if constexpr (WB == 4 * N) {
+    if constexpr (WireLe<C>::value) {
+        store_words_vec<N>(reinterpret_cast<uint32_t*>(bytes), words);
+    } else if constexpr (WB == 4 * N) {
         store_be_vec<N>(bytes, words);
     } else {
 #pragma unroll

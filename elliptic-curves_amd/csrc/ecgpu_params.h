@@ -18,7 +18,7 @@
 
 namespace ecgpu {
 
-enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8, CURVE_BP256T1 = 9, CURVE_BP384T1 = 10 };
+enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8, CURVE_BP256T1 = 9, CURVE_BP384T1 = 10, CURVE_BIGN256 = 11 };
 
 // in-register field representations (ecgpu_field.h)
 enum Repr : int {
@@ -409,6 +409,34 @@ struct Bp384t1Params : Bp384Params {
     ECGPU_CONST uint32_t GY[12] = {0x9E582928u, 0x2675BF5Bu, 0x4DC2B291u, 0x46940858u, 0xA208CCFEu, 0x3B88F2B6u, 0x5B7A1FCAu, 0x747F9347u, 0x755AD336u, 0xA114AFD2u, 0x62D30651u, 0x25AB0569u};
 };
 
+// bign-curve256v1 (STB 34.101.45-2013; bignp256 in the reference): p = 2^256 - 189, a = -3 — which the reference runs on its
+// any-a formulas (bignp256/src/arithmetic.rs:39-40, EquationAIsGeneric), and so does this path with a = p - 3 —, generator
+// (0, y).  Its field elements and scalars travel LITTLE-endian (bignp256/src/lib.rs:102 FIELD_ENDIANNESS, arithmetic/field.rs:65,
+// arithmetic/scalar.rs:56): WIRE_LE makes every wire accessor read and write the words as they lie.
+struct Bign256Params {
+    ECGPU_CONST int ID = CURVE_BIGN256;
+    ECGPU_CONST int N = 8;
+    ECGPU_CONST int NL = 10;
+    ECGPU_CONST int REPR = REPR_U28_MONT;
+    using UC = consts::BIGN256U;
+    ECGPU_CONST bool A_IS_ZERO = false;
+    ECGPU_CONST bool A_GENERIC = true;
+    ECGPU_CONST bool MONTGOMERY = true;
+    ECGPU_CONST bool WIRE_LE = true;
+    // p = 2^256 - 189                              bignp256/src/arithmetic/field.rs:60-66
+    ECGPU_CONST uint32_t P[8] = {0xFFFFFF43u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // n                                            bignp256/src/lib.rs:74
+    ECGPU_CONST uint32_t ORDER[8] = {0x263D6607u, 0x7E5ABF99u, 0x0DFB4DFCu, 0xD95C8ED6u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    // group order in Montgomery form (R = 2^256): R^2 mod n and -n^-1 mod 2^32 (ecgpu_scalar.h)
+    ECGPU_CONST uint32_t ORDER_R2[8] = {0xDBFF9431u, 0xFA44AF61u, 0x08B44A10u, 0x1B5A5BC1u, 0xA269DBF8u, 0x4A6925C6u, 0xC149A55Bu, 0x05D4EDF1u};
+    ECGPU_CONST uint32_t ORDER_NINV32 = 0x0858D849u;
+    // curve b, canonical                           bignp256/src/arithmetic.rs:45-47 (little-endian hex there)
+    ECGPU_CONST uint32_t B[8] = {0xD69C03F1u, 0xB22E7D6Bu, 0x978B9253u, 0x4CF55069u, 0xE4D8FBBEu, 0xD2C13AABu, 0x15F3A8EDu, 0x77CE6C15u};
+    // generator (0, y), canonical                  bignp256/src/arithmetic.rs:48-53
+    ECGPU_CONST uint32_t GX[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ECGPU_CONST uint32_t GY[8] = {0x04516A93u, 0x1E29CF18u, 0xC408F652u, 0x78913966u, 0x51D6835Du, 0x5CE4C9A3u, 0xFB16D69Fu, 0x6BF7FC3Cu};
+};
+
 // Whether the curve's a is neither 0 nor -3 (the parameter set says A_GENERIC = true)
 template <class C, class = void>
 struct GenericA {
@@ -430,12 +458,27 @@ struct WireBytes<C, std::void_t<decltype(C::WIRE_BYTES)>> {
     static constexpr int value = C::WIRE_BYTES;
 };
 
-// one wire record (WireBytes<C> big-endian bytes) <-> N little-endian words, host or device, any alignment the word
-// accessors above accept for 4 N-byte records, byte by byte otherwise
+// Byte order of the wire records: big-endian (`to_repr` of every curve of the reference but one) unless the parameter set
+// says WIRE_LE (bignp256).
+template <class C, class = void>
+struct WireLe {
+    static constexpr bool value = false;
+};
+template <class C>
+struct WireLe<C, std::void_t<decltype(C::WIRE_LE)>> {
+    static constexpr bool value = C::WIRE_LE;
+};
+
+// one wire record (WireBytes<C> bytes, big-endian unless WireLe<C>) <-> N little-endian words, host or device, any alignment
+// the word accessors above accept for 4 N-byte records, byte by byte otherwise
 template <class C>
 ECGPU_HD void load_be_wire(uint32_t* words, const uint8_t* bytes) {
     constexpr int WB = WireBytes<C>::value, N = C::N;
-    if constexpr (WB == 4 * N) {
+    if constexpr (WireLe<C>::value) {
+        static_assert(WB == 4 * N, "little-endian wire records are whole words");
+        for (int i = 0; i < N; i++)
+            words[i] = (uint32_t)bytes[4 * i] | (uint32_t)bytes[4 * i + 1] << 8 | (uint32_t)bytes[4 * i + 2] << 16 | (uint32_t)bytes[4 * i + 3] << 24;
+    } else if constexpr (WB == 4 * N) {
         load_be<N>(words, bytes);
     } else {
         for (int i = 0; i < N; i++) words[i] = 0;
@@ -445,7 +488,10 @@ ECGPU_HD void load_be_wire(uint32_t* words, const uint8_t* bytes) {
 template <class C>
 ECGPU_HD void store_be_wire(uint8_t* bytes, const uint32_t* words) {
     constexpr int WB = WireBytes<C>::value, N = C::N;
-    if constexpr (WB == 4 * N) {
+    if constexpr (WireLe<C>::value) {
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < 4; j++) bytes[4 * i + j] = (uint8_t)(words[i] >> (8 * j));
+    } else if constexpr (WB == 4 * N) {
         store_be<N>(bytes, words);
     } else {
         for (int j = 0; j < WB; j++) bytes[j] = (uint8_t)(words[(WB - 1 - j) / 4] >> (8 * ((WB - 1 - j) % 4)));

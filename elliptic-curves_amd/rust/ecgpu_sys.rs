@@ -27,6 +27,7 @@ pub const ECGPU_BP256: c_int = 7;
 pub const ECGPU_BP384: c_int = 8;
 pub const ECGPU_BP256T1: c_int = 9;
 pub const ECGPU_BP384T1: c_int = 10;
+pub const ECGPU_BIGN256: c_int = 11;
 pub const ECGPU_OK: c_int = 0;
 pub const ECGPU_ERR_CURVE: c_int = -1;
 pub const ECGPU_ERR_SCALAR_RANGE: c_int = -2;

@@ -11,13 +11,16 @@
  * Wire format (identical for host- and device-pointer entry points)
  *   scalars   n * L bytes, big-endian, canonical (< group order n) — `Scalar::to_repr`
  *             (k256/src/arithmetic/scalar.rs:310-316, primefield/src/monty.rs:498-500);
- *             L = 32 (k256, p256, sm2, bp256 = brainpoolP256r1, bp256t1), 48 (p384, bp384 = brainpoolP384r1, bp384t1), 28 (p224), 24 (p192) or 66 (p521) = `FieldBytesSize`.  Records are packed without
+ *             L = 32 (k256, p256, sm2, bp256 = brainpoolP256r1, bp256t1, bign256), 48 (p384, bp384 = brainpoolP384r1, bp384t1), 28 (p224), 24 (p192) or 66 (p521) = `FieldBytesSize`.  Records are packed without
  *             padding (p224: 28-byte scalars, 56-byte points); only the base pointers of device buffers must be 16-byte aligned.
  *   points    n * 2L bytes, big-endian affine x || y — `AffinePoint::{x,y}`
  *             (primeorder/src/affine.rs:106-112) + optional n-byte identity flags
  *             (`AffinePoint::infinity`, k256/src/arithmetic/affine.rs:45-49); NULL flags = none.
  *             The identity is encoded as x = y = 0 with flag 1 on output.
  *   projective inputs (batch_normalize only): n * 3L bytes X || Y || Z, canonical big-endian.
+ *   ECGPU_BIGN256 (bign-curve256v1, `bignp256`) is the exception to "big-endian": its field elements and scalars travel
+ *             LITTLE-endian, as in the reference (`FIELD_ENDIANNESS = LittleEndian`, bignp256/src/lib.rs:102); everything
+ *             else about the records is the same.
  *
  * Ownership: the caller owns every buffer passed in; the library keeps no pointer after return.
  * Device memory, streams and the precomputed basepoint tables belong to the context
@@ -59,7 +62,7 @@ extern "C" {
 
 typedef struct ecgpu_ctx ecgpu_ctx;
 
-enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3, ECGPU_P224 = 4, ECGPU_P192 = 5, ECGPU_P521 = 6, ECGPU_BP256 = 7, ECGPU_BP384 = 8, ECGPU_BP256T1 = 9, ECGPU_BP384T1 = 10 };
+enum { ECGPU_K256 = 0, ECGPU_P256 = 1, ECGPU_P384 = 2, ECGPU_SM2 = 3, ECGPU_P224 = 4, ECGPU_P192 = 5, ECGPU_P521 = 6, ECGPU_BP256 = 7, ECGPU_BP384 = 8, ECGPU_BP256T1 = 9, ECGPU_BP384T1 = 10, ECGPU_BIGN256 = 11 };
 
 enum {
     ECGPU_OK = 0,

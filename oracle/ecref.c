@@ -19,11 +19,12 @@ __attribute__((constructor)) static void ecref_init_all(void) {
     ecref_bp384_init();
     ecref_bp256t1_init();
     ecref_bp384t1_init();
+    ecref_bign256_init();
 }
 
 size_t ecref_field_bytes(int curve) {
     switch (curve) {
-    case ECREF_K256: case ECREF_P256: case ECREF_SM2: case ECREF_BP256: case ECREF_BP256T1: return 32;
+    case ECREF_K256: case ECREF_P256: case ECREF_SM2: case ECREF_BP256: case ECREF_BP256T1: case ECREF_BIGN256: return 32;
     case ECREF_P224: return 28;
     case ECREF_P192: return 24;
     case ECREF_P521: return 66;
@@ -101,6 +102,27 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     return (int)cursor;
 }
 
+/* ---- little-endian wire format of bign-curve256v1 (bignp256/src/lib.rs:102, arithmetic/field.rs:65, arithmetic/scalar.rs:56) --
+ * The curve sections all work on big-endian records; for ECREF_BIGN256 every record (scalar, coordinate) is byte-reversed on
+ * the way in and on the way out.  The algorithms themselves read the scalar's integer value (to_be_repr / le_repr). */
+#define BIGN_L 32
+static uint8_t *bign_rev_dup(const uint8_t *src, size_t nrec) {
+    if (!src) return NULL;
+    uint8_t *d = (uint8_t *)ecref_xmalloc(nrec * BIGN_L + 1);
+    for (size_t r = 0; r < nrec; r++)
+        for (int j = 0; j < BIGN_L; j++) d[r * BIGN_L + j] = src[r * BIGN_L + BIGN_L - 1 - j];
+    return d;
+}
+static void bign_rev_inplace(uint8_t *buf, size_t nrec) {
+    if (!buf) return;
+    for (size_t r = 0; r < nrec; r++)
+        for (int j = 0; j < BIGN_L / 2; j++) {
+            uint8_t t = buf[r * BIGN_L + j];
+            buf[r * BIGN_L + j] = buf[r * BIGN_L + BIGN_L - 1 - j];
+            buf[r * BIGN_L + BIGN_L - 1 - j] = t;
+        }
+}
+
 #define DISPATCH(curve, fn, args)                     \
     switch (curve) {                                  \
     case ECREF_K256: return ecref_k256_##fn args;     \
@@ -114,42 +136,112 @@ int ecref_wnaf_form(const uint8_t *le_bytes, size_t nbytes, size_t bit_len, int 
     case ECREF_BP384: return ecref_bp384_##fn args;   \
     case ECREF_BP256T1: return ecref_bp256t1_##fn args;   \
     case ECREF_BP384T1: return ecref_bp384t1_##fn args;   \
+    case ECREF_BIGN256: return ecref_bign256_##fn args;   \
     default: return ECREF_ERR_CURVE;                  \
     }
 
 int ecref_batch_mul_base(int curve, const uint8_t *s, size_t n, uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *s2 = bign_rev_dup(s, n);
+        int rc = ecref_bign256_batch_mul_base(s2, n, o, oi);
+        bign_rev_inplace(o, 2 * n);
+        free(s2);
+        return rc;
+    }
     DISPATCH(curve, batch_mul_base, (s, n, o, oi))
 }
 int ecref_batch_mul(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
                     uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *s2 = bign_rev_dup(s, n), *p2 = bign_rev_dup(p, 2 * n);
+        int rc = ecref_bign256_batch_mul(s2, p2, pi, n, 0, o, oi);
+        bign_rev_inplace(o, 2 * n);
+        free(s2); free(p2);
+        return rc;
+    }
     DISPATCH(curve, batch_mul, (s, p, pi, n, 0, o, oi))
 }
 int ecref_batch_mul_vartime(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi,
                             size_t n, uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *s2 = bign_rev_dup(s, n), *p2 = bign_rev_dup(p, 2 * n);
+        int rc = ecref_bign256_batch_mul(s2, p2, pi, n, 1, o, oi);
+        bign_rev_inplace(o, 2 * n);
+        free(s2); free(p2);
+        return rc;
+    }
     DISPATCH(curve, batch_mul, (s, p, pi, n, 1, o, oi))
 }
 int ecref_msm(int curve, const uint8_t *s, const uint8_t *p, const uint8_t *pi, size_t n,
               size_t chunk, int vartime, uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *s2 = bign_rev_dup(s, n), *p2 = bign_rev_dup(p, 2 * n);
+        int rc = ecref_bign256_msm(s2, p2, pi, n, chunk, vartime, o, oi);
+        bign_rev_inplace(o, 2);
+        free(s2); free(p2);
+        return rc;
+    }
     DISPATCH(curve, msm, (s, p, pi, n, chunk, vartime, o, oi))
 }
 int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_t *b,
                                        const uint8_t *p, int pi, uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *a2 = bign_rev_dup(a, 1), *b2 = bign_rev_dup(b, 1), *p2 = bign_rev_dup(p, 2);
+        int rc = ecref_bign256_mul_base_and_mul_add_vartime(a2, b2, p2, pi, o, oi);
+        bign_rev_inplace(o, 2);
+        free(a2); free(b2); free(p2);
+        return rc;
+    }
     DISPATCH(curve, mul_base_and_mul_add_vartime, (a, b, p, pi, o, oi))
 }
 int ecref_batch_decompress(int curve, const uint8_t *xs, const uint8_t *odd, size_t n, uint8_t *o, uint8_t *ok) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *x2 = bign_rev_dup(xs, n);
+        int rc = ecref_bign256_batch_decompress(x2, odd, n, o, ok);
+        bign_rev_inplace(o, 2 * n);
+        free(x2);
+        return rc;
+    }
     DISPATCH(curve, batch_decompress, (xs, odd, n, o, ok))
 }
 int ecref_field_op(int curve, int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *a2 = bign_rev_dup(a, 1), *b2 = bign_rev_dup(b, 1);
+        int rc = ecref_bign256_field_op(op, a2, b2, out);
+        bign_rev_inplace(out, 1);
+        free(a2); free(b2);
+        return rc;
+    }
     DISPATCH(curve, field_op, (op, a, b, out))
 }
 int ecref_point_op(int curve, int op, const uint8_t *p, int pi, const uint8_t *q, int qi,
                    uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *p2 = bign_rev_dup(p, 2), *q2 = bign_rev_dup(q, 2);
+        int rc = ecref_bign256_point_op(op, p2, pi, q2, qi, o, oi);
+        bign_rev_inplace(o, 2);
+        free(p2); free(q2);
+        return rc;
+    }
     DISPATCH(curve, point_op, (op, p, pi, q, qi, o, oi))
 }
 int ecref_batch_normalize(int curve, const uint8_t *xyz, size_t n, uint8_t *o, uint8_t *oi) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *x2 = bign_rev_dup(xyz, 3 * n);
+        int rc = ecref_bign256_batch_normalize(x2, n, o, oi);
+        bign_rev_inplace(o, 2 * n);
+        free(x2);
+        return rc;
+    }
     DISPATCH(curve, batch_normalize, (xyz, n, o, oi))
 }
 int ecref_validate_points(int curve, const uint8_t *p, const uint8_t *pi, size_t n, size_t *bad) {
+    if (curve == ECREF_BIGN256) {
+        uint8_t *p2 = bign_rev_dup(p, 2 * n);
+        int rc = ecref_bign256_validate_points(p2, pi, n, bad);
+        free(p2);
+        return rc;
+    }
     DISPATCH(curve, validate_points, (p, pi, n, bad))
 }
 int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
@@ -165,6 +257,7 @@ int ecref_scalar_reduce(int curve, uint8_t *s, size_t n) {
     case ECREF_BP384: ecref_bp384_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_BP256T1: ecref_bp256t1_scalar_reduce(s, n); return ECREF_OK;
     case ECREF_BP384T1: ecref_bp384t1_scalar_reduce(s, n); return ECREF_OK;
+    case ECREF_BIGN256: bign_rev_inplace(s, n); ecref_bign256_scalar_reduce(s, n); bign_rev_inplace(s, n); return ECREF_OK;
     default: return ECREF_ERR_CURVE;
     }
 }

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-enum { ECREF_K256 = 0, ECREF_P256 = 1, ECREF_P384 = 2, ECREF_SM2 = 3, ECREF_P224 = 4, ECREF_P192 = 5, ECREF_P521 = 6, ECREF_BP256 = 7, ECREF_BP384 = 8, ECREF_BP256T1 = 9, ECREF_BP384T1 = 10 };
+enum { ECREF_K256 = 0, ECREF_P256 = 1, ECREF_P384 = 2, ECREF_SM2 = 3, ECREF_P224 = 4, ECREF_P192 = 5, ECREF_P521 = 6, ECREF_BP256 = 7, ECREF_BP384 = 8, ECREF_BP256T1 = 9, ECREF_BP384T1 = 10, ECREF_BIGN256 = 11 };
 
 enum {
     ECREF_OK = 0,

@@ -122,5 +122,6 @@ ECREF_DECL_CURVE(bp256)
 ECREF_DECL_CURVE(bp384)
 ECREF_DECL_CURVE(bp256t1)
 ECREF_DECL_CURVE(bp384t1)
+ECREF_DECL_CURVE(bign256)
 
 #endif

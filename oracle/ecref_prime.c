@@ -916,6 +916,125 @@ static int bp256_fe_sqrt(fe_bp256 *out, const fe_bp256 *a) {
 #include "ecref_prime.inc"
 
 /* ======================================================================================
+ * bign-curve256v1 (STB 34.101.45; `bignp256`): generic Montgomery field over p = 2^256 - 189 (bignp256/src/arithmetic/field.rs:
+ * 60-66 -> primefield::MontyFieldElement) and the curve with a = -3 run on the any-a formulas like the reference
+ * (bignp256/src/arithmetic.rs:39-40, EquationAIsGeneric).  This section works on big-endian records like every other one;
+ * the curve's LITTLE-endian wire format (bignp256/src/lib.rs:102) is applied at the ABI boundary in ecref.c, which is
+ * faithful because the reference's algorithms read `to_be_repr()` / `le_repr()` of the scalar, i.e. its integer value
+ * (primeorder/src/tables/radix16.rs:37-38, wnaf/src/lib.rs:197-202).  Pinned by bignp256/src/test_vectors/group.rs.
+ * ==================================================================================== */
+
+typedef struct { uint64_t w[4]; } fe_bign256;
+
+static const uint64_t BIGN256_P[4] = {                  /* bignp256/src/arithmetic/field.rs:60-66: 2^256 - 189 */
+    0xFFFFFFFFFFFFFF43ULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint64_t BIGN256_N[4] = {                  /* bignp256/src/lib.rs:74 */
+    0x7E5ABF99263D6607ULL, 0xD95C8ED60DFB4DFCULL, 0xFFFFFFFFFFFFFFFFULL, 0xFFFFFFFFFFFFFFFFULL};
+static const uint8_t BIGN256_A_BYTES[32] = {            /* bignp256/src/arithmetic.rs:42-44 (little-endian hex there): p - 3 */
+    0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff,
+    0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0x40};
+static const uint8_t BIGN256_B_BYTES[32] = {            /* bignp256/src/arithmetic.rs:45-47 */
+    0x77, 0xce, 0x6c, 0x15, 0x15, 0xf3, 0xa8, 0xed, 0xd2, 0xc1, 0x3a, 0xab, 0xe4, 0xd8, 0xfb, 0xbe,
+    0x4c, 0xf5, 0x50, 0x69, 0x97, 0x8b, 0x92, 0x53, 0xb2, 0x2e, 0x7d, 0x6b, 0xd6, 0x9c, 0x03, 0xf1};
+static const uint8_t BIGN256_GX[32] = {                 /* bignp256/src/arithmetic.rs:48-53: (0, y) */
+    0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00,
+    0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00};
+static const uint8_t BIGN256_GY[32] = {
+    0x6b, 0xf7, 0xfc, 0x3c, 0xfb, 0x16, 0xd6, 0x9f, 0x5c, 0xe4, 0xc9, 0xa3, 0x51, 0xd6, 0x83, 0x5d,
+    0x78, 0x91, 0x39, 0x66, 0xc4, 0x08, 0xf6, 0x52, 0x1e, 0x29, 0xcf, 0x18, 0x04, 0x51, 0x6a, 0x93};
+
+static fe_bign256 BIGN256_R, BIGN256_R2, BIGN256_B_MONT, BIGN256_A_MONT;
+static uint64_t BIGN256_MINV;
+static int bign256_ready;
+
+static fe_bign256 bign256_fe_mul(const fe_bign256 *a, const fe_bign256 *b) {       /* monty.rs:346-350 */
+    uint64_t t[8];
+    fe_bign256 r;
+    ecref_mp_mul(t, a->w, b->w, 4);
+    mont_reduce(r.w, t, BIGN256_P, BIGN256_MINV, 4);
+    return r;
+}
+static fe_bign256 bign256_fe_sqr(const fe_bign256 *a) { return bign256_fe_mul(a, a); }                /* monty.rs:361-363 */
+static fe_bign256 bign256_fe_add(const fe_bign256 *a, const fe_bign256 *b) { fe_bign256 r; mont_add(r.w, a->w, b->w, BIGN256_P, 4); return r; }   /* :316-320 */
+static fe_bign256 bign256_fe_sub(const fe_bign256 *a, const fe_bign256 *b) { fe_bign256 r; mont_sub(r.w, a->w, b->w, BIGN256_P, 4); return r; }   /* :331-335 */
+static fe_bign256 bign256_fe_zero(void) { fe_bign256 z; memset(&z, 0, sizeof z); return z; }
+static fe_bign256 bign256_fe_neg(const fe_bign256 *a) { fe_bign256 z = bign256_fe_zero(); return bign256_fe_sub(&z, a); }                         /* :353-357 */
+static fe_bign256 bign256_fe_dbl(const fe_bign256 *a) { return bign256_fe_add(a, a); }                                                     /* :323-327 */
+static int bign256_fe_is_zero(const fe_bign256 *a) { return ecref_mp_is_zero(a->w, 4); }
+
+static void bign256_init(void) {
+    if (bign256_ready) return;
+    BIGN256_MINV = mont_neg_inv64(BIGN256_P[0]);
+    mont_pow2_mod(BIGN256_R.w, BIGN256_P, 4, 256);
+    mont_pow2_mod(BIGN256_R2.w, BIGN256_P, 4, 512);
+    fe_bign256 b;
+    ecref_be_to_words(BIGN256_B_BYTES, 32, b.w);
+    BIGN256_B_MONT = bign256_fe_mul(&b, &BIGN256_R2);
+    ecref_be_to_words(BIGN256_A_BYTES, 32, b.w);
+    BIGN256_A_MONT = bign256_fe_mul(&b, &BIGN256_R2);
+    bign256_ready = 1;
+}
+static fe_bign256 bign256_fe_one(void) { bign256_init(); return BIGN256_R; }
+static fe_bign256 bign256_fe_b(void) { bign256_init(); return BIGN256_B_MONT; }
+static fe_bign256 bign256_fe_a(void) { bign256_init(); return BIGN256_A_MONT; }
+
+static int bign256_fe_from_bytes(fe_bign256 *r, const uint8_t *b) {      /* monty.rs:75-100 */
+    bign256_init();
+    fe_bign256 t;
+    ecref_be_to_words(b, 32, t.w);
+    if (ecref_mp_cmp(t.w, BIGN256_P, 4) >= 0) return 0;
+    *r = bign256_fe_mul(&t, &BIGN256_R2);
+    return 1;
+}
+static void bign256_fe_to_bytes(uint8_t *out, const fe_bign256 *a) {     /* monty.rs:249-274 (retrieve) */
+    uint64_t t[8];
+    fe_bign256 c;
+    memset(t, 0, sizeof t);
+    memcpy(t, a->w, 32);
+    mont_reduce(c.w, t, BIGN256_P, BIGN256_MINV, 4);
+    ecref_words_to_be(c.w, 4, out);
+}
+static int bign256_fe_invert(fe_bign256 *out, const fe_bign256 *a) {          /* monty.rs:373-375; a^(p-2) */
+    if (bign256_fe_is_zero(a)) return 0;
+    uint64_t e[4], two[4] = {2, 0, 0, 0};
+    ecref_mp_sub(e, BIGN256_P, two, 4);
+    fe_bign256 r = bign256_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bign256_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bign256_fe_mul(&r, a);
+    }
+    *out = r;
+    return 1;
+}
+
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored); p = 3 mod 4, so the
+ * root is a^((p+1)/4), computed by square-and-multiply, then the root check. */
+static int bign256_fe_sqrt(fe_bign256 *out, const fe_bign256 *a) {
+    uint64_t e[4], one[4] = {1, 0, 0, 0};
+    ecref_mp_add(e, BIGN256_P, one, 4);                         /* p + 1 < 2^256 */
+    for (int i = 0; i < 4; i++) e[i] = (e[i] >> 2) | (i + 1 < 4 ? e[i + 1] << 62 : 0);
+    fe_bign256 r = bign256_fe_one();
+    for (int i = 255; i >= 0; i--) {
+        r = bign256_fe_sqr(&r);
+        if ((e[i / 64] >> (i % 64)) & 1) r = bign256_fe_mul(&r, a);
+    }
+    fe_bign256 sq = bign256_fe_sqr(&r);
+    fe_bign256 d = bign256_fe_sub(&sq, a);
+    *out = r;
+    return bign256_fe_is_zero(&d);
+}
+
+#define PO_PFX bign256
+#define PO_NL 4
+#define PO_A_GENERIC 1
+#define PO_FE fe_bign256
+#define PO_F(name) bign256_fe_##name
+#define PO_ORDER BIGN256_N
+#define PO_GX BIGN256_GX
+#define PO_GY BIGN256_GY
+#include "ecref_prime.inc"
+
+/* ======================================================================================
  * brainpoolP384r1: generic Montgomery field on six words (bp384/src/arithmetic/field.rs:53-62) and the generic-a curve
  * (bp384/src/r1/arithmetic.rs:32-50, EquationAIsGeneric).  No group vectors in the reference: parity rests on the big-int
  * model and on OpenSSL's brainpoolP384r1.

@@ -6,7 +6,7 @@ Run in the build container (needs /root/reference); the GPU box only ever reads 
     python tests/golden/extract_golden.py [/root/reference]
 
 Sources:
-  {k256,p256,p384,p224,p192,p521}/src/test_vectors/group.rs   ADD_TEST_VECTORS (k*G for k = 1..20, affine x,y)
+  {k256,p256,p384,p224,p192,p521,bignp256}/src/test_vectors/group.rs   ADD_TEST_VECTORS (k*G for k = 1..20, affine x,y)
                                                MUL_TEST_VECTORS ((k, x, y) with k*G = (x, y))
   {k256,p256,p384,p224,p192,p521}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
   {k256,p256}/src/test_vectors/field.rs        DBL_TEST_VECTORS (repeated doubling of 1 mod p)
@@ -123,6 +123,13 @@ def main():
             f.write("\n")
         summary[curve] = (len(data["group"]["add"]), len(data["group"]["mul"]), len(data["ecdsa"]),
                           len(dbl) if dbl else 0)
+    # bignp256: group vectors only (its signatures are not ECDSA); the hex is the LITTLE-endian wire form (`to_repr`)
+    data = {"source": "RustCrypto/elliptic-curves bignp256/src/test_vectors/group.rs (little-endian records)",
+            "group": group_vectors("bignp256")}
+    with open(os.path.join(HERE, "bign256.json"), "w") as f:
+        json.dump(data, f, indent=1)
+        f.write("\n")
+    summary["bign256"] = (len(data["group"]["add"]), len(data["group"]["mul"]), 0, 0)
     for curve, (a, m, e, d) in summary.items():
         print("%s: %d add, %d mul, %d ecdsa, %d field-dbl vectors" % (curve, a, m, e, d))
 

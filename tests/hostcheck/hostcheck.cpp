@@ -491,7 +491,7 @@ int table_rule_check(int w, int j, uint32_t e, uint8_t* out_xy) {
 
 #define DISPATCH(curve, fn, args)                                                                                   \
     switch (curve) { case 0: return fn<K256Params> args; case 1: return fn<P256Params> args; case 2: return fn<P384Params> args; \
-                     case 3: return fn<Sm2Params> args; case 4: return fn<P224Params> args; case 5: return fn<P192Params> args; case 6: return fn<P521Params> args; case 7: return fn<Bp256Params> args; case 8: return fn<Bp384Params> args; case 9: return fn<Bp256t1Params> args; case 10: return fn<Bp384t1Params> args; default: return -1; }
+                     case 3: return fn<Sm2Params> args; case 4: return fn<P224Params> args; case 5: return fn<P192Params> args; case 6: return fn<P521Params> args; case 7: return fn<Bp256Params> args; case 8: return fn<Bp384Params> args; case 9: return fn<Bp256t1Params> args; case 10: return fn<Bp384t1Params> args; case 11: return fn<Bign256Params> args; default: return -1; }
 
 }  // namespace
 

@@ -42,7 +42,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(_u8p)
 
 
-L = {0: 32, 1: 32, 2: 48, 3: 32, 4: 28, 5: 24, 6: 66, 7: 32, 8: 48, 9: 32, 10: 48}
+L = {0: 32, 1: 32, 2: 48, 3: 32, 4: 28, 5: 24, 6: 66, 7: 32, 8: 48, 9: 32, 10: 48, 11: 32}
 
 
 def field_op(curve, op, a, b=None):

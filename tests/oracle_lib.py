@@ -9,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle_ecref.so")
 
-K256, P256, P384, SM2, P224, P192, P521, BP256, BP384, BP256T1, BP384T1 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521, "bp256": BP256, "bp384": BP384, "bp256t1": BP256T1, "bp384t1": BP384T1}
-FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24, P521: 66, BP256: 32, BP384: 48, BP256T1: 32, BP384T1: 48}
+K256, P256, P384, SM2, P224, P192, P521, BP256, BP384, BP256T1, BP384T1, BIGN256 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+CURVE_IDS = {"k256": K256, "p256": P256, "p384": P384, "sm2": SM2, "p224": P224, "p192": P192, "p521": P521, "bp256": BP256, "bp384": BP384, "bp256t1": BP256T1, "bp384t1": BP384T1, "bign256": BIGN256}
+FIELD_BYTES = {K256: 32, P256: 32, P384: 48, SM2: 32, P224: 28, P192: 24, P521: 66, BP256: 32, BP384: 48, BP256T1: 32, BP384T1: 48, BIGN256: 32}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _i8p = ctypes.POINTER(ctypes.c_int8)
