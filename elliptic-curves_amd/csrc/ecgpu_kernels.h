@@ -2,7 +2,7 @@
 //
 // Data layout in HBM
 //   scalars / points in, affine points out : the wire format of include/ecgpu.h (big-endian records of L
-//       resp. 2L bytes).  One lane owns one record; a wave touches 64 consecutive records = one contiguous
+//       resp. 2L bytes; little-endian for bign256).  One lane owns one record; a wave touches 64 consecutive records = one contiguous
 //       2 KiB / 4 KiB span, loaded and stored as 16-byte vectors and byte-swapped in registers.
 //   "raw" field element      NS = ceil(NL/4)*4 u32 (12 for k256 9x29 and p256 10x28, 16 for p384 15x27): the
 //       in-register limbs as they are (lazy form), padded so that records stay 16-byte vectors
@@ -10,8 +10,9 @@
 //   projective scratch       [n][3] raw elements
 //   basepoint table          [nwin][2^(W-1)][2] packed elements, affine: entry (j, e) = e * 2^(W j) * G
 //                            (64 B per entry for the 256-bit curves: 21.5 GB at k256's default W = 26)
-//   variable-base table      [wave][8][5 NL][64] u32 (ecgpu_var.h): multiples 1..8 of each lane's point in
-//                            Jacobian form + Z^2, Z^3; a wave's access to one limb is 256 contiguous bytes
+//   variable-base table      [wave][8][3 NL][64] u32 (ecgpu_var.h): multiples 1..8 of each lane's point in AFFINE form
+//                            (x, y; the third element holds the Z ratio while the table is built); a wave's access
+//                            to one limb is 256 contiguous bytes
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -48,7 +48,9 @@
  * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
  * (everything except ecgpu_point_sum and ecgpu_batch_normalize) run batches of 2^19 units and more as a
  * pipeline over chunks of 2^18 units (ecgpu_msm: from 2^23 terms, as partial MSMs over chunks of 2^22 terms): two helper threads, alive for the duration of the call, move the next chunk in and
- * the previous one out on their own streams.
+ * the previous one out on their own streams.  A pipelined call is not all-or-nothing: when a chunk fails validation
+ * (ECGPU_ERR_SCALAR_RANGE / ECGPU_ERR_POINT) the results of the chunks before it may already have been written to the
+ * caller's output buffers; below 2^19 units nothing is written on error.
  */
 #ifndef ECGPU_H
 #define ECGPU_H
