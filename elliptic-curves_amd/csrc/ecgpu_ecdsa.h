@@ -14,6 +14,7 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_scalar.h"
 #include "ecgpu_sha256.h"
+#include "ecgpu_verify.h"
 
 namespace ecgpu {
 
@@ -30,36 +31,13 @@ k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, co
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N];
+    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], u1[N], u2[N];
     load_wire<C>(zw, z + i * WB);
     load_wire<C>(rw, r + i * WB);
     load_wire<C>(sw, s + i * WB);
     load_wire<C>(cx, q_xy + i * (2 * WB));
     load_wire<C>(cy, q_xy + i * (2 * WB) + WB);
-    bool ok = !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
-    if (reject_high_s) ok = ok && !S::is_high(sw);
-    ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
-    {
-        Affine<C> a;
-        a.x = F::from_canonical(cx).e;                   // (values >= p wrap; ok is already false for them)
-        a.y = F::from_canonical(cy).e;
-        ok = ok && Group<C>::on_curve(a, Group<C>::curve_b());
-    }
-    uint32_t u1[N], u2[N];
-    {
-        uint32_t zr[N], w[N];
-        S::reduce_wire(zr, zw);
-        S::inv(w, sw);
-        S::mul(u1, zr, w);
-        S::mul(u2, rw, w);
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        u1[j] = ok ? u1[j] : 0u;
-        u2[j] = ok ? u2[j] : 0u;
-        cx[j] = ok ? cx[j] : C::GX[j];
-        cy[j] = ok ? cy[j] : C::GY[j];
-    }
+    const bool ok = ecdsa_prepare_words<C>(zw, rw, sw, cx, cy, reject_high_s, u1, u2);      // ecgpu_verify.h
     store_wire<C>(u1_out + i * WB, u1);
     store_wire<C>(u2_out + i * WB, u2);
     store_wire<C>(q_out + i * (2 * WB), cx);
@@ -77,13 +55,10 @@ k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_i
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t x[N], xr[N], rw[N];
+    uint32_t x[N], rw[N];
     load_wire<C>(x, r_xy + i * (2 * WB));
     load_wire<C>(rw, r + i * WB);
-    S::reduce_once(xr, x);                                // x < p < 2n
-    bool eq = true;
-#pragma unroll
-    for (int j = 0; j < N; j++) eq = eq && (xr[j] == rw[j]);
+    const bool eq = ecdsa_finish_words<C>(x, rw);
     ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
 }
 
@@ -109,30 +84,8 @@ k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, 
     load_wire<C>(sw, s + i * WB);
     load_wire<C>(cx, p_xy + i * (2 * WB));
     load_wire<C>(cy, p_xy + i * (2 * WB) + WB);
-    bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw);
-    ok = ok && !mp_geq<N>(cx, C::P) && !mp_geq<N>(cy, C::P);
-    {
-        Affine<C> a;
-        a.x = F::from_canonical(cx).e;
-        a.y = F::from_canonical(cy).e;
-        ok = ok && Group<C>::on_curve(a, Group<C>::curve_b());
-    }
-    uint32_t er[N], ne[N];
-    S::reduce_once(er, ew);
-    {   // -e mod n
-        uint32_t d[N];
-        bool z = S::is_zero(er);
-        mp_sub<N>(d, C::ORDER, er);
-#pragma unroll
-        for (int j = 0; j < N; j++) ne[j] = z ? 0u : d[j];
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        sw[j] = ok ? sw[j] : 0u;
-        ne[j] = ok ? ne[j] : 0u;
-        cx[j] = ok ? cx[j] : C::GX[j];
-        cy[j] = ok ? cy[j] : C::GY[j];
-    }
+    uint32_t ne[N];
+    const bool ok = schnorr_prepare_words<C>(ew, rw, sw, cx, cy, ne);                       // ecgpu_verify.h
     store_wire<C>(a_out + i * WB, sw);
     store_wire<C>(b_out + i * WB, ne);
     store_wire<C>(q_out + i * (2 * WB), cx);
@@ -160,38 +113,12 @@ k_schnorr_prepare_raw(const uint8_t* __restrict__ pk_x, const uint8_t* __restric
     load_be_vec<N>(cx, pk_x + i * 32);
     load_be_vec<N>(rw, sigs + i * 64);
     load_be_vec<N>(sw, sigs + i * 64 + 32);
-    bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw) && !mp_geq<N>(cx, C::P);
-    {   // lift_x: y = sqrt(x^3 + 7), the even root
-        auto x = F::from_canonical(cx);
-        auto alpha = F::norm(F::add(F::mul(F::sqr(x), x), G::m(G::curve_b())));
-        bool root;
-        auto beta = F::sqrt(alpha, &root);
-        ok = ok && root;
-        F::to_canonical(cy, beta);
-        if (cy[0] & 1u) {
-            uint32_t d[N];
-            mp_sub<N>(d, C::P, cy);
-#pragma unroll
-            for (int j = 0; j < N; j++) cy[j] = d[j];
-        }
-    }
-    uint32_t ew[N], er[N], ne[N];
+    bool ok = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw);
+    ok = schnorr_lift_x<C>(cx, cy) && ok;                                                   // ecgpu_verify.h
+    uint32_t ew[N], ne[N];
     Sha256::bip340_challenge(ew, sigs + i * 64, pk_x + i * 32, msgs + i * msg_len, msg_len);
-    S::reduce_once(er, ew);
-    {
-        uint32_t d[N];
-        bool z = S::is_zero(er);
-        mp_sub<N>(d, C::ORDER, er);
-#pragma unroll
-        for (int j = 0; j < N; j++) ne[j] = z ? 0u : d[j];
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        sw[j] = ok ? sw[j] : 0u;
-        ne[j] = ok ? ne[j] : 0u;
-        cx[j] = ok ? cx[j] : C::GX[j];
-        cy[j] = ok ? cy[j] : C::GY[j];
-    }
+    schnorr_neg_challenge<C>(ne, ew);
+    verify_blank<C>(ok, sw, ne, cx, cy);
     store_be_vec<N>(a_out + i * 32, sw);
     store_be_vec<N>(b_out + i * 32, ne);
     store_be_vec<N>(q_out + i * 64, cx);
@@ -212,10 +139,7 @@ k_schnorr_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r
     load_wire<C>(x, r_xy + i * (2 * WB));
     load_wire<C>(y, r_xy + i * (2 * WB) + WB);
     load_wire<C>(rw, r + i * WB);
-    bool eq = true;
-#pragma unroll
-    for (int j = 0; j < N; j++) eq = eq && (x[j] == rw[j]);
-    ok_out[i] = (valid[i] && !r_inf[i] && !(y[0] & 1u) && eq) ? 1 : 0;
+    ok_out[i] = (valid[i] && !r_inf[i] && schnorr_finish_words<C>(x, y, rw)) ? 1 : 0;
 }
 
 // ---- ECDH: x-coordinate of k*P -----------------------------------------------------------------------------------------
@@ -252,36 +176,7 @@ k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_od
     if (i >= n) return;
     uint32_t cx[N], cy[N];
     load_wire<C>(cx, xs + i * WB);
-    bool ok = !mp_geq<N>(cx, C::P);
-    auto x = F::from_canonical(cx);
-    auto x3 = F::mul(F::sqr(x), x);
-    typename F::M1 alpha;
-    if constexpr (C::A_IS_ZERO) {
-        alpha = F::norm(F::add(x3, G::m(G::curve_b())));
-    } else {
-        if constexpr (GenericA<C>::value) {
-            alpha = F::mul(F::norm(F::add(F::add(x3, F::mul(G::curve_a(), x)), G::m(G::curve_b()))), F::one());
-        } else {
-            auto x3x = F::add(F::dbl(x), x);
-            alpha = F::mul(F::add(F::norm(F::sub(x3, x3x)), G::m(G::curve_b())), F::one());   // back to magnitude (1, 1)
-        }
-    }
-    bool root;
-    auto beta = F::sqrt(alpha, &root);
-    ok = ok && root;
-    F::to_canonical(cy, beta);
-    if (((cy[0] & 1u) != 0) != (y_is_odd[i] != 0)) {            // the other root: p - beta (beta != 0 here, or parity
-        uint32_t d[N];                                          // 0 was asked for and beta = 0 stays)
-        bool z = mp_is_zero<N>(cy);
-        mp_sub<N>(d, C::P, cy);
-#pragma unroll
-        for (int j = 0; j < N; j++) cy[j] = z ? 0u : d[j];
-    }
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-        cx[j] = ok ? cx[j] : 0u;
-        cy[j] = ok ? cy[j] : 0u;
-    }
+    const bool ok = decompress_words<C>(cx, y_is_odd[i] != 0, cy);                          // ecgpu_verify.h
     store_wire<C>(out_xy + i * (2 * WB), cx);
     store_wire<C>(out_xy + i * (2 * WB) + WB, cy);
     ok_out[i] = ok ? 1 : 0;

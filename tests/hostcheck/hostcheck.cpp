@@ -14,6 +14,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_scalar.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_sha256.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_verify.h"
 
 using namespace ecgpu;
 
@@ -453,6 +454,91 @@ int msm_plain(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, c
     return msm<C, false>(c, chunk, scalars, pxy, pinf, n, out_xy, out_inf);
 }
 
+// ---- the verification / decompression kernels' per-element logic (ecgpu_verify.h) around the CPU mirrors of the
+// fixed-base and variable-base kernels: k_ecdsa_prepare -> k_fixed_base + k_var_base + k_proj_add_pairs -> k_normalize ->
+// k_ecdsa_finish, element by element
+template <class C>
+bool sum_affine_x(const BaseTable<C>& table, const uint32_t* a, const uint32_t* b, const uint32_t* cx, const uint32_t* cy,
+                  uint32_t* x, uint32_t* y) {
+    using F = Field<C>;
+    using G = Group<C>;
+    Affine<C> q;
+    q.x = F::from_canonical(cx).e;
+    q.y = F::from_canonical(cy).e;
+    Proj<C> r = G::add(fixed_base_one<C>(table, a), var_base_one<C>(q, b), G::curve_b());
+    if (F::is_zero(G::m(r.z))) return false;
+    auto zi = F::inv(G::m(r.z));
+    F::to_canonical(x, F::mul(G::m(r.x), zi));
+    F::to_canonical(y, F::mul(G::m(r.y), zi));
+    return true;
+}
+
+template <class C>
+int ecdsa_verify(const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* q, size_t n, int reject_high_s, uint8_t* ok_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    static BaseTable<C> table;
+    if (table.w != 8) build_table<C>(table, 8);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], u1[N], u2[N], x[N], y[N];
+        load_be_wire<C>(zw, z + i * WB);
+        load_be_wire<C>(rw, r + i * WB);
+        load_be_wire<C>(sw, s + i * WB);
+        load_be_wire<C>(cx, q + i * 2 * WB);
+        load_be_wire<C>(cy, q + i * 2 * WB + WB);
+        const bool valid = ecdsa_prepare_words<C>(zw, rw, sw, cx, cy, reject_high_s, u1, u2);
+        const bool finite = sum_affine_x<C>(table, u1, u2, cx, cy, x, y);
+        ok_out[i] = valid && finite && ecdsa_finish_words<C>(x, rw);
+    }
+    return 0;
+}
+
+// mode 0: challenge given (e, r, s, P); mode 1: from wire bytes (x-only key, message, 64-byte signature) — k256 only
+int schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
+                   size_t n, uint8_t* ok_out) {
+    using C = K256Params;
+    using S = ScalarN<C>;
+    constexpr int N = 8;
+    static BaseTable<C> table;
+    if (table.w != 8) build_table<C>(table, 8);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t ew[N], rw[N], sw[N], cx[N], cy[N], ne[N], x[N], y[N];
+        bool valid;
+        if (mode == 0) {
+            load_be<N>(ew, e_or_msgs + 32 * i);
+            load_be<N>(rw, r_or_sigs + 32 * i);
+            load_be<N>(sw, s + 32 * i);
+            load_be<N>(cx, p + 64 * i);
+            load_be<N>(cy, p + 64 * i + 32);
+            valid = schnorr_prepare_words<C>(ew, rw, sw, cx, cy, ne);
+        } else {
+            load_be<N>(cx, p + 32 * i);
+            load_be<N>(rw, r_or_sigs + 64 * i);
+            load_be<N>(sw, r_or_sigs + 64 * i + 32);
+            valid = !mp_geq<N>(rw, C::P) && !S::is_zero(sw) && S::in_range(sw);
+            valid = schnorr_lift_x<C>(cx, cy) && valid;
+            Sha256::bip340_challenge(ew, r_or_sigs + 64 * i, p + 32 * i, e_or_msgs + i * msg_len, msg_len);
+            schnorr_neg_challenge<C>(ne, ew);
+            verify_blank<C>(valid, sw, ne, cx, cy);
+        }
+        const bool finite = sum_affine_x<C>(table, sw, ne, cx, cy, x, y);
+        ok_out[i] = valid && finite && schnorr_finish_words<C>(x, y, rw);
+    }
+    return 0;
+}
+
+template <class C>
+int decompress(const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t cx[N], cy[N];
+        load_be_wire<C>(cx, xs + i * WB);
+        ok_out[i] = decompress_words<C>(cx, odd[i] != 0, cy);
+        store_be_wire<C>(out_xy + i * 2 * WB, cx);
+        store_be_wire<C>(out_xy + i * 2 * WB + WB, cy);
+    }
+    return 0;
+}
+
 // ScalarN<C>: op 0 a*b mod n, 1 1/a mod n, 2 a mod n (a < 2^(32N)), 3 is_high(a) -> out[last byte]
 template <class C>
 int scalar_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
@@ -531,6 +617,19 @@ int hc_msm(int curve, int c, size_t chunk, int glv, const uint8_t* s, const uint
            uint8_t* oi) {
     if (glv) return curve == 0 ? msm<K256Params, true>(c, chunk, s, p, pi, n, o, oi) : -1;
     DISPATCH(curve, msm_plain, (c, chunk, s, p, pi, n, o, oi))
+}
+int hc_ecdsa_verify(int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* q, size_t n, int reject_high_s,
+                    uint8_t* ok) {
+    if (curve == 3 || curve == 11) return -1;                    // sm2 / bign signatures are not ECDSA
+    DISPATCH(curve, ecdsa_verify, (z, r, s, q, n, reject_high_s, ok))
+}
+int hc_schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
+                      size_t n, uint8_t* ok) {
+    return schnorr_verify(mode, e_or_msgs, msg_len, r_or_sigs, s, p, n, ok);
+}
+int hc_decompress(int curve, const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok) {
+    if (curve == 4) return -1;                                   // p224: p = 1 mod 4
+    DISPATCH(curve, decompress, (xs, odd, n, out_xy, ok))
 }
 int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {
     DISPATCH(curve, table_rule_check, (w, j, e, out_xy))

@@ -16,7 +16,7 @@ _lib = None
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_verify.h", "ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", LIB, SRC])
@@ -120,6 +120,42 @@ def msm(curve, c, scalars, pxy, pinf=None, chunk=32, glv=None):
             raise AssertionError("plain and GLV Pippenger disagree: %r vs %r" % (res, cur))
         res = cur
     return res
+
+
+def ecdsa_verify(curve, z, r, s, q, reject_high_s=False):
+    Z, R, S, Q = _a(z), _a(r), _a(s), _a(q)
+    n = Z.size // L[curve]
+    ok = np.zeros(n, np.uint8)
+    rc = lib().hc_ecdsa_verify(curve, _p(Z), _p(R), _p(S), _p(Q), ctypes.c_size_t(n), int(bool(reject_high_s)), _p(ok))
+    assert rc == 0, rc
+    return ok
+
+
+def schnorr_verify(e, r, s, p_xy):
+    E, R, S, P = _a(e), _a(r), _a(s), _a(p_xy)
+    n = E.size // 32
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_schnorr_verify(0, _p(E), ctypes.c_size_t(0), _p(R), _p(S), _p(P), ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
+
+
+def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
+    PK, SG = _a(pk_x), _a(sigs)
+    M = _a(msgs) if msg_len else np.zeros(1, np.uint8)
+    n = PK.size // 32
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_schnorr_verify(1, _p(M), ctypes.c_size_t(msg_len), _p(SG), None, _p(PK), ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
+
+
+def decompress(curve, xs, y_is_odd):
+    X, O = _a(xs), _a(y_is_odd)
+    n = X.size // L[curve]
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    ok = np.zeros(n, np.uint8)
+    rc = lib().hc_decompress(curve, _p(X), _p(O), ctypes.c_size_t(n), _p(out), _p(ok))
+    assert rc == 0, rc
+    return out, ok
 
 
 def table_rule(curve, w, j, e):

@@ -1,6 +1,7 @@
 """CPU checks of the device arithmetic: the __host__ __device__ field / point / recoding code the HIP
 kernels run, compiled with g++ (tests/hostcheck) and compared with the oracle and the big-int model.
 These do not replace the -m gpu parity tests; they pin the arithmetic the kernels are built from."""
+import os
 import random
 
 import numpy as np
@@ -332,3 +333,67 @@ def test_pippenger_exceptional_additions(oracle, curve):
         for chunk in chunks:
             rc, out, inf = hc.msm(c.cid, cbits, scal, pxy, None, chunk=chunk)
             assert rc == 0 and out == bytes(want) and inf == winf, (cbits, chunk)
+
+
+# ---- the verification / decompression kernels' per-element logic (ecgpu_verify.h) on the CPU ------------------------------
+
+@pytest.mark.parametrize("curve", [c for c in CURVES if c != "sm2"])
+def test_ecdsa_verify_logic_on_cpu(oracle, curve):
+    """k_ecdsa_prepare / k_ecdsa_finish (`ecdsa_prepare_words`, `ecdsa_finish_words`) around the CPU mirrors of the
+    fixed-base and variable-base kernels: the reference's ECDSA vectors, the generated valid / invalid / out-of-range cases
+    and the high-S policy, verdict for verdict against the oracle."""
+    from gpu_common import ecdsa_cases, ecdsa_pack
+    c = pyec.CURVES[curve]
+    zz, rr, ss, qq, exp = ecdsa_pack(ecdsa_cases(c, 0xEC5B + c.cid, nvalid=5))
+    for high in (False, True):
+        got = hc.ecdsa_verify(c.cid, zz, rr, ss, qq, high)
+        assert bytes(got) == bytes(oracle.ecdsa_verify(c.cid, zz, rr, ss, qq, high))
+        if not high:
+            assert bytes(got) == bytes(exp)
+    path = os.path.join(os.path.dirname(__file__), "golden", curve + ".json")
+    if os.path.exists(path):
+        import json
+        vec = json.load(open(path))["ecdsa"][:4]
+        z, r, s = (b"".join(bytes.fromhex(v[k]) for v in vec) for k in ("m", "r", "s"))
+        q = b"".join(bytes.fromhex(v["q_x"]) + bytes.fromhex(v["q_y"]) for v in vec)
+        assert hc.ecdsa_verify(c.cid, z, r, s, q).all()
+
+
+def test_schnorr_verify_logic_on_cpu(oracle):
+    """k_schnorr_prepare / k_schnorr_prepare_raw / k_schnorr_finish on the CPU: the BIP340 vectors of k256/src/schnorr.rs with
+    the challenge given and from wire bytes (lift_x + tagged SHA-256 in the same code the device runs)."""
+    import json
+    from gpu_common import schnorr_inputs
+    c = pyec.CURVES["k256"]
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "k256.json")))["schnorr"]
+
+    def pubkey_of(sk):
+        out, _ = oracle.batch_mul_base(c.cid, sk)
+        return bytes(out[:32])
+
+    e, r, s, pxy, liftable, exp = schnorr_inputs(vec, lambda xs, odd: hc.decompress(c.cid, xs, odd), pubkey_of)
+    assert [v["index"] for v, l in zip(vec, liftable) if not l] == [5, 14]
+    pxy = pxy.reshape(-1, 64).copy()
+    pxy[liftable == 0] = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+    got = hc.schnorr_verify(e, r, s, pxy.reshape(-1)) & liftable
+    assert bytes(got) == bytes(exp)
+    assert bytes(hc.schnorr_verify(e, r, s, pxy.reshape(-1))) == bytes(oracle.schnorr_verify(e, r, s, pxy.reshape(-1)))
+    for v in vec:                                              # from wire bytes, one message length per call
+        pk = bytes.fromhex(v["public_key"]) if "public_key" in v else pubkey_of(bytes.fromhex(v["secret_key"]))
+        msg, sig = bytes.fromhex(v["message"]), bytes.fromhex(v["signature"])
+        got = hc.schnorr_verify_raw(pk, msg, len(msg), sig)
+        assert int(got[0]) == int(v["valid"]) == int(oracle.schnorr_verify_raw(pk, msg, len(msg), sig)[0]), v["index"]
+
+
+@pytest.mark.parametrize("curve", [c for c in CURVES if c != "p224"])
+def test_decompress_logic_on_cpu(oracle, curve):
+    """k_decompress (`decompress_words`) on the CPU against the oracle's DecompressPoint::decompress: both parities, x with
+    no point above it, x >= p."""
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xDEC0 + c.cid)
+    xs = [pyec.mul(c, rng.randrange(1, c.n), pyec.G(c))[0] for _ in range(6)] + [rng.randrange(c.p) for _ in range(10)] + [0, 1, c.p - 1]
+    xb = b"".join(x.to_bytes(c.L, "big") for x in xs) * 2 + c.p.to_bytes(c.L, "big")
+    odd = np.array([0] * len(xs) + [1] * len(xs) + [0], np.uint8)
+    got, gok = hc.decompress(c.cid, xb, odd)
+    want, wok = oracle.batch_decompress(c.cid, xb, odd)
+    assert bytes(got) == bytes(want) and bytes(gok) == bytes(wok) and gok[:6].all() and not gok[-1]
