@@ -56,7 +56,7 @@ struct Rccl {
 struct Member {
     int device = 0;
     ecgpu_ctx* ctx = nullptr;
-    hipStream_t stream = nullptr;      // exchange stream (RCCL)
+    hipStream_t stream = nullptr;      // exchange stream: the RCCL collective or the peer copy, then synchronised
     nccl_comm_t comm = nullptr;
     void* d_parts = nullptr;           // this GPU's parts record
     size_t parts_cap = 0;
@@ -136,6 +136,9 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
         g->m[r].device = devices[r];
         for (int q = 0; q < r; q++) distinct = distinct && devices[q] != devices[r];
         int rc = ecgpu_init(&g->m[r].ctx, devices[r]);
+        if (rc == ECGPU_OK && (hipSetDevice(devices[r]) != hipSuccess ||
+                               hipStreamCreateWithFlags(&g->m[r].stream, hipStreamNonBlocking) != hipSuccess))
+            rc = ECGPU_ERR_HIP;
         if (rc != ECGPU_OK) {
             ecgpu_group_destroy(g);
             return rc;
@@ -155,12 +158,7 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
         std::vector<nccl_comm_t> comms(ndev, nullptr);
         if (g->rccl.comm_init_all(comms.data(), ndev, devices) == 0) {
             g->use_rccl = true;
-            for (int r = 0; r < ndev; r++) {
-                g->m[r].comm = comms[r];
-                if (hipSetDevice(devices[r]) != hipSuccess ||
-                    hipStreamCreateWithFlags(&g->m[r].stream, hipStreamNonBlocking) != hipSuccess)
-                    g->use_rccl = false;
-            }
+            for (int r = 0; r < ndev; r++) g->m[r].comm = comms[r];
         }
         if (mode && std::strcmp(mode, "rccl") == 0 && !g->use_rccl) {
             ecgpu_group_destroy(g);
@@ -234,9 +232,14 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
             if (g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream) != 0) return ECGPU_ERR_HIP;
             return hipStreamSynchronize(mb.stream) == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
         }
+        // device-to-device copies are asynchronous with respect to the host: an explicit stream + synchronisation, so that
+        // the combining half (on member 0's own stream) starts after every part has landed
+        if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
         uint8_t* dst = (uint8_t*)g->m[0].d_all + (size_t)r * bytes;
-        hipError_t he = mb.device == g->m[0].device ? hipMemcpy(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice)
-                                                    : hipMemcpyPeer(dst, g->m[0].device, mb.d_parts, mb.device, bytes);
+        hipError_t he = mb.device == g->m[0].device
+                            ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
+                            : hipMemcpyPeerAsync(dst, g->m[0].device, mb.d_parts, mb.device, bytes, mb.stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(mb.stream);
         return he == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
     });
     if (rc != ECGPU_OK) return rc == ECGPU_ERR_HIP && g->err.empty() ? fail(g, rc, "exchange of the partial sums failed") : rc;
