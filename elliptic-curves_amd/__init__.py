@@ -51,6 +51,7 @@ ABI_SYMBOLS = [
     "ecgpu_group_init", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_ctx", "ecgpu_group_last_error",
     "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
     "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",
+    "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev",
 ]
 
 
@@ -342,6 +343,15 @@ class Engine:
         _need("e", ee, n * 32); _need("r", rr, n * 32); _need("s", ss, n * 32); _need("p_xy", pp, n * 64)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_schnorr_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(pp), ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
+    def sm2dsa_verify(self, e, r, s, q_xy):
+        """Batch SM2DSA verification on the prehash (sm2): e = SM3(ZA || M) as 32 bytes, (r, s), the public keys."""
+        ee, rr, ss, qq = _host(e), _host(r), _host(s), _host(q_xy)
+        n = ee.size // 32
+        _need("e", ee, n * 32); _need("r", rr, n * 32); _need("s", ss, n * 32); _need("q_xy", qq, n * 64)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_sm2dsa_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n), _hp(ok)))
         return ok
 
     def ecdh(self, curve, scalars, points_xy):

@@ -544,12 +544,12 @@ int curve_error(ecgpu_ctx* ctx, const char* fn) {
 
 namespace {
 // shared driver of the two verification shapes: prepare -> a*G + b*Q -> normalise -> compare
-enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2 };
+enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2, VERIFY_SM2DSA = 3 };
 // mode VERIFY_SCHNORR_RAW: d_h = messages (msg_len bytes each), d_s = 64-byte signatures, d_q_xy = 32-byte x-only keys
 template <class C>
 int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
                int reject_high_s, void* d_ok, size_t msg_len = 0) {
-    const bool schnorr = mode != VERIFY_ECDSA;
+    const bool schnorr = mode == VERIFY_SCHNORR || mode == VERIFY_SCHNORR_RAW;
     constexpr int NS = Field<C>::NS;
     const size_t L = 4 * C::N;
     int rc;
@@ -576,7 +576,9 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
         launch_schnorr_prepare_raw(ctx->stream, (const uint8_t*)d_q_xy, (const uint8_t*)d_h, msg_len, (const uint8_t*)d_s, n, u1,
                                    u2, q, (uint8_t*)ctx->ec_r.p, valid);
         d_r = ctx->ec_r.p;
-    } else if (schnorr)
+    } else if (mode == VERIFY_SM2DSA)
+        launch_sm2dsa_prepare<C>(ctx->stream, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
+    else if (schnorr)
         launch_schnorr_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
                                   (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else
@@ -588,7 +590,10 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
     record(ctx, 1);
     if ((rc = normalize_out<C>(ctx, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
-    if (schnorr)
+    if (mode == VERIFY_SM2DSA)
+        launch_sm2dsa_finish<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p,
+                                (const uint8_t*)d_r, valid, n, (uint8_t*)d_ok);
+    else if (schnorr)
         launch_schnorr_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
                                  valid, n, (uint8_t*)d_ok);
     else
@@ -884,6 +889,16 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     });
 }
 
+int ecgpu_sm2dsa_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
+                                  void* d_ok) {
+    // SM2DSA on the prehash: t = r + s, (x1, y1) = s G + t Q, ok = (e + x1 mod n == r).  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_e || !d_r || !d_s || !d_q_xy || !d_ok || !aligned16(d_e) || !aligned16(d_r) || !aligned16(d_s) ||
+              !aligned16(d_q_xy)))
+        return arg_error(ctx, __func__);
+    return verify_dev<Sm2Params>(ctx, VERIFY_SM2DSA, d_e, d_r, d_s, d_q_xy, n, 0, d_ok);
+}
+
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_p_xy,
                                    size_t n, void* d_ok) {
     // BIP340 over secp256k1: R = s G - e P, ok = R finite, y(R) even, x(R) == r.  See ecgpu_ecdsa.h.
@@ -1113,6 +1128,28 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
     if ((rc = ecgpu_ecdsa_verify_batch_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, reject_high_s,
                                            ctx->out1.p)) != ECGPU_OK)
         return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_sm2dsa_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* q_xy, size_t n,
+                              uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    const size_t L = 32;
+    if (n && (!e || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{e, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in2, L}, {q_xy, &ctx->in1, 2 * L}}, {{ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_sm2dsa_verify_batch_dev(ctx, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in3.p + off * L,
+                                                                  (uint8_t*)ctx->in2.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
+                                                                  (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in0, e, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, s, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_sm2dsa_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

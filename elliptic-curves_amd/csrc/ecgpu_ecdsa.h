@@ -62,6 +62,42 @@ k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_i
     ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
 }
 
+// ---- SM2DSA verification on the prehash: sm2/src/dsa/verifying.rs:138-171 ----------------------------------------------------
+//     e = SM3(ZA || M) as 32 bytes (computed by the caller: ZA depends on the signer's identity), reduced mod n
+//     reject unless 1 <= r, s < n;  t = r + s mod n, reject t = 0;  (x1, y1) = s G + t Q;  accept iff r == e + x1 mod n
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_sm2dsa_prepare(const uint8_t* __restrict__ r, const uint8_t* __restrict__ s, const uint8_t* __restrict__ q_xy, size_t n,
+                 uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[N], sw[N], cx[N], cy[N], t[N];
+    load_wire<C>(rw, r + i * WB);
+    load_wire<C>(sw, s + i * WB);
+    load_wire<C>(cx, q_xy + i * (2 * WB));
+    load_wire<C>(cy, q_xy + i * (2 * WB) + WB);
+    const bool ok = sm2dsa_prepare_words<C>(rw, sw, cx, cy, t);                               // ecgpu_verify.h
+    store_wire<C>(a_out + i * WB, sw);
+    store_wire<C>(b_out + i * WB, t);
+    store_wire<C>(q_out + i * (2 * WB), cx);
+    store_wire<C>(q_out + i * (2 * WB) + WB, cy);
+    valid[i] = ok ? 1 : 0;
+}
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_sm2dsa_finish(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf,
+                const uint8_t* __restrict__ r, const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ew[N], x[N], rw[N];
+    load_wire<C>(ew, e + i * WB);
+    load_wire<C>(x, r_xy + i * (2 * WB));
+    load_wire<C>(rw, r + i * WB);
+    ok_out[i] = (valid[i] && sm2dsa_finish_words<C>(ew, x, r_inf[i] != 0, rw)) ? 1 : 0;
+}
+
 // ---- Schnorr (BIP340) verification: k256/src/schnorr/verifying.rs:76-99 ---------------------------------------------
 //     e = tagged_hash("BIP0340/challenge", r || pk || m) reduced mod n   (computed by the caller; reduced here)
 //     R = s*G + (-e)*P  via mul_by_generator_and_mul_add_vartime;  accept iff R != identity, y(R) even, x(R) == r

@@ -103,6 +103,14 @@ template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy,
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
 }
 
+template <> void launch_sm2dsa_prepare<CurveT>(hipStream_t s, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy, size_t n,
+                                               uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* valid) {
+    hipLaunchKernelGGL(k_sm2dsa_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r, sig_s, q_xy, n, a, b, q_out, valid);
+}
+template <> void launch_sm2dsa_finish<CurveT>(hipStream_t s, const uint8_t* e, const uint8_t* r_xy, const uint8_t* r_inf,
+                                              const uint8_t* r, const uint8_t* valid, size_t n, uint8_t* ok) {
+    hipLaunchKernelGGL(k_sm2dsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, e, r_xy, r_inf, r, valid, n, ok);
+}
 template <> void launch_selftest_field<CurveT>(hipStream_t s, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out,
                                                int* status) {
     hipLaunchKernelGGL(k_selftest_field<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, op, a, b, n, out, status);

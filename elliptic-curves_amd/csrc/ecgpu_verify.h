@@ -59,6 +59,43 @@ ECGPU_HD bool ecdsa_finish_words(const uint32_t* x, const uint32_t* rw) {
     return eq;
 }
 
+// SM2DSA on the prehash (sm2/src/dsa/verifying.rs:138-171): r, s in [1, n - 1], t = r + s mod n != 0, Q on the curve;
+// a = s, b = t for (x1, y1) = s G + t Q
+template <class C>
+ECGPU_HD bool sm2dsa_prepare_words(const uint32_t* rw, uint32_t* sw, uint32_t* cx, uint32_t* cy, uint32_t* t) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    bool ok = !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
+    uint32_t sum[N], d[N];
+    const uint32_t carry = mp_add<N>(sum, rw, sw);
+    const uint32_t borrow = mp_sub<N>(d, sum, C::ORDER);
+    const bool use_d = carry || !borrow;                      // r + s >= n (the inputs are below n when ok)
+#pragma unroll
+    for (int j = 0; j < N; j++) t[j] = use_d ? d[j] : sum[j];
+    ok = ok && !S::is_zero(t);
+    ok = verify_point_ok<C>(cx, cy) && ok;
+    verify_blank<C>(ok, sw, t, cx, cy);
+    return ok;
+}
+// r == (e mod n) + (x1 mod n) mod n; x1 = 0 for the identity (`to_affine().x()` of the identity), as in the reference
+template <class C>
+ECGPU_HD bool sm2dsa_finish_words(const uint32_t* ew, const uint32_t* x, bool identity, const uint32_t* rw) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    uint32_t er[N], xr[N], sum[N], d[N];
+    S::reduce_once(er, ew);
+    S::reduce_once(xr, x);
+#pragma unroll
+    for (int j = 0; j < N; j++) xr[j] = identity ? 0u : xr[j];
+    const uint32_t carry = mp_add<N>(sum, er, xr);
+    const uint32_t borrow = mp_sub<N>(d, sum, C::ORDER);
+    const bool use_d = carry || !borrow;
+    bool eq = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) eq = eq && ((use_d ? d[j] : sum[j]) == rw[j]);
+    return eq;
+}
+
 // -e mod n of a challenge word array (e is reduced first)
 template <class C>
 ECGPU_HD void schnorr_neg_challenge(uint32_t* ne, const uint32_t* ew) {

@@ -292,6 +292,24 @@ unsafe extern "C" {
         n: usize,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_sm2dsa_verify_batch(
+        ctx: *mut EcgpuCtx,
+        e: *const u8,
+        r: *const u8,
+        s: *const u8,
+        q_xy: *const u8,
+        n: usize,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_sm2dsa_verify_batch_dev(
+        ctx: *mut EcgpuCtx,
+        d_e: *const c_void,
+        d_r: *const c_void,
+        d_s: *const c_void,
+        d_q_xy: *const c_void,
+        n: usize,
+        d_ok: *mut c_void,
+    ) -> c_int;
     pub fn ecgpu_schnorr_verify_raw_batch(
         ctx: *mut EcgpuCtx,
         pk_x: *const u8,

@@ -284,6 +284,18 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s,
                                    const void *d_p_xy, size_t n, void *d_ok);
 
+/* Batch SM2DSA verification on the prehash — `PrehashVerifier::verify_prehash` of sm2::dsa::VerifyingKey
+ * (sm2/src/dsa/verifying.rs:138-171; GB/T 32918.2, draft-shen-sm2-ecdsa 5.3), curve sm2 only.  Per element
+ *   e     32 bytes big-endian = SM3(ZA || M), computed by the caller (ZA hashes the signer's identity and key,
+ *         sm2/src/dsa.rs); reduced mod n on the device like `Scalar::reduce`
+ *   r, s  the signature halves, q_xy the public key's affine point
+ *   ok[i] = 1 iff 1 <= r, s < n, t = r + s mod n != 0, Q is a valid non-identity curve point and
+ *         r == e + x(s G + t Q) mod n   (the `lincomb` at verifying.rs:161). */
+int ecgpu_sm2dsa_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy,
+                              size_t n, uint8_t *ok);
+int ecgpu_sm2dsa_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s, const void *d_q_xy,
+                                  size_t n, void *d_ok);
+
 /* The same verification from wire bytes — `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)`
  * (k256/src/schnorr/verifying.rs:76-99,149-160): pk_x n*32 bytes (x-only keys, lifted on the device with even y),
  * msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*64 bytes (r || s).  The challenge

@@ -88,6 +88,9 @@ int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
                              const uint8_t *q_xy, size_t n, int reject_high_s, uint8_t *ok);
 
+/* SM2DSA verification on the prehash (sm2/src/dsa/verifying.rs:138-171): e = SM3(ZA || M) as 32 bytes, (r, s), public key. */
+int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy, size_t n,
+                              uint8_t *ok);
 /* BIP340 verification over secp256k1 (k256/src/schnorr/verifying.rs:76-99) with the challenge hash e supplied by the
  * caller; see ecref_ecdsa.c. */
 int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *p_xy,

@@ -39,6 +39,7 @@ static const uint64_t ORDER_P224[4] = {0x13DD29455C5C2A3Dull, 0xFFFF16A2E0B8F03E
 static const uint64_t ORDER_P521[9] = {0xBB6FB71E91386409ull, 0x3BB5C9B8899C47AEull, 0x7FCC0148F709A5D0ull, 0x51868783BF2F966Bull, 0xFFFFFFFFFFFFFFFAull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull, 0x00000000000001FFull};   /* p521/src/lib.rs:51-60 */
 static const uint64_t ORDER_BP256[4] = {0x901E0E82974856A7ull, 0x8C397AA3B561A6F7ull, 0x3E660A909D838D71ull, 0xA9FB57DBA1EEA9BCull};   /* bp256/src/lib.rs:70 */
 static const uint64_t ORDER_BP384[6] = {0x3B883202E9046565ull, 0xCF3AB6AF6B7FC310ull, 0x1F166E6CAC0425A7ull, 0x152F7109ED5456B3ull, 0x0F5D6F7E50E641DFull, 0x8CB91E82A3386D28ull};   /* bp384/src/lib.rs:73 */
+static const uint64_t ORDER_SM2[4] = {0x53BBF40939D54123ull, 0x7203DF6B21C6052Bull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFEFFFFFFFFull};   /* sm2/src/lib.rs:86 */
 static const uint64_t ORDER_P192[3] = {0x146BC9B1B4D22831ull, 0xFFFFFFFF99DEF836ull, 0xFFFFFFFFFFFFFFFFull};   /* p192/src/lib.rs:41 */
 
 typedef struct {
@@ -77,9 +78,19 @@ static void dbl_mod(uint64_t *a, const modn_t *m) {
     }
     if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
 }
+/* a = a + b mod n  (a, b < n) */
+static void add_mod(uint64_t *a, const uint64_t *b, const modn_t *m) {
+    uint64_t carry = 0;
+    for (int i = 0; i < m->nl; i++) {
+        u128 c = (u128)a[i] + b[i] + carry;
+        a[i] = (uint64_t)c;
+        carry = (uint64_t)(c >> 64);
+    }
+    if (carry || geq(a, m->n, m->nl)) sub_n(a, m->n, m->nl);
+}
 static void modn_init(modn_t *m, int curve) {
     m->nl = curve == ECREF_P384 || curve == ECREF_BP384 || curve == ECREF_BP384T1 ? 6 : curve == ECREF_P192 ? 3 : curve == ECREF_P521 ? 9 : 4;
-    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 || curve == ECREF_BP256T1 ? ORDER_BP256 : curve == ECREF_BP384 || curve == ECREF_BP384T1 ? ORDER_BP384 : ORDER_P384;
+    m->n = curve == ECREF_K256 ? ORDER_K256 : curve == ECREF_SM2 ? ORDER_SM2 : curve == ECREF_P256 ? ORDER_P256 : curve == ECREF_P224 ? ORDER_P224 : curve == ECREF_P192 ? ORDER_P192 : curve == ECREF_P521 ? ORDER_P521 : curve == ECREF_BP256 || curve == ECREF_BP256T1 ? ORDER_BP256 : curve == ECREF_BP384 || curve == ECREF_BP384T1 ? ORDER_BP384 : ORDER_P384;
     uint64_t x = m->n[0];                       /* Newton: x = n^-1 mod 2^64 */
     for (int i = 0; i < 6; i++) x *= 2 - m->n[0] * x;
     m->ninv = 0 - x;
@@ -174,6 +185,38 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
         from_be_len(x, xy, L, nl);
         if (geq(x, m.n, nl)) sub_n(x, m.n, nl);                 /* x < p < 2n */
         ok[i] = memcmp(x, rw, 8 * nl) == 0;
+    }
+    return ECREF_OK;
+}
+
+/* SM2DSA verification (GB/T 32918.2, draft-shen-sm2-ecdsa 5.3) on the prehash — `PrehashVerifier::verify_prehash`,
+ * sm2/src/dsa/verifying.rs:138-171: e = the 32-byte digest SM3(ZA || M) reduced mod n (`Scalar::reduce`); r, s the signature
+ * halves in [1, n-1] (`Signature` holds NonZeroScalars: sm2/src/dsa.rs); t = r + s mod n, reject t = 0;
+ * (x1, y1) = s G + t Q (`ProjectivePoint::lincomb`); accept iff r == e + (x1 mod n) mod n.  Like the reference, the
+ * identity is not rejected separately: `to_affine().x()` of the identity is 0. */
+int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy, size_t n, uint8_t *ok) {
+    modn_t m;
+    modn_init(&m, ECREF_SM2);
+    for (size_t i = 0; i < n; i++) {
+        uint64_t ew[4], rw[4], sw[4], t[4], x[4];
+        ok[i] = 0;
+        from_be(ew, e + 32 * i, 4);
+        from_be(rw, r + 32 * i, 4);
+        from_be(sw, s + 32 * i, 4);
+        if (is_zero(rw, 4) || geq(rw, m.n, 4) || is_zero(sw, 4) || geq(sw, m.n, 4)) continue;
+        if (geq(ew, m.n, 4)) sub_n(ew, m.n, 4);
+        memcpy(t, rw, 32);
+        add_mod(t, sw, &m);
+        if (is_zero(t, 4)) continue;
+        uint8_t a[32], b[32], xy[64], inf = 0;
+        to_be(a, sw, 4);
+        to_be(b, t, 4);
+        if (ecref_mul_base_and_mul_add_vartime(ECREF_SM2, a, b, q_xy + 64 * i, 0, xy, &inf) != ECREF_OK) continue;
+        if (inf) memset(xy, 0, 64);
+        from_be(x, xy, 4);
+        if (geq(x, m.n, 4)) sub_n(x, m.n, 4);                    /* x < p < 2n */
+        add_mod(x, ew, &m);
+        ok[i] = memcmp(x, rw, 32) == 0;
     }
     return ECREF_OK;
 }

@@ -203,3 +203,57 @@ def schnorr_inputs(vectors, decompress, pubkey_of):
     pxy, okl = decompress(b"".join(pks), np.zeros(len(pks), np.uint8))
     exp = np.array([1 if v["valid"] else 0 for v in vectors], np.uint8)
     return e, r, s, np.asarray(pxy, np.uint8), np.asarray(okl, np.uint8), exp
+
+
+# the reference's SM2DSA test vector (sm2/tests/sm2dsa.rs:16-31: OpenSSL-generated signature over b"testing" for the identity
+# "example@rustcrypto.org"): public key (SEC1 uncompressed), r || s
+SM2DSA_KAT = {
+    "public_key": "0408D77AE04C01CC4C1104360DD8AF6B6F7DF334283D7C1A6AFD5652407B87BEE5014E2A57C36C150D16324DC664E31E6432359609C4E79847A5B161C8C7364C8A",
+    "identity": b"example@rustcrypto.org", "message": b"testing",
+    "signature": "d1dcccedd9fb785e0f67c16b7c52901625c0b69de9bca2144acc7be713cad2fcf7d1eae6e3a157b36c65f672f738ca8b46298bf149a6510072c431b49cd88b1c",
+}
+
+
+def sm2dsa_cases(seed, nvalid=10):
+    """(e, r, s, q bytes, expected) tuples for SM2DSA on the prehash: the reference's test vector (e = SM3(ZA || M) computed
+    here with hashlib's SM3), signatures made by the big-int model, and every way of breaking one."""
+    import hashlib
+    import random
+    c = pyec.CURVES["sm2"]
+    rng = random.Random(seed)
+    G = pyec.G(c)
+    cases = []
+
+    def enc(e, r, s, Q, exp):
+        qxy = Q if isinstance(Q, bytes) else pyec.enc_point(c, Q)[0]
+        cases.append((e.to_bytes(32, "big"), r.to_bytes(32, "big"), s.to_bytes(32, "big"), qxy, exp))
+
+    pk = bytes.fromhex(SM2DSA_KAT["public_key"])
+    Q = (int.from_bytes(pk[1:33], "big"), int.from_bytes(pk[33:], "big"))
+    e = int.from_bytes(hashlib.new("sm3", pyec.sm2_za(c, SM2DSA_KAT["identity"], Q) + SM2DSA_KAT["message"]).digest(), "big")
+    sig = bytes.fromhex(SM2DSA_KAT["signature"])
+    enc(e, int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big"), Q, True)
+    enc(e ^ 1, int.from_bytes(sig[:32], "big"), int.from_bytes(sig[32:], "big"), Q, False)
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n - 1)
+        e = rng.randrange(1 << 256) if i % 3 else rng.randrange(c.n, 1 << 256)            # also digests >= n
+        Q = pyec.mul(c, d, G)
+        sig = None
+        while sig is None:
+            sig = pyec.sm2dsa_sign(c, d, e, rng.randrange(1, c.n))
+        r, s = sig
+        enc(e, r, s, Q, True)
+        enc(e ^ 2, r, s, Q, False)
+        enc(e, r, (s + 1) % c.n or 1, Q, False)
+        enc(e, (r + 1) % c.n or 1, s, Q, False)
+        enc(e, r, s, pyec.neg(c, Q), False)
+        if i < 3:
+            enc(e, 0, s, Q, False)
+            enc(e, r, 0, Q, False)
+            enc(e, c.n, s, Q, False)
+            enc(e, r, c.n, Q, False)
+            enc(e, r, c.n - r, Q, False)                                                  # t = r + s = 0 mod n
+            bad = bytearray(pyec.enc_point(c, Q)[0]); bad[-1] ^= 1
+            enc(e, r, s, bytes(bad), False)
+            enc(e, r, s, bytes(64), False)
+    return cases

@@ -526,6 +526,27 @@ int schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uin
     return 0;
 }
 
+// k_sm2dsa_prepare -> s G + t Q -> k_sm2dsa_finish
+int sm2dsa_verify(const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* q, size_t n, uint8_t* ok_out) {
+    using C = Sm2Params;
+    constexpr int N = 8;
+    static BaseTable<C> table;
+    if (table.w != 8) build_table<C>(table, 8);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t ew[N], rw[N], sw[N], cx[N], cy[N], t[N], x[N], y[N];
+        load_be<N>(ew, e + 32 * i);
+        load_be<N>(rw, r + 32 * i);
+        load_be<N>(sw, s + 32 * i);
+        load_be<N>(cx, q + 64 * i);
+        load_be<N>(cy, q + 64 * i + 32);
+        const bool valid = sm2dsa_prepare_words<C>(rw, sw, cx, cy, t);
+        const bool finite = sum_affine_x<C>(table, sw, t, cx, cy, x, y);
+        if (!finite) std::memset(x, 0, sizeof x);
+        ok_out[i] = valid && sm2dsa_finish_words<C>(ew, x, !finite, rw);
+    }
+    return 0;
+}
+
 template <class C>
 int decompress(const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok_out) {
     constexpr int N = C::N, WB = WireBytes<C>::value;
@@ -626,6 +647,9 @@ int hc_ecdsa_verify(int curve, const uint8_t* z, const uint8_t* r, const uint8_t
 int hc_schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
                       size_t n, uint8_t* ok) {
     return schnorr_verify(mode, e_or_msgs, msg_len, r_or_sigs, s, p, n, ok);
+}
+int hc_sm2dsa_verify(const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* q, size_t n, uint8_t* ok) {
+    return sm2dsa_verify(e, r, s, q, n, ok);
 }
 int hc_decompress(int curve, const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok) {
     if (curve == 4) return -1;                                   // p224: p = 1 mod 4

@@ -131,6 +131,14 @@ def ecdsa_verify(curve, z, r, s, q, reject_high_s=False):
     return ok
 
 
+def sm2dsa_verify(e, r, s, q):
+    E, R, S, Q = _a(e), _a(r), _a(s), _a(q)
+    n = E.size // 32
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_sm2dsa_verify(_p(E), _p(R), _p(S), _p(Q), ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
+
+
 def schnorr_verify(e, r, s, p_xy):
     E, R, S, P = _a(e), _a(r), _a(s), _a(p_xy)
     n = E.size // 32

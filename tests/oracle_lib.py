@@ -119,6 +119,14 @@ def schnorr_verify(e, r, s, p_xy):
     return ok
 
 
+def sm2dsa_verify(e, r, s, q_xy):
+    ee, rr, ss, qq = _arr(e), _arr(r), _arr(s), _arr(q_xy)
+    n = ee.size // 32
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_sm2dsa_verify_batch(_buf(ee), _buf(rr), _buf(ss), _buf(qq), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
 def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
     pk, sg = _arr(pk_x), _arr(sigs)
     mm = _arr(msgs) if msg_len else None

@@ -227,3 +227,34 @@ def ecdsa_verify(c, Q, z, r, s, reject_high_s=False):
     w = pow(s, -1, c.n)
     R = add(c, mul(c, z % c.n * w % c.n, G(c)), mul(c, r * w % c.n, Q))
     return R is not INF and R[0] % c.n == r
+
+
+# ---- SM2DSA (GB/T 32918.2 / draft-shen-sm2-ecdsa-02 5.2-5.3), the independent model ---------------------------------------
+
+def sm2dsa_sign(c, d, e, k):
+    """(r, s) for private key d, digest integer e (= SM3(ZA || M)), nonce k; None if the nonce has to be rejected."""
+    x1 = mul(c, k, G(c))[0]
+    r = (e + x1) % c.n
+    if r == 0 or r + k == c.n:
+        return None
+    s = pow(1 + d, -1, c.n) * (k - r * d) % c.n
+    return (r, s) if s else None
+
+
+def sm2dsa_verify(c, Q, e, r, s):
+    if not (1 <= r < c.n and 1 <= s < c.n):
+        return False
+    t = (r + s) % c.n
+    if t == 0 or Q is INF or not on_curve(c, Q):
+        return False
+    R = add(c, mul(c, s, G(c)), mul(c, t, Q))
+    x1 = 0 if R is INF else R[0]
+    return (e % c.n + x1) % c.n == r
+
+
+def sm2_za(c, ident, Q):
+    """ZA = SM3(ENTL || ID || a || b || xG || yG || xA || yA) (draft-shen-sm2-ecdsa-02 5.1.4.4; sm2/src/dsa.rs hash_z)."""
+    import hashlib
+    f = lambda v: (v % c.p).to_bytes(32, "big")
+    data = (8 * len(ident)).to_bytes(2, "big") + ident + f(c.a) + f(c.b) + f(c.gx) + f(c.gy) + f(Q[0]) + f(Q[1])
+    return hashlib.new("sm3", data).digest()

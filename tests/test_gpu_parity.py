@@ -528,6 +528,20 @@ def test_ecdsa_verify_wycheproof(eng, name):
     assert bytes(got) == bytes(oracle_lib.ecdsa_verify(c.cid, p["z"], p["r"], p["s"], p["q"], p["reject_high_s"]))
 
 
+def test_sm2dsa_verify_vs_reference_vector_oracle_and_model(eng):
+    """ecgpu_sm2dsa_verify_batch (sm2/src/dsa/verifying.rs:138-171): the reference's own SM2DSA vector, signatures made by
+    the big-int model and every way of breaking them — verdict for verdict against the expectation and the oracle; and a
+    batch large enough for the pipelined host-pointer path."""
+    from gpu_common import sm2dsa_cases
+    e, r, s, q, exp = ecdsa_pack(sm2dsa_cases(0x5D2C))
+    got = eng.sm2dsa_verify(e, r, s, q)
+    assert bytes(got) == bytes(exp) == bytes(oracle_lib.sm2dsa_verify(e, r, s, q))
+    reps = (1 << 19) // len(exp) + 1
+    big = eng.sm2dsa_verify(e * reps, r * reps, s * reps, q * reps)
+    assert bytes(big) == bytes(exp) * reps
+    assert eng.sm2dsa_verify(b"", b"", b"", b"").size == 0
+
+
 def test_schnorr_bip340_vectors(eng):
     """All 19 BIP340 vectors of k256/src/schnorr.rs: x-only keys lifted on the device (decompress, even y), challenge
     hashed on the host, verdicts equal to the reference's expectations and to the oracle's."""

@@ -359,6 +359,14 @@ def test_ecdsa_verify_logic_on_cpu(oracle, curve):
         assert hc.ecdsa_verify(c.cid, z, r, s, q).all()
 
 
+def test_sm2dsa_verify_logic_on_cpu(oracle):
+    """k_sm2dsa_prepare / k_sm2dsa_finish on the CPU: the reference's SM2DSA vector, model-made signatures, broken ones."""
+    from gpu_common import ecdsa_pack, sm2dsa_cases
+    e, r, s, q, exp = ecdsa_pack(sm2dsa_cases(0x5D2B, nvalid=4))
+    got = hc.sm2dsa_verify(e, r, s, q)
+    assert bytes(got) == bytes(exp) == bytes(oracle.sm2dsa_verify(e, r, s, q))
+
+
 def test_schnorr_verify_logic_on_cpu(oracle):
     """k_schnorr_prepare / k_schnorr_prepare_raw / k_schnorr_finish on the CPU: the BIP340 vectors of k256/src/schnorr.rs with
     the challenge given and from wire bytes (lift_x + tagged SHA-256 in the same code the device runs)."""

@@ -130,6 +130,25 @@ def test_wycheproof_ecdsa_vectors(oracle, name):
         assert pyec.ecdsa_verify(c, Q, z, r, s, p["reject_high_s"]) == bool(p["expect"][i])
 
 
+def test_sm2dsa_verify_reference_vector_and_model(oracle):
+    """ecref_sm2dsa_verify_batch (sm2/src/dsa/verifying.rs:138-171): accepts the reference's own test vector
+    (sm2/tests/sm2dsa.rs:16-35, with e = SM3(ZA || M) computed by hashlib), and agrees with the big-int model on signatures
+    the model makes and on every way of breaking them (ranges, t = 0, wrong key, off-curve key)."""
+    from gpu_common import ecdsa_pack, sm2dsa_cases
+    e, r, s, q, exp = ecdsa_pack(sm2dsa_cases(0x5D2A))
+    assert exp[0] == 1 and 0 < exp.sum() < len(exp)
+    assert bytes(oracle.sm2dsa_verify(e, r, s, q)) == bytes(exp)
+    c = pyec.CURVES["sm2"]
+    for i in range(len(exp)):
+        Q = None
+        try:
+            Q = pyec.dec_point(c, q[64 * i: 64 * i + 64], 0)
+        except AssertionError:
+            pass
+        got = pyec.sm2dsa_verify(c, Q, *(int.from_bytes(b[32 * i: 32 * i + 32], "big") for b in (e, r, s))) if Q else False
+        assert got == bool(exp[i]), i
+
+
 def test_schnorr_bip340_vectors(oracle):
     """The BIP340 vectors of k256/src/schnorr.rs (0-3 signing, 4-14 verification incl. every documented failure
     mode, 15-18 variable-length messages) through decompress (lift_x) + Schnorr verification."""
