@@ -199,11 +199,21 @@ class Bench:
             args.gpus = self.world
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a gfx950 GPU; there is no CPU path")
+        # Dry-run knobs for a one-GPU box (tools/gpu_run.sh recipe `bench2`): ECGPU_BENCH_SHARE_GPU=1 puts every rank on
+        # device 0 and ECGPU_BENCH_BACKEND=gloo moves the (tiny) exchange through the host, so that the N > 1 code path —
+        # term shards, parts / finish around the all-gather, the collective check — can be exercised where RCCL cannot run
+        # (it refuses two ranks on one device).  The driver's launch uses neither: one GPU per rank, RCCL.
+        self.backend = os.environ.get("ECGPU_BENCH_BACKEND", "nccl")
+        if os.environ.get("ECGPU_BENCH_SHARE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         self.device = "cuda:%d" % local_rank
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device(self.device))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(self.device))
+            else:
+                dist.init_process_group(self.backend)
         self.ecgpu = importlib.import_module("elliptic-curves_amd")
         self.eng = self.ecgpu.Engine(local_rank)
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -315,7 +325,7 @@ class Bench:
         self.fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
@@ -382,7 +392,8 @@ class Bench:
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": wl["scaling"], "vs_baseline": None, "dtype": "u32 limbs (v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": name, "curve": wl["curve"], "units_per_gpu": n, "units_total": units_per_step,
-                       "window_bits": args.window or "default", "parallelism": "shard%d" % world},
+                       "window_bits": args.window or "default", "parallelism": "shard%d" % world,
+                       **({"dry_run": "ranks share one GPU, %s exchange" % self.backend} if os.environ.get("ECGPU_BENCH_SHARE_GPU") else {})},
             "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms,
                          "achieved": achieved / 1e12 if achieved else None, "peak": peak / 1e12, "unit": "TIMAD32-slots/s",
                          "frac": achieved / peak if achieved else None,

@@ -107,7 +107,14 @@ class RecordExchange:
         self.all = torch.zeros((self.world * nbytes,), dtype=torch.uint8, device=device)
 
     def gather(self):
-        self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
+        if self.all.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # dry runs on a one-GPU box (bench.py ECGPU_BENCH_BACKEND=gloo): the records travel through the host
+            self.torch.cuda.current_stream(self.all.device).synchronize()
+            host = self.torch.empty_like(self.all, device="cpu")
+            self.dist.all_gather_into_tensor(host, self.mine.cpu(), group=self.group)
+            self.all.copy_(host)
+        else:
+            self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
         if self.all.is_cuda:
             # a consumer that enqueues on a stream of its own (an Engine without set_stream) is not ordered after the
             # collective: wait for the gathered bytes

@@ -6,6 +6,7 @@
 #   smoke                 __graft_entry__.smoke()
 #   pytest[:<expr>]       python -m pytest tests -m gpu [-k <expr>]   (expr with + for spaces: "wycheproof+or+full_size")
 #   bench[:<workload>]    python bench.py [--workload W] --check           -> bench_<W>.json
+#   bench2                bench.py --gpus 2 as a dry run on one GPU (ranks share device 0, gloo exchange): the N > 1 code path
 #   benchall              the default bench line (all four GPU configs as sub-records) with --check
 #   prof:<workload>       rocprofv3 --kernel-trace --stats of bench.py --workload W  -> prof_<W>/ + kernel_stats summary
 #   pmc:<workload>        three rocprofv3 --pmc passes (VALU counters, FETCH_SIZE, WRITE_SIZE) of bench.py --workload W
@@ -32,6 +33,10 @@ for recipe in "$@"; do
       timeout 900 python bench.py --workload "$w" --steps "$STEPS" --warmup 2 --check > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; tail -c 3000 "$OUT/bench_$w.json"; tail -3 "$OUT/bench_$w.err" ;;
     benchall)
       timeout 1200 python bench.py --check > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"; tail -c 6000 "$OUT/bench_default.json"; tail -3 "$OUT/bench_default.err" ;;
+    bench2)   # the N = 2 code path of bench.py on ONE GPU: both ranks on device 0, exchange through the host (gloo)
+      ECGPU_BENCH_SHARE_GPU=1 ECGPU_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+        --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > "$OUT/bench2.json" 2> "$OUT/bench2.err"
+      tail -c 2500 "$OUT/bench2.json"; tail -5 "$OUT/bench2.err" ;;
     prof)
       w=${arg:-fixed_k256}
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -o "$w" -- python "$ROOT/bench.py" --only "$w" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/prof_$w.log" 2>&1)
