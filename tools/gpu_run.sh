@@ -19,7 +19,7 @@ TAG=${1:?tag}; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 ROOT=$PWD
-STEPS=${STEPS:-5}
+STEPS=${STEPS:-5}        # BENCH_ARGS: extra bench.py arguments for the prof recipe (e.g. "--n 2097152")
 for recipe in "$@"; do
   name=${recipe%%:*}; arg=""; [[ "$recipe" == *:* ]] && arg=${recipe#*:}
   echo "=== $recipe"
@@ -39,7 +39,7 @@ for recipe in "$@"; do
       tail -c 2500 "$OUT/bench2.json"; tail -5 "$OUT/bench2.err" ;;
     prof)
       w=${arg:-fixed_k256}
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -o "$w" -- python "$ROOT/bench.py" --only "$w" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/prof_$w.log" 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -o "$w" -- python "$ROOT/bench.py" --only "$w" --steps "$STEPS" --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/prof_$w.log" 2>&1)
       python tools/pmc_summary.py stats "$OUT/prof_$w" | tee "$OUT/kernel_stats_$w.txt"
       find "$OUT/prof_$w" -name "*.db" -delete; find "$OUT/prof_$w" -name "*kernel_trace.csv" -size +1M -delete ;;
     pmc)
