@@ -36,7 +36,7 @@ def test_c_example_builds():
     """CPU: the plain-C client of the ABI (examples/) compiles and links."""
     ex = os.path.join(os.path.dirname(HERE), "examples")
     subprocess.check_call(["make", "-s", "-C", ex])
-    assert os.path.exists(os.path.join(ex, "batch_pubkeys"))
+    assert os.path.exists(os.path.join(ex, "batch_pubkeys")) and os.path.exists(os.path.join(ex, "node_lincomb"))
 
 
 @pytest.mark.gpu
@@ -47,3 +47,19 @@ def test_c_example_runs():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798" in out.stdout      # x(G)
     assert "shared(1,7) == shared(7,1): yes" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndev,mode", [(2, "peer"), (1, "rccl"), (3, "peer")])
+def test_c_node_lincomb_example_runs(ndev, mode):
+    """examples/node_lincomb.c: the single-process multi-GPU `lincomb` (ecgpu_group_*) from plain C — on a one-GPU box the
+    device is listed ndev times (independent contexts, worker threads, peer-copy exchange) or once over RCCL."""
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    env = dict(os.environ, ECGPU_GROUP_EXCHANGE=mode)
+    out = subprocess.run([os.path.join(ex, "node_lincomb"), str(ndev), "17"], capture_output=True, text=True, timeout=600, env=env)
+    if mode == "rccl" and out.returncode != 0 and "no gfx950 device" in out.stderr:
+        pytest.skip("librccl could not be loaded")
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "group of %d member(s), exchange by %s" % (ndev, mode) in out.stdout
+    assert "node lincomb == single-GPU lincomb: yes" in out.stdout
