@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Randomised differential run on the GPU box: random parameter set (all twelve), sizes, window widths, chunk sizes, sort
+modes, scalar split (GLV / plain), duplicated / cancelling / identity terms, random shard splits through the parts / finish
+halves; every result against the oracle (n <= 2^13) or a group identity (larger n).  One-off evidence, not part of the test
+suite:    FUZZ_SECONDS=200 FUZZ_SEED=1 python tools/gpu_fuzz.py"""
+import importlib
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+ec = importlib.import_module("elliptic-curves_amd")
+import oracle_lib  # noqa: E402
+import pyec  # noqa: E402
+from gpu_common import rand_scalars, scalars_to_int_sum  # noqa: E402
+
+oracle_lib.build()
+e = ec.Engine(0)
+rng = random.Random(int(os.environ.get("FUZZ_SEED", "20260924")))
+budget = float(os.environ.get("FUZZ_SECONDS", "150"))
+t_end = time.time() + budget
+stats = {"msm_oracle": 0, "msm_property": 0, "msm_shards": 0, "fixed": 0, "var": 0}
+NAMES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1", "bign256"]
+DEFAULT_W = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20,
+             "bp256t1": 24, "bp384t1": 20, "bign256": 24}
+pools = {}
+
+
+def pool(c):
+    if c.name not in pools:
+        n = 1 << 16
+        pts, _ = e.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xF0 + c.cid))
+        pools[c.name] = pts.reshape(n, 2 * c.L).copy()
+    return pools[c.name]
+
+
+def int_sum(c, k):
+    """sum of the scalars mod n (records in the curve's byte order)"""
+    a = np.ascontiguousarray(k, np.uint8).reshape(-1, c.L)
+    if c.le:
+        a = a[:, ::-1]
+    return scalars_to_int_sum(np.ascontiguousarray(a).reshape(-1), c.L, c.n)
+
+
+def msm_knobs(c):
+    os.environ["ECGPU_MSM_SORT2"] = rng.choice(["0", "1"])
+    if rng.random() < 0.3:
+        os.environ["ECGPU_MSM_CHUNK"] = str(rng.choice([1, 2, 3, 7, 33, 500, 100000]))
+    else:
+        os.environ.pop("ECGPU_MSM_CHUNK", None)
+    os.environ["ECGPU_MSM_SMALL_LOG2"] = rng.choice(["-1", "16"])
+    if c.name == "k256":
+        os.environ["ECGPU_MSM_GLV"] = rng.choice(["0", "1", "auto"])
+    else:
+        os.environ.pop("ECGPU_MSM_GLV", None)
+
+
+while time.time() < t_end:
+    c = pyec.CURVES[rng.choice(NAMES)]
+    L = c.L
+    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var"])
+    if kind == "msm":
+        big = rng.random() < 0.25
+        n = rng.randrange(1 << 14, 1 << 19) if big else rng.randrange(1, 1 << 13)
+        cb = rng.choice([0, 0, rng.randrange(4, 17)])
+        msm_knobs(c)
+        e.set_msm_window(cb)
+        k = rand_scalars(c.cid, n, rng.randrange(1 << 30)).copy().reshape(n, L)
+        if big:
+            gxy = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
+            o, f = e.lincomb(c.cid, k.reshape(-1), np.tile(gxy, n))
+            w, wf = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, int_sum(c, k)))
+            assert bytes(o) == bytes(w) and f == int(wf[0]), ("msm property", c.name, n, cb, dict(os.environ))
+            stats["msm_property"] += 1
+        else:
+            P = pool(c)
+            idx = np.array([rng.randrange(1 << 16) for _ in range(n)])
+            pts = P[idx].copy()
+            inf = np.zeros(n, np.uint8)
+            for _ in range(rng.randrange(0, 6)):           # duplicates, cancelling pairs, identities, tiny / huge scalars
+                i, j = rng.randrange(n), rng.randrange(n)
+                what = rng.randrange(5)
+                if what == 0:
+                    pts[j] = pts[i]; k[j] = k[i]
+                elif what == 1:
+                    pts[j] = pts[i]
+                    k[j] = np.frombuffer(pyec.enc_scalar(c, (c.n - int.from_bytes(bytes(k[i]), c.order)) % c.n), np.uint8)
+                elif what == 2:
+                    inf[i] = 1; pts[i] = 0
+                elif what == 3:
+                    k[i] = np.frombuffer(pyec.enc_scalar(c, rng.choice([0, 1, 2, c.n - 1, c.n - 2])), np.uint8)
+                else:
+                    k[j] = k[i]
+            o, f = e.lincomb(c.cid, k.reshape(-1), pts.reshape(-1), inf)
+            w, wf = oracle_lib.msm(c.cid, k.reshape(-1), pts.reshape(-1), inf, vartime=True)
+            assert bytes(o) == bytes(w) and f == wf, ("msm oracle", c.name, n, cb, dict(os.environ))
+            stats["msm_oracle"] += 1
+    elif kind == "shards":
+        # the two halves of a multi-GPU MSM on random, unequal shards (some empty) == the one-call MSM
+        n = rng.randrange(1, 1 << 15)
+        nsh = rng.randrange(1, 6)
+        msm_knobs(c)
+        e.set_msm_window(0)
+        k = rand_scalars(c.cid, n, rng.randrange(1 << 30))
+        P = pool(c)
+        pts = P[np.array([rng.randrange(1 << 16) for _ in range(n)])].copy().reshape(-1)
+        cuts = sorted(rng.randrange(n + 1) for _ in range(nsh - 1))
+        bounds = list(zip([0] + cuts, cuts + [n]))
+        plan_terms = max(hi - lo for lo, hi in bounds) or 1
+        want, wf = e.lincomb(c.cid, k, pts)
+        nbytes = e.msm_parts_bytes(c.cid, plan_terms)
+        d_all = e.dev_alloc(nsh * nbytes)
+        for r_, (lo, hi) in enumerate(bounds):
+            m = hi - lo
+            dk = e.to_device(k[lo * L: hi * L]) if m else None
+            dp = e.to_device(pts[lo * 2 * L: hi * 2 * L]) if m else None
+            e.msm_parts_dev(c.cid, dk, dp, None, m, plan_terms, d_all.at(r_ * nbytes))
+            for b in (dk, dp):
+                if b is not None:
+                    b.free()
+        d_o, d_f = e.dev_alloc((2 * L + 15) // 16 * 16), e.dev_alloc(16)
+        e.msm_finish_dev(c.cid, d_all, nsh, plan_terms, d_o, d_f)
+        got, gf = e.to_host(d_o, 2 * L), int(e.to_host(d_f, 1)[0])
+        assert bytes(got) == bytes(want) and gf == wf, ("shards", c.name, n, bounds, dict(os.environ))
+        for b in (d_all, d_o, d_f):
+            b.free()
+        stats["msm_shards"] += 1
+    elif kind == "fixed":
+        n = rng.randrange(1, 3000)
+        wdt = rng.choice([0, 0, rng.randrange(4, 17)])
+        if wdt:
+            e.set_base_window(c.cid, wdt)
+        k = rand_scalars(c.cid, n, rng.randrange(1 << 30))
+        o, f = e.mul_by_generator(c.cid, k)
+        w, wf = oracle_lib.batch_mul_base(c.cid, k)
+        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("fixed", c.name, n, wdt)
+        if wdt:
+            e.set_base_window(c.cid, DEFAULT_W[c.name])
+        stats["fixed"] += 1
+    else:
+        n = rng.randrange(1, 1500)
+        k = rand_scalars(c.cid, n, rng.randrange(1 << 30))
+        P = pool(c)
+        pts = P[np.array([rng.randrange(1 << 16) for _ in range(n)])].copy().reshape(-1)
+        o, f = e.mul(c.cid, k, pts)
+        w, wf = oracle_lib.batch_mul(c.cid, k, pts)
+        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("var", c.name, n)
+        stats["var"] += 1
+print("fuzz ok: %s in %.0f s, seed %s" % (stats, budget, os.environ.get("FUZZ_SEED", "20260924")))
