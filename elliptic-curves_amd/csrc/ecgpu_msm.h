@@ -46,31 +46,51 @@ namespace ecgpu {
 // per half.  Everything after this kernel sees nsub = SUB * npad independent entries.
 // A digit is 16 bits: bucket | sign << 15 (all 2^16 codes are real at c = 16).  Whether sub-term j has a digit in
 // window w at all (non-zero digit, finite point) is one bit of vmask[w][j / 64], written with a wave ballot.
+// counts_a != nullptr (two-level sort): the level-A histogram — entries per (window, top `8` bits of the bucket) — is
+// taken here as well, in dynamic LDS (nwin * npart counters, LDS atomics, one global atomicAdd per non-empty counter and
+// workgroup): the sort then needs no pass of its own over the digits to count them.
 template <class C, bool GLV>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, size_t npad, int c, int nwin, uint32_t* __restrict__ pts,
-              uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status) {
+              uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status,
+              uint32_t* __restrict__ counts_a, int bits_b, int npart) {
     using G = Group<C>;
     using F = Field<C>;
     using S = MsmSplit<C, GLV>;
     constexpr int N = C::N;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    extern __shared__ uint32_t lds_count_a[];
+    const int ncount = counts_a ? nwin * npart : 0;
+    for (int t = threadIdx.x; t < ncount; t += BLOCK) lds_count_a[t] = 0;
+    if (counts_a) __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < n;                                      // no early return: the workgroup meets again below
+    const size_t ii = active ? i : 0;
     uint32_t k[N];
-    load_scalar<C>(k, scalars, i, status);
+    bool finite = false;
     uint32_t sub[S::SUB][S::KW];
     bool flip[S::SUB];
-    S::split(k, sub, flip);
-    Fe<C::NL> b = G::curve_b();
-    Affine<C> a;
-    bool finite = load_affine<C>(&a, points_xy, points_inf, i, b, status);
-    if (finite) {
-        store_packed_affine<C>(pts + i * (2 * N), a.x, a.y);
-        if constexpr (S::SUB == 2)
-            store_packed_affine<C>(pts + (npad + i) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+    if (active) {
+        load_scalar<C>(k, scalars, ii, status);
+        S::split(k, sub, flip);
+        Fe<C::NL> b = G::curve_b();
+        Affine<C> a;
+        finite = load_affine<C>(&a, points_xy, points_inf, ii, b, status);
+        if (finite) {
+            store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
+            if constexpr (S::SUB == 2)
+                store_packed_affine<C>(pts + (npad + ii) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < S::SUB; h++) {
+            flip[h] = false;
+#pragma unroll
+            for (int t = 0; t < S::KW; t++) sub[h][t] = 0;
+        }
     }
     const size_t nsub = S::SUB * npad, nmask = nsub / 64;
+    const bool wave_in_range = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u) < npad;
 #pragma unroll
     for (int h = 0; h < S::SUB; h++) {
         const size_t j = (size_t)h * npad + i;
@@ -78,9 +98,18 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
 #pragma unroll 1
         for (int w = 0; w < nwin; w++) {
             MsmDigit d = msm_digit<S::KW>(sub[h], w, c, nwin, &carry, (uint32_t)j, flip[h], S::KBITS);
-            digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
-            unsigned long long m = __ballot(finite && d.nonzero);          // lanes past n have already returned
-            if ((threadIdx.x & 63) == 0) vmask[(size_t)w * nmask + (j >> 6)] = m;
+            const bool valid = active && finite && d.nonzero;
+            if (active) digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
+            unsigned long long m = __ballot(valid);
+            if ((threadIdx.x & 63) == 0 && wave_in_range) vmask[(size_t)w * nmask + (j >> 6)] = m;
+            if (counts_a && valid) atomicAdd(&lds_count_a[w * npart + (int)(d.bucket >> bits_b)], 1u);
+        }
+    }
+    if (counts_a) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < ncount; t += BLOCK) {
+            const uint32_t v = lds_count_a[t];
+            if (v) atomicAdd(&counts_a[t], v);
         }
     }
 }
@@ -688,14 +717,20 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
             done.store(true);
         }
     }
+    uint32_t* counts_a0 = p.sort_bits_b ? (uint32_t*)(ws + p.off_count_a) : nullptr;
+    const size_t prep_lds = p.sort_bits_b ? (size_t)p.nwin * p.npart * 4 : 0;
+    if (p.sort_bits_b) {
+        (void)hipMemsetAsync(counts_a0, 0, (size_t)p.nwin * p.npart * 4, stream);
+        (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
+    }
     if constexpr (MsmHasGlv<C>::value) {
         if (p.glv)
-            hipLaunchKernelGGL((k_msm_prepare<C, true>), dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin,
-                               pts, digits, vmask, d_status);
+            hipLaunchKernelGGL((k_msm_prepare<C, true>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
+                               p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart);
     }
     if (!p.glv)
-        hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), 0, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c, p.nwin,
-                           pts, digits, vmask, d_status);
+        hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
+                           p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart);
     if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
         uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);
@@ -704,10 +739,7 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
         uint32_t* cursor = (uint32_t*)(ws + p.off_cursor);
         const dim3 grid2((unsigned)p.ntiles2, (unsigned)p.nwin);
         MsmSort2Src sa{digits, vmask, nullptr, nullptr, nullptr, 0};
-        (void)hipMemsetAsync(counts_a, 0, (size_t)p.nwin * p.npart * 4, stream);
-        (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
-        hipLaunchKernelGGL((k_msm_sort2<false, true>), grid2, dim3(1024), 0, stream, sa, ne, p.sort_bits_b, p.npart, counts_a,
-                           (uint32_t*)nullptr, (uint16_t*)nullptr);
+        // (the level-A histogram counts_a was taken by k_msm_prepare)
         hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart);
         (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
         hipLaunchKernelGGL((k_msm_sort2<false, false>), grid2, dim3(1024), 0, stream, sa, ne, p.sort_bits_b, p.npart, cursor,

@@ -248,13 +248,21 @@ struct K256Scalar {
         add(r, res, one);
     }
 
+    // b2 = n - MINUS_B2 (126 bits): c2 = t * (-b2) = n - t * b2
+    ECGPU_CONST uint32_t B2[4] = {0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+
     // k -> (r1, r2), r1 + r2*lambda = k mod n         mul/glv.rs:149-156
+    // The same values as the reference's four modular multiplications, with the two by -b1 and -b2 done as 128 x 128-bit
+    // products: t1 = round(k g1 / 2^384) < 2^126 and t2 = round(k g2 / 2^384) < 2^128, so t1 * (-b1) < 2^254 < n needs no
+    // reduction and t2 * (-b2) = n - t2 * b2 with t2 * b2 < 2^254 (tests: test_k256_glv_equals_reference on the CPU,
+    // test_k256_glv_decompose_vs_oracle on the GPU).
     static ECGPU_HD void decompose(uint32_t* r1, uint32_t* r2, const uint32_t* k) {
-        uint32_t t[8], c1[8], c2[8];
+        uint32_t t[8], c1[8], c2[8], prod[8];
         mul_shift_384(t, k, G1);
-        mul(c1, t, MINUS_B1);
+        mp_mul<4>(c1, t, MINUS_B1);
         mul_shift_384(t, k, G2);
-        mul(c2, t, MINUS_B2);
+        mp_mul<4>(prod, t, B2);
+        neg(c2, prod);
         add(r2, c1, c2);
         mul(t, r2, MINUS_LAMBDA);
         add(r1, k, t);

@@ -159,7 +159,9 @@ def test_signed_windows_reconstruct():
 def test_k256_glv_equals_reference(oracle):
     c = pyec.K256
     rng = random.Random(0x61F)
-    cases = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 2 ** 128, pyec.K256_LAMBDA] + [rng.randrange(c.n) for _ in range(1000)]
+    cases = [0, 1, 2, c.n - 1, c.n - 2, (c.n - 1) // 2, (c.n + 1) // 2, 2 ** 128, pyec.K256_LAMBDA, c.n - pyec.K256_LAMBDA,
+             2 ** 255, 2 ** 255 - 1, 2 ** 254, int("ff" * 32, 16) % c.n, int("aa" * 32, 16), int("55" * 32, 16)]
+    cases += [2 ** j for j in range(256)] + [(2 ** j - 1) % c.n for j in range(1, 257)] + [rng.randrange(c.n) for _ in range(6000)]
     for k in cases:
         kb = k.to_bytes(32, "big")
         r1, r2, flags = hc.k256_glv(kb)
