@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, size_t npad, int c, int nwin, uint32_t* __restrict__ pts,
               uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status,
-              uint32_t* __restrict__ counts_a, int bits_b, int npart) {
+              uint32_t* __restrict__ counts_a, int bits_b, int npart, int reps) {
     using G = Group<C>;
     using F = Field<C>;
     using S = MsmSplit<C, GLV>;
@@ -63,46 +63,49 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     const int ncount = counts_a ? nwin * npart : 0;
     for (int t = threadIdx.x; t < ncount; t += BLOCK) lds_count_a[t] = 0;
     if (counts_a) __syncthreads();
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < n;                                      // no early return: the workgroup meets again below
-    const size_t ii = active ? i : 0;
-    uint32_t k[N];
-    bool finite = false;
-    uint32_t sub[S::SUB][S::KW];
-    bool flip[S::SUB];
-    if (active) {
-        load_scalar<C>(k, scalars, ii, status);
-        S::split(k, sub, flip);
-        Fe<C::NL> b = G::curve_b();
-        Affine<C> a;
-        finite = load_affine<C>(&a, points_xy, points_inf, ii, b, status);
-        if (finite) {
-            store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
-            if constexpr (S::SUB == 2)
-                store_packed_affine<C>(pts + (npad + ii) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+#pragma unroll 1
+    for (int rep = 0; rep < reps; rep++) {      // `reps` consecutive groups of BLOCK terms per workgroup: one flush of the counters for all
+        const size_t i = ((size_t)blockIdx.x * reps + rep) * BLOCK + threadIdx.x;
+        if (i - (threadIdx.x & 63) >= npad) break;                      // wave-uniform: nothing of this wave is inside the plan
+        const bool active = i < n;
+        const size_t ii = active ? i : 0;
+        uint32_t k[N];
+        bool finite = false;
+        uint32_t sub[S::SUB][S::KW];
+        bool flip[S::SUB];
+        if (active) {
+            load_scalar<C>(k, scalars, ii, status);
+            S::split(k, sub, flip);
+            Fe<C::NL> b = G::curve_b();
+            Affine<C> a;
+            finite = load_affine<C>(&a, points_xy, points_inf, ii, b, status);
+            if (finite) {
+                store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
+                if constexpr (S::SUB == 2)
+                    store_packed_affine<C>(pts + (npad + ii) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < S::SUB; h++) {
+                flip[h] = false;
+#pragma unroll
+                for (int t = 0; t < S::KW; t++) sub[h][t] = 0;
+            }
         }
-    } else {
+        const size_t nsub = S::SUB * npad, nmask = nsub / 64;
 #pragma unroll
         for (int h = 0; h < S::SUB; h++) {
-            flip[h] = false;
-#pragma unroll
-            for (int t = 0; t < S::KW; t++) sub[h][t] = 0;
-        }
-    }
-    const size_t nsub = S::SUB * npad, nmask = nsub / 64;
-    const bool wave_in_range = (size_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u) < npad;
-#pragma unroll
-    for (int h = 0; h < S::SUB; h++) {
-        const size_t j = (size_t)h * npad + i;
-        uint32_t carry = 0;
+            const size_t j = (size_t)h * npad + i;
+            uint32_t carry = 0;
 #pragma unroll 1
-        for (int w = 0; w < nwin; w++) {
-            MsmDigit d = msm_digit<S::KW>(sub[h], w, c, nwin, &carry, (uint32_t)j, flip[h], S::KBITS);
-            const bool valid = active && finite && d.nonzero;
-            if (active) digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
-            unsigned long long m = __ballot(valid);
-            if ((threadIdx.x & 63) == 0 && wave_in_range) vmask[(size_t)w * nmask + (j >> 6)] = m;
-            if (counts_a && valid) atomicAdd(&lds_count_a[w * npart + (int)(d.bucket >> bits_b)], 1u);
+            for (int w = 0; w < nwin; w++) {
+                MsmDigit d = msm_digit<S::KW>(sub[h], w, c, nwin, &carry, (uint32_t)j, flip[h], S::KBITS);
+                const bool valid = active && finite && d.nonzero;
+                if (active) digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
+                unsigned long long m = __ballot(valid);
+                if ((threadIdx.x & 63) == 0) vmask[(size_t)w * nmask + (j >> 6)] = m;
+                if (counts_a && valid) atomicAdd(&lds_count_a[w * npart + (int)(d.bucket >> bits_b)], 1u);
+            }
         }
     }
     if (counts_a) {
@@ -705,7 +708,13 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
     uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
-    unsigned g = (unsigned)((n + BLOCK - 1) / BLOCK);
+    // k_msm_prepare: each workgroup takes `reps` groups of BLOCK terms, so that its LDS histogram is flushed once for all of
+    // them (one global atomic per counter and workgroup); at least ~2048 workgroups stay in flight
+    int reps = 1;
+    if (p.sort_bits_b) {
+        while (reps < 32 && (n + (size_t)BLOCK * reps * 2 - 1) / ((size_t)BLOCK * reps * 2) >= 2048) reps *= 2;
+    }
+    unsigned g = (unsigned)((n + (size_t)BLOCK * reps - 1) / ((size_t)BLOCK * reps));
     const size_t lds_bytes = p.nb * 4;
     {
         int dev = 0;
@@ -726,11 +735,11 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     if constexpr (MsmHasGlv<C>::value) {
         if (p.glv)
             hipLaunchKernelGGL((k_msm_prepare<C, true>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
-                               p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart);
+                               p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart, reps);
     }
     if (!p.glv)
         hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
-                           p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart);
+                           p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart, reps);
     if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
         uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);

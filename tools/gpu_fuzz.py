@@ -60,6 +60,14 @@ def msm_knobs(c):
         os.environ.pop("ECGPU_MSM_GLV", None)
 
 
+def note(exc_type, exc, tb):
+    print("FUZZ CASE FAILED: kind=%s curve=%s n=%s knobs=%s" % (
+        kind, c.name, n, {k_: v for k_, v in os.environ.items() if k_.startswith("ECGPU_")}), flush=True)
+    sys.__excepthook__(exc_type, exc, tb)
+
+
+sys.excepthook = note
+kind = c = n = None
 while time.time() < t_end:
     c = pyec.CURVES[rng.choice(NAMES)]
     L = c.L
@@ -86,9 +94,9 @@ while time.time() < t_end:
                 i, j = rng.randrange(n), rng.randrange(n)
                 what = rng.randrange(5)
                 if what == 0:
-                    pts[j] = pts[i]; k[j] = k[i]
+                    pts[j] = pts[i]; k[j] = k[i]; inf[j] = inf[i]
                 elif what == 1:
-                    pts[j] = pts[i]
+                    pts[j] = pts[i]; inf[j] = inf[i]
                     k[j] = np.frombuffer(pyec.enc_scalar(c, (c.n - int.from_bytes(bytes(k[i]), c.order)) % c.n), np.uint8)
                 elif what == 2:
                     inf[i] = 1; pts[i] = 0
