@@ -51,7 +51,7 @@ ABI_SYMBOLS = [
     "ecgpu_group_init", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_ctx", "ecgpu_group_last_error",
     "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
     "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",
-    "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev",
+    "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev", "ecgpu_set_async", "ecgpu_synchronize",
 ]
 
 
@@ -254,6 +254,13 @@ class Engine:
 
     def set_msm_window(self, bits):
         self._chk(self._lib.ecgpu_set_msm_window(self._ctx, bits))
+
+    def set_async(self, on=True):
+        """Device-pointer calls return once queued; input-check errors surface at synchronize() (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_set_async(self._ctx, 1 if on else 0))
+
+    def synchronize(self):
+        self._chk(self._lib.ecgpu_synchronize(self._ctx))
 
     def last_timing(self, name="total"):
         ms = ctypes.c_double(0)

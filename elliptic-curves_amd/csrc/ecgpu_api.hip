@@ -53,6 +53,11 @@ struct ecgpu_ctx {
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r;   // signature verification scratch
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
+    std::vector<std::pair<std::string, std::pair<int, int>>> spans;   // event pairs of the last call not yet turned into `timing`
+    // asynchronous mode (ecgpu_set_async): device-pointer calls return once their work is queued; the status word
+    // accumulates on the device until ecgpu_synchronize (or a host-pointer call) collects it into `deferred`
+    bool async = false, pending = false;
+    int deferred = 0;
 };
 
 namespace {
@@ -104,30 +109,78 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK);
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int reset_status(ecgpu_ctx* ctx) {
+    if (ctx->async) return ECGPU_OK;          // flags accumulate until ecgpu_synchronize
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     return ECGPU_OK;
 }
 
-// reads the status word back (synchronises the stream) and maps it to an error code
-int finish(ecgpu_ctx* ctx) {
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    int st = *ctx->h_status;
+int status_error(ecgpu_ctx* ctx, int st) {
     if (st & ST_BAD_SCALAR) { ctx->err = "scalar not in [0, n)"; return ECGPU_ERR_SCALAR_RANGE; }
     if (st & ST_BAD_POINT) { ctx->err = "point coordinate >= p or not on curve"; return ECGPU_ERR_POINT; }
     return ECGPU_OK;
 }
 
+// reads the status word back (synchronises the stream) and maps it to an error code; asynchronous mode: returns at once,
+// the word is read by drain()
+int finish(ecgpu_ctx* ctx) {
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->async) {
+        ctx->pending = true;
+        return ECGPU_OK;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return status_error(ctx, *ctx->h_status);
+}
+
+// asynchronous mode: wait for the queued work, move its status flags into ctx->deferred, clear the device word
+int drain(ecgpu_ctx* ctx) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->deferred |= *ctx->h_status;
+    ctx->pending = false;
+    return ECGPU_OK;
+}
+
+// A host-pointer call on an asynchronous context runs synchronously: it first waits for the queued work (whose errors stay
+// deferred for ecgpu_synchronize), and reports its own errors itself.
+struct SyncScope {
+    ecgpu_ctx* ctx;
+    bool was;
+    explicit SyncScope(ecgpu_ctx* c) : ctx(c), was(c->async) {
+        if (was) {
+            (void)drain(ctx);
+            ctx->async = false;
+        }
+    }
+    ~SyncScope() {
+        if (was) {
+            (void)hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream);
+            ctx->async = true;
+        }
+    }
+};
+
 void record(ecgpu_ctx* ctx, int i) { (void)hipEventRecord(ctx->ev[i], ctx->stream); }
 
-void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*, std::pair<int, int>>> spans) {
+void resolve_timing(ecgpu_ctx* ctx) {
+    if (ctx->spans.empty()) return;
     ctx->timing.clear();
-    for (auto& s : spans) {
+    for (auto& s : ctx->spans) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev[s.second.first], ctx->ev[s.second.second]) == hipSuccess)
             ctx->timing[s.first] = ms;
     }
+    ctx->spans.clear();
+}
+
+// the spans of the call just made; turned into milliseconds now, or (asynchronous mode: the events have not happened
+// yet) when ecgpu_last_timing asks
+void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*, std::pair<int, int>>> spans) {
+    ctx->spans.clear();
+    for (auto& s : spans) ctx->spans.emplace_back(s.first, s.second);
+    if (!ctx->async) resolve_timing(ctx);
 }
 
 // ---- basepoint table ---------------------------------------------------------------------------------
@@ -728,6 +781,7 @@ int ecgpu_copy_to_host(ecgpu_ctx* ctx, void* h_dst, const void* d_src, size_t by
 
 int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
     if (!ctx) return arg_error(ctx, __func__);
+    if (ctx->async && ctx->pending && check_ctx(ctx)) (void)drain(ctx);     // the status word follows the old stream
     ctx->stream = stream ? reinterpret_cast<hipStream_t>(stream) : ctx->own_stream;
     return ECGPU_OK;
 }
@@ -746,8 +800,37 @@ int ecgpu_set_msm_window(ecgpu_ctx* ctx, int window_bits) {
     return ECGPU_OK;
 }
 
-int ecgpu_last_timing(const ecgpu_ctx* ctx, const char* name, double* ms) {
-    if (!ctx || !name || !ms) return ECGPU_ERR_ARG;
+int ecgpu_set_async(ecgpu_ctx* ctx, int on) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    int rc = ecgpu_synchronize(ctx);          // what was queued so far is reported here
+    if (on && !ctx->async) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
+        ctx->deferred = 0;
+    }
+    ctx->async = on != 0;
+    return rc;
+}
+
+int ecgpu_synchronize(ecgpu_ctx* ctx) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!ctx->async) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return ECGPU_OK;
+    }
+    int rc = drain(ctx);
+    if (rc != ECGPU_OK) return rc;
+    const int st = ctx->deferred;
+    ctx->deferred = 0;
+    return status_error(ctx, st);
+}
+
+int ecgpu_last_timing(const ecgpu_ctx* ctx_in, const char* name, double* ms) {
+    if (!ctx_in || !name || !ms) return ECGPU_ERR_ARG;
+    ecgpu_ctx* ctx = const_cast<ecgpu_ctx*>(ctx_in);
+    if (!ctx->spans.empty()) {                 // asynchronous call: its events are complete once the stream has drained
+        if (!check_ctx(ctx) || hipStreamSynchronize(ctx->stream) != hipSuccess) return ECGPU_ERR_HIP;
+        resolve_timing(ctx);
+    }
     auto it = ctx->timing.find(name);
     if (it == ctx->timing.end()) return ECGPU_ERR_ARG;
     *ms = it->second;
@@ -935,7 +1018,7 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const
         launch_extract_x<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, n, (uint8_t*)d_out_x,
                             (uint8_t*)d_ok);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!ctx->async) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return (int)ECGPU_OK;
     });
 }
@@ -967,6 +1050,7 @@ int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, cons
 int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy,
                          uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !out_xy)) return arg_error(ctx, __func__);
@@ -988,6 +1072,7 @@ int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size
 int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_x,
                                     uint8_t* out_tag) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !out_x || !out_tag)) return arg_error(ctx, __func__);
@@ -1008,6 +1093,7 @@ int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* sc
 int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy,
                     const uint8_t* points_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
@@ -1034,6 +1120,7 @@ int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
 int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf,
               size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (!out_xy || (n && (!scalars || !points_xy))) return arg_error(ctx, __func__);
@@ -1081,6 +1168,7 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
                                      const uint8_t* points_xy, const uint8_t* points_inf, size_t n, uint8_t* out_xy,
                                      uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
@@ -1109,6 +1197,7 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
 int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s,
                              const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!z || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
@@ -1134,6 +1223,7 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
 int ecgpu_sm2dsa_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* q_xy, size_t n,
                               uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     const size_t L = 32;
     if (n && (!e || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
@@ -1156,6 +1246,7 @@ int ecgpu_sm2dsa_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r
 int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* p_xy,
                                size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     const size_t L = 32;
     if (n && (!e || !r || !s || !p_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
@@ -1179,6 +1270,7 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
 int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
                                    size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
@@ -1200,6 +1292,7 @@ int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const ui
 int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x,
                      uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, __func__);
@@ -1222,6 +1315,7 @@ int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const ui
 int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const uint8_t* y_is_odd, size_t n, uint8_t* out_xy,
                            uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!xs || !y_is_odd || !out_xy || !ok)) return arg_error(ctx, __func__);
@@ -1244,6 +1338,7 @@ int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const u
 int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, size_t n, uint8_t* out_xy,
                           uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!points_xyz || !out_xy)) return arg_error(ctx, __func__);
@@ -1259,6 +1354,7 @@ int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, 
 int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const uint8_t* points_inf, size_t n,
                     uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (!out_xy || (n && !points_xy)) return arg_error(ctx, __func__);
@@ -1276,6 +1372,7 @@ int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const u
 
 int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     if (n && (!scalars || !r1 || !r2)) return arg_error(ctx, __func__);
     if (n == 0) return ECGPU_OK;
     int rc;
@@ -1291,6 +1388,7 @@ int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, u
 
 int ecgpu_selftest_field(ecgpu_ctx* ctx, int curve, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!a || !out)) return arg_error(ctx, __func__);
@@ -1313,6 +1411,7 @@ int ecgpu_selftest_field(ecgpu_ctx* ctx, int curve, int op, const uint8_t* a, co
 int ecgpu_selftest_point(ecgpu_ctx* ctx, int curve, int op, const uint8_t* p_xy, const uint8_t* p_inf, const uint8_t* q_xy,
                          const uint8_t* q_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!p_xy || !out_xy || !out_inf)) return arg_error(ctx, __func__);

@@ -52,6 +52,8 @@ unsafe extern "C" {
     pub fn ecgpu_copy_to_host(ctx: *mut EcgpuCtx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn ecgpu_set_base_window(ctx: *mut EcgpuCtx, curve: c_int, window_bits: c_int) -> c_int;
     pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
+    pub fn ecgpu_set_async(ctx: *mut EcgpuCtx, on: c_int) -> c_int;
+    pub fn ecgpu_synchronize(ctx: *mut EcgpuCtx) -> c_int;
     pub fn ecgpu_batch_mul_base(
         ctx: *mut EcgpuCtx,
         curve: c_int,

@@ -902,6 +902,70 @@ def test_fixed_base_compressed_output(eng, curve):
         assert bytes(x[i * c.L: (i + 1) * c.L]) == P[0].to_bytes(c.L, "big") and tag[i] == 2 + (P[1] & 1)
 
 
+def test_asynchronous_mode_queues_calls_and_defers_input_errors(eng):
+    """ecgpu_set_async: `_dev` calls return once queued, results after ecgpu_synchronize equal the oracle's, an input-check
+    error of a queued call surfaces at ecgpu_synchronize (once), host-pointer calls stay synchronous and report only
+    their own errors (include/ecgpu.h, 'Asynchronous mode')."""
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES["k256"]
+    L, n = c.L, 3000
+    pad = lambda x: (x + 15) // 16 * 16
+    ks = [rand_scalars(c.cid, n, 0xA5F0 + i) for i in range(3)]
+    pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xA5FF))
+    d_k = [eng.to_device(k) for k in ks]
+    d_p = eng.to_device(pts)
+    d_o = [eng.dev_alloc(pad(n * 2 * L)) for _ in range(4)]
+    d_f = [eng.dev_alloc(pad(n)) for _ in range(4)]
+    eng.set_async(True)
+    try:
+        eng.mul_by_generator_dev(c.cid, d_k[0], n, d_o[0], d_f[0])
+        eng.mul_by_generator_dev(c.cid, d_k[1], n, d_o[1], d_f[1])
+        eng.mul_dev(c.cid, d_k[2], d_p, None, n, d_o[2], d_f[2])
+        eng.lincomb_dev(c.cid, d_k[0], d_p, None, n, d_o[3], d_f[3])
+        eng.synchronize()
+        assert eng.last_timing("total") is not None
+        for i in range(2):
+            w, wf = oracle_lib.batch_mul_base(c.cid, ks[i])
+            assert bytes(eng.to_host(d_o[i], n * 2 * L)) == bytes(w) and bytes(eng.to_host(d_f[i], n)) == bytes(wf)
+        w, wf = oracle_lib.batch_mul(c.cid, ks[2], pts)
+        assert bytes(eng.to_host(d_o[2], n * 2 * L)) == bytes(w) and bytes(eng.to_host(d_f[2], n)) == bytes(wf)
+        w, wf = oracle_lib.msm(c.cid, ks[0], pts, np.zeros(n, np.uint8), vartime=True)
+        assert bytes(eng.to_host(d_o[3], 2 * L)) == bytes(w) and int(eng.to_host(d_f[3], 1)[0]) == wf
+        # a scalar >= n in a queued batch: the call returns, the error arrives with synchronize, once
+        bad = ks[1].copy()
+        bad[5 * L: 6 * L] = 0xFF
+        d_bad = eng.to_device(bad)
+        eng.mul_by_generator_dev(c.cid, d_k[0], n, d_o[0], d_f[0])
+        eng.mul_by_generator_dev(c.cid, d_bad, n, d_o[1], d_f[1])
+        eng.mul_by_generator_dev(c.cid, d_k[1], n, d_o[2], d_f[2])
+        # a host-pointer call in between runs synchronously and does not report the queued call's error
+        o, f = eng.mul_by_generator(c.cid, ks[2])
+        w, wf = oracle_lib.batch_mul_base(c.cid, ks[2])
+        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf)
+        with pytest.raises(ecgpu.EcgpuError) as ei:
+            eng.synchronize()
+        assert ei.value.code == ecgpu.ERR_SCALAR_RANGE
+        eng.synchronize()
+        w, wf = oracle_lib.batch_mul_base(c.cid, ks[1])          # the batch queued after the bad one is intact
+        assert bytes(eng.to_host(d_o[2], n * 2 * L)) == bytes(w)
+        # an error of a host-pointer call on the asynchronous context is its own, and immediate
+        with pytest.raises(ecgpu.EcgpuError) as ei:
+            eng.mul_by_generator(c.cid, bad)
+        assert ei.value.code == ecgpu.ERR_SCALAR_RANGE
+        eng.synchronize()
+        d_bad.free()
+    finally:
+        eng.set_async(False)
+    # back in the synchronous mode errors are immediate again
+    d_bad = eng.to_device(bad)
+    with pytest.raises(ecgpu.EcgpuError) as ei:
+        eng.mul_by_generator_dev(c.cid, d_bad, n, d_o[1], d_f[1])
+    assert ei.value.code == ecgpu.ERR_SCALAR_RANGE
+    eng.mul_by_generator_dev(c.cid, d_k[0], n, d_o[0], d_f[0])
+    for b in d_k + d_o + d_f + [d_p, d_bad]:
+        b.free()
+
+
 def test_device_pointer_entry_points():
     """The *_dev forms on torch tensors (what bench.py and a torch-based caller use) give the same bytes as the
     host-pointer forms: tests/gpu_dev_pointer_check.py, in a process of its own — torch has to be imported before
