@@ -187,6 +187,39 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
             "wall_s": dt, "single_thread_value": single, "thread_scaling": total / dt / single}
 
 
+def cpu_plumbing_record():
+    """BASELINE.json configs[0]: k256 `ProjectivePoint::GENERATOR * random Scalar`, batch of 1024, on the CPU reference path —
+    the oracle's restatement of mul_by_generator (k256/src/arithmetic/mul.rs:180-197), one thread, checked here against the
+    pure-Python model (tests/pyec.py) on a few of the 1024 and against the group law (sum of the outputs == (sum of the
+    scalars) G).  No GPU involved: `python bench.py --cpu-plumbing` runs anywhere; the default run files it under
+    configs["cpu_k256_1024"]."""
+    import oracle_lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pyec
+    oracle_lib.build()
+    c = pyec.CURVES["k256"]
+    n, L = 1024, 32
+    rng = np.random.default_rng(20260924)
+    ks = [int.from_bytes(rng.bytes(40), "big") % (c.n - 1) + 1 for _ in range(n)]
+    scal = np.frombuffer(b"".join(k.to_bytes(L, "big") for k in ks), np.uint8)
+    oracle_lib.batch_mul_base(0, scal[:32 * L])                  # first touch (table build)
+    t0 = time.perf_counter()
+    out, inf = oracle_lib.batch_mul_base(0, scal)
+    dt = time.perf_counter() - t0
+    ok = not inf.any()
+    for i in (0, 1, 511, 1023):
+        P = pyec.mul(c, ks[i], pyec.G(c))
+        ok = ok and bytes(out[i * 2 * L:(i + 1) * 2 * L]) == P[0].to_bytes(L, "big") + P[1].to_bytes(L, "big")
+    tot, tf = oracle_lib.msm(0, np.tile(np.frombuffer((1).to_bytes(L, "big"), np.uint8), n), out, vartime=True)
+    want, _ = oracle_lib.batch_mul_base(0, np.frombuffer((sum(ks) % c.n).to_bytes(L, "big"), np.uint8))
+    ok = ok and tf == 0 and bytes(tot) == bytes(want)
+    return {"metric": "k256 fixed-base scalar-muls/sec (CPU reference path)", "value": n / dt, "unit": "scalar-muls/s", "n_gpus": 0,
+            "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "u64 limbs (oracle, 5x52 field)", "data": "synthetic",
+            "config": {"workload": "cpu_k256_1024", "curve": "k256", "units": n, "threads": 1,
+                       "path": "oracle/ C restatement of mul_by_generator (kind \"port\")"},
+            "check_vs_model": bool(ok)}
+
+
 class Bench:
     def __init__(self, args):
         import torch
@@ -459,7 +492,13 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--sync-calls", action="store_true", help="fixed / variable base: one synchronous call per step instead of the queued calls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-plumbing", action="store_true",
+                    help="BASELINE configs[0] alone: 1024 k256 generator multiplications on the CPU reference path (no GPU needed)")
     args = ap.parse_args()
+    if args.cpu_plumbing:
+        rec = cpu_plumbing_record()
+        print(json.dumps(rec), flush=True)
+        return rec
 
     b = Bench(args)
     top = args.only or "fixed_k256"
@@ -475,6 +514,8 @@ def main():
             if "cpu_baseline" in r:
                 sub_recs[name]["cpu_baseline"] = r["cpu_baseline"]
     if rec is not None:
+        if sub_recs and cpu_leg:
+            sub_recs["cpu_k256_1024"] = cpu_plumbing_record()
         if sub_recs:
             rec["configs"] = sub_recs
         print(json.dumps(rec), flush=True)

@@ -432,3 +432,17 @@ def test_batch_normalize_and_validation(oracle, curve):
     with pytest.raises(oracle.OracleError) as e:
         oracle.batch_mul_base(c.cid, c.n.to_bytes(c.L, "big"))
     assert e.value.code == -2
+
+
+def test_baseline_config0_cpu_plumbing_record():
+    """BASELINE.json configs[0] (k256 GENERATOR * random Scalar, batch of 1024, CPU reference path, no GPU) as a named
+    artefact: `python bench.py --cpu-plumbing` prints one JSON line whose 1024 results passed the model / group-law check."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-plumbing"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["config"]["workload"] == "cpu_k256_1024" and rec["config"]["units"] == 1024 and rec["n_gpus"] == 0
+    assert rec["check_vs_model"] is True and rec["value"] > 1000
