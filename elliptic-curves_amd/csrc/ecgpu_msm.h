@@ -235,7 +235,7 @@ template <bool LEVEL_B, bool COUNT_ONLY>
 static __global__ void __launch_bounds__(1024)
 k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __restrict__ gcnt, uint32_t* __restrict__ out_idx,
             uint16_t* __restrict__ out_key) {
-    __shared__ uint32_t cnt[256], loc[256], gbase[256];
+    __shared__ uint32_t cnt[256], loc[256], gbase[256], wtot[4];
     __shared__ uint32_t stage[COUNT_ONLY ? 1 : MSM_SORT2_TILE];
     __shared__ uint16_t stage_k[COUNT_ONLY ? 1 : MSM_SORT2_TILE];
     const size_t w = blockIdx.y;
@@ -282,18 +282,24 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
             continue;
         }
         if (mine) gbase[tid] = atomicAdd(&gcnt[gi], mine);
-        if (tid < 256) loc[tid] = mine;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {                              // inclusive scan of the (<= 256) counts
-            uint32_t v = tid < 256 && (int)tid >= d ? loc[tid - d] : 0;
-            __syncthreads();
-            if (tid < 256) loc[tid] += v;
-            __syncthreads();
+        // exclusive scan of the (<= 256) counts: inside each of the first four waves by lane shuffles, then the four wave
+        // totals (two barriers instead of the nineteen of a scan through LDS)
+        uint32_t incl = mine;
+        if (tid < 256) {
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if ((int)(tid & 63) >= d) incl += v;
+            }
+            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
         }
-        const uint32_t total_r = loc[255];
-        const uint32_t excl = tid < 256 ? loc[tid] - mine : 0;          // -> exclusive
         __syncthreads();
-        if (tid < 256) loc[tid] = excl;
+        const uint32_t total_r = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+        if (tid < 256) {
+            uint32_t before = 0;
+            for (uint32_t k = 0; k < (tid >> 6); k++) before += wtot[k];
+            loc[tid] = before + incl - mine;
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
