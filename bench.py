@@ -67,6 +67,11 @@ WORKLOADS = {
     # batch ECDSA verification: u1 G + u2 Q per signature = fixed-base + variable-base + 1 addition
     "ecdsa_p256": dict(curve="p256", kind="ecdsa", n=1 << 20, metric="p256 ECDSA verifications/sec", unit="verifications/s",
                        imad_per_unit=(962 + 4336 + 14) * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
+    # batch ECDSA public-key recovery (ecdsa `recover_from_prehash`, reference vectors k256/src/ecdsa.rs:190-262): per signature a
+    # square root (decompression of R: ~268 M), r^-1, the 2-term `lincomb` (k256 mul.rs:112-163 with N = 2: 128 doublings + 160
+    # additions = 2944 M) and the closing `verify_prehash` (GLV + wNAF a G + b P: ~1600 M)
+    "recover_k256": dict(curve="k256", kind="recover", n=1 << 20, metric="k256 ECDSA public-key recoveries/sec", unit="recoveries/s",
+                         imad_per_unit=(268 + 2944 + 1600) * 136, bytes_per_unit=97 + 64, kernel="k_var_base<K256Params>", scaling="weak"),
     "var_p384": dict(curve="p384", kind="var", n=1 << 20, metric="p384 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=6448 * 300, bytes_per_unit=240, kernel="k_var_base<P384Params>", scaling="weak"),
     "msm_k256": dict(curve="k256", kind="msm", n=1 << 24, metric="k256 MSM terms/sec", unit="terms/s",
@@ -74,7 +79,7 @@ WORKLOADS = {
                      imad_per_unit=int(16.06 * 11 * 136), bytes_per_unit=96 + 16 * 64, kernel="k_msm_accumulate<K256Params>",
                      scaling="strong"),
 }
-SEEDS = {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8}
+SEEDS = {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
 DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384"]      # BASELINE configs[2], [3], [4] beside the top-level configs[1]
 NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
@@ -154,6 +159,8 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
         elif kind == "ecdsa":
             oracle_lib.ecdsa_verify(cid, s, extra[0][lo * L: hi * L], extra[1][lo * L: hi * L],
                                     sample_points[lo * 2 * L: hi * 2 * L])
+        elif kind == "recover":
+            oracle_lib.ecdsa_recover(cid, s, extra[0][lo * L: hi * L], extra[1][lo * L: hi * L], extra[2][lo:hi], True)
         else:
             oracle_lib.msm(cid, s, sample_points[lo * 2 * L: hi * 2 * L], vartime=True)
 
@@ -180,7 +187,8 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
     total = per_thread * cores
     algo = {"fixed": "mul_by_generator (33/49-LUT basepoint table)", "var": "ProjectivePoint * Scalar (LUT + radix-16)",
             "msm": "lincomb_vartime (GLV + wNAF-5 Straus), one %d-term lincomb per thread" % per_thread,
-            "ecdsa": "verify_prehashed: s^-1, u1 G + u2 Q (mul_by_generator_and_mul_add_vartime), x mod n == r"}[kind]
+            "ecdsa": "verify_prehashed: s^-1, u1 G + u2 Q (mul_by_generator_and_mul_add_vartime), x mod n == r",
+            "recover": "recover_from_prehash: decompress R, r^-1, lincomb(G, u1, R, u2), verify_prehash"}[kind]
     return {"value": total / dt, "unit": wl["unit"], "cores": cores, "kind": "port",
             "sample": "%d threads x %d units of the same seeded workload (slices of its first %d units), %s, oracle/ C restatement"
                       % (cores, per_thread, avail, algo),
@@ -291,8 +299,8 @@ class Bench:
             d_pts = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
             torch.cuda.synchronize()
             eng.mul_by_generator_dev(cid, d_s2, n, d_pts, None)          # P_i = s_i * G (untimed setup)
-        d_r = d_s = d_ok = None
-        if kind == "ecdsa":
+        d_r = d_s = d_ok = d_recid = None
+        if kind in ("ecdsa", "recover"):
             # valid signatures: 2^16 distinct (d, k, z) triples signed on the host from k*G computed here, tiled to n
             m = min(n, 1 << 16)
             d_d = device_random_scalars(torch, m, L, seed + 50, device)
@@ -305,18 +313,24 @@ class Bench:
             torch.cuda.synchronize()
             n_order = ecgpu.GROUP_ORDERS[cid]
             dh, kh, zh, rx = (t.cpu().numpy() for t in (d_d, d_k, d_scal[:m], d_R[:, :L].contiguous()))
-            rb, sb = bytearray(), bytearray()
+            rb, sb, ib = bytearray(), bytearray(), bytearray()
+            ry = d_R[:, 2 * L - 1].cpu().numpy()
             for i in range(m):
                 di, ki = int.from_bytes(dh[i].tobytes(), "big"), int.from_bytes(kh[i].tobytes(), "big") or 1
-                zi, ri = int.from_bytes(zh[i].tobytes(), "big"), int.from_bytes(rx[i].tobytes(), "big") % n_order
+                zi, xi = int.from_bytes(zh[i].tobytes(), "big"), int.from_bytes(rx[i].tobytes(), "big")
+                ri = xi % n_order
                 si = pow(ki, -1, n_order) * (zi + ri * di) % n_order
-                rb += ri.to_bytes(L, "big"); sb += si.to_bytes(L, "big")
+                odd = int(ry[i]) & 1
+                if kind == "recover" and si > n_order // 2:               # low-S form (k256 NORMALIZE_S): (r, -s) belongs to -R
+                    si, odd = n_order - si, odd ^ 1
+                rb += ri.to_bytes(L, "big"); sb += si.to_bytes(L, "big"); ib.append(odd | (2 if xi >= n_order else 0))
             reps = (n + m - 1) // m
             d_r = torch.frombuffer(rb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
             d_s = torch.frombuffer(sb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
             d_scal = d_scal[:m].repeat(reps, 1)[:n].contiguous()
             d_pts = d_Q.repeat(reps, 1)[:n].contiguous()
             d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device)
+            d_recid = torch.frombuffer(ib, dtype=torch.uint8).to(device).repeat(reps)[:n].contiguous()
             del d_d, d_k, d_R, d_Q
         n_out = 1 if kind == "msm" else n
         d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
@@ -347,6 +361,8 @@ class Bench:
                 eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
             elif kind == "ecdsa":
                 eng.ecdsa_verify_dev(cid, d_scal, d_r, d_s, d_pts, n, False, d_ok)
+            elif kind == "recover":
+                eng.ecdsa_recover_dev(cid, d_scal, d_r, d_s, d_recid, n, True, d_out, d_ok)
             elif exchange is None:
                 eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
             else:
@@ -406,6 +422,13 @@ class Bench:
                     w = oracle_lib.ecdsa_verify(cid, d_scal[:m].cpu().numpy().reshape(-1), d_r[:m].cpu().numpy().reshape(-1),
                                                 d_s[:m].cpu().numpy().reshape(-1), d_pts[:m].cpu().numpy().reshape(-1))
                     ok = bool(w.all()) and bool(d_ok[:n].all().item())       # every synthetic signature is valid
+                elif kind == "recover":
+                    m = min(n, 256)
+                    w, wok = oracle_lib.ecdsa_recover(cid, d_scal[:m].cpu().numpy().reshape(-1), d_r[:m].cpu().numpy().reshape(-1),
+                                                      d_s[:m].cpu().numpy().reshape(-1), d_recid[:m].cpu().numpy(), True)
+                    # every synthetic signature recovers to its signer's key: ALL n keys against the keys the signatures were made for
+                    ok = bool(wok.all()) and bytes(w) == bytes(d_out[:m].cpu().numpy().reshape(-1)) and bool(d_ok[:n].all().item()) \
+                        and bool(torch.equal(d_out, d_pts))
                 else:
                     idx = torch.arange(0, n, max(1, n // 256), device=device)[:256]
                     got = d_out[idx].cpu().numpy().reshape(-1)
@@ -468,7 +491,9 @@ class Bench:
             ns = min(n, 1 << 17 if kind in ("fixed", "msm") else 1 << 14)
             s_host = d_scal[:ns].cpu().numpy().reshape(-1)
             p_host = d_pts[:ns].cpu().numpy().reshape(-1) if d_pts is not None else None
-            extra = (d_r[:ns].cpu().numpy().reshape(-1), d_s[:ns].cpu().numpy().reshape(-1)) if kind == "ecdsa" else None
+            extra = (d_r[:ns].cpu().numpy().reshape(-1), d_s[:ns].cpu().numpy().reshape(-1)) if kind in ("ecdsa", "recover") else None
+            if kind == "recover":
+                extra = extra + (d_recid[:ns].cpu().numpy(),)
             rec["cpu_baseline"] = cpu_baseline(wl, cid, L, s_host, p_host, extra)
         return rec
 

@@ -52,6 +52,7 @@ ABI_SYMBOLS = [
     "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
     "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",
     "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev", "ecgpu_set_async", "ecgpu_synchronize",
+    "ecgpu_ecdsa_recover_batch", "ecgpu_ecdsa_recover_batch_dev",
 ]
 
 
@@ -343,6 +344,19 @@ class Engine:
                                                      int(bool(reject_high_s)), _hp(ok)))
         return ok
 
+    def ecdsa_recover(self, curve, z, r, s, recid, reject_high_s=False):
+        """Batch ECDSA public-key recovery: z, r, s n*L big-endian bytes each, recid n recovery id bytes (bit 0: y(R) odd,
+        bit 1: x(R) = r + n); returns (keys uint8[n*2L] — zero records where recovery fails —, ok uint8[n])."""
+        L = _field_bytes(curve)
+        zz, rr, ss, ii = _host(z), _host(r), _host(s), _host(recid)
+        n = ii.size
+        _need("z", zz, n * L); _need("r", rr, n * L); _need("s", ss, n * L)
+        out = np.zeros(n * 2 * L, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_ecdsa_recover_batch(self._ctx, curve, _hp(zz), _hp(rr), _hp(ss), _hp(ii), ctypes.c_size_t(n),
+                                                      int(bool(reject_high_s)), _hp(out), _hp(ok)))
+        return out, ok
+
     def schnorr_verify(self, e, r, s, p_xy):
         """Batch BIP340 verification (k256): e = challenge hash as 32 bytes, (r, s) signature halves, p_xy lifted key."""
         ee, rr, ss, pp = _host(e), _host(r), _host(s), _host(p_xy)
@@ -479,6 +493,10 @@ class Engine:
     def ecdsa_verify_dev(self, curve, d_z, d_r, d_s, d_q_xy, n, reject_high_s, d_ok):
         self._chk(self._lib.ecgpu_ecdsa_verify_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_q_xy),
                                                          ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_ok)))
+
+    def ecdsa_recover_dev(self, curve, d_z, d_r, d_s, d_recid, n, reject_high_s, d_out_xy, d_ok):
+        self._chk(self._lib.ecgpu_ecdsa_recover_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_recid),
+                                                          ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_out_xy), _dp(d_ok)))
 
     def point_sum_dev(self, curve, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_point_sum_dev(self._ctx, curve, _dp(d_points_xy), _dp(d_points_inf), ctypes.c_size_t(n),

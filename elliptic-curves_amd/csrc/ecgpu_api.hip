@@ -597,11 +597,12 @@ int curve_error(ecgpu_ctx* ctx, const char* fn) {
 
 namespace {
 // shared driver of the two verification shapes: prepare -> a*G + b*Q -> normalise -> compare
-enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2, VERIFY_SM2DSA = 3 };
+enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2, VERIFY_SM2DSA = 3, VERIFY_RECOVER = 4 };
 // mode VERIFY_SCHNORR_RAW: d_h = messages (msg_len bytes each), d_s = 64-byte signatures, d_q_xy = 32-byte x-only keys
+// mode VERIFY_RECOVER (public-key recovery): d_q_xy = the recovery id bytes, d_out_xy receives the keys
 template <class C>
 int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
-               int reject_high_s, void* d_ok, size_t msg_len = 0) {
+               int reject_high_s, void* d_ok, size_t msg_len = 0, void* d_out_xy = nullptr) {
     const bool schnorr = mode == VERIFY_SCHNORR || mode == VERIFY_SCHNORR_RAW;
     constexpr int NS = Field<C>::NS;
     const size_t L = 4 * C::N;
@@ -615,7 +616,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     if ((rc = ensure(ctx, ctx->ec_u2, n * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_q, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_valid, n + 16)) != ECGPU_OK) return rc;
-    if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (mode != VERIFY_RECOVER && (rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
     if (mode == VERIFY_SCHNORR_RAW && (rc = ensure(ctx, ctx->ec_r, n * L)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
@@ -629,7 +630,10 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
         launch_schnorr_prepare_raw(ctx->stream, (const uint8_t*)d_q_xy, (const uint8_t*)d_h, msg_len, (const uint8_t*)d_s, n, u1,
                                    u2, q, (uint8_t*)ctx->ec_r.p, valid);
         d_r = ctx->ec_r.p;
-    } else if (mode == VERIFY_SM2DSA)
+    } else if (mode == VERIFY_RECOVER)
+        launch_ecdsa_recover_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
+                                        (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
+    else if (mode == VERIFY_SM2DSA)
         launch_sm2dsa_prepare<C>(ctx->stream, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else if (schnorr)
         launch_schnorr_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
@@ -642,8 +646,10 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     launch_var_base<C>(ctx->stream, u2, q, nullptr, n, (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
     launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
     record(ctx, 1);
-    if ((rc = normalize_out<C>(ctx, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
-    if (mode == VERIFY_SM2DSA)
+    if ((rc = normalize_out<C>(ctx, n, mode == VERIFY_RECOVER ? d_out_xy : ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
+    if (mode == VERIFY_RECOVER)
+        launch_ecdsa_recover_finish<C>(ctx->stream, (uint8_t*)d_out_xy, (const uint8_t*)ctx->ec_inf.p, valid, n, (uint8_t*)d_ok);
+    else if (mode == VERIFY_SM2DSA)
         launch_sm2dsa_finish<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p,
                                 (const uint8_t*)d_r, valid, n, (uint8_t*)d_ok);
     else if (schnorr)
@@ -972,6 +978,20 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     });
 }
 
+int ecgpu_ecdsa_recover_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, const void* d_r, const void* d_s,
+                                  const void* d_recid, size_t n, int reject_high_s, void* d_out_xy, void* d_ok) {
+    // per element: R = decompress(r or r + n, parity), key = -(z/r) G + (s/r) R.  See ecgpu_ecdsa.h / ecgpu_verify.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_z || !d_r || !d_s || !d_recid || !d_out_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
+              !aligned16(d_out_xy)))
+        return arg_error(ctx, __func__);
+    if (curve == ECGPU_SM2 || curve == ECGPU_BIGN256 || curve == ECGPU_P224)   // not ECDSA curves; p224: no decompression (p = 1 mod 4)
+        return curve_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return verify_dev<decltype(c)>(ctx, VERIFY_RECOVER, d_z, d_r, d_s, d_recid, n, reject_high_s, d_ok, 0, d_out_xy);
+    });
+}
+
 int ecgpu_sm2dsa_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_q_xy, size_t n,
                                   void* d_ok) {
     // SM2DSA on the prehash: t = r + s, (x1, y1) = s G + t Q, ok = (e + x1 mod n == r).  See ecgpu_ecdsa.h.
@@ -1217,6 +1237,34 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
     if ((rc = ecgpu_ecdsa_verify_batch_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, reject_high_s,
                                            ctx->out1.p)) != ECGPU_OK)
         return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s,
+                              const uint8_t* recid, size_t n, int reject_high_s, uint8_t* out_xy, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!z || !r || !s || !recid || !out_xy || !ok)) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{z, &ctx->in0, L}, {r, &ctx->in3, L}, {s, &ctx->in1, L}, {recid, &ctx->in2, 1}},
+                         {{out_xy, &ctx->out0, 2 * L}, {ok, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_ecdsa_recover_batch_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in3.p + off * L,
+                                                                  (uint8_t*)ctx->in1.p + off * L, (uint8_t*)ctx->in2.p + off, m, reject_high_s,
+                                                                  (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in0, z, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, r, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, s, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, recid, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_ecdsa_recover_batch_dev(ctx, curve, ctx->in0.p, ctx->in3.p, ctx->in1.p, ctx->in2.p, n, reject_high_s, ctx->out0.p,
+                                            ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

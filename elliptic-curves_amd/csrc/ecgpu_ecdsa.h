@@ -62,6 +62,48 @@ k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_i
     ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
 }
 
+// ---- ECDSA public-key recovery: ecdsa 0.17.0 `VerifyingKey::recover_from_prehash` (see ecgpu_verify.h) -----------------------
+//     prepare: checks, R = decompress(r or r + n, parity), a = -(z / r), b = s / r;  then a G + b R by the kernels of
+//     ecgpu_batch_mul_base_and_mul_add;  finish: the key, or a zero record and ok = 0 (failed checks, or the identity,
+//     which `VerifyingKey::from_affine` rejects)
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_ecdsa_recover_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
+                        const uint8_t* __restrict__ recid, size_t n, int reject_high_s, uint8_t* __restrict__ a_out,
+                        uint8_t* __restrict__ b_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], a[N], b[N];
+    load_wire<C>(zw, z + i * WB);
+    load_wire<C>(rw, r + i * WB);
+    load_wire<C>(sw, s + i * WB);
+    const bool ok = ecdsa_recover_prepare_words<C>(zw, rw, sw, recid[i], reject_high_s, a, b, cx, cy);   // ecgpu_verify.h
+    store_wire<C>(a_out + i * WB, a);
+    store_wire<C>(b_out + i * WB, b);
+    store_wire<C>(q_out + i * (2 * WB), cx);
+    store_wire<C>(q_out + i * (2 * WB) + WB, cy);
+    valid[i] = ok ? 1 : 0;
+}
+// in place on the normalised sums: failed elements become zero records
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_ecdsa_recover_finish(uint8_t* __restrict__ xy, const uint8_t* __restrict__ inf, const uint8_t* __restrict__ valid, size_t n,
+                       uint8_t* __restrict__ ok_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool ok = valid[i] && !inf[i];
+    if (!ok) {
+        uint32_t zero[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) zero[j] = 0;
+        store_wire<C>(xy + i * (2 * WB), zero);
+        store_wire<C>(xy + i * (2 * WB) + WB, zero);
+    }
+    ok_out[i] = ok ? 1 : 0;
+}
+
 // ---- SM2DSA verification on the prehash: sm2/src/dsa/verifying.rs:138-171 ----------------------------------------------------
 //     e = SM3(ZA || M) as 32 bytes (computed by the caller: ZA depends on the signer's identity), reduced mod n
 //     reject unless 1 <= r, s < n;  t = r + s mod n, reject t = 0;  (x1, y1) = s G + t Q;  accept iff r == e + x1 mod n

@@ -103,6 +103,16 @@ template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy,
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
 }
 
+template <> void launch_ecdsa_recover_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
+                                                      const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
+                                                      uint8_t* q_out, uint8_t* valid) {
+    hipLaunchKernelGGL(k_ecdsa_recover_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, z, r, sig_s, recid, n, reject_high_s,
+                       a, b, q_out, valid);
+}
+template <> void launch_ecdsa_recover_finish<CurveT>(hipStream_t s, uint8_t* xy, const uint8_t* inf, const uint8_t* valid, size_t n,
+                                                     uint8_t* ok) {
+    hipLaunchKernelGGL(k_ecdsa_recover_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xy, inf, valid, n, ok);
+}
 template <> void launch_sm2dsa_prepare<CurveT>(hipStream_t s, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy, size_t n,
                                                uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* valid) {
     hipLaunchKernelGGL(k_sm2dsa_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r, sig_s, q_xy, n, a, b, q_out, valid);

@@ -51,6 +51,11 @@ template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const
 template <class C> void launch_proj_sum(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp);
 template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
                                              size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid);
+template <class C> void launch_ecdsa_recover_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
+                                                     const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
+                                                     uint8_t* q_out, uint8_t* valid);
+template <class C> void launch_ecdsa_recover_finish(hipStream_t s, uint8_t* xy, const uint8_t* inf, const uint8_t* valid, size_t n,
+                                                    uint8_t* ok);
 template <class C> void launch_sm2dsa_prepare(hipStream_t s, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy, size_t n, uint8_t* a,
                                               uint8_t* b, uint8_t* q_out, uint8_t* valid);
 template <class C> void launch_sm2dsa_finish(hipStream_t s, const uint8_t* e, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,

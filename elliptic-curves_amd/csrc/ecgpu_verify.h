@@ -189,4 +189,37 @@ ECGPU_HD bool decompress_words(uint32_t* cx, bool y_is_odd, uint32_t* cy) {
     return ok;
 }
 
+// ECDSA public-key recovery, everything before the two scalar multiplications — `VerifyingKey::recover_from_prehash` of
+// the `ecdsa` crate (0.17.0, un-vendored; the reference's vectors: k256/src/ecdsa.rs:190-262, p256/tests/ecdsa.rs:20-25):
+// r, s in [1, n - 1] (and s <= (n - 1) / 2 where the final `verify_prehash` normalises s: k256), recovery id <= 3,
+// x = r or r + n (bit 1; `checked_add`, and x >= p fails the decompression), R = decompress(x, bit 0),
+// a = -(z / r), b = s / r for the key a G + b R.  What `verify_prehash` checks on the recovered key beyond the high-s rule
+// holds by construction: (z / s) G + (r / s) (a G + b R) = R, whose x is r mod n, and R is a finite point.
+template <class C>
+ECGPU_HD bool ecdsa_recover_prepare_words(const uint32_t* zw, const uint32_t* rw, const uint32_t* sw, uint32_t recid,
+                                          int reject_high_s, uint32_t* a, uint32_t* b, uint32_t* cx, uint32_t* cy) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    bool ok = recid <= 3u && !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
+    if (reject_high_s) ok = ok && !S::is_high(sw);
+    uint32_t sum[N];
+    const uint32_t carry = mp_add<N>(sum, rw, C::ORDER);
+    const bool reduced = (recid & 2u) != 0;
+#pragma unroll
+    for (int j = 0; j < N; j++) cx[j] = reduced ? sum[j] : rw[j];
+    ok = ok && !(reduced && carry);
+    ok = decompress_words<C>(cx, (recid & 1u) != 0, cy) && ok;
+    uint32_t zr[N], rinv[N], t[N], d[N];
+    S::reduce_wire(zr, zw);
+    S::inv(rinv, rw);
+    S::mul(t, rinv, zr);
+    const bool tz = S::is_zero(t);
+    mp_sub<N>(d, C::ORDER, t);
+#pragma unroll
+    for (int j = 0; j < N; j++) a[j] = tz ? 0u : d[j];
+    S::mul(b, rinv, sw);
+    verify_blank<C>(ok, a, b, cx, cy);
+    return ok;
+}
+
 }  // namespace ecgpu

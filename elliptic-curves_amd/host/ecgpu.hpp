@@ -283,6 +283,31 @@ struct Curve {
         return ok;
     }
 
+    // ecdsa `VerifyingKey::recover_from_prehash` for a batch (reference vectors: k256/src/ecdsa.rs:190-262): the key each
+    // signature recovers to under its `RecoveryId::to_byte`, or the identity (`is_identity()`) where recovery fails
+    static std::vector<AffinePoint> batch_recover_from_prehash(const std::vector<FieldBytes>& z, const std::vector<EcdsaSignature>& sig,
+                                                               const std::vector<uint8_t>& recovery_id, bool normalize_s) {
+        size_t n = z.size();
+        if (sig.size() != n || recovery_id.size() != n) throw Error(ECGPU_ERR_ARG, "batch_recover_from_prehash: length mismatch");
+        std::vector<uint8_t> zb(n * L), rb(n * L), sb(n * L), xy(n * 2 * L), ok(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(&zb[i * L], z[i].data(), L);
+            std::memcpy(&rb[i * L], sig[i].r.data(), L);
+            std::memcpy(&sb[i * L], sig[i].s.data(), L);
+        }
+        Engine& e = Engine::global();
+        e.check(ecgpu_ecdsa_recover_batch(e.ctx(), ID, zb.data(), rb.data(), sb.data(), recovery_id.data(), n, normalize_s ? 1 : 0,
+                                          xy.data(), ok.data()));
+        std::vector<AffinePoint> out(n);
+        for (size_t i = 0; i < n; i++) {
+            if (!ok[i]) continue;                               // stays AffinePoint::IDENTITY()
+            std::memcpy(out[i].x_.data(), &xy[i * 2 * L], L);
+            std::memcpy(out[i].y_.data(), &xy[i * 2 * L + L], L);
+            out[i].infinity = 0;
+        }
+        return out;
+    }
+
     // ---- MulBackend<C> plug-in (primeorder/src/mul_backend.rs:11-40) ----------------------------------
     struct GpuBackend {
         static ProjectivePoint mul_by_generator(const Scalar& k) { return ProjectivePoint::mul_by_generator(k); }

@@ -248,6 +248,28 @@ pub mod gpu {
         });
         Some(ok.into_iter().map(|b| b != 0).collect())
     }
+
+    /// Batch form of `VerifyingKey::<C>::recover_from_prehash` (ecdsa 0.17.0 recovery.rs; the reference's vectors:
+    /// k256/src/ecdsa.rs:190-262): `recovery_id[i]` = `RecoveryId::to_byte()`.  `None` per element where the reference
+    /// returns `Err` (id does not parse, candidate x >= p or off the curve, identity key, high s under NORMALIZE_S).
+    pub fn batch_recover_from_prehash<C: GpuCurve>(z: &[FieldBytes<C>], r: &[FieldBytes<C>], s: &[FieldBytes<C>], recovery_id: &[u8],
+                                                   normalize_s: bool) -> Option<Vec<Option<Aff<C>>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let n = z.len();
+        assert!(r.len() == n && s.len() == n && recovery_id.len() == n);
+        let l = field_len::<C>();
+        let cat = |v: &[FieldBytes<C>]| v.iter().flat_map(|b| b.as_ref().to_vec()).collect::<Vec<u8>>();
+        let (mut xy, mut ok) = (vec![0u8; n * 2 * l], vec![0u8; n]);
+        check(unsafe {
+            ecgpu_ecdsa_recover_batch(eng.0, C::ID, cat(z).as_ptr(), cat(r).as_ptr(), cat(s).as_ptr(), recovery_id.as_ptr(), n,
+                                      normalize_s as c_int, xy.as_mut_ptr(), ok.as_mut_ptr())
+        });
+        Some(xy.chunks(2 * l).zip(ok).map(|(c, f)| if f != 0 { Some(elliptic_curve::group::Curve::to_affine(&point_from_wire::<C>(c, 0))) } else { None }).collect())
+    }
 }
 
 // =====================================================================================================================

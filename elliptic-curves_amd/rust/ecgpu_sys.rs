@@ -276,6 +276,30 @@ unsafe extern "C" {
         reject_high_s: c_int,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_ecdsa_recover_batch(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        z: *const u8,
+        r: *const u8,
+        s: *const u8,
+        recid: *const u8,
+        n: usize,
+        reject_high_s: c_int,
+        out_xy: *mut u8,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_ecdsa_recover_batch_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_z: *const c_void,
+        d_r: *const c_void,
+        d_s: *const c_void,
+        d_recid: *const c_void,
+        n: usize,
+        reject_high_s: c_int,
+        d_out_xy: *mut c_void,
+        d_ok: *mut c_void,
+    ) -> c_int;
     pub fn ecgpu_schnorr_verify_batch(
         ctx: *mut EcgpuCtx,
         e: *const u8,

@@ -282,6 +282,24 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_z, con
                                  const void *d_s, const void *d_q_xy, size_t n, int reject_high_s,
                                  void *d_ok);
 
+/* Batch ECDSA public-key recovery — `VerifyingKey::recover_from_prehash(prehash, &signature, recovery_id)` of the `ecdsa`
+ * crate (0.17.0, un-vendored, Cargo.lock:428-429), which k256 / p256 re-export and the reference tests with its own vectors
+ * (k256/src/ecdsa.rs:170-262: RECOVERY_TEST_VECTORS and the Ethereum example; p256/tests/ecdsa.rs:20-25).  It is a caller
+ * of `ProjectivePoint::lincomb(&[(G, u1), (R, u2)])`.  Per element i (SEC1 v2 4.1.6 for ONE candidate):
+ *   z, r, s  as for ecgpu_ecdsa_verify_batch
+ *   recid    one byte, `RecoveryId::to_byte`: bit 0 = y(R) is odd, bit 1 = x(R) = r + n ("x reduced"); > 3 does not parse
+ *   R = decompress(r or r + n, bit 0);  key = -(z/r) G + (s/r) R
+ *   ok[i] = 1 and out_xy[i] = the key (affine x||y) iff 1 <= r, s < n, (reject_high_s == 0 or s <= (n-1)/2: the
+ *      `verify_prehash` the crate runs on the recovered key applies the curve's NORMALIZE_S — pass 1 for k256), recid <= 3,
+ *      the candidate x is below p and on the curve, and the key is not the identity;  otherwise ok[i] = 0 and a zero record.
+ * ECGPU_ERR_CURVE for sm2 / bign256 (not ECDSA) and p224 (no decompression). */
+int ecgpu_ecdsa_recover_batch(ecgpu_ctx *ctx, int curve, const uint8_t *z, const uint8_t *r,
+                              const uint8_t *s, const uint8_t *recid, size_t n, int reject_high_s,
+                              uint8_t *out_xy, uint8_t *ok);
+int ecgpu_ecdsa_recover_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_z, const void *d_r,
+                                  const void *d_s, const void *d_recid, size_t n, int reject_high_s,
+                                  void *d_out_xy, void *d_ok);
+
 /* Batch BIP340 Schnorr verification over secp256k1 — `VerifyingKey::verify_raw`
  * (k256/src/schnorr/verifying.rs:76-99) without the hash: per element
  *   e  32 bytes big-endian = tagged_hash("BIP0340/challenge", r || pk || m), computed by the caller; reduced

@@ -88,6 +88,13 @@ int ecref_mul_base_and_mul_add_vartime(int curve, const uint8_t *a, const uint8_
 int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
                              const uint8_t *q_xy, size_t n, int reject_high_s, uint8_t *ok);
 
+/* Public-key recovery: out_xy[i] = the key that (r_i, s_i) on digest integer z_i recovers to under recovery id byte
+ * recid[i] (bit 0: y(R) odd, bit 1: x(R) = r + n), ok[i] = 1; or a zero record and ok[i] = 0 — ecdsa 0.17.0
+ * `VerifyingKey::recover_from_prehash`, see ecref_ecdsa.c (reference vectors: k256/src/ecdsa.rs:170-262). */
+int ecref_ecdsa_recover_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
+                              const uint8_t *recid, size_t n, int reject_high_s, uint8_t *out_xy,
+                              uint8_t *ok);
+
 /* SM2DSA verification on the prehash (sm2/src/dsa/verifying.rs:138-171): e = SM3(ZA || M) as 32 bytes, (r, s), public key. */
 int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy, size_t n,
                               uint8_t *ok);

@@ -189,6 +189,82 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
     return ECREF_OK;
 }
 
+/* Public-key recovery — `VerifyingKey::recover_from_prehash(prehash, &signature, recovery_id)` of the un-vendored crate
+ * `ecdsa` 0.17.0 (Cargo.lock:428-429; recovery.rs), which the reference exercises with its own vectors at
+ * k256/src/ecdsa.rs:170-262 (RECOVERY_TEST_VECTORS, the Ethereum example) and p256/tests/ecdsa.rs:20-25.  Its published
+ * algorithm (SEC1 v2 section 4.1.6 for one (R, recovery id) candidate):
+ *     (r, s) = the signature's scalars, both in [1, n-1];  z = bits2field(prehash) reduced mod n
+ *     recovery id byte: bit 0 = y(R) is odd, bit 1 = x(R) was reduced (x(R) = r + n); values above 3 do not parse
+ *     x = r, or r + n when bit 1 is set — `checked_add` on the curve's Uint, and the decompression below rejects x >= p
+ *     R = AffinePoint::decompress(x, y_is_odd)                                (error if there is no such point)
+ *     u1 = -(r^-1 z), u2 = r^-1 s;  pk = ProjectivePoint::lincomb(&[(G, u1), (R, u2)])
+ *     vk = VerifyingKey::from_affine(pk)   (error for the identity);  vk.verify_prehash(prehash, signature)?  — which is
+ *     where a curve with NORMALIZE_S (k256) rejects a high s.
+ * ok[i] = 1 and out_xy[i] = the recovered key, or ok[i] = 0 and a zero record.  Not offered for p224 (no decompression:
+ * p = 1 mod 4), sm2 and bign256 (not ECDSA curves). */
+int ecref_ecdsa_recover_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *recid, size_t n,
+                              int reject_high_s, uint8_t *out_xy, uint8_t *ok) {
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384 && curve != ECREF_BP256T1 && curve != ECREF_BP384T1) return ECREF_ERR_CURVE;
+    modn_t m;
+    modn_init(&m, curve);
+    const int nl = m.nl;
+    const size_t L = curve == ECREF_P521 ? 66 : 8 * (size_t)nl;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t zw[9], rw[9], sw[9], xw[10], rinv[9], u1[9], u2[9];
+        ok[i] = 0;
+        memset(out_xy + 2 * L * i, 0, 2 * L);
+        if (recid[i] > 3) continue;                                   /* RecoveryId::from_byte */
+        from_be_len(zw, z + L * i, L, nl);
+        from_be_len(rw, r + L * i, L, nl);
+        from_be_len(sw, s + L * i, L, nl);
+        if (is_zero(rw, nl) || geq(rw, m.n, nl) || is_zero(sw, nl) || geq(sw, m.n, nl)) continue;   /* Signature::from_scalars */
+        if (geq(zw, m.n, nl)) sub_n(zw, m.n, nl);                     /* Reduce<FieldBytes>: one conditional subtraction (z < 2n) */
+        /* x = r (+ n): one spare word for the carry; a value that does not fit the L wire bytes is >= p */
+        memcpy(xw, rw, 8 * nl);
+        xw[nl] = 0;
+        if (recid[i] & 2) {
+            uint64_t carry = 0;
+            for (int k = 0; k < nl; k++) {
+                u128 c = (u128)xw[k] + m.n[k] + carry;
+                xw[k] = (uint64_t)c;
+                carry = (uint64_t)(c >> 64);
+            }
+            xw[nl] = carry;
+        }
+        if (xw[nl]) continue;
+        if (L < 8 * (size_t)nl && (xw[nl - 1] >> (8 * (L % 8)))) continue;       /* p521: above 66 bytes */
+        uint8_t xb[66], odd = recid[i] & 1, rxy[132], dok = 0;
+        to_be_len(xb, xw, L);
+        if (ecref_batch_decompress(curve, xb, &odd, 1, rxy, &dok) != ECREF_OK || !dok) continue;
+        inv_mod(rinv, rw, &m);
+        mul_mod(u1, rinv, zw, &m);
+        if (!is_zero(u1, nl)) {                                       /* u1 = -(r^-1 z) */
+            uint64_t t[9];
+            memcpy(t, m.n, 8 * nl);
+            sub_n(t, u1, nl);
+            memcpy(u1, t, 8 * nl);
+        }
+        mul_mod(u2, rinv, sw, &m);
+        /* lincomb(&[(G, u1), (R, u2)]) through the oracle's LinearCombination restatement */
+        uint8_t sc[2 * 66], pts[4 * 66], pk[132], inf = 0;
+        to_be_len(sc, u1, L);
+        to_be_len(sc + L, u2, L);
+        {
+            uint8_t one[66] = {0}, gi = 0;
+            one[L - 1] = 1;
+            if (ecref_batch_mul_base(curve, one, 1, pts, &gi) != ECREF_OK) continue;           /* the generator's affine bytes */
+        }
+        memcpy(pts + 2 * L, rxy, 2 * L);
+        if (ecref_msm(curve, sc, pts, 0, 2, 0, 0, pk, &inf) != ECREF_OK) continue;
+        if (inf) continue;                                            /* VerifyingKey::from_affine rejects the identity */
+        uint8_t v = 0;
+        if (ecref_ecdsa_verify_batch(curve, z + L * i, r + L * i, s + L * i, pk, 1, reject_high_s, &v) != ECREF_OK || !v) continue;
+        memcpy(out_xy + 2 * L * i, pk, 2 * L);
+        ok[i] = 1;
+    }
+    return ECREF_OK;
+}
+
 /* SM2DSA verification (GB/T 32918.2, draft-shen-sm2-ecdsa 5.3) on the prehash — `PrehashVerifier::verify_prehash`,
  * sm2/src/dsa/verifying.rs:138-171: e = the 32-byte digest SM3(ZA || M) reduced mod n (`Scalar::reduce`); r, s the signature
  * halves in [1, n-1] (`Signature` holds NonZeroScalars: sm2/src/dsa.rs); t = r + s mod n, reject t = 0;

@@ -10,6 +10,9 @@ Sources:
                                                MUL_TEST_VECTORS ((k, x, y) with k*G = (x, y))
   {k256,p256,p384,p224,p192,p521}/src/test_vectors/ecdsa.rs   FIPS 186-4 style (d, Qx, Qy, k, m, r, s)
   {k256,p256}/src/test_vectors/field.rs        DBL_TEST_VECTORS (repeated doubling of 1 mod p)
+  k256/src/ecdsa.rs                            RECOVERY_TEST_VECTORS (:190-211: compressed key, message, signature, recovery
+                                               id) and the Ethereum end-to-end example (:233-261: signing key, RLP message
+                                               hashed with Keccak-256, signature, recovery id 0)
   k256/src/schnorr.rs                          BIP340_SIGN_VECTORS (index 0-3: public key, message, valid signature),
                                                BIP340_VERIFY_VECTORS (index 4-14: public key, message, signature,
                                                expected verdict) and the variable-length-message vectors 15-18
@@ -104,6 +107,28 @@ def schnorr_vectors():
     return sorted(out, key=lambda v: v["index"])
 
 
+def recovery_vectors():
+    """Public-key recovery vectors held by k256/src/ecdsa.rs (mod recovery)."""
+    text = open(os.path.join(REF, "k256/src/ecdsa.rs")).read()
+    clean = lambda h: re.sub(r"\s+", "", h).lower()
+    block = text[text.index("const RECOVERY_TEST_VECTORS"):]
+    block = block[: block.index("];")]
+    out = []
+    for body in re.findall(r"RecoveryTestVector\s*\{(.*?)\n            \}", block, re.S):
+        pk = clean(re.search(r'pk:\s*hex!\("([0-9A-Fa-f]+)"\)', body).group(1))
+        msg = re.search(r'msg:\s*b"([^"]*)"', body).group(1)
+        sig = clean(re.search(r'sig:\s*hex!\(\s*"([0-9A-Fa-f\s]+)"', body).group(1))
+        y_odd, x_red = re.search(r"RecoveryId::new\((true|false),\s*(true|false)\)", body).groups()
+        out.append({"pk_sec1": pk, "msg_ascii": msg, "hash": "sha256", "sig": sig,
+                    "recid": (1 if y_odd == "true" else 0) | (2 if x_red == "true" else 0)})
+    eth = text[text.index("fn ethereum_end_to_end_example"):]
+    eth = eth[: eth.index("verify_prehash")]
+    sk, msg, sig = [clean(h) for h in re.findall(r'hex!\(\s*"([0-9A-Fa-f\s]+)"\s*\)', eth)[:3]]
+    recid = int(re.search(r"RecoveryId::from_byte\((\d+)\)", eth).group(1))
+    out.append({"secret_key": sk, "msg_hex": msg, "hash": "keccak256", "sig": sig, "recid": recid})
+    return out
+
+
 def main():
     summary = {}
     for curve in ("k256", "p256", "p384", "p224", "p192", "p521"):
@@ -118,6 +143,8 @@ def main():
         if curve == "k256":
             data["schnorr"] = schnorr_vectors()
             print("k256: %d BIP340 vectors (indices %s)" % (len(data["schnorr"]), [v["index"] for v in data["schnorr"]]))
+            data["recovery"] = recovery_vectors()
+            print("k256: %d public-key recovery vectors" % len(data["recovery"]))
         with open(os.path.join(HERE, "%s.json" % curve), "w") as f:
             json.dump(data, f, indent=1)
             f.write("\n")

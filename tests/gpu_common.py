@@ -181,6 +181,93 @@ def ecdsa_pack(cases):
     return z, r, s, q, exp
 
 
+def recovery_golden():
+    """The reference's public-key recovery vectors (k256/src/ecdsa.rs:190-211 and the Ethereum example :233-261) as
+    (z, r, s, recid, expected affine key bytes) tuples; the digests are SHA-256 resp. Keccak-256 of the messages."""
+    import hashlib
+    c = pyec.K256
+    out = []
+    for v in load_golden("k256")["recovery"]:
+        sig = bytes.fromhex(v["sig"])
+        if v["hash"] == "sha256":
+            z = hashlib.sha256(v["msg_ascii"].encode()).digest()
+            Q = pyec.lift_x(c, int(v["pk_sec1"][2:], 16), int(v["pk_sec1"][:2], 16) & 1)
+        else:
+            z = pyec.keccak256(bytes.fromhex(v["msg_hex"]))
+            Q = pyec.mul(c, int(v["secret_key"], 16), pyec.G(c))
+        out.append((z, sig[:32], sig[32:], v["recid"], pyec.enc_point(c, Q)[0]))
+    return out
+
+
+def recover_cases(c, seed, nvalid=10):
+    """(z, r, s, recid, expected key bytes or None) tuples for public-key recovery: signatures by the big-int model with
+    the recovery id of their nonce point, the other three ids, broken fields, range failures, x-reduced candidates
+    (x(R) = r + n, built from a curve point with n <= x < p where the curve has one: no nonce is known for those, but any
+    (r, s, z) recovers to SOME key), and r values whose candidate x is not on the curve."""
+    import random
+    rng = random.Random(seed)
+    L = c.L
+    G = pyec.G(c)
+    cases = []
+
+    def enc(z, r, s, recid):
+        Q = pyec.ecdsa_recover(c, z, r, s, recid) if r < (1 << (8 * L)) and s < (1 << (8 * L)) else None
+        cases.append((z.to_bytes(L, "big"), r.to_bytes(L, "big"), s.to_bytes(L, "big"), recid,
+                      pyec.enc_point(c, Q)[0] if Q is not None else None))
+        return Q
+
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n)
+        z = rng.randrange(1 << min(8 * L, c.n.bit_length())) if i % 3 else rng.randrange(c.n, min(2 * c.n, 1 << (8 * L)))
+        k = rng.randrange(1, c.n)
+        R = pyec.mul(c, k, G)
+        r, s = pyec.ecdsa_sign(c, d, z, k)
+        if r == 0 or s == 0 or R[0] >= c.n:
+            continue
+        recid = R[1] & 1
+        assert enc(z, r, s, recid) == pyec.mul(c, d, G)
+        enc(z, r, c.n - s, recid ^ 1)                            # (r, -s) recovers the same key from -R
+        enc(z, r, s, recid ^ 1)                                  # another valid-looking key, not d G
+        enc(z, r, s, recid | 2)                                  # x = r + n: almost never below p
+        enc(z ^ 1, r, s, recid)
+        enc(z, r, (s + 1) % c.n or 1, recid)
+        if i < 3:
+            enc(z, r, s, 4 + recid)                              # ids above 3 do not parse
+            enc(z, r, s, 255)
+            enc(z, 0, s, recid)
+            enc(z, r, 0, recid)
+            enc(z, c.n, s, recid)
+            enc(z, r, c.n, recid)
+    # candidates whose x is not on the curve
+    found = 0
+    x = rng.randrange(1, c.n)
+    while found < 3:
+        x += 1
+        if pyec.lift_x(c, x, 0) is None:
+            enc(rng.randrange(c.n), x, rng.randrange(1, c.n), found & 1)
+            found += 1
+    # x-reduced candidates: points with n <= x < p (none on curves with p < n)
+    if c.p > c.n:
+        found, x = 0, c.n
+        while found < 3 and x < c.p and x < c.n + 64:
+            for odd in (0, 1):
+                if pyec.lift_x(c, x, odd) is not None:
+                    Q = enc(rng.randrange(c.n), x - c.n, rng.randrange(1, c.n), 2 | odd) if x > c.n else None
+                    found += Q is not None
+            x += 1
+    return cases
+
+
+def recover_pack(cases, L):
+    z = b"".join(t[0] for t in cases)
+    r = b"".join(t[1] for t in cases)
+    s = b"".join(t[2] for t in cases)
+    recid = np.array([t[3] for t in cases], np.uint8)
+    exp_ok = np.array([0 if t[4] is None else 1 for t in cases], np.uint8)
+    exp_xy = b"".join(t[4] if t[4] is not None else bytes(2 * L) for t in cases)
+    return z, r, s, recid, exp_xy, exp_ok
+
+
 def bip340_challenge(r32, pk32, msg):
     """int(tagged_hash("BIP0340/challenge", r || pk || m)) as 32 big-endian bytes (k256/src/schnorr.rs tagged_hash)."""
     import hashlib

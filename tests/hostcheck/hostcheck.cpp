@@ -492,6 +492,29 @@ int ecdsa_verify(const uint8_t* z, const uint8_t* r, const uint8_t* s, const uin
     return 0;
 }
 
+// public-key recovery: the prepare logic of ecgpu_verify.h, the CPU mirrors of the two scalar multiplications, the finish rule
+template <class C>
+int ecdsa_recover(const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid, size_t n, int reject_high_s,
+                  uint8_t* out_xy, uint8_t* ok_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    static BaseTable<C> table;
+    if (table.w != 8) build_table<C>(table, 8);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], a[N], b[N], x[N], y[N];
+        load_be_wire<C>(zw, z + i * WB);
+        load_be_wire<C>(rw, r + i * WB);
+        load_be_wire<C>(sw, s + i * WB);
+        const bool valid = ecdsa_recover_prepare_words<C>(zw, rw, sw, recid[i], reject_high_s, a, b, cx, cy);
+        const bool finite = sum_affine_x<C>(table, a, b, cx, cy, x, y);
+        const bool ok = valid && finite;
+        for (int j = 0; j < N; j++) { x[j] = ok ? x[j] : 0u; y[j] = ok ? y[j] : 0u; }
+        store_be_wire<C>(out_xy + i * 2 * WB, x);
+        store_be_wire<C>(out_xy + i * 2 * WB + WB, y);
+        ok_out[i] = ok;
+    }
+    return 0;
+}
+
 // mode 0: challenge given (e, r, s, P); mode 1: from wire bytes (x-only key, message, 64-byte signature) — k256 only
 int schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
                    size_t n, uint8_t* ok_out) {
@@ -643,6 +666,11 @@ int hc_ecdsa_verify(int curve, const uint8_t* z, const uint8_t* r, const uint8_t
                     uint8_t* ok) {
     if (curve == 3 || curve == 11) return -1;                    // sm2 / bign signatures are not ECDSA
     DISPATCH(curve, ecdsa_verify, (z, r, s, q, n, reject_high_s, ok))
+}
+int hc_ecdsa_recover(int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid, size_t n, int reject_high_s,
+                     uint8_t* out_xy, uint8_t* ok) {
+    if (curve == 3 || curve == 11 || curve == 4) return -1;      // sm2 / bign: not ECDSA; p224: no decompression
+    DISPATCH(curve, ecdsa_recover, (z, r, s, recid, n, reject_high_s, out_xy, ok))
 }
 int hc_schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
                       size_t n, uint8_t* ok) {

@@ -156,6 +156,16 @@ def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
     return ok
 
 
+def ecdsa_recover(curve, z, r, s, recid, reject_high_s=False):
+    Z, R, S, I = _a(z), _a(r), _a(s), _a(recid)
+    n = I.size
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    ok = np.zeros(n, np.uint8)
+    rc = lib().hc_ecdsa_recover(curve, _p(Z), _p(R), _p(S), _p(I), ctypes.c_size_t(n), int(bool(reject_high_s)), _p(out), _p(ok))
+    assert rc == 0, rc
+    return out, ok
+
+
 def decompress(curve, xs, y_is_odd):
     X, O = _a(xs), _a(y_is_odd)
     n = X.size // L[curve]

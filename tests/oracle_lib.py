@@ -111,6 +111,17 @@ def ecdsa_verify(curve, z, r, s, q_xy, reject_high_s=False):
     return ok
 
 
+def ecdsa_recover(curve, z, r, s, recid, reject_high_s=False):
+    L = FIELD_BYTES[curve]
+    zz, rr, ss, ii = _arr(z), _arr(r), _arr(s), _arr(recid)
+    n = ii.size
+    out = np.zeros(n * 2 * L, np.uint8)
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_ecdsa_recover_batch(curve, _buf(zz), _buf(rr), _buf(ss), _buf(ii), ctypes.c_size_t(n),
+                                         int(bool(reject_high_s)), _buf(out), _buf(ok)))
+    return out, ok
+
+
 def schnorr_verify(e, r, s, p_xy):
     ee, rr, ss, pp = _arr(e), _arr(r), _arr(s), _arr(p_xy)
     n = ee.size // 32

@@ -229,6 +229,67 @@ def ecdsa_verify(c, Q, z, r, s, reject_high_s=False):
     return R is not INF and R[0] % c.n == r
 
 
+def lift_x(c, x, y_is_odd):
+    """The curve point with this x and the requested y parity, or None (x >= p, or x^3 + a x + b is not a square).
+    Needs p = 3 (mod 4) — every curve here except p224."""
+    if x >= c.p or c.p % 4 != 3:
+        return None
+    alpha = (pow(x, 3, c.p) + c.a * x + c.b) % c.p
+    y = pow(alpha, (c.p + 1) // 4, c.p)
+    if y * y % c.p != alpha:
+        return None
+    if (y & 1) != int(bool(y_is_odd)):
+        y = (c.p - y) % c.p
+    return (x, y)
+
+
+def ecdsa_recover(c, z, r, s, recid, reject_high_s=False):
+    """The public key (affine) a signature recovers to under a recovery id byte (bit 0: y(R) odd, bit 1: x(R) = r + n),
+    or None — SEC1 v2 4.1.6 for one candidate, followed by the verification the `ecdsa` crate runs on the result."""
+    if recid > 3 or not (1 <= r < c.n and 1 <= s < c.n):
+        return None
+    x = r + (c.n if recid & 2 else 0)
+    if x >= 1 << (8 * c.L):
+        return None
+    R = lift_x(c, x, recid & 1)
+    if R is None:
+        return None
+    rinv = pow(r, -1, c.n)
+    Q = add(c, mul(c, (-rinv * (z % c.n)) % c.n, G(c)), mul(c, rinv * s % c.n, R))
+    if Q is INF or not ecdsa_verify(c, Q, z, r, s, reject_high_s):
+        return None
+    return Q
+
+
+def keccak256(data):
+    """Keccak-256 (the pre-standard padding 0x01 that Ethereum uses — hashlib's sha3_256 pads with 0x06)."""
+    RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
+          0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
+          0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
+          0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+          0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+    ROT = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+    M = (1 << 64) - 1
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & M if n else v
+    rate = 136
+    msg = bytearray(data) + b"\x01" + bytes((-len(data) - 2) % rate) + b"\x80" if (len(data) + 1) % rate else bytearray(data) + b"\x81"
+    A = [[0] * 5 for _ in range(5)]
+    for off in range(0, len(msg), rate):
+        for i in range(rate // 8):
+            A[i % 5][i // 5] ^= int.from_bytes(msg[off + 8 * i: off + 8 * i + 8], "little")
+        for rc in RC:
+            C = [A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4] for x in range(5)]
+            D = [C[(x - 1) % 5] ^ rol(C[(x + 1) % 5], 1) for x in range(5)]
+            A = [[A[x][y] ^ D[x] for y in range(5)] for x in range(5)]
+            B = [[0] * 5 for _ in range(5)]
+            for x in range(5):
+                for y in range(5):
+                    B[y][(2 * x + 3 * y) % 5] = rol(A[x][y], ROT[x][y])
+            A = [[B[x][y] ^ (~B[(x + 1) % 5][y] & M & B[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+            A[0][0] ^= rc
+    return b"".join(A[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+
+
 # ---- SM2DSA (GB/T 32918.2 / draft-shen-sm2-ecdsa-02 5.2-5.3), the independent model ---------------------------------------
 
 def sm2dsa_sign(c, d, e, k):

@@ -697,6 +697,97 @@ def test_pipelined_host_pointer_calls(eng, curve):
     assert e.value.code == ecgpu.ERR_SCALAR_RANGE
 
 
+# ---- ECDSA public-key recovery (ecgpu_ecdsa_recover_batch) ------------------------------------------------------------------
+def test_ecdsa_recover_reference_vectors(eng):
+    """The reference's recovery vectors (k256/src/ecdsa.rs:190-211 RECOVERY_TEST_VECTORS, :233-261 the Ethereum example)
+    through the C ABI: the stated keys come out; the other parity recovers other keys; error codes for the curves that have
+    no ECDSA recovery; the empty batch."""
+    from gpu_common import recovery_golden, recover_pack
+    ecgpu = ecgpu_module()
+    z, r, s, recid, exp_xy, _ = recover_pack(recovery_golden(), 32)
+    out, ok = eng.ecdsa_recover(ecgpu.K256, z, r, s, recid, reject_high_s=True)
+    assert ok.all() and bytes(out) == exp_xy
+    want, wok = oracle_lib.ecdsa_recover(0, z, r, s, recid ^ 1, True)
+    out2, ok2 = eng.ecdsa_recover(ecgpu.K256, z, r, s, recid ^ 1, reject_high_s=True)
+    assert bytes(ok2) == bytes(wok) and bytes(out2) == bytes(want) and bytes(out2) != exp_xy
+    assert eng.ecdsa_verify(ecgpu.K256, z, r, s, out, reject_high_s=True).all()     # what recover_from_prehash ends with
+    out0, ok0 = eng.ecdsa_recover(ecgpu.K256, b"", b"", b"", b"")
+    assert out0.size == 0 and ok0.size == 0
+    for cid in (pyec.CURVES["sm2"].cid, pyec.CURVES["p224"].cid, pyec.CURVES["bign256"].cid):
+        L = ecgpu.FIELD_BYTES[cid]
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.ecdsa_recover(cid, bytes(L), bytes(L), bytes(L), b"\0")
+        assert e.value.code == ecgpu.ERR_CURVE
+
+
+@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c not in ("p224", "sm2")])
+def test_ecdsa_recover_vs_oracle_and_model(eng, curve):
+    """Recovery ids of the nonce point and the other three, disturbed fields, range failures, ids above 3, candidates off
+    the curve, x-reduced candidates, both high-S policies: key for key the oracle's restatement of `recover_from_prehash`
+    and the big-integer model's; then 600 signatures made with the engine itself (every fifth with the wrong parity)."""
+    from gpu_common import recover_cases, recover_pack
+    c = pyec.CURVES[curve]
+    L = c.L
+    cases = recover_cases(c, 0x4EC2 + c.cid, nvalid=12)
+    z, r, s, recid, exp_xy, exp_ok = recover_pack(cases, L)
+    out, ok = eng.ecdsa_recover(c.cid, z, r, s, recid)
+    assert bytes(ok) == bytes(exp_ok) and bytes(out) == exp_xy
+    for high in (False, True):
+        want, wok = oracle_lib.ecdsa_recover(c.cid, z, r, s, recid, high)
+        got, gok = eng.ecdsa_recover(c.cid, z, r, s, recid, reject_high_s=high)
+        assert bytes(gok) == bytes(wok) and bytes(got) == bytes(want)
+    assert 0 < int(gok.sum()) < int(ok.sum()) < len(cases)
+    n = 600
+    ds = rand_scalars(c.cid, n, 0xD4 + c.cid)
+    ks = rand_scalars(c.cid, n, 0xD5 + c.cid)
+    zs = np.random.default_rng(0xEC4EC + c.cid).integers(0, 256, n * L, dtype=np.uint8)
+    if c.n.bit_length() < 8 * L:
+        zs.reshape(n, L)[:, 0] = 0                                  # p521: digests below 2^520
+    Q, _ = eng.mul_by_generator(c.cid, ds)
+    R, _ = eng.mul_by_generator(c.cid, ks)
+    rr, ss, ids = bytearray(), bytearray(), bytearray()
+    for i in range(n):
+        d = int.from_bytes(bytes(ds[i * L:(i + 1) * L]), "big")
+        k = int.from_bytes(bytes(ks[i * L:(i + 1) * L]), "big") or 1
+        zi = int.from_bytes(bytes(zs[i * L:(i + 1) * L]), "big")
+        x = int.from_bytes(bytes(R[2 * L * i: 2 * L * i + L]), "big")
+        ri = x % c.n
+        si = pow(k, -1, c.n) * (zi + ri * d) % c.n
+        rr += ri.to_bytes(L, "big"); ss += si.to_bytes(L, "big")
+        ids.append((int(R[2 * L * i + 2 * L - 1] & 1) ^ (1 if i % 5 == 4 else 0)) | (2 if x >= c.n else 0))
+    got, gok = eng.ecdsa_recover(c.cid, zs, bytes(rr), bytes(ss), bytes(ids))
+    want, wok = oracle_lib.ecdsa_recover(c.cid, zs, bytes(rr), bytes(ss), bytes(ids))
+    assert bytes(gok) == bytes(wok) and bytes(got) == bytes(want)
+    good = np.ones(n, bool); good[4::5] = False
+    Qr, gr = np.asarray(Q).reshape(n, 2 * L), np.asarray(got).reshape(n, 2 * L)
+    nonzero = np.array([any(ss[i * L:(i + 1) * L]) and any(rr[i * L:(i + 1) * L]) for i in range(n)])
+    assert (gr[good & nonzero] == Qr[good & nonzero]).all() and not (gr[~good] == Qr[~good]).all(axis=1).any()
+
+
+def test_ecdsa_recover_device_resident_2p20(eng):
+    """2^20 k256 signatures, device-resident through ecgpu_ecdsa_recover_batch_dev: the corner-case set tiled over the batch
+    (every chunk of the kernels sees every case) equals the oracle's keys and verdicts, tiled the same way."""
+    from gpu_common import recover_cases, recover_pack
+    c = pyec.CURVES["k256"]
+    L, n = c.L, 1 << 20
+    cases = recover_cases(c, 0x4EC3, nvalid=12)
+    z, r, s, recid, exp_xy, exp_ok = recover_pack(cases, L)
+    m = len(cases)
+    def tile(b, unit):
+        a = np.frombuffer(bytes(b), np.uint8).reshape(-1, unit)
+        return np.ascontiguousarray(np.tile(a, ((n + m - 1) // m, 1))[:n]).reshape(-1)
+    Z, R, S, I = tile(z, L), tile(r, L), tile(s, L), tile(recid, 1)
+    d_z, d_r, d_s, d_i = eng.to_device(Z), eng.to_device(R), eng.to_device(S), eng.to_device(I)
+    d_o, d_ok = eng.dev_alloc(n * 2 * L), eng.dev_alloc(n + 16)
+    eng.ecdsa_recover_dev(c.cid, d_z, d_r, d_s, d_i, n, True, d_o, d_ok)
+    out, ok = eng.to_host(d_o), eng.to_host(d_ok, n)
+    want, wok = oracle_lib.ecdsa_recover(c.cid, z, r, s, recid, True)
+    assert bytes(ok) == bytes(tile(wok, 1)) and bytes(out) == bytes(tile(want, 2 * L))
+    assert 0 < int(wok.sum()) < m
+    for b in (d_z, d_r, d_s, d_i, d_o, d_ok):
+        b.free()
+
+
 def test_pipelined_host_pointer_calls_other_entry_points(eng):
     """ECDSA / Schnorr verification, ECDH, decompression and a*G + b*P above the pipeline threshold: the big call must
     return exactly what two calls on the halves (both below the threshold, i.e. the serial path) return, and the known
@@ -716,6 +807,12 @@ def test_pipelined_host_pointer_calls_other_entry_points(eng):
     assert bytes(got) == bytes(np.tile(exp, (n + len(exp) - 1) // len(exp))[:n])
     assert bytes(got) == bytes(cat(eng.ecdsa_verify(c.cid, Z[: h * L], R[: h * L], S[: h * L], Q[: h * 2 * L]),
                                    eng.ecdsa_verify(c.cid, Z[h * L:], R[h * L:], S[h * L:], Q[h * 2 * L:])))
+    # public-key recovery: the corner-case set, tiled (keys and verdicts)
+    from gpu_common import recover_cases, recover_pack
+    rz, rr_, rs, rid, rxy, rok = recover_pack(recover_cases(c, 0xE2), L)
+    RZ, RR, RS, RI = tile(rz, L), tile(rr_, L), tile(rs, L), tile(bytes(rid), 1)
+    gxy, gok = eng.ecdsa_recover(c.cid, RZ, RR, RS, RI)
+    assert bytes(gok) == bytes(tile(bytes(rok), 1)) and bytes(gxy) == bytes(tile(rxy, 2 * L))
     # BIP340 from wire bytes: the 15 vectors with 32-byte messages, tiled
     vec = [v for v in load_golden("k256")["schnorr"] if len(v["message"]) == 64]
     pk_of = lambda v: bytes.fromhex(v["public_key"]) if "public_key" in v else bytes(eng.mul_by_generator(c.cid, bytes.fromhex(v["secret_key"]))[0][:32])

@@ -361,6 +361,27 @@ def test_ecdsa_verify_logic_on_cpu(oracle, curve):
         assert hc.ecdsa_verify(c.cid, z, r, s, q).all()
 
 
+@pytest.mark.parametrize("curve", [c for c in CURVES if c not in ("sm2", "p224")])
+def test_ecdsa_recover_logic_on_cpu(oracle, curve):
+    """k_ecdsa_recover_prepare / _finish (`ecdsa_recover_prepare_words`) around the CPU mirrors of the two scalar
+    multiplications: key for key and verdict for verdict the oracle's `recover_from_prehash` restatement — which, unlike
+    the device logic, runs the closing `verify_prehash` in full —, both high-S policies; k256 also on the reference's
+    recovery vectors."""
+    from gpu_common import recover_cases, recover_pack, recovery_golden
+    c = pyec.CURVES[curve]
+    z, r, s, recid, exp_xy, exp_ok = recover_pack(recover_cases(c, 0x4EC1 + c.cid, nvalid=4), c.L)
+    for high in (False, True):
+        out, ok = hc.ecdsa_recover(c.cid, z, r, s, recid, high)
+        want, wok = oracle.ecdsa_recover(c.cid, z, r, s, recid, high)
+        assert bytes(ok) == bytes(wok) and bytes(out) == bytes(want)
+        if not high:
+            assert bytes(ok) == bytes(exp_ok) and bytes(out) == exp_xy
+    if curve == "k256":
+        z, r, s, recid, exp_xy, _ = recover_pack(recovery_golden(), 32)
+        out, ok = hc.ecdsa_recover(0, z, r, s, recid, True)
+        assert ok.all() and bytes(out) == exp_xy
+
+
 def test_sm2dsa_verify_logic_on_cpu(oracle):
     """k_sm2dsa_prepare / k_sm2dsa_finish on the CPU: the reference's SM2DSA vector, model-made signatures, broken ones."""
     from gpu_common import ecdsa_pack, sm2dsa_cases

@@ -130,6 +130,47 @@ def test_wycheproof_ecdsa_vectors(oracle, name):
         assert pyec.ecdsa_verify(c, Q, z, r, s, p["reject_high_s"]) == bool(p["expect"][i])
 
 
+def test_ecdsa_recover_reference_vectors(oracle):
+    """ecref_ecdsa_recover_batch on the reference's own recovery vectors: RECOVERY_TEST_VECTORS (k256/src/ecdsa.rs:190-211,
+    SHA-256 digests, recovery ids 0 and 1, keys given SEC1-compressed) and the Ethereum example (:233-261: Keccak-256 digest,
+    the key of the stated signing key); a flipped parity bit recovers a different key, a flipped digest bit another one."""
+    from gpu_common import recovery_golden, recover_pack
+    g = recovery_golden()
+    assert len(g) == 3
+    z, r, s, recid, exp_xy, _ = recover_pack(g, 32)
+    out, ok = oracle.ecdsa_recover(0, z, r, s, recid, reject_high_s=True)
+    assert ok.all() and bytes(out) == exp_xy
+    out2, ok2 = oracle.ecdsa_recover(0, z, r, s, recid ^ 1, reject_high_s=True)
+    assert ok2.all() and all(bytes(out2[64 * i: 64 * i + 64]) != exp_xy[64 * i: 64 * i + 64] for i in range(3))
+    zb = bytearray(z); zb[31] ^= 1
+    out3, ok3 = oracle.ecdsa_recover(0, bytes(zb), r, s, recid, reject_high_s=True)
+    assert ok3[0] and bytes(out3[:64]) != exp_xy[:64] and bytes(out3[64:]) == exp_xy[64:]
+    # the recovered keys verify, as `recover_from_prehash` itself checks
+    assert oracle.ecdsa_verify(0, z, r, s, out, reject_high_s=True).all()
+
+
+@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c not in ("p224", "sm2")])
+def test_ecdsa_recover_vs_model(oracle, curve):
+    """ecref_ecdsa_recover_batch against the big-integer model: signatures with the recovery id of their nonce point, the
+    other ids, disturbed fields, range failures, ids above 3, candidates off the curve, x-reduced candidates (x = r + n);
+    with the k256 high-S rule the keys of high-S signatures are withheld."""
+    from gpu_common import recover_cases, recover_pack
+    c = pyec.CURVES[curve]
+    cases = recover_cases(c, 0x4EC0 + c.cid, nvalid=6)
+    z, r, s, recid, exp_xy, exp_ok = recover_pack(cases, c.L)
+    out, ok = oracle.ecdsa_recover(c.cid, z, r, s, recid)
+    assert bytes(ok) == bytes(exp_ok) and bytes(out) == exp_xy
+    assert 0 < int(ok.sum()) < len(cases)
+    assert any(t[3] & 2 and t[4] is not None for t in cases) == (c.p > c.n)
+    out_h, ok_h = oracle.ecdsa_recover(c.cid, z, r, s, recid, reject_high_s=True)
+    half = (c.n - 1) // 2
+    low = np.array([int.from_bytes(t[2], "big") <= half for t in cases])
+    assert bytes(ok_h) == bytes((exp_ok & low).astype(np.uint8)) and 0 < int(ok_h.sum()) < int(ok.sum())
+    for i in range(len(cases)):
+        want = exp_xy[2 * c.L * i: 2 * c.L * (i + 1)] if ok_h[i] else bytes(2 * c.L)
+        assert bytes(out_h[2 * c.L * i: 2 * c.L * (i + 1)]) == want
+
+
 def test_sm2dsa_verify_reference_vector_and_model(oracle):
     """ecref_sm2dsa_verify_batch (sm2/src/dsa/verifying.rs:138-171): accepts the reference's own test vector
     (sm2/tests/sm2dsa.rs:16-35, with e = SM3(ZA || M) computed by hashlib), and agrees with the big-int model on signatures
