@@ -797,6 +797,12 @@ struct Field {
             r = mul(sqr_n(r, 32), a);
             r = mul(sqr_n(r, 96), a);
             r = sqr_n(r, 94);
+        } else if constexpr (C::ID == CURVE_P521) {
+            // (p + 1) / 4 = 2^519: squarings only.  (Also keeps the window table — a dynamically indexed private array,
+            // i.e. scratch memory — out of the 20-limb kernels: k_ecdsa_recover_prepare<P521Params> with the table AND
+            // AGPR-parked registers computed wrong scalars on gfx950 while the host build of the same source was right;
+            // profiles/r02/diag_recover_p521.txt.)
+            r = sqr_n(a, 519);
         } else {
             M1 tab[16];
             tab[0] = one();

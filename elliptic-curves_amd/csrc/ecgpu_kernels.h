@@ -81,10 +81,18 @@ __device__ __forceinline__ void load_wire(uint32_t* words, const uint8_t* bytes)
     } else if constexpr (WB == 4 * N) {
         load_be_vec<N>(words, bytes);
     } else {
+        // 4 (N - 1) + 2 bytes (p521: 66).  Records are 2-byte aligned (WB is even, the bases are 16-byte aligned), so the
+        // record is ONE halfword — the top word — followed by N - 1 big-endian words, read as explicit 16-bit pieces.
+        // The first version read byte by byte; the compiler merges such loads into wide ones and extracts the bytes with
+        // perm / SDWA sequences, and for some kernel shapes (k_selftest_field<P521Params>, then
+        // k_ecdsa_recover_prepare<P521Params>: profiles/r02/diag_recover_p521.txt) the extracted operand came out with wrong
+        // bits on gfx950 while the host build of the same source was right.  Whole-halfword pieces leave nothing to extract.
+        static_assert(WB == 4 * (N - 1) + 2, "wire records are whole words or whole words + 2 bytes");
+        const uint16_t* h = reinterpret_cast<const uint16_t*>(bytes);
+        const uint32_t top = h[0];
+        words[N - 1] = ((top & 0xffu) << 8) | (top >> 8);
 #pragma unroll
-        for (int i = 0; i < N; i++) words[i] = 0;
-#pragma unroll
-        for (int j = 0; j < WB; j++) words[(WB - 1 - j) / 4] |= (uint32_t)bytes[j] << (8 * ((WB - 1 - j) % 4));
+        for (int m = 0; m < N - 1; m++) words[N - 2 - m] = bswap32((uint32_t)h[2 * m + 1] | ((uint32_t)h[2 * m + 2] << 16));
     }
 }
 template <class C>
@@ -95,8 +103,16 @@ __device__ __forceinline__ void store_wire(uint8_t* bytes, const uint32_t* words
     } else if constexpr (WB == 4 * N) {
         store_be_vec<N>(bytes, words);
     } else {
+        static_assert(WB == 4 * (N - 1) + 2, "wire records are whole words or whole words + 2 bytes");
+        uint16_t* h = reinterpret_cast<uint16_t*>(bytes);               // see load_wire
+        const uint32_t top = words[N - 1];
+        h[0] = (uint16_t)(((top & 0xffu) << 8) | ((top >> 8) & 0xffu));
 #pragma unroll
-        for (int j = 0; j < WB; j++) bytes[j] = (uint8_t)(words[(WB - 1 - j) / 4] >> (8 * ((WB - 1 - j) % 4)));
+        for (int m = 0; m < N - 1; m++) {
+            const uint32_t d = bswap32(words[N - 2 - m]);
+            h[2 * m + 1] = (uint16_t)d;
+            h[2 * m + 2] = (uint16_t)(d >> 16);
+        }
     }
 }
 template <class C>
