@@ -59,5 +59,14 @@ for name in ("k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp
         v = e.ecdsa_verify(c.cid, z, r, s_, got[: 8192 * 2 * L])
         res = par(lambda lo, hi: oracle_lib.ecdsa_verify(c.cid, z[lo * L: hi * L], r[lo * L: hi * L], s_[lo * L: hi * L], got[lo * 2 * L: hi * 2 * L]), 8192, L)
         ok4 = bytes(v) == b"".join(bytes(x) for x in res)
-    print("%s: fixed 2^17 %s, var 2^15 %s, 64 msm(512) %s, msm 2^18 %s, ecdsa 8192 %s  (%.1f s)" % (name, ok1, ok2, ok3, ok5, ok4, time.time() - t0), flush=True)
+    ok6 = None
+    if name not in ("sm2", "bign256", "p224"):
+        # public-key recovery: random (z, r, s, id) — about half of the r values are x coordinates of curve points, so about
+        # half of the elements recover to some key — keys and verdicts against the oracle
+        zb = np.frombuffer(bytes(z), np.uint8)[:: L][:8192]
+        ids = np.where(zb & 0x70, zb & 1, zb & 3).astype(np.uint8)           # one in eight also tries the x-reduced ids
+        gk, gv = e.ecdsa_recover(c.cid, z, r, s_, ids)
+        res = par(lambda lo, hi: oracle_lib.ecdsa_recover(c.cid, z[lo * L: hi * L], r[lo * L: hi * L], s_[lo * L: hi * L], ids[lo:hi]), 8192, L)
+        ok6 = bytes(gk) == b"".join(bytes(x[0]) for x in res) and bytes(gv) == b"".join(bytes(x[1]) for x in res) and 3000 < int(gv.sum()) < 4800
+    print("%s: fixed 2^17 %s, var 2^15 %s, 64 msm(512) %s, msm 2^18 %s, ecdsa 8192 %s, recover 8192 %s  (%.1f s)" % (name, ok1, ok2, ok3, ok5, ok4, ok6, time.time() - t0), flush=True)
 PY
