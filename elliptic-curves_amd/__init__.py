@@ -53,6 +53,8 @@ ABI_SYMBOLS = [
     "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",
     "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev", "ecgpu_set_async", "ecgpu_synchronize",
     "ecgpu_ecdsa_recover_batch", "ecgpu_ecdsa_recover_batch_dev",
+    "ecgpu_sm2dsa_verify_msg_batch", "ecgpu_sm2dsa_verify_msg_batch_dev",
+    "ecgpu_ecdsa_verify_msg_batch", "ecgpu_ecdsa_verify_msg_batch_dev",
 ]
 
 
@@ -373,6 +375,31 @@ class Engine:
         _need("e", ee, n * 32); _need("r", rr, n * 32); _need("s", ss, n * 32); _need("q_xy", qq, n * 64)
         ok = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_sm2dsa_verify_batch(self._ctx, _hp(ee), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
+    def ecdsa_verify_msg(self, curve, q_xy, msgs, msg_len, sigs, reject_high_s=False):
+        """Batch ECDSA verification of messages: keys n*2L, messages n*msg_len, signatures n*2L (r || s); the curve's digest
+        (SHA-256 / 384 / 224 / 512) and bits2field run on the device."""
+        L = _field_bytes(curve)
+        qq, sg = _host(q_xy), _host(sigs)
+        mm = _host(msgs) if msg_len else None
+        n = qq.size // (2 * L)
+        _need("q_xy", qq, n * 2 * L); _need("sigs", sg, n * 2 * L); _need("msgs", mm, n * msg_len)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_ecdsa_verify_msg_batch(self._ctx, curve, _hp(qq), _hp(mm), ctypes.c_size_t(msg_len), _hp(sg),
+                                                         ctypes.c_size_t(n), int(bool(reject_high_s)), _hp(ok)))
+        return ok
+
+    def sm2dsa_verify_msg(self, distid, q_xy, msgs, msg_len, sigs):
+        """Batch SM2DSA verification of messages (sm2): one distinguishing identifier, keys n*64, messages n*msg_len, signatures
+        n*64 (r || s); Z and e = SM3(Z || M) are computed on the device."""
+        dd, qq, sg = _host(distid) if len(distid) else None, _host(q_xy), _host(sigs)
+        mm = _host(msgs) if msg_len else None
+        n = qq.size // 64
+        _need("q_xy", qq, n * 64); _need("sigs", sg, n * 64); _need("msgs", mm, n * msg_len)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_sm2dsa_verify_msg_batch(self._ctx, _hp(dd), ctypes.c_size_t(len(distid)), _hp(qq), _hp(mm),
+                                                          ctypes.c_size_t(msg_len), _hp(sg), ctypes.c_size_t(n), _hp(ok)))
         return ok
 
     def ecdh(self, curve, scalars, points_xy):

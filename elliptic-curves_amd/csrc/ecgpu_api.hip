@@ -50,7 +50,7 @@ struct ecgpu_ctx {
     int want_w[12] = {26, 24, 20, 24, 24, 24, 20, 24, 20, 24, 20, 24};
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
-    DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r;   // signature verification scratch
+    DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r, ec_e, ec_s, ec_id;   // signature verification scratch
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
     std::vector<std::pair<std::string, std::pair<int, int>>> spans;   // event pairs of the last call not yet turned into `timing`
@@ -715,7 +715,7 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3,
                       &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
-                      &ctx->ec_inf, &ctx->ec_r})
+                      &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
     for (auto& t : ctx->table)
         if (t.d) (void)hipFree(t.d);
@@ -978,6 +978,27 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, con
     });
 }
 
+int ecgpu_ecdsa_verify_msg_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_q_xy, const void* d_msgs, size_t msg_len,
+                                     const void* d_sigs, size_t n, int reject_high_s, void* d_ok) {
+    // Verifier::verify(msg, sig): the curve's digest on the device, z = bits2field(digest), then the prehash path.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_q_xy || !d_sigs || !d_ok || (msg_len && !d_msgs) || !aligned16(d_q_xy) || !aligned16(d_sigs))) return arg_error(ctx, __func__);
+    if (curve == ECGPU_SM2 || curve == ECGPU_BIGN256 || curve == ECGPU_P192)   // not ECDSA curves; p192 has no `DigestAlgorithm` (p192/src/ecdsa.rs)
+        return curve_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        using C = decltype(c);
+        if (n == 0) return (int)ECGPU_OK;
+        const size_t L = WireBytes<C>::value;
+        int rc;
+        if ((rc = ensure(ctx, ctx->ec_e, n * L + 16)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_r, n * L + 16)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->ec_s, n * L + 16)) != ECGPU_OK) return rc;
+        launch_ecdsa_hash_msg<C>(ctx->stream, (const uint8_t*)d_msgs, msg_len, (const uint8_t*)d_sigs, n, (uint8_t*)ctx->ec_e.p,
+                                 (uint8_t*)ctx->ec_r.p, (uint8_t*)ctx->ec_s.p);
+        return verify_dev<C>(ctx, VERIFY_ECDSA, ctx->ec_e.p, ctx->ec_r.p, ctx->ec_s.p, d_q_xy, n, reject_high_s, d_ok);
+    });
+}
+
 int ecgpu_ecdsa_recover_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, const void* d_r, const void* d_s,
                                   const void* d_recid, size_t n, int reject_high_s, void* d_out_xy, void* d_ok) {
     // per element: R = decompress(r or r + n, parity), key = -(z/r) G + (s/r) R.  See ecgpu_ecdsa.h / ecgpu_verify.h.
@@ -1000,6 +1021,23 @@ int ecgpu_sm2dsa_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d
               !aligned16(d_q_xy)))
         return arg_error(ctx, __func__);
     return verify_dev<Sm2Params>(ctx, VERIFY_SM2DSA, d_e, d_r, d_s, d_q_xy, n, 0, d_ok);
+}
+
+int ecgpu_sm2dsa_verify_msg_batch_dev(ecgpu_ctx* ctx, const void* d_distid, size_t distid_len, const void* d_q_xy, const void* d_msgs,
+                                      size_t msg_len, const void* d_sigs, size_t n, void* d_ok) {
+    // VerifyingKey::new(distid, Q)?.verify(msg, sig): Z and e = SM3(Z || M) on the device, then the prehash path.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (distid_len > 8191 || (n && (!d_q_xy || !d_sigs || !d_ok || (msg_len && !d_msgs) || (distid_len && !d_distid) || !aligned16(d_q_xy) ||
+                                    !aligned16(d_sigs))))
+        return arg_error(ctx, __func__);
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->ec_e, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_r, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ec_s, n * 32)) != ECGPU_OK) return rc;
+    launch_sm2dsa_hash_msg(ctx->stream, (const uint8_t*)d_distid, distid_len, (const uint8_t*)d_q_xy, (const uint8_t*)d_msgs, msg_len,
+                           (const uint8_t*)d_sigs, n, (uint8_t*)ctx->ec_e.p, (uint8_t*)ctx->ec_r.p, (uint8_t*)ctx->ec_s.p);
+    return verify_dev<Sm2Params>(ctx, VERIFY_SM2DSA, ctx->ec_e.p, ctx->ec_r.p, ctx->ec_s.p, d_q_xy, n, 0, d_ok);
 }
 
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_p_xy,
@@ -1240,6 +1278,31 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
     return download(ctx, ok, ctx->out1, n);
 }
 
+int ecgpu_ecdsa_verify_msg_batch(ecgpu_ctx* ctx, int curve, const uint8_t* q_xy, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
+                                 size_t n, int reject_high_s, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!q_xy || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{q_xy, &ctx->in1, 2 * L}, {msg_len ? msgs : nullptr, &ctx->in0, msg_len}, {sigs, &ctx->in3, 2 * L}},
+                         {{ok, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_ecdsa_verify_msg_batch_dev(ctx, curve, (uint8_t*)ctx->in1.p + off * 2 * L,
+                                                                     msg_len ? (uint8_t*)ctx->in0.p + off * msg_len : nullptr, msg_len,
+                                                                     (uint8_t*)ctx->in3.p + off * 2 * L, m, reject_high_s, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in0, msgs, n * msg_len)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, sigs, n * 2 * L)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_ecdsa_verify_msg_batch_dev(ctx, curve, ctx->in1.p, ctx->in0.p, msg_len, ctx->in3.p, n, reject_high_s, ctx->out1.p)) !=
+        ECGPU_OK)
+        return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
 int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s,
                               const uint8_t* recid, size_t n, int reject_high_s, uint8_t* out_xy, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
@@ -1288,6 +1351,30 @@ int ecgpu_sm2dsa_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r
     if ((rc = upload(ctx, ctx->in1, q_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
     if ((rc = ecgpu_sm2dsa_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in2.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK) return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_sm2dsa_verify_msg_batch(ecgpu_ctx* ctx, const uint8_t* distid, size_t distid_len, const uint8_t* q_xy, const uint8_t* msgs,
+                                  size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (distid_len > 8191 || (distid_len && !distid) || (n && (!q_xy || !sigs || !ok || (msg_len && !msgs)))) return arg_error(ctx, __func__);
+    int rc;
+    if ((rc = upload(ctx, ctx->ec_id, distid, distid_len)) != ECGPU_OK) return rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{q_xy, &ctx->in1, 64}, {msg_len ? msgs : nullptr, &ctx->in0, msg_len}, {sigs, &ctx->in3, 64}},
+                         {{ok, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_sm2dsa_verify_msg_batch_dev(ctx, ctx->ec_id.p, distid_len, (uint8_t*)ctx->in1.p + off * 64,
+                                                                      msg_len ? (uint8_t*)ctx->in0.p + off * msg_len : nullptr, msg_len,
+                                                                      (uint8_t*)ctx->in3.p + off * 64, m, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 64)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in0, msgs, n * msg_len)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, sigs, n * 64)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_sm2dsa_verify_msg_batch_dev(ctx, ctx->ec_id.p, distid_len, ctx->in1.p, ctx->in0.p, msg_len, ctx->in3.p, n, ctx->out1.p)) !=
+        ECGPU_OK)
+        return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

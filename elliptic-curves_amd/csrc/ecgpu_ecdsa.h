@@ -14,6 +14,8 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_scalar.h"
 #include "ecgpu_sha256.h"
+#include "ecgpu_hash.h"
+#include "ecgpu_sm3.h"
 #include "ecgpu_verify.h"
 
 namespace ecgpu {
@@ -60,6 +62,39 @@ k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_i
     load_wire<C>(rw, r + i * WB);
     const bool eq = ecdsa_finish_words<C>(x, rw);
     ok_out[i] = (valid[i] && !r_inf[i] && eq) ? 1 : 0;
+}
+
+// ECDSA verification of MESSAGES — `Verifier::verify(msg, &signature)` of `ecdsa::VerifyingKey<C>`: the curve's digest
+// (`DigestAlgorithm`, EcdsaDigest<C> in ecgpu_hash.h) on the device, z = bits2field(digest) (ecdsa `hazmat::bits2field`: the
+// leftmost L bytes, left-padded with zeros when the digest is shorter: p521 with SHA-512), r and s split out of the 2L-byte
+// signatures; k_ecdsa_prepare and the rest as for the prehash entry point.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_ecdsa_hash_msg(const uint8_t* __restrict__ msgs, size_t msg_len, const uint8_t* __restrict__ sigs, size_t n,
+                 uint8_t* __restrict__ z_out, uint8_t* __restrict__ r_out, uint8_t* __restrict__ s_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value, D = EcdsaDigest<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if constexpr (D != 0) {
+        uint8_t digest[D];
+        const HashPiece one[1] = {{msgs + i * msg_len, msg_len}};
+        sha2_pieces<D, 1>(digest, one);
+        uint32_t zw[N];
+#pragma unroll
+        for (int j = 0; j < N; j++) zw[j] = 0;
+        constexpr int TAKE = D < WB ? D : WB;                       // digest bytes used: the leftmost TAKE
+#pragma unroll
+        for (int j = 0; j < TAKE; j++) {
+            const int pos = TAKE - 1 - j;                           // significance of digest byte j within the integer
+            zw[pos / 4] |= (uint32_t)digest[j] << (8 * (pos % 4));
+        }
+        store_wire<C>(z_out + i * WB, zw);
+        uint32_t w[N];
+        load_wire<C>(w, sigs + i * (2 * WB));
+        store_wire<C>(r_out + i * WB, w);
+        load_wire<C>(w, sigs + i * (2 * WB) + WB);
+        store_wire<C>(s_out + i * WB, w);
+    }
 }
 
 // ---- ECDSA public-key recovery: ecdsa 0.17.0 `VerifyingKey::recover_from_prehash` (see ecgpu_verify.h) -----------------------
@@ -138,6 +173,28 @@ k_sm2dsa_finish(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r_xy,
     load_wire<C>(x, r_xy + i * (2 * WB));
     load_wire<C>(rw, r + i * WB);
     ok_out[i] = (valid[i] && sm2dsa_finish_words<C>(ew, x, r_inf[i] != 0, rw)) ? 1 : 0;
+}
+
+// SM2DSA verification of MESSAGES — `VerifyingKey::new(distid, Q)?.verify(msg, sig)`: the identity hash
+// Z = SM3(ENTL || ID || a || b || xG || yG || xA || yA) (`hash_z`, sm2/src/distid.rs:21-44) and e = SM3(Z || M) (`hash_msg`,
+// sm2/src/dsa/verifying.rs:126-130) on the device (ecgpu_sm3.h); r and s are split out of the 64-byte signatures, and the
+// prehash kernels above do the rest.  A key with a coordinate >= p hashes as given and is rejected by k_sm2dsa_prepare.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_sm2dsa_hash_msg(const uint8_t* __restrict__ distid, size_t distid_len, const uint8_t* __restrict__ q_xy,
+                  const uint8_t* __restrict__ msgs, size_t msg_len, const uint8_t* __restrict__ sigs, size_t n,
+                  uint8_t* __restrict__ e_out, uint8_t* __restrict__ r_out, uint8_t* __restrict__ s_out) {
+    constexpr int N = C::N;
+    static_assert(N == 8, "SM2DSA is defined over the 256-bit sm2 curve");
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[N], sw[N], ew[N];
+    load_be_vec<N>(rw, sigs + i * 64);
+    load_be_vec<N>(sw, sigs + i * 64 + 32);
+    Sm3::sm2_message_hash<C>(ew, distid, distid_len, q_xy + i * 64, msgs + i * msg_len, msg_len);
+    store_be_vec<N>(e_out + i * 32, ew);
+    store_be_vec<N>(r_out + i * 32, rw);
+    store_be_vec<N>(s_out + i * 32, sw);
 }
 
 // ---- Schnorr (BIP340) verification: k256/src/schnorr/verifying.rs:76-99 ---------------------------------------------

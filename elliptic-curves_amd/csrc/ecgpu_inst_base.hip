@@ -103,6 +103,10 @@ template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy,
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);
 }
 
+template <> void launch_ecdsa_hash_msg<CurveT>(hipStream_t s, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n,
+                                               uint8_t* z_out, uint8_t* r_out, uint8_t* s_out) {
+    hipLaunchKernelGGL(k_ecdsa_hash_msg<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, msgs, msg_len, sigs, n, z_out, r_out, s_out);
+}
 template <> void launch_ecdsa_recover_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                                       const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
                                                       uint8_t* q_out, uint8_t* valid) {

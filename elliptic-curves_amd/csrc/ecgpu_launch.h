@@ -51,6 +51,8 @@ template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const
 template <class C> void launch_proj_sum(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp);
 template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
                                              size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid);
+template <class C> void launch_ecdsa_hash_msg(hipStream_t s, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* z_out,
+                                              uint8_t* r_out, uint8_t* s_out);
 template <class C> void launch_ecdsa_recover_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                                      const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
                                                      uint8_t* q_out, uint8_t* valid);
@@ -97,6 +99,8 @@ template <class C> void launch_msm_finish(const MsmPlan& p, hipStream_t s, const
 // ---- curve-independent ----
 void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
                                 size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* r_out, uint8_t* valid);
+void launch_sm2dsa_hash_msg(hipStream_t s, const uint8_t* distid, size_t distid_len, const uint8_t* q_xy, const uint8_t* msgs,
+                            size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* e_out, uint8_t* r_out, uint8_t* s_out);
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status);
 void launch_valu_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
 void launch_isa_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);

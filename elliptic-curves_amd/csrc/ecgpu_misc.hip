@@ -193,6 +193,12 @@ void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_
                        msg_len, sigs, n, a, b, q_out, r_out, valid);
 }
 
+void launch_sm2dsa_hash_msg(hipStream_t s, const uint8_t* distid, size_t distid_len, const uint8_t* q_xy, const uint8_t* msgs,
+                            size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* e_out, uint8_t* r_out, uint8_t* s_out) {
+    hipLaunchKernelGGL(k_sm2dsa_hash_msg<Sm2Params>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, distid, distid_len,
+                       q_xy, msgs, msg_len, sigs, n, e_out, r_out, s_out);
+}
+
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status) {
     hipLaunchKernelGGL(k_k256_glv, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, scalars, n, r1, r2, status);
 }

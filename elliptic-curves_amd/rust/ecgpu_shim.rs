@@ -249,6 +249,21 @@ pub mod gpu {
         Some(ok.into_iter().map(|b| b != 0).collect())
     }
 
+    /// Batch form of `sm2::dsa::VerifyingKey::new(distid, pk)?.verify(msg, &sig)` for signers that share one distinguishing
+    /// identifier and messages of one length (sm2/src/distid.rs:21-44 `hash_z`, sm2/src/dsa/verifying.rs:126-171): the two SM3
+    /// hashes run on the device.  `keys` = affine x || y (64 bytes each), `sigs` = r || s (64 bytes each).
+    pub fn sm2dsa_batch_verify(distid: &[u8], keys: &[[u8; 64]], msgs: &[u8], msg_len: usize, sigs: &[[u8; 64]]) -> Option<Vec<bool>> {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let n = keys.len();
+        assert!(sigs.len() == n && msgs.len() == n * msg_len && distid.len() <= 8191);
+        let mut ok = vec![0u8; n];
+        check(unsafe {
+            ecgpu_sm2dsa_verify_msg_batch(eng.0, distid.as_ptr(), distid.len(), keys.as_ptr() as *const u8, msgs.as_ptr(), msg_len,
+                                          sigs.as_ptr() as *const u8, n, ok.as_mut_ptr())
+        });
+        Some(ok.into_iter().map(|b| b != 0).collect())
+    }
+
     /// Batch form of `VerifyingKey::<C>::recover_from_prehash` (ecdsa 0.17.0 recovery.rs; the reference's vectors:
     /// k256/src/ecdsa.rs:190-262): `recovery_id[i]` = `RecoveryId::to_byte()`.  `None` per element where the reference
     /// returns `Err` (id does not parse, candidate x >= p or off the curve, identity key, high s under NORMALIZE_S).

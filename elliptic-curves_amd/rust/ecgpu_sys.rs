@@ -276,6 +276,28 @@ unsafe extern "C" {
         reject_high_s: c_int,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_ecdsa_verify_msg_batch(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        q_xy: *const u8,
+        msgs: *const u8,
+        msg_len: usize,
+        sigs: *const u8,
+        n: usize,
+        reject_high_s: c_int,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_ecdsa_verify_msg_batch_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_q_xy: *const c_void,
+        d_msgs: *const c_void,
+        msg_len: usize,
+        d_sigs: *const c_void,
+        n: usize,
+        reject_high_s: c_int,
+        d_ok: *mut c_void,
+    ) -> c_int;
     pub fn ecgpu_ecdsa_recover_batch(
         ctx: *mut EcgpuCtx,
         curve: c_int,
@@ -333,6 +355,28 @@ unsafe extern "C" {
         d_r: *const c_void,
         d_s: *const c_void,
         d_q_xy: *const c_void,
+        n: usize,
+        d_ok: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_sm2dsa_verify_msg_batch(
+        ctx: *mut EcgpuCtx,
+        distid: *const u8,
+        distid_len: usize,
+        q_xy: *const u8,
+        msgs: *const u8,
+        msg_len: usize,
+        sigs: *const u8,
+        n: usize,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_sm2dsa_verify_msg_batch_dev(
+        ctx: *mut EcgpuCtx,
+        d_distid: *const c_void,
+        distid_len: usize,
+        d_q_xy: *const c_void,
+        d_msgs: *const c_void,
+        msg_len: usize,
+        d_sigs: *const c_void,
         n: usize,
         d_ok: *mut c_void,
     ) -> c_int;

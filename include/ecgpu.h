@@ -282,6 +282,18 @@ int ecgpu_ecdsa_verify_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_z, con
                                  const void *d_s, const void *d_q_xy, size_t n, int reject_high_s,
                                  void *d_ok);
 
+/* Batch ECDSA verification of messages — `signature::Verifier::verify(msg, &signature)` of `ecdsa::VerifyingKey<C>`: the
+ * curve's digest (the reference's `DigestAlgorithm`: SHA-256 for k256 / p256 / brainpoolP256 — k256/src/ecdsa.rs:117-119,
+ * p256/src/ecdsa.rs:72-74 —, SHA-384 for p384 / brainpoolP384, SHA-224 for p224, SHA-512 for p521) is computed on the device,
+ * z = bits2field(digest) (the leftmost L bytes, left-padded when the digest is shorter), then ecgpu_ecdsa_verify_batch.
+ * The reference's message-level vectors: its Wycheproof blobs (k256/src/ecdsa.rs:263-384 and the new_wycheproof_test! calls).
+ *   q_xy n*2L bytes, msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*2L bytes (r || s, the fixed-size
+ *   `Signature::from_slice` form; DER is parsed by the caller).  ECGPU_ERR_CURVE for p192 (no DigestAlgorithm), sm2, bign256. */
+int ecgpu_ecdsa_verify_msg_batch(ecgpu_ctx *ctx, int curve, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len,
+                                 const uint8_t *sigs, size_t n, int reject_high_s, uint8_t *ok);
+int ecgpu_ecdsa_verify_msg_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_q_xy, const void *d_msgs, size_t msg_len,
+                                     const void *d_sigs, size_t n, int reject_high_s, void *d_ok);
+
 /* Batch ECDSA public-key recovery — `VerifyingKey::recover_from_prehash(prehash, &signature, recovery_id)` of the `ecdsa`
  * crate (0.17.0, un-vendored, Cargo.lock:428-429), which k256 / p256 re-export and the reference tests with its own vectors
  * (k256/src/ecdsa.rs:170-262: RECOVERY_TEST_VECTORS and the Ethereum example; p256/tests/ecdsa.rs:20-25).  It is a caller
@@ -325,6 +337,18 @@ int ecgpu_sm2dsa_verify_batch(ecgpu_ctx *ctx, const uint8_t *e, const uint8_t *r
                               size_t n, uint8_t *ok);
 int ecgpu_sm2dsa_verify_batch_dev(ecgpu_ctx *ctx, const void *d_e, const void *d_r, const void *d_s, const void *d_q_xy,
                                   size_t n, void *d_ok);
+
+/* SM2DSA verification of messages — `sm2::dsa::VerifyingKey::new(distid, public_key)?.verify(msg, &signature)`: the identity
+ * hash Z = SM3(ENTL || ID || a || b || xG || yG || xA || yA) (`hash_z`, sm2/src/distid.rs:21-44) and e = SM3(Z || M)
+ * (`hash_msg`, sm2/src/dsa/verifying.rs:126-130) are computed on the device, then the verification above.  The reference's
+ * message-level vector: sm2/tests/sm2dsa.rs:16-35.
+ *   distid  the signers' distinguishing identifier, distid_len <= 8191 bytes (ENTL is a 16-bit bit count), one per call
+ *   q_xy    n*64 bytes, msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*64 bytes (r || s)
+ *   ok[i] as for ecgpu_sm2dsa_verify_batch. */
+int ecgpu_sm2dsa_verify_msg_batch(ecgpu_ctx *ctx, const uint8_t *distid, size_t distid_len, const uint8_t *q_xy,
+                                  const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n, uint8_t *ok);
+int ecgpu_sm2dsa_verify_msg_batch_dev(ecgpu_ctx *ctx, const void *d_distid, size_t distid_len, const void *d_q_xy,
+                                      const void *d_msgs, size_t msg_len, const void *d_sigs, size_t n, void *d_ok);
 
 /* The same verification from wire bytes — `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)`
  * (k256/src/schnorr/verifying.rs:76-99,149-160): pk_x n*32 bytes (x-only keys, lifted on the device with even y),

@@ -98,6 +98,20 @@ int ecref_ecdsa_recover_batch(int curve, const uint8_t *z, const uint8_t *r, con
 /* SM2DSA verification on the prehash (sm2/src/dsa/verifying.rs:138-171): e = SM3(ZA || M) as 32 bytes, (r, s), public key. */
 int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *q_xy, size_t n,
                               uint8_t *ok);
+/* SM2DSA verification of messages: `VerifyingKey::new(distid, Q)?.verify(msg, sig)` — Z = SM3(ENTL || ID || a || b || G || Q)
+ * (sm2/src/distid.rs:21-44), e = SM3(Z || M) (sm2/src/dsa/verifying.rs:126-130), then the prehash verification above.  One
+ * identifier per batch, messages of one length, sigs = r || s.  ecref_sm3: the hash alone (test hook). */
+int ecref_sm2dsa_verify_msg_batch(const uint8_t *distid, size_t distid_len, const uint8_t *q_xy,
+                                  const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n,
+                                  uint8_t *ok);
+int ecref_sm3(const uint8_t *msg, size_t len, uint8_t *out32);
+
+/* ECDSA verification of messages: the curve's `DigestAlgorithm` digest (SHA-256 / 384 / 224 / 512), `bits2field`, then
+ * ecref_ecdsa_verify_batch; sigs = r || s (2L bytes).  ecref_curve_digest: the digest alone (test hook). */
+int ecref_ecdsa_verify_msg_batch(int curve, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len,
+                                 const uint8_t *sigs, size_t n, int reject_high_s, uint8_t *ok);
+int ecref_curve_digest(int curve, const uint8_t *msg, size_t len, uint8_t *out, size_t *out_len);
+
 /* BIP340 verification over secp256k1 (k256/src/schnorr/verifying.rs:76-99) with the challenge hash e supplied by the
  * caller; see ecref_ecdsa.c. */
 int ecref_schnorr_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t *s, const uint8_t *p_xy,

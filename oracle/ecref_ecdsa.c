@@ -297,6 +297,85 @@ int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t 
     return ECREF_OK;
 }
 
+/* ---- SM3 (GB/T 32905-2016; the reference uses the un-vendored crate sm3 0.5.0, Cargo.lock:1330-1331) and SM2DSA verification
+ * of a MESSAGE: `VerifyingKey::new(distid, public_key)` -> `hash_z` (sm2/src/distid.rs:21-44):
+ *     Z = SM3(ENTL || ID || a || b || xG || yG || xA || yA), ENTL = bit length of ID as 2 big-endian bytes
+ * `Verifier::verify(msg, sig)` -> `hash_msg` (sm2/src/dsa/verifying.rs:126-130): e = SM3(Z || M), then `verify_prehash`
+ * (:138-171 = ecref_sm2dsa_verify_batch above).  Pinned by the reference's message-level vector sm2/tests/sm2dsa.rs:16-35
+ * and by OpenSSL's SM3 in the tests. --------------------------------------------------------------------------------- */
+static uint32_t rol32(uint32_t x, int n) { n &= 31; return n ? (x << n) | (x >> (32 - n)) : x; }
+static void sm3_block(uint32_t v[8], const uint8_t b[64]) {
+    uint32_t w[68], w1[64];
+    for (int j = 0; j < 16; j++) w[j] = ((uint32_t)b[4 * j] << 24) | ((uint32_t)b[4 * j + 1] << 16) | ((uint32_t)b[4 * j + 2] << 8) | b[4 * j + 3];
+    for (int j = 16; j < 68; j++) {
+        uint32_t x = w[j - 16] ^ w[j - 9] ^ rol32(w[j - 3], 15);
+        w[j] = (x ^ rol32(x, 15) ^ rol32(x, 23)) ^ rol32(w[j - 13], 7) ^ w[j - 6];
+    }
+    for (int j = 0; j < 64; j++) w1[j] = w[j] ^ w[j + 4];
+    uint32_t a = v[0], bb = v[1], c = v[2], d = v[3], e = v[4], f = v[5], g = v[6], h = v[7];
+    for (int j = 0; j < 64; j++) {
+        uint32_t t = j < 16 ? 0x79cc4519u : 0x7a879d8au;
+        uint32_t ss1 = rol32(rol32(a, 12) + e + rol32(t, j), 7);
+        uint32_t ss2 = ss1 ^ rol32(a, 12);
+        uint32_t ff = j < 16 ? (a ^ bb ^ c) : ((a & bb) | (a & c) | (bb & c));
+        uint32_t gg = j < 16 ? (e ^ f ^ g) : ((e & f) | (~e & g));
+        uint32_t tt1 = ff + d + ss2 + w1[j];
+        uint32_t tt2 = gg + h + ss1 + w[j];
+        d = c; c = rol32(bb, 9); bb = a; a = tt1;
+        h = g; g = rol32(f, 19); f = e; e = tt2 ^ rol32(tt2, 9) ^ rol32(tt2, 17);
+    }
+    v[0] ^= a; v[1] ^= bb; v[2] ^= c; v[3] ^= d; v[4] ^= e; v[5] ^= f; v[6] ^= g; v[7] ^= h;
+}
+static void sm3(uint8_t out[32], const uint8_t *msg, size_t len) {
+    uint32_t v[8] = {0x7380166fu, 0x4914b2b9u, 0x172442d7u, 0xda8a0600u, 0xa96f30bcu, 0x163138aau, 0xe38dee4du, 0xb0fb0e4eu};
+    size_t full = len / 64;
+    for (size_t i = 0; i < full; i++) sm3_block(v, msg + 64 * i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - 64 * full;
+    memcpy(tail, msg + 64 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sm3_block(v, tail);
+    if (tl == 128) sm3_block(v, tail + 64);
+    for (int i = 0; i < 8; i++) { out[4 * i] = (uint8_t)(v[i] >> 24); out[4 * i + 1] = (uint8_t)(v[i] >> 16); out[4 * i + 2] = (uint8_t)(v[i] >> 8); out[4 * i + 3] = (uint8_t)v[i]; }
+}
+int ecref_sm3(const uint8_t *msg, size_t len, uint8_t *out32) { sm3(out32, msg, len); return ECREF_OK; }
+
+/* curve constants as the 32-byte big-endian strings `to_bytes()` yields: a = p - 3 (sm2/src/arithmetic.rs:53-54), b (:57-59),
+ * the generator (:67-74) */
+static const uint8_t SM2_A_B_G[128] = {
+    0xFF,0xFF,0xFF,0xFE,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0x00,0x00,0x00,0x00,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFF,0xFC,
+    0x28,0xE9,0xFA,0x9E,0x9D,0x9F,0x5E,0x34,0x4D,0x5A,0x9E,0x4B,0xCF,0x65,0x09,0xA7,0xF3,0x97,0x89,0xF5,0x15,0xAB,0x8F,0x92,0xDD,0xBC,0xBD,0x41,0x4D,0x94,0x0E,0x93,
+    0x32,0xC4,0xAE,0x2C,0x1F,0x19,0x81,0x19,0x5F,0x99,0x04,0x46,0x6A,0x39,0xC9,0x94,0x8F,0xE3,0x0B,0xBF,0xF2,0x66,0x0B,0xE1,0x71,0x5A,0x45,0x89,0x33,0x4C,0x74,0xC7,
+    0xBC,0x37,0x36,0xA2,0xF4,0xF6,0x77,0x9C,0x59,0xBD,0xCE,0xE3,0x6B,0x69,0x21,0x53,0xD0,0xA9,0x87,0x7C,0xC6,0x2A,0x47,0x40,0x02,0xDF,0x32,0xE5,0x21,0x39,0xF0,0xA0};
+
+/* ok[i] = `VerifyingKey::new(distid, Q_i)?.verify(msg_i, sig_i)`: one distinguishing identifier for the batch (at most 8191
+ * bytes: ENTL is a u16 bit count, distid.rs:22-26), keys as affine x||y, messages of one length, signatures r || s. */
+int ecref_sm2dsa_verify_msg_batch(const uint8_t *distid, size_t distid_len, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len,
+                                  const uint8_t *sigs, size_t n, uint8_t *ok) {
+    if (distid_len > 8191) return ECREF_ERR_CURVE;
+    size_t zlen = 2 + distid_len + 128 + 64;
+    uint8_t *zin = (uint8_t *)malloc(zlen), *ein = (uint8_t *)malloc(32 + msg_len);
+    if (!zin || !ein) { free(zin); free(ein); return ECREF_ERR_CURVE; }
+    zin[0] = (uint8_t)((distid_len * 8) >> 8);
+    zin[1] = (uint8_t)(distid_len * 8);
+    if (distid_len) memcpy(zin + 2, distid, distid_len);
+    memcpy(zin + 2 + distid_len, SM2_A_B_G, 128);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t e[32];
+        memcpy(zin + 2 + distid_len + 128, q_xy + 64 * i, 64);
+        sm3(ein, zin, zlen);                                     /* Z */
+        if (msg_len) memcpy(ein + 32, msgs + msg_len * i, msg_len);
+        sm3(e, ein, 32 + msg_len);
+        ecref_sm2dsa_verify_batch(e, sigs + 64 * i, sigs + 64 * i + 32, q_xy + 64 * i, 1, ok + i);
+    }
+    free(zin);
+    free(ein);
+    return ECREF_OK;
+}
+
 /* BIP340 Schnorr verification over secp256k1 — `VerifyingKey::verify_raw`, k256/src/schnorr/verifying.rs:76-99, without
  * the hash: e is the challenge tagged_hash("BIP0340/challenge", r || pk || m) as 32 bytes (reduced mod n here like
  * `<Scalar as Reduce<FieldBytes>>::reduce`), (r, s) the signature halves parsed as in k256/src/schnorr.rs:132-150
@@ -394,5 +473,121 @@ int ecref_schnorr_verify_raw_batch(const uint8_t *pk_x, const uint8_t *msgs, siz
         ecref_schnorr_verify_batch(e, sigs + 64 * i, sigs + 64 * i + 32, pxy, 1, ok + i);
     }
     free(buf);
+    return ECREF_OK;
+}
+
+/* ---- SHA-224 / SHA-384 / SHA-512 (FIPS 180-4; the reference takes them from the un-vendored crate sha2) and ECDSA
+ * verification of a MESSAGE: `signature::Verifier::verify(msg, &sig)` of `ecdsa::VerifyingKey<C>` hashes with the curve's
+ * `DigestAlgorithm` (k256/src/ecdsa.rs:117-119 and p256/src/ecdsa.rs:72-74: Sha256; p384/src/ecdsa.rs:69-71: Sha384;
+ * p224/src/ecdsa.rs:69-71: Sha224; p521/src/ecdsa.rs:69-71: Sha512; bp256 / bp384: Sha256 / Sha384), converts with
+ * `bits2field` (leftmost L bytes, left-padded when shorter) and calls `verify_prehashed` (above).  Pinned by hashlib and by the
+ * reference's Wycheproof blobs at the message level in the tests. ------------------------------------------------------- */
+static const uint64_t SHA512_K[80] = {
+        0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL,
+        0x3956c25bf348b538ULL, 0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL,
+        0xd807aa98a3030242ULL, 0x12835b0145706fbeULL, 0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL,
+        0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL, 0xc19bf174cf692694ULL,
+        0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+        0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL,
+        0x983e5152ee66dfabULL, 0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL,
+        0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL, 0x06ca6351e003826fULL, 0x142929670a0e6e70ULL,
+        0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL, 0x53380d139d95b3dfULL,
+        0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+        0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL,
+        0xd192e819d6ef5218ULL, 0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL,
+        0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL, 0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL,
+        0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL, 0x682e6ff3d6b2b8a3ULL,
+        0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+        0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL,
+        0xca273eceea26619cULL, 0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL,
+        0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL, 0x113f9804bef90daeULL, 0x1b710b35131c471bULL,
+        0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL, 0x431d67c49c100d4cULL,
+        0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+static uint64_t ror64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+static void sha512_block(uint64_t h[8], const uint8_t b[128]) {
+    uint64_t w[80];
+    for (int i = 0; i < 16; i++) {
+        w[i] = 0;
+        for (int k = 0; k < 8; k++) w[i] = (w[i] << 8) | b[8 * i + k];
+    }
+    for (int i = 16; i < 80; i++)
+        w[i] = w[i - 16] + (ror64(w[i - 15], 1) ^ ror64(w[i - 15], 8) ^ (w[i - 15] >> 7)) + w[i - 7] +
+               (ror64(w[i - 2], 19) ^ ror64(w[i - 2], 61) ^ (w[i - 2] >> 6));
+    uint64_t a = h[0], bb = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 80; i++) {
+        uint64_t t1 = hh + (ror64(e, 14) ^ ror64(e, 18) ^ ror64(e, 41)) + ((e & f) ^ (~e & g)) + SHA512_K[i] + w[i];
+        uint64_t t2 = (ror64(a, 28) ^ ror64(a, 34) ^ ror64(a, 39)) + ((a & bb) ^ (a & c) ^ (bb & c));
+        hh = g; g = f; f = e; e = d + t1; d = c; c = bb; bb = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += bb; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+/* digest_len 48 (SHA-384) or 64 (SHA-512) */
+static void sha512_family(uint8_t *out, size_t digest_len, const uint8_t *msg, size_t len) {
+    static const uint64_t IV512[8] = {
+        0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+        0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    static const uint64_t IV384[8] = {
+        0xcbbb9d5dc1059ed8ULL, 0x629a292a367cd507ULL, 0x9159015a3070dd17ULL, 0x152fecd8f70e5939ULL,
+        0x67332667ffc00b31ULL, 0x8eb44a8768581511ULL, 0xdb0c2e0d64f98fa7ULL, 0x47b5481dbefa4fa4ULL};
+    uint64_t h[8];
+    memcpy(h, digest_len == 48 ? IV384 : IV512, sizeof h);
+    size_t full = len / 128;
+    for (size_t i = 0; i < full; i++) sha512_block(h, msg + 128 * i);
+    uint8_t tail[256] = {0};
+    size_t rem = len - 128 * full;
+    memcpy(tail, msg + 128 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 17 <= 128 ? 128 : 256;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha512_block(h, tail);
+    if (tl == 256) sha512_block(h, tail + 128);
+    for (size_t i = 0; i < digest_len; i++) out[i] = (uint8_t)(h[i / 8] >> (8 * (7 - i % 8)));
+}
+/* SHA-224: SHA-256 with its own initial value, truncated to 28 bytes */
+static void sha224(uint8_t out[28], const uint8_t *msg, size_t len) {
+    uint32_t h[8] = {
+        0xc1059ed8u, 0x367cd507u, 0x3070dd17u, 0xf70e5939u, 0xffc00b31u, 0x68581511u, 0x64f98fa7u, 0xbefa4fa4u};
+    size_t full = len / 64;
+    for (size_t i = 0; i < full; i++) sha256_block(h, msg + 64 * i);
+    uint8_t tail[128] = {0};
+    size_t rem = len - 64 * full;
+    memcpy(tail, msg + 64 * full, rem);
+    tail[rem] = 0x80;
+    size_t tl = rem + 9 <= 64 ? 64 : 128;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) tail[tl - 1 - i] = (uint8_t)(bits >> (8 * i));
+    sha256_block(h, tail);
+    if (tl == 128) sha256_block(h, tail + 64);
+    for (int i = 0; i < 7; i++) { out[4 * i] = (uint8_t)(h[i] >> 24); out[4 * i + 1] = (uint8_t)(h[i] >> 16); out[4 * i + 2] = (uint8_t)(h[i] >> 8); out[4 * i + 3] = (uint8_t)h[i]; }
+}
+/* the digest the reference binds to the curve; returns its length, 0 if the curve has none */
+static size_t curve_digest(int curve, uint8_t *out, const uint8_t *msg, size_t len) {
+    switch (curve) {
+    case ECREF_K256: case ECREF_P256: case ECREF_BP256: case ECREF_BP256T1: sha256(out, msg, len); return 32;
+    case ECREF_P384: case ECREF_BP384: case ECREF_BP384T1: sha512_family(out, 48, msg, len); return 48;
+    case ECREF_P224: sha224(out, msg, len); return 28;
+    case ECREF_P521: sha512_family(out, 64, msg, len); return 64;
+    default: return 0;
+    }
+}
+int ecref_curve_digest(int curve, const uint8_t *msg, size_t len, uint8_t *out, size_t *out_len) {
+    *out_len = curve_digest(curve, out, msg, len);
+    return *out_len ? ECREF_OK : ECREF_ERR_CURVE;
+}
+/* ok[i] = `VerifyingKey::from_affine(Q_i)?.verify(msg_i, sig_i)`: keys n*2L, messages of one length, sigs n*2L (r || s) */
+int ecref_ecdsa_verify_msg_batch(int curve, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n,
+                                 int reject_high_s, uint8_t *ok) {
+    const size_t L = ecref_field_bytes(curve);
+    uint8_t digest[64], z[66];
+    if (!L || !curve_digest(curve, digest, (const uint8_t *)"", 0)) return ECREF_ERR_CURVE;
+    for (size_t i = 0; i < n; i++) {
+        size_t d = curve_digest(curve, digest, msgs + msg_len * i, msg_len);
+        memset(z, 0, sizeof z);
+        if (d >= L) memcpy(z, digest, L);                        /* bits2field: the leftmost L bytes ... */
+        else memcpy(z + (L - d), digest, d);                     /* ... or left-padded */
+        int rc = ecref_ecdsa_verify_batch(curve, z, sigs + 2 * L * i, sigs + 2 * L * i + L, q_xy + 2 * L * i, 1, reject_high_s, ok + i);
+        if (rc != ECREF_OK) return rc;
+    }
     return ECREF_OK;
 }

@@ -344,3 +344,44 @@ def sm2dsa_cases(seed, nvalid=10):
             enc(e, r, s, bytes(bad), False)
             enc(e, r, s, bytes(64), False)
     return cases
+
+
+def sm2dsa_msg_cases(seed, distid, msg_len, nvalid=8):
+    """(q bytes, msg, sig bytes, expected) tuples for SM2DSA verification of MESSAGES under one distinguishing identifier:
+    signatures made by the big-int model over e = SM3(Z || M) (hashlib's SM3), and the ways of breaking one — another
+    message, another key (Z changes), disturbed r / s, range failures, an off-curve key."""
+    import hashlib
+    import random
+    c = pyec.CURVES["sm2"]
+    rng = random.Random(seed)
+    G = pyec.G(c)
+    cases = []
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n - 1)
+        Q = pyec.mul(c, d, G)
+        msg = bytes(rng.randrange(256) for _ in range(msg_len))
+        e = int.from_bytes(hashlib.new("sm3", pyec.sm2_za(c, distid, Q) + msg).digest(), "big")
+        sig = None
+        while sig is None:
+            sig = pyec.sm2dsa_sign(c, d, e, rng.randrange(1, c.n))
+        r, s = sig
+        q = pyec.enc_point(c, Q)[0]
+        enc = lambda rr, ss: rr.to_bytes(32, "big") + ss.to_bytes(32, "big")
+        cases.append((q, msg, enc(r, s), True))
+        if msg_len:
+            other = bytearray(msg); other[rng.randrange(msg_len)] ^= 1 << rng.randrange(8)
+            cases.append((q, bytes(other), enc(r, s), False))
+        cases.append((pyec.enc_point(c, pyec.mul(c, d + 1, G))[0], msg, enc(r, s), False))
+        cases.append((q, msg, enc(r, (s + 1) % c.n or 1), False))
+        cases.append((q, msg, enc((r + 1) % c.n or 1, s), False))
+        if i < 2:
+            cases.append((q, msg, enc(0, s), False))
+            cases.append((q, msg, enc(r, c.n), False))
+            bad = bytearray(q); bad[-1] ^= 1
+            cases.append((bytes(bad), msg, enc(r, s), False))
+    return cases
+
+
+def sm2dsa_msg_pack(cases):
+    return (b"".join(t[0] for t in cases), b"".join(t[1] for t in cases), b"".join(t[2] for t in cases),
+            np.array([1 if t[3] else 0 for t in cases], np.uint8))

@@ -14,6 +14,8 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_scalar.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_sha256.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_hash.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_sm3.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_verify.h"
 
 using namespace ecgpu;
@@ -492,6 +494,30 @@ int ecdsa_verify(const uint8_t* z, const uint8_t* r, const uint8_t* s, const uin
     return 0;
 }
 
+// the per-element code of k_ecdsa_hash_msg: the curve's digest and bits2field (-> L wire bytes)
+template <class C>
+int ecdsa_hash_msg(const uint8_t* msgs, size_t msg_len, size_t n, uint8_t* z_out) {
+    constexpr int N = C::N, WB = WireBytes<C>::value, D = EcdsaDigest<C>::value;
+    if constexpr (D == 0) {
+        return -1;
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            uint8_t digest[D];
+            const HashPiece one[1] = {{msgs + i * msg_len, msg_len}};
+            sha2_pieces<D, 1>(digest, one);
+            uint32_t zw[N];
+            for (int j = 0; j < N; j++) zw[j] = 0;
+            constexpr int TAKE = D < WB ? D : WB;
+            for (int j = 0; j < TAKE; j++) {
+                const int pos = TAKE - 1 - j;
+                zw[pos / 4] |= (uint32_t)digest[j] << (8 * (pos % 4));
+            }
+            store_be_wire<C>(z_out + i * WB, zw);
+        }
+        return 0;
+    }
+}
+
 // public-key recovery: the prepare logic of ecgpu_verify.h, the CPU mirrors of the two scalar multiplications, the finish rule
 template <class C>
 int ecdsa_recover(const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid, size_t n, int reject_high_s,
@@ -566,6 +592,20 @@ int sm2dsa_verify(const uint8_t* e, const uint8_t* r, const uint8_t* s, const ui
         const bool finite = sum_affine_x<C>(table, sw, t, cx, cy, x, y);
         if (!finite) std::memset(x, 0, sizeof x);
         ok_out[i] = valid && sm2dsa_finish_words<C>(ew, x, !finite, rw);
+    }
+    return 0;
+}
+
+// `VerifyingKey::new(distid, pk)?.verify(msg, sig)`: the hashes of ecgpu_sm3.h, then the prehash logic above
+int sm2dsa_verify_msg(const uint8_t* distid, size_t distid_len, const uint8_t* q, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
+                      size_t n, uint8_t* ok_out) {
+    using C = Sm2Params;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t ew[8];
+        Sm3::sm2_message_hash<C>(ew, distid, distid_len, q + 64 * i, msgs + i * msg_len, msg_len);
+        uint8_t e[32];
+        store_be<8>(e, ew);
+        sm2dsa_verify(e, sigs + 64 * i, sigs + 64 * i + 32, q + 64 * i, 1, ok_out + i);
     }
     return 0;
 }
@@ -667,6 +707,9 @@ int hc_ecdsa_verify(int curve, const uint8_t* z, const uint8_t* r, const uint8_t
     if (curve == 3 || curve == 11) return -1;                    // sm2 / bign signatures are not ECDSA
     DISPATCH(curve, ecdsa_verify, (z, r, s, q, n, reject_high_s, ok))
 }
+int hc_ecdsa_hash_msg(int curve, const uint8_t* msgs, size_t msg_len, size_t n, uint8_t* z_out) {
+    DISPATCH(curve, ecdsa_hash_msg, (msgs, msg_len, n, z_out))
+}
 int hc_ecdsa_recover(int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid, size_t n, int reject_high_s,
                      uint8_t* out_xy, uint8_t* ok) {
     if (curve == 3 || curve == 11 || curve == 4) return -1;      // sm2 / bign: not ECDSA; p224: no decompression
@@ -678,6 +721,17 @@ int hc_schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const 
 }
 int hc_sm2dsa_verify(const uint8_t* e, const uint8_t* r, const uint8_t* s, const uint8_t* q, size_t n, uint8_t* ok) {
     return sm2dsa_verify(e, r, s, q, n, ok);
+}
+int hc_sm2dsa_verify_msg(const uint8_t* distid, size_t distid_len, const uint8_t* q, const uint8_t* msgs, size_t msg_len,
+                         const uint8_t* sigs, size_t n, uint8_t* ok) {
+    return sm2dsa_verify_msg(distid, distid_len, q, msgs, msg_len, sigs, n, ok);
+}
+// SM3 of an arbitrary message through the device-side absorber
+int hc_sm3(const uint8_t* msg, size_t len, uint8_t* out32) {
+    uint32_t d[8];
+    Sm3::hash(d, msg, len);
+    for (int i = 0; i < 8; i++) { out32[4 * i] = d[i] >> 24; out32[4 * i + 1] = d[i] >> 16; out32[4 * i + 2] = d[i] >> 8; out32[4 * i + 3] = d[i]; }
+    return 0;
 }
 int hc_decompress(int curve, const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok) {
     if (curve == 4) return -1;                                   // p224: p = 1 mod 4

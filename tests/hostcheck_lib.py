@@ -156,6 +156,33 @@ def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
     return ok
 
 
+def ecdsa_hash_msg(curve, msgs, msg_len):
+    """z = bits2field(digest(msg)) per message through the device-side hashing code: n*L bytes, or None for a curve without a digest."""
+    M = _a(msgs) if msg_len else np.zeros(1, np.uint8)
+    n = (M.size // msg_len) if msg_len else 1
+    out = np.zeros(n * L[curve], np.uint8)
+    rc = lib().hc_ecdsa_hash_msg(curve, _p(M), ctypes.c_size_t(msg_len), ctypes.c_size_t(n), _p(out))
+    return None if rc != 0 else bytes(out)
+
+
+def sm3(msg):
+    M = _a(msg) if len(msg) else np.zeros(1, np.uint8)
+    out = np.zeros(32, np.uint8)
+    assert lib().hc_sm3(_p(M), ctypes.c_size_t(len(msg)), _p(out)) == 0
+    return bytes(out)
+
+
+def sm2dsa_verify_msg(distid, q, msgs, msg_len, sigs):
+    D = _a(distid) if len(distid) else np.zeros(1, np.uint8)
+    Q, SG = _a(q), _a(sigs)
+    M = _a(msgs) if msg_len else np.zeros(1, np.uint8)
+    n = Q.size // 64
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_sm2dsa_verify_msg(_p(D), ctypes.c_size_t(len(distid)), _p(Q), _p(M), ctypes.c_size_t(msg_len), _p(SG),
+                                      ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
+
+
 def ecdsa_recover(curve, z, r, s, recid, reject_high_s=False):
     Z, R, S, I = _a(z), _a(r), _a(s), _a(recid)
     n = I.size

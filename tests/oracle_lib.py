@@ -138,6 +138,43 @@ def sm2dsa_verify(e, r, s, q_xy):
     return ok
 
 
+def curve_digest(curve, msg):
+    m = _arr(msg) if len(msg) else None
+    out = np.zeros(64, np.uint8)
+    ln = ctypes.c_size_t(0)
+    _chk(lib().ecref_curve_digest(curve, _buf(m), ctypes.c_size_t(len(msg)), _buf(out), ctypes.byref(ln)))
+    return bytes(out[: ln.value])
+
+
+def ecdsa_verify_msg(curve, q_xy, msgs, msg_len, sigs, reject_high_s=False):
+    L = FIELD_BYTES[curve]
+    qq, sg = _arr(q_xy), _arr(sigs)
+    mm = _arr(msgs) if msg_len else None
+    n = qq.size // (2 * L)
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_ecdsa_verify_msg_batch(curve, _buf(qq), _buf(mm), ctypes.c_size_t(msg_len), _buf(sg), ctypes.c_size_t(n),
+                                            int(bool(reject_high_s)), _buf(ok)))
+    return ok
+
+
+def sm3(msg):
+    m = _arr(msg) if len(msg) else None
+    out = np.zeros(32, np.uint8)
+    _chk(lib().ecref_sm3(_buf(m), ctypes.c_size_t(len(msg)), _buf(out)))
+    return bytes(out)
+
+
+def sm2dsa_verify_msg(distid, q_xy, msgs, msg_len, sigs):
+    qq, sg = _arr(q_xy), _arr(sigs)
+    dd = _arr(distid) if len(distid) else None
+    mm = _arr(msgs) if msg_len else None
+    n = qq.size // 64
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_sm2dsa_verify_msg_batch(_buf(dd), ctypes.c_size_t(len(distid)), _buf(qq), _buf(mm), ctypes.c_size_t(msg_len),
+                                             _buf(sg), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
 def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
     pk, sg = _arr(pk_x), _arr(sigs)
     mm = _arr(msgs) if msg_len else None

@@ -697,6 +697,91 @@ def test_pipelined_host_pointer_calls(eng, curve):
     assert e.value.code == ecgpu.ERR_SCALAR_RANGE
 
 
+@pytest.mark.parametrize("name", ["k256_der", "k256_p1363", "p256_der", "p384_der", "p224_der", "p521_der"])
+def test_ecdsa_verify_messages_wycheproof(eng, name):
+    """The reference's Wycheproof blobs at the message level through ecgpu_ecdsa_verify_msg_batch — `Verifier::verify(msg,
+    &sig)`: the curve's digest (SHA-256 / 384 / 224 / 512) and bits2field on the device, one call per message length; every
+    verdict equals the pass flag and the oracle's."""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    for ln, (idx, q, m, sg) in wycheproof_lib.by_message_length(p).items():
+        got = eng.ecdsa_verify_msg(c.cid, q, m, ln, sg, p["reject_high_s"])
+        assert bytes(got) == bytes(p["expect"][idx]), (name, ln)
+        assert bytes(got) == bytes(oracle_lib.ecdsa_verify_msg(c.cid, q, m, ln, sg, p["reject_high_s"]))
+
+
+@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c not in ("sm2", "p192")])
+def test_ecdsa_verify_messages_vs_oracle(eng, curve):
+    """Model-made signatures over messages whose lengths put the padding on every side of a block boundary (64-byte blocks for
+    SHA-224 / 256, 128-byte blocks for SHA-384 / 512), every third one broken: the oracle's verdicts; a 2^19 + 333 batch through
+    the pipelined host path; no digest for p192 / sm2 / bign256."""
+    import hashlib
+    import random
+    import wycheproof_lib
+    ecgpu = ecgpu_module()
+    H = {"k256": "sha256", "p256": "sha256", "p384": "sha384", "p224": "sha224", "p521": "sha512", "bp256": "sha256", "bp384": "sha384",
+         "bp256t1": "sha256", "bp384t1": "sha384"}
+    c = pyec.CURVES[curve]
+    L = c.L
+    rng = random.Random(0x3E55 + c.cid)
+    G = pyec.G(c)
+    for msg_len in (0, 1, 55, 56, 64, 111, 112, 119, 120, 128, 200):
+        q = m = sg = b""
+        exp = []
+        for i in range(6):
+            d, k = rng.randrange(1, c.n), rng.randrange(1, c.n)
+            msg = bytes(rng.randrange(256) for _ in range(msg_len))
+            z = int.from_bytes(wycheproof_lib.bits2field(hashlib.new(H[curve], msg).digest(), L), "big")
+            r, s_ = pyec.ecdsa_sign(c, d, z, k)
+            if i % 3 == 2:
+                s_ = (s_ + 1) % c.n or 1
+            q += pyec.enc_point(c, pyec.mul(c, d, G))[0]; m += msg; sg += r.to_bytes(L, "big") + s_.to_bytes(L, "big")
+            exp.append(0 if i % 3 == 2 else 1)
+        got = eng.ecdsa_verify_msg(c.cid, q, m, msg_len, sg)
+        assert list(got) == exp, (curve, msg_len)
+        assert bytes(got) == bytes(oracle_lib.ecdsa_verify_msg(c.cid, q, m, msg_len, sg))
+    if curve in ("k256", "p521"):
+        reps = ((1 << 19) + 333) // 6 + 1
+        big = eng.ecdsa_verify_msg(c.cid, q * reps, m * reps, msg_len, sg * reps)
+        assert bytes(big) == bytes(np.tile(np.array(exp, np.uint8), reps))
+    assert eng.ecdsa_verify_msg(c.cid, b"", b"", 7, b"").size == 0
+    if curve == "k256":
+        for name in ("p192", "sm2", "bign256"):
+            cid = pyec.CURVES[name].cid
+            l2 = ecgpu.FIELD_BYTES[cid]
+            with pytest.raises(ecgpu.EcgpuError) as e:
+                eng.ecdsa_verify_msg(cid, bytes(2 * l2), b"abc", 3, bytes(2 * l2))
+            assert e.value.code == ecgpu.ERR_CURVE
+
+
+def test_sm2dsa_verify_messages_vs_reference_vector_oracle_and_model(eng):
+    """ecgpu_sm2dsa_verify_msg_batch — `VerifyingKey::new(distid, pk)?.verify(msg, sig)` with Z and e = SM3(Z || M) hashed on
+    the device: the reference's message-level vector (sm2/tests/sm2dsa.rs:16-35) verifies, another identifier / message does
+    not; model-made signatures and broken ones under four identifiers (empty ... 200 bytes) and message lengths that put the
+    SM3 padding on every side of a block boundary; a 70,000-element batch; the empty batch; an over-long identifier."""
+    from gpu_common import SM2DSA_KAT as K, sm2dsa_msg_cases, sm2dsa_msg_pack
+    ecgpu = ecgpu_module()
+    pk, sig, msg = bytes.fromhex(K["public_key"])[1:], bytes.fromhex(K["signature"]), K["message"]
+    assert eng.sm2dsa_verify_msg(K["identity"], pk, msg, len(msg), sig)[0] == 1
+    assert eng.sm2dsa_verify_msg(K["identity"] + b"x", pk, msg, len(msg), sig)[0] == 0
+    assert eng.sm2dsa_verify_msg(K["identity"], pk, b"testinh", len(msg), sig)[0] == 0
+    for distid, msg_len in ((b"", 0), (b"1234567812345678", 32), (bytes(range(100)), 77), (bytes(200), 23), (b"id", 150)):
+        q, m, sg, exp = sm2dsa_msg_pack(sm2dsa_msg_cases(0x5D50 + msg_len, distid, msg_len))
+        got = eng.sm2dsa_verify_msg(distid, q, m, msg_len, sg)
+        assert bytes(got) == bytes(exp) == bytes(oracle_lib.sm2dsa_verify_msg(distid, q, m, msg_len, sg))
+    reps = 70000 // len(exp) + 1
+    big = eng.sm2dsa_verify_msg(distid, q * reps, m * reps, msg_len, sg * reps)
+    assert bytes(big) == bytes(np.tile(exp, reps))
+    reps = ((1 << 19) + 777) // len(exp) + 1                     # above the pipeline threshold of the host-pointer entry
+    big = eng.sm2dsa_verify_msg(distid, q * reps, m * reps, msg_len, sg * reps)
+    assert bytes(big) == bytes(np.tile(exp, reps))
+    assert eng.sm2dsa_verify_msg(b"x", b"", b"", 5, b"").size == 0
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.sm2dsa_verify_msg(bytes(8192), pk, msg, len(msg), sig)
+    assert e.value.code == ecgpu.ERR_ARG
+
+
 # ---- ECDSA public-key recovery (ecgpu_ecdsa_recover_batch) ------------------------------------------------------------------
 def test_ecdsa_recover_reference_vectors(eng):
     """The reference's recovery vectors (k256/src/ecdsa.rs:190-211 RECOVERY_TEST_VECTORS, :233-261 the Ethereum example)

@@ -361,6 +361,42 @@ def test_ecdsa_verify_logic_on_cpu(oracle, curve):
         assert hc.ecdsa_verify(c.cid, z, r, s, q).all()
 
 
+@pytest.mark.parametrize("curve", [c for c in CURVES if c not in ("sm2", "p192")])
+def test_ecdsa_message_hash_logic_on_cpu(oracle, curve):
+    """k_ecdsa_hash_msg's per-element code (ecgpu_hash.h: the block producer, SHA-256 / 224 / 384 / 512, bits2field) on the
+    CPU: z for messages of every length around the padding boundaries equals bits2field(hashlib digest) and the oracle's."""
+    import hashlib
+    import wycheproof_lib
+    H = {"k256": "sha256", "p256": "sha256", "p384": "sha384", "p224": "sha224", "p521": "sha512", "bp256": "sha256", "bp384": "sha384",
+         "bp256t1": "sha256", "bp384t1": "sha384"}
+    c = pyec.CURVES[curve]
+    for n in (0, 1, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 239, 240, 300):
+        msgs = bytes((i * 31 + n) & 0xff for i in range(3 * n))
+        got = hc.ecdsa_hash_msg(c.cid, msgs, n)
+        want = b"".join(wycheproof_lib.bits2field(hashlib.new(H[curve], msgs[i * n:(i + 1) * n]).digest(), c.L) for i in range(3 if n else 1))
+        assert got == want
+        assert wycheproof_lib.bits2field(oracle.curve_digest(c.cid, msgs[:n]), c.L) == want[: c.L]
+    assert hc.ecdsa_hash_msg(pyec.CURVES["p192"].cid, b"abc", 3) is None
+
+
+def test_sm2dsa_verify_messages_logic_on_cpu(oracle):
+    """k_sm2dsa_hash_msg's per-element code (ecgpu_sm3.h: the byte-serial SM3 absorber, `hash_z`, `hash_msg`) on the CPU: SM3
+    against OpenSSL's around the block boundaries, the reference's message-level vector (sm2/tests/sm2dsa.rs:16-35), and the
+    oracle's verdicts on model-made signatures and broken ones under several identifiers and message lengths."""
+    import hashlib
+    from gpu_common import SM2DSA_KAT as K, sm2dsa_msg_cases, sm2dsa_msg_pack
+    for n in (0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, 300):
+        m = bytes((7 * i + n) & 0xff for i in range(n))
+        assert hc.sm3(m) == hashlib.new("sm3", m).digest() == oracle.sm3(m)
+    pk, sig, msg = bytes.fromhex(K["public_key"])[1:], bytes.fromhex(K["signature"]), K["message"]
+    assert hc.sm2dsa_verify_msg(K["identity"], pk, msg, len(msg), sig)[0] == 1
+    assert hc.sm2dsa_verify_msg(b"1234567812345678", pk, msg, len(msg), sig)[0] == 0
+    for distid, msg_len in ((b"", 0), (b"1234567812345678", 32), (bytes(range(60)), 61)):
+        q, m, sg, exp = sm2dsa_msg_pack(sm2dsa_msg_cases(0x5D40 + msg_len, distid, msg_len, nvalid=3))
+        got = hc.sm2dsa_verify_msg(distid, q, m, msg_len, sg)
+        assert bytes(got) == bytes(exp) == bytes(oracle.sm2dsa_verify_msg(distid, q, m, msg_len, sg))
+
+
 @pytest.mark.parametrize("curve", [c for c in CURVES if c not in ("sm2", "p224")])
 def test_ecdsa_recover_logic_on_cpu(oracle, curve):
     """k_ecdsa_recover_prepare / _finish (`ecdsa_recover_prepare_words`) around the CPU mirrors of the two scalar

@@ -171,6 +171,37 @@ def test_ecdsa_recover_vs_model(oracle, curve):
         assert bytes(out_h[2 * c.L * i: 2 * c.L * (i + 1)]) == want
 
 
+@pytest.mark.parametrize("name", ["k256_der", "k256_p1363", "p256_der", "p384_der", "p224_der", "p521_der"])
+def test_wycheproof_ecdsa_vectors_message_level(oracle, name):
+    """The same blobs through ecref_ecdsa_verify_msg_batch — `Verifier::verify(msg, &sig)`: digest (the curve's
+    `DigestAlgorithm`: SHA-256 / 384 / 224 / 512), bits2field and verification from the raw messages, grouped by message
+    length; every verdict equals the pass flag.  (The harness normalises s for k256 before verifying, k256/src/ecdsa.rs.)"""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    groups = wycheproof_lib.by_message_length(p)
+    assert sum(len(g[0]) for g in groups.values()) == len(p["expect"]) and len(groups) >= 3
+    for ln, (idx, q, m, sg) in groups.items():
+        ok = oracle.ecdsa_verify_msg(c.cid, q, m, ln, sg, p["reject_high_s"])
+        assert bytes(ok) == bytes(p["expect"][idx]), (name, ln)
+
+
+def test_curve_digests_against_hashlib(oracle):
+    """ecref_curve_digest: SHA-256 / 384 / 224 / 512 per curve against hashlib on lengths around every padding boundary; p192,
+    sm2 and bign256 have no ECDSA digest."""
+    import hashlib
+    H = {"k256": "sha256", "p256": "sha256", "p384": "sha384", "p224": "sha224", "p521": "sha512", "bp256": "sha256", "bp384": "sha384",
+         "bp256t1": "sha256", "bp384t1": "sha384"}
+    rng = random.Random(11)
+    for name, h in H.items():
+        for n in (0, 1, 55, 56, 63, 64, 65, 111, 112, 119, 120, 127, 128, 129, 239, 240, 300, 1000):
+            m = bytes(rng.randrange(256) for _ in range(n))
+            assert oracle.curve_digest(pyec.CURVES[name].cid, m) == hashlib.new(h, m).digest()
+    for name in ("p192", "sm2", "bign256"):
+        with pytest.raises(Exception):
+            oracle.curve_digest(pyec.CURVES[name].cid, b"abc")
+
+
 def test_sm2dsa_verify_reference_vector_and_model(oracle):
     """ecref_sm2dsa_verify_batch (sm2/src/dsa/verifying.rs:138-171): accepts the reference's own test vector
     (sm2/tests/sm2dsa.rs:16-35, with e = SM3(ZA || M) computed by hashlib), and agrees with the big-int model on signatures
@@ -188,6 +219,26 @@ def test_sm2dsa_verify_reference_vector_and_model(oracle):
             pass
         got = pyec.sm2dsa_verify(c, Q, *(int.from_bytes(b[32 * i: 32 * i + 32], "big") for b in (e, r, s))) if Q else False
         assert got == bool(exp[i]), i
+
+
+def test_sm2dsa_verify_messages_reference_vector_sm3_and_model(oracle):
+    """ecref_sm3 against OpenSSL's SM3 around the block boundaries; ecref_sm2dsa_verify_msg_batch — `VerifyingKey::new(distid,
+    pk)?.verify(msg, sig)`, sm2/src/distid.rs:21-44 + sm2/src/dsa/verifying.rs:126-171 — on the reference's message-level
+    vector (sm2/tests/sm2dsa.rs:16-35: it verifies; another identifier or message does not) and on model-made signatures
+    under three identifiers (empty, the default, 100 bytes) and three message lengths."""
+    import hashlib
+    from gpu_common import SM2DSA_KAT as K, sm2dsa_msg_cases, sm2dsa_msg_pack
+    rng = random.Random(3)
+    for n in (0, 1, 55, 56, 57, 63, 64, 65, 119, 120, 128, 300):
+        m = bytes(rng.randrange(256) for _ in range(n))
+        assert oracle.sm3(m) == hashlib.new("sm3", m).digest()
+    pk, sig, msg = bytes.fromhex(K["public_key"])[1:], bytes.fromhex(K["signature"]), K["message"]
+    assert oracle.sm2dsa_verify_msg(K["identity"], pk, msg, len(msg), sig)[0] == 1
+    assert oracle.sm2dsa_verify_msg(K["identity"] + b"x", pk, msg, len(msg), sig)[0] == 0
+    assert oracle.sm2dsa_verify_msg(K["identity"], pk, b"testinh", len(msg), sig)[0] == 0
+    for distid, msg_len in ((b"", 0), (b"1234567812345678", 32), (bytes(range(100)), 77)):
+        q, m, sg, exp = sm2dsa_msg_pack(sm2dsa_msg_cases(0x5D30 + msg_len, distid, msg_len, nvalid=4))
+        assert bytes(oracle.sm2dsa_verify_msg(distid, q, m, msg_len, sg)) == bytes(exp) and 0 < int(exp.sum()) < len(exp)
 
 
 def test_schnorr_bip340_vectors(oracle):

@@ -138,7 +138,7 @@ def prepare(name):
     r = bytearray()
     s = bytearray()
     q = bytearray()
-    expect, unparsed = [], []
+    expect, unparsed, msgs = [], [], []
     for i, (iwx, iwy, imsg, isig, ok) in enumerate(rec["vectors"]):
         x = element_from_padded_slice(strs[iwx], L)
         y = element_from_padded_slice(strs[iwy], L)
@@ -153,10 +153,26 @@ def prepare(name):
         if NORMALIZE_S[rec["curve"]] and si > c.n // 2:
             si = c.n - si
         z += bits2field(hash_fn(strs[imsg]).digest(), L)
+        msgs.append(strs[imsg])
         r += ri.to_bytes(L, "big")
         s += si.to_bytes(L, "big")
         q += x + y
         expect.append(ok)
     u8 = lambda b: np.frombuffer(bytes(b), np.uint8).copy()
     return {"curve": c, "z": u8(z), "r": u8(r), "s": u8(s), "q": u8(q), "expect": np.array(expect, np.uint8),
-            "unparsed": unparsed, "reject_high_s": NORMALIZE_S[rec["curve"]], "total": len(rec["vectors"])}
+            "unparsed": unparsed, "reject_high_s": NORMALIZE_S[rec["curve"]], "total": len(rec["vectors"]), "msgs": msgs}
+
+
+def by_message_length(p):
+    """The parsed vectors of prepare() grouped by message length, for the message-level entry points (one length per call):
+    {length: (indices, q bytes, messages bytes, r || s bytes)}."""
+    L = p["curve"].L
+    groups = {}
+    for i, m in enumerate(p["msgs"]):
+        groups.setdefault(len(m), []).append(i)
+    out = {}
+    for ln, idx in groups.items():
+        q = b"".join(bytes(p["q"][2 * L * i: 2 * L * (i + 1)]) for i in idx)
+        sg = b"".join(bytes(p["r"][L * i: L * (i + 1)]) + bytes(p["s"][L * i: L * (i + 1)]) for i in idx)
+        out[ln] = (idx, q, b"".join(p["msgs"][i] for i in idx), sg)
+    return out
