@@ -24,7 +24,7 @@ e = ec.Engine(0)
 rng = random.Random(int(os.environ.get("FUZZ_SEED", "20260924")))
 budget = float(os.environ.get("FUZZ_SECONDS", "150"))
 t_end = time.time() + budget
-stats = {"msm_oracle": 0, "msm_property": 0, "msm_shards": 0, "fixed": 0, "var": 0}
+stats = {"msm_oracle": 0, "msm_property": 0, "msm_shards": 0, "fixed": 0, "var": 0, "verify": 0, "recover": 0, "verify_msg": 0}
 NAMES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1", "bign256"]
 DEFAULT_W = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20,
              "bp256t1": 24, "bp384t1": 20, "bign256": 24}
@@ -71,7 +71,9 @@ kind = c = n = None
 while time.time() < t_end:
     c = pyec.CURVES[rng.choice(NAMES)]
     L = c.L
-    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var"])
+    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var", "sig"])
+    if kind == "sig" and c.name in ("sm2", "bign256"):
+        kind = "var"
     if kind == "msm":
         big = rng.random() < 0.25
         n = rng.randrange(1 << 14, 1 << 19) if big else rng.randrange(1, 1 << 13)
@@ -138,6 +140,56 @@ while time.time() < t_end:
         for b in (d_all, d_o, d_f):
             b.free()
         stats["msm_shards"] += 1
+    elif kind == "sig":
+        # signatures made from engine-computed nonce points (valid ones), some disturbed: verification, public-key recovery
+        # and message-level verification against the oracle, verdict for verdict and key for key
+        import hashlib
+        n = rng.randrange(1, 400)
+        L = c.L
+        ds = rand_scalars(c.cid, n, rng.randrange(1 << 30))
+        ks = rand_scalars(c.cid, n, rng.randrange(1 << 30))
+        Q, _ = e.mul_by_generator(c.cid, ds)
+        R, _ = e.mul_by_generator(c.cid, ks)
+        H = {"k256": "sha256", "p256": "sha256", "p384": "sha384", "p224": "sha224", "p521": "sha512", "bp256": "sha256", "bp384": "sha384",
+             "bp256t1": "sha256", "bp384t1": "sha384"}.get(c.name)
+        msg_len = rng.choice([0, 1, 31, 55, 56, 64, 111, 112, 127, 128, 129, 300])
+        msgs = bytes(rng.randrange(256) for _ in range(n * msg_len))
+        zs, rr, ss, ids = bytearray(), bytearray(), bytearray(), bytearray()
+        for i in range(n):
+            d = int.from_bytes(bytes(ds[i * L:(i + 1) * L]), "big")
+            k = int.from_bytes(bytes(ks[i * L:(i + 1) * L]), "big") or 1
+            if H:
+                dg = hashlib.new(H, msgs[i * msg_len:(i + 1) * msg_len]).digest()
+                zb = dg[:L] if len(dg) >= L else bytes(L - len(dg)) + dg
+            else:
+                zb = bytes(rng.randrange(256) for _ in range(L))
+                if c.n.bit_length() < 8 * L:
+                    zb = b"\0" + zb[1:]
+            zi = int.from_bytes(zb, "big")
+            x = int.from_bytes(bytes(R[2 * L * i: 2 * L * i + L]), "big")
+            ri = x % c.n
+            si = pow(k, -1, c.n) * (zi + ri * d) % c.n
+            flip = rng.randrange(6)
+            if flip == 0:
+                si = (si + 1) % c.n
+            if flip == 1:
+                ri = (ri + 1) % c.n
+            zs += zb; rr += ri.to_bytes(L, "big"); ss += si.to_bytes(L, "big")
+            ids.append((int(R[2 * L * i + 2 * L - 1]) & 1) ^ (1 if flip == 2 else 0) | (2 if x >= c.n or flip == 3 else 0))
+        high = bool(rng.randrange(2))
+        v = e.ecdsa_verify(c.cid, bytes(zs), bytes(rr), bytes(ss), Q, reject_high_s=high)
+        assert bytes(v) == bytes(oracle_lib.ecdsa_verify(c.cid, bytes(zs), bytes(rr), bytes(ss), Q, reject_high_s=high)), ("verify", c.name, n)
+        stats["verify"] += 1
+        if c.name != "p224":
+            gk, gv = e.ecdsa_recover(c.cid, bytes(zs), bytes(rr), bytes(ss), bytes(ids), reject_high_s=high)
+            wk, wv = oracle_lib.ecdsa_recover(c.cid, bytes(zs), bytes(rr), bytes(ss), bytes(ids), reject_high_s=high)
+            assert bytes(gk) == bytes(wk) and bytes(gv) == bytes(wv), ("recover", c.name, n)
+            stats["recover"] += 1
+        if H:
+            sg = b"".join(bytes(rr[i * L:(i + 1) * L]) + bytes(ss[i * L:(i + 1) * L]) for i in range(n))
+            vm = e.ecdsa_verify_msg(c.cid, Q, msgs, msg_len, sg, reject_high_s=high)
+            assert bytes(vm) == bytes(v) == bytes(oracle_lib.ecdsa_verify_msg(c.cid, Q, msgs, msg_len, sg, reject_high_s=high)), ("verify_msg", c.name, n, msg_len)
+            stats["verify_msg"] += 1
     elif kind == "fixed":
         n = rng.randrange(1, 3000)
         wdt = rng.choice([0, 0, rng.randrange(4, 17)])
