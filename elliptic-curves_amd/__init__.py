@@ -55,6 +55,7 @@ ABI_SYMBOLS = [
     "ecgpu_ecdsa_recover_batch", "ecgpu_ecdsa_recover_batch_dev",
     "ecgpu_sm2dsa_verify_msg_batch", "ecgpu_sm2dsa_verify_msg_batch_dev",
     "ecgpu_ecdsa_verify_msg_batch", "ecgpu_ecdsa_verify_msg_batch_dev",
+    "ecgpu_group_ecdsa_verify_batch", "ecgpu_group_ecdsa_verify_msg_batch", "ecgpu_group_ecdsa_recover_batch",
 ]
 
 
@@ -593,6 +594,39 @@ class Group:
         inf = np.zeros(n, np.uint8)
         self._chk(self._lib.ecgpu_group_batch_mul(self._g, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
+
+    def ecdsa_verify(self, curve, z, r, s, q_xy, reject_high_s=False):
+        L = _field_bytes(curve)
+        zz, rr, ss, qq = _host(z), _host(r), _host(s), _host(q_xy)
+        n = zz.size // L
+        _need("r", rr, n * L); _need("s", ss, n * L); _need("q_xy", qq, n * 2 * L)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_group_ecdsa_verify_batch(self._g, curve, _hp(zz), _hp(rr), _hp(ss), _hp(qq), ctypes.c_size_t(n),
+                                                           int(bool(reject_high_s)), _hp(ok)))
+        return ok
+
+    def ecdsa_verify_msg(self, curve, q_xy, msgs, msg_len, sigs, reject_high_s=False):
+        L = _field_bytes(curve)
+        qq, sg = _host(q_xy), _host(sigs)
+        mm = _host(msgs) if msg_len else None
+        n = qq.size // (2 * L)
+        _need("sigs", sg, n * 2 * L); _need("msgs", mm, n * msg_len)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_group_ecdsa_verify_msg_batch(self._g, curve, _hp(qq), _hp(mm), ctypes.c_size_t(msg_len), _hp(sg),
+                                                               ctypes.c_size_t(n), int(bool(reject_high_s)), _hp(ok)))
+        return ok
+
+    def ecdsa_recover(self, curve, z, r, s, recid, reject_high_s=False):
+        L = _field_bytes(curve)
+        zz, rr, ss, ii = _host(z), _host(r), _host(s), _host(recid)
+        n = ii.size
+        _need("z", zz, n * L); _need("r", rr, n * L); _need("s", ss, n * L)
+        out = np.zeros(n * 2 * L, np.uint8)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_group_ecdsa_recover_batch(self._g, curve, _hp(zz), _hp(rr), _hp(ss), _hp(ii), ctypes.c_size_t(n),
+                                                            int(bool(reject_high_s)), _hp(out), _hp(ok)))
+        return out, ok
+
 
 
 def version():

@@ -323,4 +323,53 @@ int ecgpu_group_batch_mul(ecgpu_group* g, int curve, const uint8_t* scalars, con
     });
 }
 
+// ---- the signature entry points over the group: index-range slices, no exchange ----------------------------------------------
+int ecgpu_group_ecdsa_verify_batch(ecgpu_group* g, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* q_xy,
+                                   size_t n, int reject_high_s, uint8_t* ok) {
+    if (!g) return ECGPU_ERR_ARG;
+    g->err.clear();
+    const size_t L = ecgpu_field_bytes(curve);
+    if (!L) return fail(g, ECGPU_ERR_CURVE, "unknown curve id");
+    if (n && (!z || !r || !s || !q_xy || !ok)) return fail(g, ECGPU_ERR_ARG, "ecgpu_group_ecdsa_verify_batch: NULL argument");
+    const int nd = (int)g->m.size();
+    return for_each_member(g, [&](int m) -> int {
+        size_t lo, hi;
+        shard(n, m, nd, &lo, &hi);
+        return ecgpu_ecdsa_verify_batch(g->m[m].ctx, curve, z + lo * L, r + lo * L, s + lo * L, q_xy + lo * 2 * L, hi - lo, reject_high_s,
+                                        ok + lo);
+    });
+}
+
+int ecgpu_group_ecdsa_verify_msg_batch(ecgpu_group* g, int curve, const uint8_t* q_xy, const uint8_t* msgs, size_t msg_len,
+                                       const uint8_t* sigs, size_t n, int reject_high_s, uint8_t* ok) {
+    if (!g) return ECGPU_ERR_ARG;
+    g->err.clear();
+    const size_t L = ecgpu_field_bytes(curve);
+    if (!L) return fail(g, ECGPU_ERR_CURVE, "unknown curve id");
+    if (n && (!q_xy || !sigs || !ok || (msg_len && !msgs))) return fail(g, ECGPU_ERR_ARG, "ecgpu_group_ecdsa_verify_msg_batch: NULL argument");
+    const int nd = (int)g->m.size();
+    return for_each_member(g, [&](int m) -> int {
+        size_t lo, hi;
+        shard(n, m, nd, &lo, &hi);
+        return ecgpu_ecdsa_verify_msg_batch(g->m[m].ctx, curve, q_xy + lo * 2 * L, msg_len ? msgs + lo * msg_len : nullptr, msg_len,
+                                            sigs + lo * 2 * L, hi - lo, reject_high_s, ok + lo);
+    });
+}
+
+int ecgpu_group_ecdsa_recover_batch(ecgpu_group* g, int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid,
+                                    size_t n, int reject_high_s, uint8_t* out_xy, uint8_t* ok) {
+    if (!g) return ECGPU_ERR_ARG;
+    g->err.clear();
+    const size_t L = ecgpu_field_bytes(curve);
+    if (!L) return fail(g, ECGPU_ERR_CURVE, "unknown curve id");
+    if (n && (!z || !r || !s || !recid || !out_xy || !ok)) return fail(g, ECGPU_ERR_ARG, "ecgpu_group_ecdsa_recover_batch: NULL argument");
+    const int nd = (int)g->m.size();
+    return for_each_member(g, [&](int m) -> int {
+        size_t lo, hi;
+        shard(n, m, nd, &lo, &hi);
+        return ecgpu_ecdsa_recover_batch(g->m[m].ctx, curve, z + lo * L, r + lo * L, s + lo * L, recid + lo, hi - lo, reject_high_s,
+                                         out_xy + lo * 2 * L, ok + lo);
+    });
+}
+
 }  // extern "C"

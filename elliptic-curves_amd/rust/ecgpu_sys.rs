@@ -247,6 +247,40 @@ unsafe extern "C" {
         out_xy: *mut u8,
         out_inf: *mut u8,
     ) -> c_int;
+    pub fn ecgpu_group_ecdsa_verify_batch(
+        group: *mut EcgpuGroup,
+        curve: c_int,
+        z: *const u8,
+        r: *const u8,
+        s: *const u8,
+        q_xy: *const u8,
+        n: usize,
+        reject_high_s: c_int,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_group_ecdsa_verify_msg_batch(
+        group: *mut EcgpuGroup,
+        curve: c_int,
+        q_xy: *const u8,
+        msgs: *const u8,
+        msg_len: usize,
+        sigs: *const u8,
+        n: usize,
+        reject_high_s: c_int,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_group_ecdsa_recover_batch(
+        group: *mut EcgpuGroup,
+        curve: c_int,
+        z: *const u8,
+        r: *const u8,
+        s: *const u8,
+        recid: *const u8,
+        n: usize,
+        reject_high_s: c_int,
+        out_xy: *mut u8,
+        ok: *mut u8,
+    ) -> c_int;
     pub fn ecgpu_k256_glv_decompose(
         ctx: *mut EcgpuCtx,
         scalars: *const u8,

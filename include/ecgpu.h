@@ -256,6 +256,15 @@ int ecgpu_group_batch_mul_base(ecgpu_group *group, int curve, const uint8_t *sca
 int ecgpu_group_batch_mul(ecgpu_group *group, int curve, const uint8_t *scalars, const uint8_t *points_xy,
                           const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);
 
+/* ecgpu_ecdsa_verify_batch / ecgpu_ecdsa_verify_msg_batch / ecgpu_ecdsa_recover_batch over all GPUs of the group (index-range
+ * slices, no exchange; host buffers). */
+int ecgpu_group_ecdsa_verify_batch(ecgpu_group *group, int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
+                                   const uint8_t *q_xy, size_t n, int reject_high_s, uint8_t *ok);
+int ecgpu_group_ecdsa_verify_msg_batch(ecgpu_group *group, int curve, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len,
+                                       const uint8_t *sigs, size_t n, int reject_high_s, uint8_t *ok);
+int ecgpu_group_ecdsa_recover_batch(ecgpu_group *group, int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s,
+                                    const uint8_t *recid, size_t n, int reject_high_s, uint8_t *out_xy, uint8_t *ok);
+
 /* ---- introspection / measurement ---------------------------------------------------------------- */
 
 /* k256 GLV split on the device: k -> (r1, r2) with r1 + r2*lambda = k (mod n), canonical scalars

@@ -1035,6 +1035,16 @@ def test_group_multi_device_entry_points(eng, devices, mode, monkeypatch):
             a2, ai2 = grp.mul(c.cid, k2, b)
             b2, bi2 = eng.mul(c.cid, k2, b)
             assert bytes(a2) == bytes(b2) and bytes(ai2) == bytes(bi2)
+            # the signature entry points: index-range slices over the members == the single-context calls
+            from gpu_common import recover_cases, recover_pack
+            z, r, s_, q, exp = ecdsa_pack(ecdsa_cases(c, 0x6E0 + c.cid, nvalid=5))
+            assert bytes(grp.ecdsa_verify(c.cid, z, r, s_, q)) == bytes(exp) == bytes(eng.ecdsa_verify(c.cid, z, r, s_, q))
+            rz, rr_, rs, rid, rxy, rok = recover_pack(recover_cases(c, 0x6E1 + c.cid, nvalid=5), c.L)
+            gk, gv = grp.ecdsa_recover(c.cid, rz, rr_, rs, rid)
+            assert bytes(gk) == rxy and bytes(gv) == bytes(rok)
+            sg = b"".join(r[i * c.L:(i + 1) * c.L] + s_[i * c.L:(i + 1) * c.L] for i in range(len(exp)))
+            msgs = bytes(range(7)) * len(exp)
+            assert bytes(grp.ecdsa_verify_msg(c.cid, q, msgs, 7, sg)) == bytes(eng.ecdsa_verify_msg(c.cid, q, msgs, 7, sg))
     finally:
         grp.close()
 
