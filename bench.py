@@ -80,7 +80,9 @@ WORKLOADS = {
                      scaling="strong"),
 }
 SEEDS = {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
-DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384"]      # BASELINE configs[2], [3], [4] beside the top-level configs[1]
+# BASELINE configs[2], [3], [4] beside the top-level configs[1], then the two signature workloads of SURVEY.md 8(f) (callers of the
+# path: p256 verification, k256 public-key recovery) so that they are driver-timed too
+DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "ecdsa_p256", "recover_k256"]
 NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 ROOFLINE_CONSTS = os.path.join(ROOT, "profiles", "roofline_consts.json")
