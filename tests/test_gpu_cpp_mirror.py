@@ -36,7 +36,7 @@ def test_c_example_builds():
     """CPU: the plain-C client of the ABI (examples/) compiles and links."""
     ex = os.path.join(os.path.dirname(HERE), "examples")
     subprocess.check_call(["make", "-s", "-C", ex])
-    assert os.path.exists(os.path.join(ex, "batch_pubkeys")) and os.path.exists(os.path.join(ex, "node_lincomb"))
+    assert all(os.path.exists(os.path.join(ex, name)) for name in ("batch_pubkeys", "node_lincomb", "verify_and_recover"))
 
 
 @pytest.mark.gpu
@@ -47,6 +47,17 @@ def test_c_example_runs():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "79be667ef9dcbbac55a06295ce870b07029bfcdb2dce28d959f2815b16f81798" in out.stdout      # x(G)
     assert "shared(1,7) == shared(7,1): yes" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_verify_and_recover_example_runs():
+    """examples/verify_and_recover.c: the reference's recovery vectors (k256/src/ecdsa.rs:190-211), message-level ECDSA
+    verification under the recovered keys and the SM2DSA message-level vector (sm2/tests/sm2dsa.rs:16-31) from plain C."""
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    subprocess.check_call(["make", "-s", "-C", ex])
+    out = subprocess.run([os.path.join(ex, "verify_and_recover")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(": yes") == 5 and "NO" not in out.stdout
 
 
 @pytest.mark.gpu
