@@ -179,6 +179,14 @@ int run(const char* name, const uint8_t* n_be, int cases) {
             for (auto& sg : bad) sg.s[C::FieldBytesSize - 1] ^= 1;
             ok = C::batch_verify_prehashed(vec.q, vec.z, bad, false);
             for (auto v : ok) CHECK(v == 0);
+            // recover_from_prehash: one of the two parities of the unreduced candidate gives back the signer's key
+            // (the vectors carry no recovery id); the recovered keys are finite and verify
+            std::vector<uint8_t> id0(vec.q.size(), 0), id1(vec.q.size(), 1);
+            auto k0 = C::batch_recover_from_prehash(vec.z, vec.sig, id0, false);
+            auto k1 = C::batch_recover_from_prehash(vec.z, vec.sig, id1, false);
+            for (size_t i = 0; i < vec.q.size(); i++) CHECK((k0[i] == vec.q[i]) != (k1[i] == vec.q[i]));
+            std::vector<uint8_t> bad_id(vec.q.size(), 7);
+            for (auto& k : C::batch_recover_from_prehash(vec.z, vec.sig, bad_id, false)) CHECK(k.is_identity());
         }
         (void)Q;
     }
