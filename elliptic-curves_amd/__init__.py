@@ -522,6 +522,15 @@ class Engine:
         self._chk(self._lib.ecgpu_ecdsa_verify_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_q_xy),
                                                          ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_ok)))
 
+    def ecdsa_verify_msg_dev(self, curve, d_q_xy, d_msgs, msg_len, d_sigs, n, reject_high_s, d_ok):
+        self._chk(self._lib.ecgpu_ecdsa_verify_msg_batch_dev(self._ctx, curve, _dp(d_q_xy), _dp(d_msgs), ctypes.c_size_t(msg_len),
+                                                             _dp(d_sigs), ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_ok)))
+
+    def sm2dsa_verify_msg_dev(self, d_distid, distid_len, d_q_xy, d_msgs, msg_len, d_sigs, n, d_ok):
+        self._chk(self._lib.ecgpu_sm2dsa_verify_msg_batch_dev(self._ctx, _dp(d_distid), ctypes.c_size_t(distid_len), _dp(d_q_xy),
+                                                              _dp(d_msgs), ctypes.c_size_t(msg_len), _dp(d_sigs), ctypes.c_size_t(n),
+                                                              _dp(d_ok)))
+
     def ecdsa_recover_dev(self, curve, d_z, d_r, d_s, d_recid, n, reject_high_s, d_out_xy, d_ok):
         self._chk(self._lib.ecgpu_ecdsa_recover_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_recid),
                                                           ctypes.c_size_t(n), int(bool(reject_high_s)), _dp(d_out_xy), _dp(d_ok)))
