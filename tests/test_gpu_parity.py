@@ -849,6 +849,20 @@ def test_ecdsa_recover_vs_oracle_and_model(eng, curve):
     assert (gr[good & nonzero] == Qr[good & nonzero]).all() and not (gr[~good] == Qr[~good]).all(axis=1).any()
 
 
+@pytest.mark.parametrize("name", ["k256_der", "p256_der", "p384_der", "p521_der"])
+def test_ecdsa_recover_wycheproof(eng, name):
+    """The reference's Wycheproof blobs through ecgpu_ecdsa_recover_batch: every parsed vector under all four recovery ids; one
+    of them gives back the vector's public key exactly when the vector is valid; keys and verdicts equal the oracle's."""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    z, r, s, ids = wycheproof_lib.recovery_batch(p)
+    keys, ok = eng.ecdsa_recover(c.cid, z, r, s, ids, reject_high_s=p["reject_high_s"])
+    assert bytes(wycheproof_lib.recovery_matches(p, keys, ok)) == bytes(p["expect"])
+    wk, wok = oracle_lib.ecdsa_recover(c.cid, z, r, s, ids, p["reject_high_s"])
+    assert bytes(keys) == bytes(wk) and bytes(ok) == bytes(wok)
+
+
 def test_ecdsa_recover_device_resident_2p20(eng):
     """2^20 k256 signatures, device-resident through ecgpu_ecdsa_recover_batch_dev: the corner-case set tiled over the batch
     (every chunk of the kernels sees every case) equals the oracle's keys and verdicts, tiled the same way."""

@@ -186,6 +186,21 @@ def test_wycheproof_ecdsa_vectors_message_level(oracle, name):
         assert bytes(ok) == bytes(p["expect"][idx]), (name, ln)
 
 
+@pytest.mark.parametrize("name", ["k256_der", "p256_der", "p384_der", "p521_der"])
+def test_wycheproof_vectors_through_recovery(oracle, name):
+    """The Wycheproof blobs once more, through public-key recovery: for every vector whose signature parses, one of the four
+    recovery ids gives back the vector's public key exactly when the vector is a valid one (a recovered key always verifies
+    the signature it came from, so an invalid vector's key can never come out).  Keys off the curve (a few invalid vectors)
+    are never recovered either."""
+    import wycheproof_lib
+    p = wycheproof_lib.prepare(name)
+    c = p["curve"]
+    z, r, s, ids = wycheproof_lib.recovery_batch(p)
+    keys, ok = oracle.ecdsa_recover(c.cid, z, r, s, ids, p["reject_high_s"])
+    assert bytes(wycheproof_lib.recovery_matches(p, keys, ok)) == bytes(p["expect"])
+    assert int(p["expect"].sum()) > 100
+
+
 def test_curve_digests_against_hashlib(oracle):
     """ecref_curve_digest: SHA-256 / 384 / 224 / 512 per curve against hashlib on lengths around every padding boundary; p192,
     sm2 and bign256 have no ECDSA digest."""

@@ -176,3 +176,22 @@ def by_message_length(p):
         sg = b"".join(bytes(p["r"][L * i: L * (i + 1)]) + bytes(p["s"][L * i: L * (i + 1)]) for i in idx)
         out[ln] = (idx, q, b"".join(p["msgs"][i] for i in idx), sg)
     return out
+
+
+def recovery_batch(p):
+    """Every parsed vector of prepare() under all four recovery ids: (z, r, s, ids) with 4 consecutive elements per vector,
+    for the rule 'some id recovers the vector's key  <=>  the signature is valid for that key' (a recovered key always
+    verifies the signature it was recovered from)."""
+    L = p["curve"].L
+    n = len(p["expect"])
+    rep = lambda a: np.repeat(np.asarray(a, np.uint8).reshape(n, L), 4, axis=0).reshape(-1)
+    return rep(p["z"]), rep(p["r"]), rep(p["s"]), np.tile(np.arange(4, dtype=np.uint8), n)
+
+
+def recovery_matches(p, keys, ok):
+    """Per vector: does one of its four ids recover exactly the vector's public key?"""
+    L = p["curve"].L
+    n = len(p["expect"])
+    k = np.asarray(keys, np.uint8).reshape(n, 4, 2 * L)
+    q = np.asarray(p["q"], np.uint8).reshape(n, 1, 2 * L)
+    return ((k == q).all(axis=2) & (np.asarray(ok).reshape(n, 4) != 0)).any(axis=1).astype(np.uint8)
