@@ -84,11 +84,23 @@ struct Field {
         for (int k = 0; k < 9; k++) lo[k] = c[k];
         lo[9] = 0;
         lo[10] = 0;
+        // High columns 9..15: the upper 32 bits of a column move into the NEXT high column first (2^32 = 8 * 2^29, one
+        // multiply-add by 8 — a 64-bit shift + mask + add would cost three issue slots: c[k + 1] < 56 LB^2 + 2^35 < 2^64), so that only the lower half is left to fold — two multiply-adds
+        // instead of four per column.  The last one (and the second-stage column 10) has no next column and folds in full.
 #pragma unroll
-        for (int k = 9; k < 17; k++) k_fold(lo, k - 9, c[k]);
+        for (int k = 9; k < 16; k++) {
+            const uint32_t cl = (uint32_t)c[k], ch = (uint32_t)(c[k] >> 32);
+            c[k + 1] += (uint64_t)ch * opaque_const(8u);
+            lo[k - 9] += (uint64_t)cl * KC::F0;
+            lo[k - 8] += (uint64_t)cl * opaque_const(KC::F1);
+        }
+        k_fold(lo, 7, c[16]);
         {
             uint64_t c9 = lo[9], c10 = lo[10];
-            k_fold(lo, 0, c9);
+            const uint32_t cl = (uint32_t)c9, ch = (uint32_t)(c9 >> 32);
+            c10 += (uint64_t)ch * opaque_const(8u);
+            lo[0] += (uint64_t)cl * KC::F0;
+            lo[1] += (uint64_t)cl * opaque_const(KC::F1);
             k_fold(lo, 1, c10);
         }
         E r;

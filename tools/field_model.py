@@ -51,19 +51,29 @@ def k256_columns(a, b):
 def k256_reduce(c):
     """17 64-bit columns -> 9 limbs, magnitude 1 (limbs < K_LB, value congruent mod p)."""
     lo = c[:9] + [0, 0]
-    for k in range(9, 17):                     # fold high columns through their 32-bit halves
-        cl, ch = c[k] & 0xFFFFFFFF, c[k] >> 32
-        j = k - 9
+    c = list(c)
+
+    def fold_full(j, col):                     # both 32-bit halves of a column of weight 2^(261 + 29 j): four multiply-adds
+        cl, ch = col & 0xFFFFFFFF, col >> 32
         lo[j] = chk64(lo[j] + cl * K_F0)
         lo[j + 1] = chk64(lo[j + 1] + cl * K_F1 + ch * K_G1)
         lo[j + 2] = chk64(lo[j + 2] + ch * K_G2)
-    # columns 9 and 10 (weights 2^261, 2^290) are folded once more, again by halves
-    for k in (9, 10):
-        cl, ch = lo[k] & 0xFFFFFFFF, lo[k] >> 32
+
+    for k in range(9, 16):                     # columns 9..15: the upper half moves into the next column (2^32 = 8 * 2^29),
+        cl, ch = c[k] & 0xFFFFFFFF, c[k] >> 32  # the lower half folds with two multiply-adds
+        c[k + 1] = chk64(c[k + 1] + ch * 8)
         j = k - 9
         lo[j] = chk64(lo[j] + cl * K_F0)
-        lo[j + 1] = chk64(lo[j + 1] + cl * K_F1 + ch * K_G1)
-        lo[j + 2] = chk64(lo[j + 2] + ch * K_G2)
+        lo[j + 1] = chk64(lo[j + 1] + cl * K_F1)
+    fold_full(7, c[16])
+    # columns 9 and 10 (weights 2^261, 2^290) are folded once more, the same way
+    c9, c10 = lo[9], lo[10]
+    cl, ch = c9 & 0xFFFFFFFF, c9 >> 32
+    c10 = chk64(c10 + ch * 8)
+    lo[0] = chk64(lo[0] + cl * K_F0)
+    lo[1] = chk64(lo[1] + cl * K_F1)
+    lo[9] = lo[10] = 0                         # (fold_full below may touch index 3 at most)
+    fold_full(1, c10)
     lo = lo[:9]
     # sequential carry propagation 0 -> 8
     r = [0] * 9
