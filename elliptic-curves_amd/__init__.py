@@ -36,7 +36,7 @@ ERR_CURVE, ERR_SCALAR_RANGE, ERR_POINT, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_ARG
 
 # every symbol include/ecgpu.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
-    "ecgpu_init", "ecgpu_destroy", "ecgpu_last_error", "ecgpu_field_bytes", "ecgpu_set_stream",
+    "ecgpu_init", "ecgpu_device_count", "ecgpu_destroy", "ecgpu_last_error", "ecgpu_field_bytes", "ecgpu_set_stream",
     "ecgpu_set_base_window", "ecgpu_set_msm_window", "ecgpu_batch_mul_base", "ecgpu_batch_mul", "ecgpu_msm",
     "ecgpu_batch_mul_base_and_mul_add", "ecgpu_batch_normalize", "ecgpu_batch_mul_base_dev",
     "ecgpu_batch_mul_dev", "ecgpu_msm_dev", "ecgpu_batch_mul_base_and_mul_add_dev", "ecgpu_batch_normalize_dev",
@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
     "ecgpu_batch_mul_base_compressed", "ecgpu_batch_mul_base_compressed_dev",
     "ecgpu_dev_alloc", "ecgpu_dev_free", "ecgpu_copy_to_device", "ecgpu_copy_to_host",
-    "ecgpu_msm_parts_bytes", "ecgpu_msm_parts_dev", "ecgpu_msm_finish_dev",
+    "ecgpu_msm_parts_bytes", "ecgpu_msm_plan_window", "ecgpu_msm_parts_dev", "ecgpu_msm_finish_dev",
     "ecgpu_group_init", "ecgpu_group_destroy", "ecgpu_group_size", "ecgpu_group_ctx", "ecgpu_group_last_error",
     "ecgpu_group_exchange", "ecgpu_group_set_msm_window", "ecgpu_group_msm", "ecgpu_group_msm_dev",
     "ecgpu_group_batch_mul_base", "ecgpu_group_batch_mul", "ecgpu_selftest_field", "ecgpu_selftest_point",

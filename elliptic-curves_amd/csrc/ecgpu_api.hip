@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../include/ecgpu.h"
@@ -29,10 +30,27 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// A context's view of a basepoint comb table.  The table itself is owned by the per-device registry below and shared by
+// every context of the process on that device (the analogue of the reference's process-wide `LazyLock<BasepointTable>`,
+// k256/src/arithmetic/tables.rs:18): the 21.5 GB k256 table is built and held once per GPU however many contexts exist.
 struct Table {
     uint32_t* d = nullptr;
-    int w = 0, nwin = 0;
+    int w = 0, nwin = 0;      // the width actually in use (may be narrower than asked for after an out-of-memory fallback)
+    int asked = 0;            // the width this view was made for (ctx->want_w at that time)
 };
+
+struct SharedTable {
+    uint32_t* d = nullptr;
+    int nwin = 0, refs = 0;
+};
+struct TableRegistry {
+    std::mutex mu;                                               // held while a table is built: a second context of the device waits
+    std::map<std::tuple<int, int, int>, SharedTable> tabs;       // (device, curve id, comb width)
+};
+TableRegistry& table_registry(int device) {                      // one per device: the GPUs of a group build in parallel
+    static TableRegistry* r = new TableRegistry[64];             // never destroyed: contexts may outlive static destructors
+    return r[device & 63];
+}
 
 }  // namespace
 
@@ -148,9 +166,10 @@ int drain(ecgpu_ctx* ctx) {
 struct SyncScope {
     ecgpu_ctx* ctx;
     bool was;
+    int rc = ECGPU_OK;      // a failed drain (sticky device fault of the queued work, failed copy): the entry point returns it
     explicit SyncScope(ecgpu_ctx* c) : ctx(c), was(c->async) {
         if (was) {
-            (void)drain(ctx);
+            rc = drain(ctx);
             ctx->async = false;
         }
     }
@@ -185,18 +204,25 @@ void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*,
 
 // ---- basepoint table ---------------------------------------------------------------------------------
 
-template <class C>
-int ensure_table(ecgpu_ctx* ctx) {
-    constexpr int N = C::N, NS = Field<C>::NS;
-    (void)N;
-    Table& t = ctx->table[C::ID];
-    int w = ctx->want_w[C::ID];
-    if (t.d && t.w == w) return ECGPU_OK;
-    if (t.d) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        HIP_TRY(ctx, hipFree(t.d));
-        t.d = nullptr;
+// drops this context's reference to its table of curve `id`; the last reference frees the device memory
+void release_table(ecgpu_ctx* ctx, int id) {
+    Table& t = ctx->table[id];
+    if (!t.d) return;
+    TableRegistry& reg = table_registry(ctx->device);
+    std::lock_guard<std::mutex> lock(reg.mu);
+    auto it = reg.tabs.find(std::make_tuple(ctx->device, id, t.w));
+    if (it != reg.tabs.end() && it->second.d == t.d && --it->second.refs == 0) {
+        (void)hipFree(it->second.d);
+        reg.tabs.erase(it);
     }
+    t = Table();
+}
+
+// builds the comb table of width w into freshly allocated device memory; ECGPU_ERR_OOM when the table (or its build
+// scratch) does not fit
+template <class C>
+int build_table(ecgpu_ctx* ctx, int w, SharedTable* out) {
+    constexpr int N = C::N, NS = Field<C>::NS;
     const int bits = 32 * N;
     const int nwin = signed_window_count(bits - 1, w);       // scalars are folded to bits - 1 bits (fold_scalar)
     const size_t half = (size_t)1 << (w - 1);
@@ -209,27 +235,83 @@ int ensure_table(ecgpu_ctx* ctx) {
     if ((rc = ensure(ctx, ctx->bases, (size_t)nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->proj, slab * half * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->prefix, slab * half * NS * 4)) != ECGPU_OK) return rc;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.d), entries * 2 * N * 4));
+    uint32_t* d = nullptr;
+    if (const char* e = getenv("ECGPU_TEST_TABLE_MAX_MB")) {     // fault injection for the fallback path (tests): pretend larger tables do not fit
+        if (entries * 2 * N * 4 > (size_t)atol(e) << 20) {
+            ctx->err = "basepoint table: allocation refused by ECGPU_TEST_TABLE_MAX_MB";
+            return ECGPU_ERR_OOM;
+        }
+    }
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), entries * 2 * N * 4));
     launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, w, nwin);
     for (size_t j0 = 0; j0 < (size_t)nwin; j0 += slab) {
         const size_t ws = j0 + slab <= (size_t)nwin ? slab : (size_t)nwin - j0;
         launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p + j0 * (3 * NS), (uint32_t*)ctx->proj.p, w, (int)ws);
         launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, ws * half, nullptr,
-                            nullptr, t.d + j0 * half * (2 * N));
+                            nullptr, d + j0 * half * (2 * N));
     }
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    t.w = w;
-    t.nwin = nwin;
-    // the build scratch is larger than most batches need: give it back
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     // visible to every stream of the device from here on
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        ctx->err = std::string("basepoint table build: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? ECGPU_ERR_OOM : ECGPU_ERR_HIP;
+    }
+    out->d = d;
+    out->nwin = nwin;
+    return ECGPU_OK;
+}
+
+// the build scratch is larger than most batches need: give it back
+int drop_build_scratch(ecgpu_ctx* ctx) {
     for (DevBuf* b : {&ctx->proj, &ctx->prefix}) {
         if (b->cap > ((size_t)64 << 20)) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             HIP_TRY(ctx, hipFree(b->p));
             b->p = nullptr;
             b->cap = 0;
         }
     }
     return ECGPU_OK;
+}
+
+// Makes ctx->table[C::ID] point at the device's shared comb table of the width the context asks for (ecgpu_set_base_window;
+// defaults in ecgpu_ctx::want_w), building it if no context of this process has yet.  When the table does not fit — the
+// k256 default is 21.5 GB — the width is lowered two bits at a time (a quarter of the memory, one or two more additions
+// per scalar; results do not depend on it) down to 16 bits (36 MB) before ECGPU_ERR_OOM is returned.
+template <class C>
+int ensure_table(ecgpu_ctx* ctx) {
+    Table& t = ctx->table[C::ID];
+    const int want = ctx->want_w[C::ID];
+    if (t.d && t.asked == want) return ECGPU_OK;
+    if (t.d) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // queued kernels may still read the old table
+        release_table(ctx, C::ID);
+    }
+    TableRegistry& reg = table_registry(ctx->device);
+    std::lock_guard<std::mutex> lock(reg.mu);
+    int rc = ECGPU_ERR_OOM;
+    for (int w = want;; w -= 2) {
+        SharedTable& st = reg.tabs[std::make_tuple(ctx->device, (int)C::ID, w)];
+        if (!st.d) {
+            rc = build_table<C>(ctx, w, &st);
+            if (rc != ECGPU_OK) {
+                reg.tabs.erase(std::make_tuple(ctx->device, (int)C::ID, w));
+                (void)hipGetLastError();                         // an out-of-memory error is not sticky
+                int rc2 = drop_build_scratch(ctx);
+                if (rc == ECGPU_ERR_OOM && rc2 == ECGPU_OK && w - 2 >= 16) continue;
+                if (rc == ECGPU_ERR_OOM) ctx->err = "basepoint comb table does not fit in device memory (even at 16-bit windows)";
+                return rc;
+            }
+        }
+        st.refs++;
+        t.d = st.d;
+        t.w = w;
+        t.nwin = st.nwin;
+        t.asked = want;
+        break;
+    }
+    return drop_build_scratch(ctx);
 }
 
 // launches the normalisation of n projective points in ctx->proj to wire-format output
@@ -681,6 +763,20 @@ size_t ecgpu_field_bytes(int curve) {
     }
 }
 
+int ecgpu_device_count(void) {
+    int count = 0, usable = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    for (int d = 0; d < count; d++) {          // the leading run of gfx950 devices: a group lists devices 0 .. count - 1
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) break;
+        usable++;
+    }
+    return usable;
+}
+
 int ecgpu_init(ecgpu_ctx** out, int device) {
     if (!out) return ECGPU_ERR_ARG;
     *out = nullptr;
@@ -717,8 +813,7 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
                       &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
                       &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
-    for (auto& t : ctx->table)
-        if (t.d) (void)hipFree(t.d);
+    for (int id = 0; id < 12; id++) release_table(ctx, id);     // the last context of the device frees the shared tables
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (auto& e : ctx->ev)
@@ -888,6 +983,16 @@ size_t ecgpu_msm_parts_bytes(ecgpu_ctx* ctx, int curve, size_t plan_terms) {
         return (int)ECGPU_OK;
     });
     return bytes;
+}
+
+int ecgpu_msm_plan_window(ecgpu_ctx* ctx, int curve, size_t plan_terms) {
+    if (!check_ctx(ctx)) return 0;
+    int c = 0;
+    (void)dispatch(curve, [&](auto cv) {
+        c = ctx->msm_c ? ctx->msm_c : msm_choose_window<decltype(cv)>(plan_terms);
+        return (int)ECGPU_OK;
+    });
+    return c;
 }
 
 int ecgpu_msm_parts_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
@@ -1109,6 +1214,7 @@ int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size
                          uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !out_xy)) return arg_error(ctx, __func__);
@@ -1131,6 +1237,7 @@ int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* sc
                                     uint8_t* out_tag) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !out_x || !out_tag)) return arg_error(ctx, __func__);
@@ -1152,6 +1259,7 @@ int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
                     const uint8_t* points_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
@@ -1179,6 +1287,7 @@ int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* 
               size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (!out_xy || (n && (!scalars || !points_xy))) return arg_error(ctx, __func__);
@@ -1227,6 +1336,7 @@ int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a
                                      uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!a_scalars || !b_scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
@@ -1256,6 +1366,7 @@ int ecgpu_ecdsa_verify_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const 
                              const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!z || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
@@ -1282,6 +1393,7 @@ int ecgpu_ecdsa_verify_msg_batch(ecgpu_ctx* ctx, int curve, const uint8_t* q_xy,
                                  size_t n, int reject_high_s, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!q_xy || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
@@ -1307,6 +1419,7 @@ int ecgpu_ecdsa_recover_batch(ecgpu_ctx* ctx, int curve, const uint8_t* z, const
                               const uint8_t* recid, size_t n, int reject_high_s, uint8_t* out_xy, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!z || !r || !s || !recid || !out_xy || !ok)) return arg_error(ctx, __func__);
@@ -1335,6 +1448,7 @@ int ecgpu_sm2dsa_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* r
                               uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     const size_t L = 32;
     if (n && (!e || !r || !s || !q_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
@@ -1358,6 +1472,7 @@ int ecgpu_sm2dsa_verify_msg_batch(ecgpu_ctx* ctx, const uint8_t* distid, size_t 
                                   size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     if (distid_len > 8191 || (distid_len && !distid) || (n && (!q_xy || !sigs || !ok || (msg_len && !msgs)))) return arg_error(ctx, __func__);
     int rc;
     if ((rc = upload(ctx, ctx->ec_id, distid, distid_len)) != ECGPU_OK) return rc;
@@ -1382,6 +1497,7 @@ int ecgpu_schnorr_verify_batch(ecgpu_ctx* ctx, const uint8_t* e, const uint8_t* 
                                size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     const size_t L = 32;
     if (n && (!e || !r || !s || !p_xy || !ok)) return arg_error(ctx, __func__);
     int rc;
@@ -1406,6 +1522,7 @@ int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const ui
                                    size_t n, uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     if (n && (!pk_x || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
     int rc;
     if (n >= PIPE_MIN)
@@ -1428,6 +1545,7 @@ int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const ui
                      uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, __func__);
@@ -1451,6 +1569,7 @@ int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const u
                            uint8_t* ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!xs || !y_is_odd || !out_xy || !ok)) return arg_error(ctx, __func__);
@@ -1474,6 +1593,7 @@ int ecgpu_batch_normalize(ecgpu_ctx* ctx, int curve, const uint8_t* points_xyz, 
                           uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!points_xyz || !out_xy)) return arg_error(ctx, __func__);
@@ -1490,6 +1610,7 @@ int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const u
                     uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (!out_xy || (n && !points_xy)) return arg_error(ctx, __func__);
@@ -1508,6 +1629,7 @@ int ecgpu_point_sum(ecgpu_ctx* ctx, int curve, const uint8_t* points_xy, const u
 int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     if (n && (!scalars || !r1 || !r2)) return arg_error(ctx, __func__);
     if (n == 0) return ECGPU_OK;
     int rc;
@@ -1524,6 +1646,7 @@ int ecgpu_k256_glv_decompose(ecgpu_ctx* ctx, const uint8_t* scalars, size_t n, u
 int ecgpu_selftest_field(ecgpu_ctx* ctx, int curve, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!a || !out)) return arg_error(ctx, __func__);
@@ -1547,6 +1670,7 @@ int ecgpu_selftest_point(ecgpu_ctx* ctx, int curve, int op, const uint8_t* p_xy,
                          const uint8_t* q_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     if (n && (!p_xy || !out_xy || !out_inf)) return arg_error(ctx, __func__);

@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -73,12 +74,14 @@ struct ecgpu_group {
     bool use_rccl = false;
     Rccl rccl;
     std::string err;
+    std::mutex err_mu;                 // fail() may be called from several per-device worker threads at once
 };
 
 namespace {
 
 int fail(ecgpu_group* g, int rc, const std::string& msg) {
-    g->err = msg;
+    std::lock_guard<std::mutex> lock(g->err_mu);
+    if (g->err.empty()) g->err = msg;          // the first failure of a call is the one reported
     return rc;
 }
 
@@ -112,11 +115,9 @@ int for_each_member(ecgpu_group* g, F&& f) {
     }
     rc[0] = f(0);
     for (auto& t : th) t.join();
-    for (int r = 0; r < nd; r++)
-        if (rc[r] != ECGPU_OK) {
-            if (g->err.empty()) g->err = std::string("device ") + std::to_string(g->m[r].device) + ": " + ecgpu_last_error(g->m[r].ctx);
-            return rc[r];
-        }
+    for (int r = 0; r < nd; r++)           // (the workers have been joined: no concurrent writer of g->err any more)
+        if (rc[r] != ECGPU_OK)
+            return fail(g, rc[r], std::string("device ") + std::to_string(g->m[r].device) + ": " + ecgpu_last_error(g->m[r].ctx));
     return ECGPU_OK;
 }
 
@@ -196,6 +197,7 @@ const char* ecgpu_group_exchange(const ecgpu_group* g) { return g && g->use_rccl
 
 int ecgpu_group_set_msm_window(ecgpu_group* g, int window_bits) {
     if (!g) return ECGPU_ERR_ARG;
+    g->err.clear();
     for (auto& mb : g->m) {
         int rc = ecgpu_set_msm_window(mb.ctx, window_bits);
         if (rc != ECGPU_OK) return fail(g, rc, ecgpu_last_error(mb.ctx));
@@ -216,6 +218,14 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
         if (n_per_device[r] > plan_terms) plan_terms = n_per_device[r];
     const size_t bytes = ecgpu_msm_parts_bytes(g->m[0].ctx, curve, plan_terms);
     if (!bytes) return fail(g, ECGPU_ERR_CURVE, ecgpu_last_error(g->m[0].ctx));
+    // Every member plans for itself (its own context's window override).  The parts records only add up when all of them
+    // cut the scalars into the same windows and write records of the same size: a caller who reached one member through
+    // ecgpu_group_ctx and changed its window is refused here instead of overflowing d_parts / mis-striding the gather.
+    const int c0 = ecgpu_msm_plan_window(g->m[0].ctx, curve, plan_terms);
+    for (int r = 1; r < nd; r++)
+        if (ecgpu_msm_plan_window(g->m[r].ctx, curve, plan_terms) != c0 || ecgpu_msm_parts_bytes(g->m[r].ctx, curve, plan_terms) != bytes)
+            return fail(g, ECGPU_ERR_ARG, "the group's members plan different MSM windows (ecgpu_set_msm_window on one member's context?): "
+                                          "use ecgpu_group_set_msm_window");
     int rc;
     for (int r = 0; r < nd; r++) {
         if ((rc = grow(g, g->m[r], &g->m[r].d_parts, &g->m[r].parts_cap, bytes)) != ECGPU_OK) return rc;

@@ -54,7 +54,13 @@ pub struct Node(*mut EcgpuGroup);
 unsafe impl Send for Node {}
 
 pub static NODE: LazyLock<Option<Mutex<Node>>> = LazyLock::new(|| {
-    let ndev = std::env::var("ECGPU_DEVICES").ok().and_then(|v| v.parse::<usize>().ok()).unwrap_or(8);
+    // every gfx950 device the runtime shows (ecgpu_device_count), capped by ECGPU_DEVICES; fewer than two: no group, the
+    // single-GPU engine handles everything
+    let have = unsafe { ecgpu_device_count() }.max(0) as usize;
+    let ndev = std::env::var("ECGPU_DEVICES").ok().and_then(|v| v.parse::<usize>().ok()).map_or(have, |v| v.min(have));
+    if ndev < 2 {
+        return None;
+    }
     let devices: Vec<c_int> = (0..ndev as c_int).collect();
     let mut g = core::ptr::null_mut();
     (unsafe { ecgpu_group_init(&mut g, devices.as_ptr(), devices.len() as c_int) } == ECGPU_OK).then(|| Mutex::new(Node(g)))
@@ -142,13 +148,20 @@ where
     a.into()
 }
 
-/// The safe batch layer.  Every function returns `None` when there is no usable GPU (the caller then runs the
-/// reference's CPU code) and panics only on a contract violation (ECGPU_ERR_ARG).
+/// The safe batch layer.  Every function returns `None` when there is no usable GPU — no device, or a runtime failure of
+/// this call (ECGPU_ERR_HIP, ECGPU_ERR_OOM, ECGPU_ERR_NO_DEVICE) — and the caller then runs the reference's CPU code; it
+/// panics only on a contract violation (ECGPU_ERR_ARG / ECGPU_ERR_CURVE, or a range / on-curve error for values that came
+/// out of the reference's own validated types, which cannot be out of range).
 pub mod gpu {
     use super::*;
 
-    fn check(rc: c_int) {
-        assert!(rc == ECGPU_OK, "libecgpu: error {rc}");
+    /// `Some(())` on success, `None` for "the GPU could not do it this time" (the CPU path takes over).
+    fn check(rc: c_int) -> Option<()> {
+        match rc {
+            ECGPU_OK => Some(()),
+            ECGPU_ERR_HIP | ECGPU_ERR_OOM | ECGPU_ERR_NO_DEVICE => None,
+            _ => panic!("libecgpu: contract violation, error {rc}"),
+        }
     }
 
     /// `k[i] * G` — batch form of `MulByGeneratorVartime::mul_by_generator_vartime`.
@@ -161,7 +174,7 @@ pub mod gpu {
         let l = field_len::<C>();
         let scalars = scalars_to_wire::<C>(ks.iter().copied());
         let (mut xy, mut inf) = (vec![0u8; ks.len() * 2 * l], vec![0u8; ks.len()]);
-        check(unsafe { ecgpu_batch_mul_base(eng.0, C::ID, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) });
+        check(unsafe { ecgpu_batch_mul_base(eng.0, C::ID, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) })?;
         Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
     }
 
@@ -178,7 +191,7 @@ pub mod gpu {
         let (mut xy, mut inf) = (vec![0u8; n * 2 * l], vec![0u8; n]);
         check(unsafe {
             ecgpu_batch_mul(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr())
-        });
+        })?;
         Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
     }
 
@@ -196,14 +209,18 @@ pub mod gpu {
         let (mut xy, mut inf) = (vec![0u8; 2 * l], 0u8);
         if n >= NODE_MIN_TERMS {
             if let Some(node) = NODE.as_ref().and_then(|m| m.lock().ok()) {
-                check(unsafe {
+                // a failed group call (one GPU of the node gone, out of memory) falls through to the single-GPU engine
+                if check(unsafe {
                     ecgpu_group_msm(node.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf)
-                });
-                return Some(point_from_wire::<C>(&xy, inf));
+                })
+                .is_some()
+                {
+                    return Some(point_from_wire::<C>(&xy, inf));
+                }
             }
         }
         let eng = ENGINE.as_ref()?.lock().ok()?;
-        check(unsafe { ecgpu_msm(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf) });
+        check(unsafe { ecgpu_msm(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf) })?;
         Some(point_from_wire::<C>(&xy, inf))
     }
 
@@ -223,7 +240,7 @@ pub mod gpu {
         check(unsafe {
             ecgpu_batch_mul_base_and_mul_add(eng.0, C::ID, a.as_ptr(), b.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(),
                                              inf.as_mut_ptr())
-        });
+        })?;
         Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
     }
 
@@ -245,7 +262,7 @@ pub mod gpu {
         check(unsafe {
             ecgpu_ecdsa_verify_batch(eng.0, C::ID, cat(z).as_ptr(), cat(r).as_ptr(), cat(s).as_ptr(), qxy.as_ptr(), n,
                                      normalize_s as c_int, ok.as_mut_ptr())
-        });
+        })?;
         Some(ok.into_iter().map(|b| b != 0).collect())
     }
 
@@ -260,7 +277,7 @@ pub mod gpu {
         check(unsafe {
             ecgpu_sm2dsa_verify_msg_batch(eng.0, distid.as_ptr(), distid.len(), keys.as_ptr() as *const u8, msgs.as_ptr(), msg_len,
                                           sigs.as_ptr() as *const u8, n, ok.as_mut_ptr())
-        });
+        })?;
         Some(ok.into_iter().map(|b| b != 0).collect())
     }
 
@@ -282,7 +299,7 @@ pub mod gpu {
         check(unsafe {
             ecgpu_ecdsa_recover_batch(eng.0, C::ID, cat(z).as_ptr(), cat(r).as_ptr(), cat(s).as_ptr(), recovery_id.as_ptr(), n,
                                       normalize_s as c_int, xy.as_mut_ptr(), ok.as_mut_ptr())
-        });
+        })?;
         Some(xy.chunks(2 * l).zip(ok).map(|(c, f)| if f != 0 { Some(elliptic_curve::group::Curve::to_affine(&point_from_wire::<C>(c, 0))) } else { None }).collect())
     }
 }

@@ -39,6 +39,7 @@ pub const ECGPU_ERR_ARG: c_int = -7;
 
 #[link(name = "ecgpu")]
 unsafe extern "C" {
+    pub fn ecgpu_device_count() -> c_int;
     pub fn ecgpu_init(ctx: *mut *mut EcgpuCtx, device: c_int) -> c_int;
     pub fn ecgpu_destroy(ctx: *mut EcgpuCtx);
     pub fn ecgpu_last_error(ctx: *const EcgpuCtx) -> *const c_char;
@@ -183,6 +184,7 @@ unsafe extern "C" {
         d_out_inf: *mut c_void,
     ) -> c_int;
     pub fn ecgpu_msm_parts_bytes(ctx: *mut EcgpuCtx, curve: c_int, plan_terms: usize) -> usize;
+    pub fn ecgpu_msm_plan_window(ctx: *mut EcgpuCtx, curve: c_int, plan_terms: usize) -> c_int;
     pub fn ecgpu_msm_parts_dev(
         ctx: *mut EcgpuCtx,
         curve: c_int,

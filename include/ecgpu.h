@@ -80,8 +80,16 @@ enum {
 
 /* ---- context -------------------------------------------------------------------------------- */
 
+/* Number of gfx950 devices the HIP runtime shows this process (0: none / runtime unusable) — what a single-process
+ * caller sizes its ecgpu_group from (elliptic-curves_amd/rust/ecgpu_shim.rs `NODE`). */
+int ecgpu_device_count(void);
+
 /* Creates a context on HIP device `device` (as numbered by the HIP runtime in this process).
- * Basepoint tables are built lazily on first use per curve and kept on the device. */
+ * Basepoint tables are built lazily on first use per curve and kept on the device: ONE table per (device, curve, width)
+ * for the whole process, shared by every context on that device and freed with the last of them — the analogue of the
+ * reference's process-wide `LazyLock<BasepointTable>` (k256/src/arithmetic/tables.rs:18).  If a table does not fit (k256's
+ * default is 21.5 GB) its comb width is lowered two bits at a time (a quarter of the memory, one or two more additions per
+ * scalar, identical results) down to 16 bits before ECGPU_ERR_OOM is returned. */
 int ecgpu_init(ecgpu_ctx **ctx, int device);
 void ecgpu_destroy(ecgpu_ctx *ctx);
 
@@ -219,6 +227,10 @@ int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
  * plus a point sum.  `plan_terms` is the term count the window width is chosen from and must be the same on every GPU
  * (at least the largest shard); so must ecgpu_set_msm_window and the ECGPU_MSM_* environment knobs.  `lincomb` semantics as for ecgpu_msm_dev. */
 size_t ecgpu_msm_parts_bytes(ecgpu_ctx *ctx, int curve, size_t plan_terms);
+/* The Pippenger window width (bits) the two halves use for `plan_terms` on this context — ecgpu_set_msm_window's override
+ * or the measured default; every GPU of a sharded MSM must report the same value (ecgpu_group_msm_dev checks it).
+ * 0 for an unknown curve id. */
+int ecgpu_msm_plan_window(ecgpu_ctx *ctx, int curve, size_t plan_terms);
 int ecgpu_msm_parts_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
                         size_t n, size_t plan_terms, void *d_parts);
 /* d_parts_all: nranks consecutive parts records (the all-gather's output). */
