@@ -5,13 +5,20 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM when the
-timed region starts.  The top-level record is BASELINE.json's configs[1]; the other three GPU configs are timed in the
-same run, with the same K / W and the same fences, and reported under "configs":
+timed region starts.  The top-level record is BASELINE.json's configs[1]; the other GPU configs are timed in the same run,
+with the same K / W and the same fences.  Their headline numbers are ALSO top-level keys (`var_p256_value`,
+`msm_k256_value`, `var_p384_value` + `_ms_per_step`, `_frac`, `_check`), their compact records are under "configs", and the
+prose that used to be repeated per record is once under "notes": the line stays below 8 KB.
 
     fixed_k256  (top level, configs[1])  k256 fixed-base, 2^20 random scalars per GPU      -> scalar-muls/s
     var_p256    (configs[2])             p256 variable-base (ECDH shape), 2^20 pairs/GPU   -> scalar-muls/s
     msm_k256    (configs[3])             k256 MSM, 2^24 terms in total, sharded over GPUs  -> terms/s
     var_p384    (configs[4])             p384 variable-base, 2^20 pairs per GPU            -> scalar-muls/s
+    msm_k256_2p21  (N = 1 only)          one GPU's share of configs[3] on 8 GPUs; its per-term rate over the 2^24 rate is the
+                                         single-GPU projection of the 8-GPU efficiency (`projected_8gpu_efficiency`)
+    ecdsa_p256, recover_k256             the signature callers of the path
+    msm_k256.e2e_ms  (N = 1)             the 2^24-term MSM from HOST memory through ecgpu_msm (PCIe-inclusive; never `value`)
+    group_msm_k256   (N > 1, rank 0)     the 2^24-term MSM through the single-process entry ecgpu_group_msm_dev
 
 `--only NAME` times a single workload as the top-level record (profiling runs; also var_k256, msm_p256, ecdsa_p256).
 Batch workloads shard embarrassingly (weak scaling, no data-path collective).  The MSM shards its terms (strong
@@ -79,10 +86,13 @@ WORKLOADS = {
                      imad_per_unit=int(16.06 * 11 * 136), bytes_per_unit=96 + 16 * 64, kernel="k_msm_accumulate<K256Params>",
                      scaling="strong"),
 }
-SEEDS = {"fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
+# one GPU's share of configs[3] on an 8-GPU node (2^24 / 8 terms): the part of the bucket method that does not shrink with n
+# shows here; its per-term rate against the 2^24 rate is the single-GPU projection of the 8-GPU scaling efficiency
+WORKLOADS["msm_k256_2p21"] = dict(WORKLOADS["msm_k256"], n=1 << 21, metric="k256 MSM terms/sec (2^21-term share)")
+SEEDS = {"msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
 # BASELINE configs[2], [3], [4] beside the top-level configs[1], then the two signature workloads of SURVEY.md 8(f) (callers of the
 # path: p256 verification, k256 public-key recovery) so that they are driver-timed too
-DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "ecdsa_p256", "recover_k256"]
+DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "msm_k256_2p21", "ecdsa_p256", "recover_k256"]
 NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 ROOFLINE_CONSTS = os.path.join(ROOT, "profiles", "roofline_consts.json")
@@ -432,6 +442,7 @@ class Bench:
                     ok = bool(wok.all()) and bytes(w) == bytes(d_out[:m].cpu().numpy().reshape(-1)) and bool(d_ok[:n].all().item()) \
                         and bool(torch.equal(d_out, d_pts))
                 else:
+                    # (1) 256 outputs spread over the batch, byte for byte against the oracle
                     idx = torch.arange(0, n, max(1, n // 256), device=device)[:256]
                     got = d_out[idx].cpu().numpy().reshape(-1)
                     sh = d_scal[idx].cpu().numpy().reshape(-1)
@@ -440,6 +451,18 @@ class Bench:
                     else:
                         w, _ = oracle_lib.batch_mul(cid, sh, d_pts[idx].cpu().numpy().reshape(-1))
                     ok = bytes(w) == bytes(got)
+                    # (2) EVERY output, through the group law: sum_i out_i == (sum_i k_i [s_i]) G — one wrong element
+                    # anywhere in the batch changes the sum (a checksum of the whole launch, exact)
+                    order = ecgpu.GROUP_ORDERS[cid]
+                    ones = torch.zeros((n, L), dtype=torch.uint8, device=device)
+                    ones[:, L - 1] = 1
+                    tot = device_dot_mod(torch, d_scal, d_s2 if kind == "var" else ones, order)
+                    d_sum = torch.empty((1, 2 * L), dtype=torch.uint8, device=device)
+                    d_sf = torch.zeros((16,), dtype=torch.uint8, device=device)
+                    torch.cuda.synchronize()
+                    eng.point_sum_dev(cid, d_out, d_inf, n, d_sum, d_sf)
+                    w, wf = oracle_lib.batch_mul_base(cid, np.frombuffer(tot.to_bytes(L, "big"), np.uint8))
+                    ok = ok and bytes(w) == bytes(d_sum[0].cpu().numpy()) and int(wf[0]) == int(d_sf[0].item())
         if rank != 0:
             return None
 
@@ -500,11 +523,154 @@ class Bench:
             rec["cpu_baseline"] = cpu_baseline(wl, cid, L, s_host, p_host, extra)
         return rec
 
+    def e2e_msm(self, name="msm_k256"):
+        """SURVEY.md 8d, config 4 "end-to-end incl. PCIe": the same 2^24-term problem handed over in (page-locked) HOST memory
+        to the host-pointer entry point ecgpu_msm — upload of 1.5 GB in chunks under the compute of the previous chunk, partial
+        MSMs, point sum, download of 65 bytes.  One warm-up call, then the best of two; never `value`."""
+        torch, eng, ecgpu = self.torch, self.eng, self.ecgpu
+        wl = WORKLOADS[name]
+        cid = ecgpu.CURVE_IDS[wl["curve"]]
+        L = ecgpu.FIELD_BYTES[cid]
+        n = self.args.n or wl["n"]
+        seed = 0xEC000000 + SEEDS[name]
+        d_scal = device_random_scalars(torch, n, L, seed, self.device)
+        d_s2 = device_random_scalars(torch, n, L, seed + 50, self.device)
+        d_pts = torch.empty((n, 2 * L), dtype=torch.uint8, device=self.device)
+        torch.cuda.synchronize()
+        eng.mul_by_generator_dev(cid, d_s2, n, d_pts, None)
+        torch.cuda.synchronize()
+        h_s, h_p = eng.host_alloc(n * L), eng.host_alloc(n * 2 * L)
+        try:
+            torch.from_numpy(h_s).copy_(d_scal.view(-1))
+            torch.from_numpy(h_p).copy_(d_pts.view(-1))
+            torch.cuda.synchronize()
+            best, out = None, None
+            for it in range(3):
+                t0 = time.perf_counter()
+                out = eng.lincomb(cid, h_s, h_p)
+                dt = time.perf_counter() - t0
+                if it and (best is None or dt < best):
+                    best = dt
+            ok = None
+            if not self.args.no_check:
+                import oracle_lib
+                oracle_lib.build()
+                tot = device_dot_mod(torch, d_scal, d_s2, ecgpu.GROUP_ORDERS[cid])
+                w, wf = oracle_lib.batch_mul_base(cid, np.frombuffer(tot.to_bytes(L, "big"), np.uint8))
+                ok = bytes(w) == bytes(out[0]) and int(wf[0]) == int(out[1])
+        finally:
+            eng.host_free(h_s)
+            eng.host_free(h_p)
+        return {"e2e_ms": best * 1e3, "e2e_value": n / best, "e2e_check": ok,
+                "e2e_bytes_h2d": n * 3 * L}
+
+    def group_msm(self, name="msm_k256"):
+        """N > 1 only, rank 0 only (the other ranks wait at the barrier that follows): the SAME 2^24-term problem through the
+        single-process entry ecgpu_group_msm_dev — one context + worker thread per GPU inside this process, the shards
+        resident on their devices, the library's own exchange (RCCL ncclAllGather via dlopen, or peer copies) — what a Rust
+        caller of `lincomb` reaches the node with.  Timed like a step: K synchronous calls between fences."""
+        torch, ecgpu, args = self.torch, self.ecgpu, self.args
+        wl = WORKLOADS[name]
+        cid = ecgpu.CURVE_IDS[wl["curve"]]
+        L = ecgpu.FIELD_BYTES[cid]
+        n_total = args.n or wl["n"]
+        world = self.world
+        if torch.cuda.device_count() < world:
+            return {"skipped": "this process sees %d devices" % torch.cuda.device_count()}
+        try:
+            grp = ecgpu.Group(list(range(world)))
+        except ecgpu.EcgpuError as e:
+            return {"skipped": "ecgpu_group_init: %s" % e}
+        try:
+            ds, dp, ns, dot = [], [], [], 0
+            for r in range(world):
+                lo, hi = ecgpu.shard_range(n_total, r, world)
+                dev = "cuda:%d" % r
+                seed = 0xEC000000 + SEEDS[name] + 1000 * r
+                k = device_random_scalars(torch, hi - lo, L, seed, dev)
+                s2 = device_random_scalars(torch, hi - lo, L, seed + 50, dev)
+                pts = torch.empty((hi - lo, 2 * L), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev)
+                e = self.eng if r == 0 else ecgpu.Engine(r)
+                e.mul_by_generator_dev(cid, s2, hi - lo, pts, None)
+                torch.cuda.synchronize(dev)
+                if r:
+                    e.close()
+                if not args.no_check:
+                    dot += device_dot_mod(torch, k, s2, ecgpu.GROUP_ORDERS[cid])
+                ds.append(k); dp.append(pts); ns.append(hi - lo)
+            for _ in range(max(1, args.warmup)):
+                out, inf = grp.lincomb_dev(cid, ds, dp, ns)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out, inf = grp.lincomb_dev(cid, ds, dp, ns)
+            dt = (time.perf_counter() - t0) / args.steps
+            ok = None
+            if not args.no_check:
+                import oracle_lib
+                oracle_lib.build()
+                w, wf = oracle_lib.batch_mul_base(cid, np.frombuffer((dot % ecgpu.GROUP_ORDERS[cid]).to_bytes(L, "big"), np.uint8))
+                ok = bytes(w) == bytes(out) and int(wf[0]) == int(inf)
+            return {"value": n_total / dt, "unit": "terms/s", "ms_per_step": dt * 1e3, "exchange": grp.exchange, "check_vs_oracle": ok,
+                    "calls": "synchronous ecgpu_group_msm_dev from one process, result (65 bytes) downloaded inside the call"}
+        finally:
+            grp.close()
+
     def close(self):
         if self.world > 1:
             self.dist.barrier()
             self.dist.destroy_process_group()
         self.eng.close()
+
+
+NOTES = {
+    "roofline": "bound valu-int (SURVEY 8d: neither HBM nor MFMA bounds the path). peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz "
+                "v_mad_u64_u32 slots/s (MI355X_MICROARCH.md; full-rate issue measured by ecgpu_valu_probe = peak_probe). achieved = "
+                "SQ_INSTS_VALU per launch (rocprofv3 PMC pass under profiles/, roofline_consts.json) x issue slots per instruction "
+                "(ISA histogram) x 64 / kernel_ms (HIP events on the launch stream, this run). frac = achieved/peak; cyc = issue "
+                "cycles / GRBM_GUI_ACTIVE of the PMC pass (no clock in it); algo_x = reference algorithm's IMAD32 (SURVEY 8d) over "
+                "the same time and peak (>1: fewer operations than the reference's algorithm); traffic = FETCH_SIZE + WRITE_SIZE "
+                "bytes per launch",
+    "cpu": "oracle/ C restatement of the reference's own CPU algorithm (kind port; no rustc in the image), all granted host "
+           "cores busy ~1.2 s on slices of the same seeded workload after a single-thread pilot; one = single-thread rate",
+    "check": "last timed step vs the oracle: batch workloads 256 sampled outputs byte for byte AND the sum of ALL outputs == "
+             "(sum k_i [s_i]) G; MSMs == (sum k_i s_i mod n) G exactly; signatures: every verdict / every recovered key",
+    "calls": "fixed / variable base: batches queued (ecgpu_set_async) and drained inside the timed region; others synchronous",
+}
+
+
+def compact(r):
+    """A sub-record for the one-line output: numbers only (the prose lives once in NOTES), < 600 bytes each — the driver keeps
+    the last 8 KB of the line."""
+    rf = r.get("roofline", {})
+    g = lambda v, d=4: None if v is None else float(("%%.%dg" % d) % v)
+    out = {"metric": r["metric"], "value": g(r["value"], 5), "unit": r["unit"], "ms_per_step": g(r["ms_per_step"], 5),
+           "units": r["config"]["units_total"], "scaling": r["scaling"],
+           "kernel": rf.get("kernel"), "kernel_ms": g(rf.get("kernel_ms")), "frac": g(rf.get("frac")), "cyc": g(rf.get("frac_cycles_pmc")),
+           "mad_frac": g(rf.get("mad_frac")), "algo_x": g(rf.get("algorithmic_speedup")), "traffic": g(rf.get("traffic")),
+           "stage_ms": {k: g(v, 3) for k, v in r.get("stage_ms", {}).items() if k not in ("main", "total")},
+           "check": r.get("check_vs_oracle")}
+    cb = r.get("cpu_baseline")
+    if cb:
+        out["cpu"] = {"value": g(cb["value"]), "cores": cb["cores"], "one": g(cb["single_thread_value"]), "kind": cb["kind"]}
+    for k in ("e2e_ms", "e2e_value", "e2e_check", "share_of_2p24_rate", "projected_8gpu_efficiency"):
+        if k in r:
+            out[k] = g(r[k]) if isinstance(r[k], float) else r[k]
+    return out
+
+
+def cargo_probe():
+    """"re-probe cargo on the benchmark box; if present, time the real crates".  The workspace needs ~150
+    crates.io packages and there is no network, so a present cargo is reported, not used."""
+    import shutil
+    import subprocess
+    exe = shutil.which("cargo")
+    if not exe:
+        return None
+    try:
+        return subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=20).stdout.strip() or exe
+    except Exception:
+        return exe
 
 
 def main():
@@ -520,6 +686,7 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--sync-calls", action="store_true", help="fixed / variable base: one synchronous call per step instead of the queued calls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="default run: skip the PCIe-inclusive host-pointer MSM (N = 1) / the single-process group MSM (N > 1)")
     ap.add_argument("--cpu-plumbing", action="store_true",
                     help="BASELINE configs[0] alone: 1024 k256 generator multiplications on the CPU reference path (no GPU needed)")
     args = ap.parse_args()
@@ -531,22 +698,64 @@ def main():
     b = Bench(args)
     top = args.only or "fixed_k256"
     cpu_leg = not args.no_cpu_baseline and b.world == 1          # the CPU leg is timed at N = 1 only
+    single = bool(args.only or args.n or args.window)
     rec = b.run(top, cpu_leg)
-    subs = [] if (args.only or args.n or args.window) else DEFAULT_SUBS
-    sub_recs = {}
+    subs = [] if single else [x for x in DEFAULT_SUBS if b.world == 1 or x != "msm_k256_2p21"]
+    full = {}
     for name in subs:
         r = b.run(name, cpu_leg)
         if r is not None:
-            sub_recs[name] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "config", "roofline", "stage_ms",
-                                                "check_vs_oracle") if k in r}
-            if "cpu_baseline" in r:
-                sub_recs[name]["cpu_baseline"] = r["cpu_baseline"]
-    if rec is not None:
-        if sub_recs and cpu_leg:
-            sub_recs["cpu_k256_1024"] = cpu_plumbing_record()
-        if sub_recs:
-            rec["configs"] = sub_recs
-        print(json.dumps(rec), flush=True)
+            full[name] = r
+    e2e = group = None
+    if not single and not args.no_extras:
+        if b.world == 1:
+            e2e = b.e2e_msm()
+        else:
+            if b.rank == 0:
+                group = b.group_msm()
+            b.fence()
+    if rec is not None and single:
+        print(json.dumps(rec), flush=True)                       # profiling / sweep runs: the full record of one workload
+    elif rec is not None:
+        # ---- the driver's line: every BASELINE config in one record below 8 KB (the driver keeps the last 8 KB) ----
+        rf = rec["roofline"]
+        rec["roofline"] = {k: rf[k] for k in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "mad_frac",
+                                              "frac_cycles_pmc", "peak_probe", "frac_vs_probe", "clock_ghz_kernel", "algorithmic_speedup")}
+        rec["roofline"]["hbm_algorithmic_gbps"] = rf["hbm"]["achieved"]
+        rec["roofline"]["source"] = "profiles/roofline_consts.json"
+        rec.pop("calls", None)
+        if "cpu_baseline" in rec:
+            cb = rec["cpu_baseline"]
+            cb["sample"] = "%d threads x %d units of the seeded workload, ~%.1f s wall, after a 1-thread pilot" % (
+                cb["cores"], int(round(cb["value"] * cb["wall_s"] / cb["cores"])), cb["wall_s"])
+        for name in ("var_p256", "msm_k256", "var_p384"):        # BASELINE's other metrics as top-level keys
+            if name in full:
+                r = full[name]
+                rec[name + "_value"] = r["value"]
+                rec[name + "_unit"] = r["unit"]
+                rec[name + "_ms_per_step"] = r["ms_per_step"]
+                rec[name + "_frac"] = r["roofline"]["frac"]
+                rec[name + "_check"] = r["check_vs_oracle"]
+        if "msm_k256" in full and e2e:
+            full["msm_k256"].update(e2e)
+            rec["msm_k256_e2e_ms"] = e2e["e2e_ms"]
+        if "msm_k256" in full and "msm_k256_2p21" in full:
+            share = full["msm_k256"]["ms_per_step"] / (8.0 * full["msm_k256_2p21"]["ms_per_step"])
+            full["msm_k256_2p21"]["share_of_2p24_rate"] = share   # per-term rate of a 2^21-term share / per-term rate at 2^24
+            full["msm_k256_2p21"]["projected_8gpu_efficiency"] = share
+            rec["msm_k256_2p21_ms"] = full["msm_k256_2p21"]["ms_per_step"]
+        rec["configs"] = {k: compact(v) for k, v in full.items()}
+        if group:
+            rec["configs"]["group_msm_k256"] = group
+        if cpu_leg:
+            c0 = cpu_plumbing_record()
+            rec["configs"]["cpu_k256_1024"] = {k: c0[k] for k in ("metric", "value", "unit", "ms_per_step", "check_vs_model")}
+        rec["cargo"] = cargo_probe()
+        rec["notes"] = NOTES
+        line = json.dumps(rec, separators=(",", ":"))
+        print(line, flush=True)
+        if len(line) > 8000:
+            print("bench.py: the record is %d bytes (> 8000)" % len(line), file=sys.stderr)
     b.close()
     return rec
 

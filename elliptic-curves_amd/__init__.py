@@ -584,6 +584,22 @@ class Group:
         self._chk(self._lib.ecgpu_group_msm(self._g, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, int(inf[0])
 
+    def lincomb_dev(self, curve, d_scalars, d_points_xy, n_per_device, d_points_inf=None):
+        """ecgpu_group_msm_dev: shard i (n_per_device[i] terms) already resident on member i's device — lists of torch
+        tensors / DeviceBuffers / None, one per member.  Returns (xy uint8[2L], inf) on the host."""
+        L = _field_bytes(curve)
+        m = self.size
+        if not (len(d_scalars) == len(d_points_xy) == len(n_per_device) == m) or (d_points_inf is not None and len(d_points_inf) != m):
+            raise EcgpuError(ERR_ARG, "lincomb_dev: one entry per group member expected")
+        arr = lambda xs: (ctypes.c_void_p * m)(*[(_dp(x).value if x is not None else None) for x in xs])
+        ds, dp = arr(d_scalars), arr(d_points_xy)
+        di = arr(d_points_inf) if d_points_inf is not None else None
+        cnt = (ctypes.c_size_t * m)(*[int(v) for v in n_per_device])
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_group_msm_dev(self._g, curve, ds, dp, di, cnt, _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
     def mul_by_generator(self, curve, scalars):
         L = _field_bytes(curve)
         s = _host(scalars)
