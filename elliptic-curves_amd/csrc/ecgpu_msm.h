@@ -37,6 +37,10 @@
 #include "ecgpu_launch.h"
 #include "ecgpu_msm_chunk.h"
 
+#ifndef ECGPU_MSM_TAIL_DEFAULT
+#define ECGPU_MSM_TAIL_DEFAULT 0
+#endif
+
 namespace ecgpu {
 
 // ---- prepare ----------------------------------------------------------------------------------------------
@@ -232,7 +236,7 @@ struct MsmSort2Src {
 // COUNT_ONLY: gcnt[w][index] += number of entries (histogram pass).  Otherwise gcnt holds the cursors (initialised to the
 // run starts) and the entries are written: level A out_idx = term, out_key = code; level B out_idx = term | sign << 31.
 template <bool LEVEL_B, bool COUNT_ONLY>
-static __global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024, 8)       // two workgroups per CU: 64 VGPRs (level B needed 80 and ran one per CU)
 k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __restrict__ gcnt, uint32_t* __restrict__ out_idx,
             uint16_t* __restrict__ out_key) {
     __shared__ uint32_t cnt[256], loc[256], gbase[256], wtot[4];
@@ -248,7 +252,10 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
     const uint16_t* cw = src.codes + w * n;
     const uint32_t nkeys = LEVEL_B ? 1u << bits_b : (uint32_t)nindex;
     const uint32_t mask_b = (1u << bits_b) - 1;
-    uint32_t code[MSM_SORT2_PER_LANE], term[MSM_SORT2_PER_LANE], rank[MSM_SORT2_PER_LANE];   // code 0xFFFFFFFF: no entry
+    // per entry: the 16-bit code in the low half, its rank among the tile's entries of the same key in the high half (filled in
+    // below; < 8192); 0xFFFFFFFF: no entry.  One register per entry instead of two: level B fits 64 VGPRs, i.e. two workgroups
+    // per CU, without spilling.
+    uint32_t code[MSM_SORT2_PER_LANE], term[MSM_SORT2_PER_LANE];
 #pragma unroll
     for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
         const size_t i = lo + (size_t)u * 1024 + tid;                 // tiles start at multiples of 64
@@ -256,7 +263,6 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
         if (!LEVEL_B && ok) ok = (src.vmask[w * ((n + 63) / 64) + (i >> 6)] >> (i & 63)) & 1;
         code[u] = ok ? (uint32_t)cw[i] : 0xFFFFFFFFu;
         term[u] = LEVEL_B ? (ok ? src.idx[w * n + i] : 0u) : (uint32_t)i;
-        rank[u] = 0;
     }
     uint32_t r_lo = 0, r_hi = 0;
     if (LEVEL_B) {                                                      // the tile is sorted by partition
@@ -271,7 +277,8 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
             if (code[u] == 0xFFFFFFFFu) continue;
             const uint32_t b = code[u] & 0x7FFFu;
             if (LEVEL_B && (b >> bits_b) != r) continue;
-            rank[u] = atomicAdd(&cnt[LEVEL_B ? b & mask_b : b >> bits_b], 1u);
+            const uint32_t rank = atomicAdd(&cnt[LEVEL_B ? b & mask_b : b >> bits_b], 1u);
+            code[u] = (code[u] & 0xFFFFu) | (rank << 16);
         }
         __syncthreads();
         const uint32_t mine = tid < nkeys ? cnt[tid] : 0;
@@ -281,7 +288,11 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
             __syncthreads();
             continue;
         }
-        if (mine) gbase[tid] = atomicAdd(&gcnt[gi], mine);
+        // The run starts come from a device-scope atomic on a cursor every tile of the window hammers: its round trip
+        // (microseconds) is the longest single wait of the tile.  It is issued here and its result is only stored to LDS
+        // after the scan and the staging of the entries, so that it flies under them instead of in front of them.
+        uint32_t gb = 0;
+        if (mine) gb = atomicAdd(&gcnt[gi], mine);
         // exclusive scan of the (<= 256) counts: inside each of the first four waves by lane shuffles, then the four wave
         // totals (two barriers instead of the nineteen of a scan through LDS)
         uint32_t incl = mine;
@@ -306,10 +317,11 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
             if (code[u] == 0xFFFFFFFFu) continue;
             const uint32_t b = code[u] & 0x7FFFu;
             if (LEVEL_B && (b >> bits_b) != r) continue;
-            const uint32_t slot = loc[LEVEL_B ? b & mask_b : b >> bits_b] + rank[u];
-            stage[slot] = LEVEL_B ? term[u] | ((code[u] >> 15) << 31) : term[u];
+            const uint32_t slot = loc[LEVEL_B ? b & mask_b : b >> bits_b] + (code[u] >> 16);
+            stage[slot] = LEVEL_B ? term[u] | (((code[u] >> 15) & 1u) << 31) : term[u];
             stage_k[slot] = (uint16_t)code[u];
         }
+        if (mine) gbase[tid] = gb;
         __syncthreads();
         for (uint32_t slot = tid; slot < total_r; slot += 1024) {
             const uint32_t c16 = stage_k[slot];
@@ -375,9 +387,14 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
 // being walked by a single lane.
 constexpr uint32_t MSM_BIG_PARTIALS = 32;
 
-// one lane per (window, bucket); big_list[0] = number of deferred buckets, big_list[1..] their ids
-template <class C>
-__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : C::N <= 12 ? 2 : 1)     // the redo path may spill; the common path is short
+// one lane per (window, bucket); big_list[0] = number of deferred buckets, big_list[1..] their ids.
+// One wave per SIMD at most (a few thousand waves in all): the whole register file, so that nothing spills — at three waves
+// per SIMD 83 registers went to scratch and every lane paid ~100 scratch round trips (0.13 ms for a kernel whose arithmetic
+// is 10 us; profiles/r03/).
+// V: build variant of the latency-bound tail kernels (0: this translation unit's flags, 1: ecgpu_inst_msmtail.hip, scheduled
+// for instruction-level parallelism: these kernels run one wave per SIMD and wait on their own dependency chains)
+template <class C, int V = 0>
+__global__ void __launch_bounds__(64, 1)
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
                     const uint32_t* __restrict__ sorted, size_t n, size_t nb, int nwin, size_t chunk, size_t nchunks,
@@ -444,7 +461,7 @@ __device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const
 // shift_w = 0 except for the last window (sub-buckets, see msm_digit).  Running-sum trick: walking the
 // segment downwards, `running` is added to `local` once per unit drop of the weight, and the weight of the
 // lowest bucket multiplies the whole segment sum at the end.
-template <class C>
+template <class C, int V = 0>
 __global__ void __launch_bounds__(64)
 k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin, int top_shift,
                       uint32_t* __restrict__ segs) {
@@ -470,7 +487,7 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
 // parts[w][g] = sum of the segment sums segs[w][g * per .. (g + 1) * per): one workgroup per (g, w), a strided pass
 // and an LDS tree.  With the default plan (4 buckets per segment, 256 segments per workgroup) a lane adds one segment:
 // the depth is the 8 levels of the tree, where one workgroup per window used to walk 32 segments per lane first.
-template <class C>
+template <class C, int V = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per, uint32_t* __restrict__ parts) {
     using G = Group<C>;
@@ -486,7 +503,7 @@ k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per,
 
 // wins[w] = sum over ranks r and workgroups g of parts[r][w][g] — the one place where the partial results of several
 // GPUs meet (nranks = 1: this GPU's own).  One workgroup per window.
-template <class C>
+template <class C, int V = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int nparts, uint32_t* __restrict__ wins) {
     using G = Group<C>;
@@ -494,7 +511,7 @@ k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int 
     Fe<C::NL> b = G::curve_b();
     Proj<C> acc = G::identity();
     const int items = nranks * nparts;
-    for (int t = threadIdx.x; t < items; t += BLOCK) {
+    for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
         const int r = t / nparts, g = t % nparts;
         acc = G::add(acc, load_proj<C>(parts, ((size_t)r * nwin + blockIdx.x) * nparts + g), b);
     }
@@ -503,7 +520,7 @@ k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int 
 }
 
 // out = sum_w 2^(c w) wins[w]   (Horner)
-template <class C>
+template <class C, int V = 0>
 __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -687,6 +704,46 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     return p;
 }
 
+// Which build of the latency-bound tail kernels runs: ECGPU_MSM_TAIL = 0 (this translation unit's flags) / 1 (the build of
+// ecgpu_inst_msmtail.hip, scheduled for instruction-level parallelism); results do not depend on it.
+inline int msm_tail_variant() {
+    static const int v = [] {
+        const char* e = getenv("ECGPU_MSM_TAIL");
+        return e ? atoi(e) : ECGPU_MSM_TAIL_DEFAULT;
+    }();
+    return v;
+}
+
+// Everything between the accumulation and the per-window partial sums: bucket finish, running sums over segments of buckets,
+// the tree over the segment sums.  These kernels hold a few thousand waves at most and each lane walks a chain of dependent
+// point operations: their time is latency, not throughput.
+template <class C, int V>
+void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t* parts, hipEvent_t ev_accumulated) {
+    const size_t ne = p.nsub;
+    uint32_t* pts = (uint32_t*)(ws + p.off_points);
+    uint32_t* sorted = (uint32_t*)(ws + p.off_sorted);
+    uint32_t* counts = (uint32_t*)(ws + p.off_count);
+    uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
+    uint32_t* partials = (uint32_t*)(ws + p.off_partials);
+    uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
+    uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
+    uint32_t* segs = (uint32_t*)(ws + p.off_segs);
+    const size_t nbk = p.nb * p.nwin;
+    (void)hipMemsetAsync(big_list, 0, 4, stream);
+    hipLaunchKernelGGL((k_msm_bucket_finish<C, V>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
+                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
+                       (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
+    hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
+                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
+                       p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
+    (void)hipEventRecord(ev_accumulated, stream);
+    size_t nsg = p.nseg * p.nwin;
+    hipLaunchKernelGGL((k_msm_reduce_segments<C, V>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
+                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
+    hipLaunchKernelGGL((k_msm_reduce_windows<C, V>), dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
+                       (const uint32_t*)segs, p.nseg, p.per_part, parts);
+}
+
 // First half of the pipeline: everything up to the per-window partial sums parts[nwin][nparts] (projective, internal
 // form, plan.parts_bytes bytes) — what a GPU contributes to an MSM whose terms are spread over several GPUs.
 template <class C>
@@ -711,9 +768,6 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     uint32_t* counts = (uint32_t*)(ws + p.off_count);
     uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
     uint32_t* partials = (uint32_t*)(ws + p.off_partials);
-    uint32_t* buckets = (uint32_t*)(ws + p.off_buckets);
-    uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
-    uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     // k_msm_prepare: each workgroup takes `reps` groups of BLOCK terms, so that its LDS histogram is flushed once for all of
     // them (one global atomic per counter and workgroup); at least ~2048 workgroups stay in flight
     int reps = 1;
@@ -778,31 +832,32 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
                            (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
     }
     (void)hipEventRecord(ev_sorted, stream);
-    size_t nbk = p.nb * p.nwin, nlanes = p.nchunks * p.nwin;
+    size_t nlanes = p.nchunks * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
                        (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials);
-    (void)hipMemsetAsync(big_list, 0, 4, stream);
-    hipLaunchKernelGGL(k_msm_bucket_finish<C>, dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
-                       (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
-    hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
-                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
-                       p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
-    (void)hipEventRecord(ev_accumulated, stream);
-    size_t nsg = p.nseg * p.nwin;
-    hipLaunchKernelGGL(k_msm_reduce_segments<C>, dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
-    hipLaunchKernelGGL(k_msm_reduce_windows<C>, dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
-                       (const uint32_t*)segs, p.nseg, p.per_part, parts);
+    if (msm_tail_variant() == 1)
+        launch_msm_tail<C, 1>(p, stream, ws, parts, ev_accumulated);
+    else
+        launch_msm_tail<C, 0>(p, stream, ws, parts, ev_accumulated);
 }
 
 // Second half: the window sums over `nranks` sets of partial sums (laid out [rank][nwin][nparts]) and the Horner chain
 // over the windows; the result (projective, internal form) lands in out[0].  `wins` is nwin points of scratch.
+template <class C, int V>
+void launch_msm_finish_v(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
+    // the tree of k_msm_window_sums is as wide as the parts of all ranks need, not wider (16 parts: 4 levels, not 8)
+    int items = nranks * (int)p.nparts, block = 64;
+    while (block < items && block < BLOCK) block *= 2;
+    hipLaunchKernelGGL((k_msm_window_sums<C, V>), dim3((unsigned)p.nwin), dim3(block), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
+    hipLaunchKernelGGL((k_msm_combine<C, V>), dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
+}
 template <class C>
 void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
-    hipLaunchKernelGGL(k_msm_window_sums<C>, dim3((unsigned)p.nwin), dim3(BLOCK), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
-    hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
+    if (msm_tail_variant() == 1)
+        launch_msm_finish_v<C, 1>(p, stream, parts_all, nranks, wins, out);
+    else
+        launch_msm_finish_v<C, 0>(p, stream, parts_all, nranks, wins, out);
 }
 
 // The whole pipeline on one GPU.
