@@ -56,6 +56,8 @@ ABI_SYMBOLS = [
     "ecgpu_sm2dsa_verify_msg_batch", "ecgpu_sm2dsa_verify_msg_batch_dev",
     "ecgpu_ecdsa_verify_msg_batch", "ecgpu_ecdsa_verify_msg_batch_dev",
     "ecgpu_group_ecdsa_verify_batch", "ecgpu_group_ecdsa_verify_msg_batch", "ecgpu_group_ecdsa_recover_batch",
+    "ecgpu_batch_mul_base_ct", "ecgpu_batch_mul_base_ct_dev", "ecgpu_batch_mul_ct", "ecgpu_batch_mul_ct_dev",
+    "ecgpu_batch_ecdh_ct", "ecgpu_batch_ecdh_ct_dev",
 ]
 
 
@@ -277,15 +279,17 @@ class Engine:
         return v.value
 
     # ---- host-buffer operations (numpy uint8 / bytes in, numpy out) ----
-    def mul_by_generator(self, curve, scalars, out=None, inf=None):
-        """out / inf: optional preallocated uint8 arrays (n*2L, n), e.g. from host_alloc."""
+    def mul_by_generator(self, curve, scalars, out=None, inf=None, constant_time=False):
+        """out / inf: optional preallocated uint8 arrays (n*2L, n), e.g. from host_alloc.
+        constant_time: the uniform-schedule entry point (ecgpu_batch_mul_base_ct) for secret scalars."""
         L = _field_bytes(curve)
         s = _host(scalars)
         n = s.size // L
         out = np.zeros(n * 2 * L, np.uint8) if out is None else out
         inf = np.zeros(n, np.uint8) if inf is None else inf
         assert out.dtype == np.uint8 and out.size >= n * 2 * L and inf.size >= n and out.flags.c_contiguous
-        self._chk(self._lib.ecgpu_batch_mul_base(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        fn = self._lib.ecgpu_batch_mul_base_ct if constant_time else self._lib.ecgpu_batch_mul_base
+        self._chk(fn(self._ctx, curve, _hp(s), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
 
     def mul_by_generator_compressed(self, curve, scalars, out_x=None, out_tag=None):
@@ -305,14 +309,16 @@ class Engine:
         self._chk(self._lib.ecgpu_batch_mul_base_compressed_dev(self._ctx, curve, _dp(d_scalars), ctypes.c_size_t(n), _dp(d_out_x),
                                                                 _dp(d_out_tag)))
 
-    def mul(self, curve, scalars, points_xy, points_inf=None):
+    def mul(self, curve, scalars, points_xy, points_inf=None, constant_time=False):
+        """k_i * P_i.  constant_time: the uniform-schedule entry point (ecgpu_batch_mul_ct) for secret scalars."""
         L = _field_bytes(curve)
         s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
         n = s.size // L
         _need("scalars", s, n * L); _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
         out = np.zeros(n * 2 * L, np.uint8)
         inf = np.zeros(n, np.uint8)
-        self._chk(self._lib.ecgpu_batch_mul(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        fn = self._lib.ecgpu_batch_mul_ct if constant_time else self._lib.ecgpu_batch_mul
+        self._chk(fn(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, inf
 
     def lincomb(self, curve, scalars, points_xy, points_inf=None):
@@ -403,20 +409,22 @@ class Engine:
                                                           ctypes.c_size_t(msg_len), _hp(sg), ctypes.c_size_t(n), _hp(ok)))
         return ok
 
-    def ecdh(self, curve, scalars, points_xy):
-        """x-coordinates of k_i * P_i (ECDH shared secrets): returns (x uint8[n*L], ok uint8[n])."""
+    def ecdh(self, curve, scalars, points_xy, constant_time=False):
+        """x-coordinates of k_i * P_i (ECDH shared secrets): returns (x uint8[n*L], ok uint8[n]).
+        constant_time: the uniform-schedule entry point (ecgpu_batch_ecdh_ct) for secret scalars."""
         L = _field_bytes(curve)
         k, p = _host(scalars), _host(points_xy)
         n = k.size // L
         _need("scalars", k, n * L); _need("points_xy", p, n * 2 * L)
         out = np.zeros(n * L, np.uint8)
         ok = np.zeros(n, np.uint8)
-        self._chk(self._lib.ecgpu_batch_ecdh(self._ctx, curve, _hp(k), _hp(p), ctypes.c_size_t(n), _hp(out), _hp(ok)))
+        fn = self._lib.ecgpu_batch_ecdh_ct if constant_time else self._lib.ecgpu_batch_ecdh
+        self._chk(fn(self._ctx, curve, _hp(k), _hp(p), ctypes.c_size_t(n), _hp(out), _hp(ok)))
         return out, ok
 
-    def ecdh_dev(self, curve, d_scalars, d_points_xy, n, d_out_x, d_ok):
-        self._chk(self._lib.ecgpu_batch_ecdh_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), ctypes.c_size_t(n),
-                                                 _dp(d_out_x), _dp(d_ok)))
+    def ecdh_dev(self, curve, d_scalars, d_points_xy, n, d_out_x, d_ok, constant_time=False):
+        fn = self._lib.ecgpu_batch_ecdh_ct_dev if constant_time else self._lib.ecgpu_batch_ecdh_dev
+        self._chk(fn(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), ctypes.c_size_t(n), _dp(d_out_x), _dp(d_ok)))
 
     def schnorr_verify_raw(self, pk_x, msgs, msg_len, sigs):
         """BIP340 verification from wire bytes: x-only keys (n*32), messages (n*msg_len), signatures (n*64)."""
@@ -494,13 +502,14 @@ class Engine:
         return out, inf
 
     # ---- device-resident operations (torch uint8 CUDA tensors or raw device pointers) ----
-    def mul_by_generator_dev(self, curve, d_scalars, n, d_out_xy, d_out_inf=None):
-        self._chk(self._lib.ecgpu_batch_mul_base_dev(self._ctx, curve, _dp(d_scalars), ctypes.c_size_t(n), _dp(d_out_xy),
-                                                     _dp(d_out_inf)))
+    def mul_by_generator_dev(self, curve, d_scalars, n, d_out_xy, d_out_inf=None, constant_time=False):
+        fn = self._lib.ecgpu_batch_mul_base_ct_dev if constant_time else self._lib.ecgpu_batch_mul_base_dev
+        self._chk(fn(self._ctx, curve, _dp(d_scalars), ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
 
-    def mul_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf=None):
-        self._chk(self._lib.ecgpu_batch_mul_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
-                                                ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+    def mul_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf=None, constant_time=False):
+        fn = self._lib.ecgpu_batch_mul_ct_dev if constant_time else self._lib.ecgpu_batch_mul_dev
+        self._chk(fn(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf), ctypes.c_size_t(n), _dp(d_out_xy),
+                     _dp(d_out_inf)))
 
     def lincomb_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_msm_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),

@@ -62,6 +62,7 @@ struct ecgpu_ctx {
     int* d_status = nullptr;
     int* h_status = nullptr;
     Table table[12];
+    uint32_t* ct_lut[12] = {};   // uniform-schedule generator LUTs (shared per device like the comb tables; registry width key -1)
     // fixed-base comb width: every addition removed is worth 8 % and HBM keeps up with the gathers, so the tables are
     // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
     // p256 and sm2: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
@@ -69,6 +70,7 @@ struct ecgpu_ctx {
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r, ec_e, ec_s, ec_id;   // signature verification scratch
+    DevBuf ct_flags;             // one verdict byte per element of a uniform-schedule batch
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
     std::vector<std::pair<std::string, std::pair<int, int>>> spans;   // event pairs of the last call not yet turned into `timing`
@@ -314,6 +316,64 @@ int ensure_table(ecgpu_ctx* ctx) {
     return drop_build_scratch(ctx);
 }
 
+// ---- generator LUTs of the uniform-schedule fixed-base kernel (ecgpu_ctmul.h) ----------------------------------------
+// [CT_BASE_LUTS][8][2] packed elements: lut i = {e * 2^(8 i) * G, e = 1..8} — `BasepointTable::new`
+// (primeorder/src/tables/basepoint.rs:41-76) with affine entries.  17 KB for k256: built with the comb-table kernels
+// (bases 2^(8 i) G, eight multiples each, one normalisation), shared per device under the registry key width -1.
+void release_ct_lut(ecgpu_ctx* ctx, int id) {
+    if (!ctx->ct_lut[id]) return;
+    TableRegistry& reg = table_registry(ctx->device);
+    std::lock_guard<std::mutex> lock(reg.mu);
+    auto it = reg.tabs.find(std::make_tuple(ctx->device, id, -1));
+    if (it != reg.tabs.end() && it->second.d == ctx->ct_lut[id] && --it->second.refs == 0) {
+        (void)hipFree(it->second.d);
+        reg.tabs.erase(it);
+    }
+    ctx->ct_lut[id] = nullptr;
+}
+
+template <class C>
+int ensure_ct_lut(ecgpu_ctx* ctx) {
+    if (ctx->ct_lut[C::ID]) return ECGPU_OK;
+    constexpr int N = C::N, NS = Field<C>::NS;
+    const int nlut = ct_base_luts<C>();
+    const size_t entries = (size_t)nlut * 8;
+    TableRegistry& reg = table_registry(ctx->device);
+    std::lock_guard<std::mutex> lock(reg.mu);
+    SharedTable& st = reg.tabs[std::make_tuple(ctx->device, (int)C::ID, -1)];
+    if (!st.d) {
+        int rc;
+        auto fail = [&](int code) {
+            reg.tabs.erase(std::make_tuple(ctx->device, (int)C::ID, -1));
+            return code;
+        };
+        if ((rc = ensure(ctx, ctx->bases, (size_t)nlut * 3 * NS * 4)) != ECGPU_OK) return fail(rc);
+        if ((rc = ensure(ctx, ctx->proj, entries * 3 * NS * 4)) != ECGPU_OK) return fail(rc);
+        if ((rc = ensure(ctx, ctx->prefix, entries * NS * 4)) != ECGPU_OK) return fail(rc);
+        uint32_t* d = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&d), entries * 2 * N * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->err = "generator LUTs: hipMalloc failed";
+            return fail(ECGPU_ERR_OOM);
+        }
+        launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, 8, nlut);                          // 2^(8 i) G
+        launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, 4, nlut);   // e = 1..8
+        launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, entries, nullptr, nullptr, d);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            ctx->err = std::string("generator LUT build: ") + hipGetErrorString(e);
+            return fail(ECGPU_ERR_HIP);
+        }
+        st.d = d;
+        st.nwin = nlut;
+    }
+    st.refs++;
+    ctx->ct_lut[C::ID] = st.d;
+    return ECGPU_OK;
+}
+
 // launches the normalisation of n projective points in ctx->proj to wire-format output
 template <class C>
 int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
@@ -367,6 +427,49 @@ int mul_var_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, 
     record(ctx, 0);
     launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
                        (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+// ---- uniform-schedule variants (ecgpu_ct.h): the reference's constant-time drivers as they are ---------------------------
+template <class C>
+int mul_base_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf) {
+    constexpr int NS = Field<C>::NS;
+    int rc;
+    if ((rc = ensure_ct_lut<C>(ctx)) != ECGPU_OK) return rc;
+    if (n == 0) return ECGPU_OK;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ct_flags, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_fixed_base_ct<C>(ctx->stream, (const uint8_t*)d_scalars, n, (const uint32_t*)ctx->ct_lut[C::ID], (uint32_t*)ctx->proj.p,
+                            (uint8_t*)ctx->ct_flags.p, ctx->d_status);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});
+    return rc;
+}
+
+template <class C>
+int mul_var_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_xy, const void* d_points_inf, size_t n,
+                   void* d_out_xy, void* d_out_inf) {
+    constexpr int NS = Field<C>::NS;
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    size_t tstride = var_base_slots<C>(n);
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ct_flags, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_var_base_ct<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
+                          (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, (uint8_t*)ctx->ct_flags.p, ctx->d_status);
     record(ctx, 1);
     if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
     record(ctx, 2);
@@ -813,7 +916,11 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
                       &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
                       &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
-    for (int id = 0; id < 12; id++) release_table(ctx, id);     // the last context of the device frees the shared tables
+    if (ctx->ct_flags.p) (void)hipFree(ctx->ct_flags.p);
+    for (int id = 0; id < 12; id++) {                            // the last context of the device frees the shared tables
+        release_table(ctx, id);
+        release_ct_lut(ctx, id);
+    }
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (auto& e : ctx->ev)
@@ -962,6 +1069,23 @@ int ecgpu_batch_mul_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const 
         return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return mul_var_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_batch_mul_base_ct_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_out_xy))) return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) { return mul_base_ct_dev<decltype(c)>(ctx, d_scalars, n, d_out_xy, d_out_inf); });
+}
+
+int ecgpu_batch_mul_ct_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
+                           size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_points_xy || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_points_xy) ||
+              !aligned16(d_out_xy)))
+        return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return mul_var_ct_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
     });
 }
 
@@ -1163,9 +1287,10 @@ int ecgpu_schnorr_verify_raw_batch_dev(ecgpu_ctx* ctx, const void* d_pk_x, const
     return verify_dev<K256Params>(ctx, VERIFY_SCHNORR_RAW, d_msgs, nullptr, d_sigs, d_pk_x, n, 0, d_ok, msg_len);
 }
 
-int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x,
-                         void* d_ok) {
-    // SharedSecret_i = x(k_i * P_i): the variable-base kernel, normalisation into scratch, x extraction
+static int ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x, void* d_ok,
+                    bool ct) {
+    // SharedSecret_i = x(k_i * P_i): the variable-base kernel (ct: its uniform-schedule form), normalisation into scratch,
+    // x extraction
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_out_x || !d_ok || !aligned16(d_out_x))) return arg_error(ctx, __func__);
     size_t L = ecgpu_field_bytes(curve);
@@ -1173,8 +1298,9 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const
     int rc;
     if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
-    if ((rc = ecgpu_batch_mul_dev(ctx, curve, d_scalars, d_points_xy, nullptr, n, ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK)
-        return rc;
+    rc = ct ? ecgpu_batch_mul_ct_dev(ctx, curve, d_scalars, d_points_xy, nullptr, n, ctx->ec_xy.p, ctx->ec_inf.p)
+            : ecgpu_batch_mul_dev(ctx, curve, d_scalars, d_points_xy, nullptr, n, ctx->ec_xy.p, ctx->ec_inf.p);
+    if (rc != ECGPU_OK) return rc;
     if (n == 0) return ECGPU_OK;
     return dispatch(curve, [&](auto c) -> int {
         using C = decltype(c);
@@ -1184,6 +1310,14 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const
         if (!ctx->async) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return (int)ECGPU_OK;
     });
+}
+int ecgpu_batch_ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x,
+                         void* d_ok) {
+    return ecdh_dev(ctx, curve, d_scalars, d_points_xy, n, d_out_x, d_ok, false);
+}
+int ecgpu_batch_ecdh_ct_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, size_t n, void* d_out_x,
+                            void* d_ok) {
+    return ecdh_dev(ctx, curve, d_scalars, d_points_xy, n, d_out_x, d_ok, true);
 }
 
 int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, const void* d_y_is_odd, size_t n, void* d_out_xy,
@@ -1210,27 +1344,36 @@ int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, cons
 
 // ---- host-pointer entry points ----
 
-int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy,
-                         uint8_t* out_inf) {
+// (ct: the uniform-schedule form; the host-side plumbing is the same)
+static int batch_mul_base_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy, uint8_t* out_inf,
+                               bool ct, const char* fn) {
+    const auto dev = ct ? ecgpu_batch_mul_base_ct_dev : ecgpu_batch_mul_base_dev;
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
     if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return curve_error(ctx, __func__);
-    if (n && (!scalars || !out_xy)) return arg_error(ctx, __func__);
+    if (!L) return curve_error(ctx, fn);
+    if (n && (!scalars || !out_xy)) return arg_error(ctx, fn);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}},
                          [&](size_t off, size_t m) {
-                             return ecgpu_batch_mul_base_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, m,
+                             return dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, m,
                                                              (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
                          });
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
-    if ((rc = ecgpu_batch_mul_base_dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = dev(ctx, curve, ctx->in0.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
     if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_batch_mul_base(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    return batch_mul_base_host(ctx, curve, scalars, n, out_xy, out_inf, false, __func__);
+}
+int ecgpu_batch_mul_base_ct(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    return batch_mul_base_host(ctx, curve, scalars, n, out_xy, out_inf, true, __func__);
 }
 
 int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, size_t n, uint8_t* out_x,
@@ -1255,19 +1398,20 @@ int ecgpu_batch_mul_base_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* sc
     return download(ctx, out_tag, ctx->out1, n);
 }
 
-int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy,
-                    const uint8_t* points_inf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+static int batch_mul_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf,
+                          size_t n, uint8_t* out_xy, uint8_t* out_inf, bool ct, const char* fn) {
+    const auto dev = ct ? ecgpu_batch_mul_ct_dev : ecgpu_batch_mul_dev;
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
     if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return curve_error(ctx, __func__);
-    if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, __func__);
+    if (!L) return curve_error(ctx, fn);
+    if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, fn);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
                          {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}}, [&](size_t off, size_t m) {
-                             return ecgpu_batch_mul_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
+                             return dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L,
                                                         points_inf ? (uint8_t*)ctx->in2.p + off : nullptr, m,
                                                         (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
                          });
@@ -1276,11 +1420,20 @@ int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uin
     if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
-    if ((rc = ecgpu_batch_mul_dev(ctx, curve, ctx->in0.p, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
+    if ((rc = dev(ctx, curve, ctx->in0.p, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
                                   ctx->out1.p)) != ECGPU_OK)
         return rc;
     if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, out_inf, ctx->out1, n);
+}
+
+int ecgpu_batch_mul(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf, size_t n,
+                    uint8_t* out_xy, uint8_t* out_inf) {
+    return batch_mul_host(ctx, curve, scalars, points_xy, points_inf, n, out_xy, out_inf, false, __func__);
+}
+int ecgpu_batch_mul_ct(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf, size_t n,
+                       uint8_t* out_xy, uint8_t* out_inf) {
+    return batch_mul_host(ctx, curve, scalars, points_xy, points_inf, n, out_xy, out_inf, true, __func__);
 }
 
 int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf,
@@ -1541,28 +1694,37 @@ int ecgpu_schnorr_verify_raw_batch(ecgpu_ctx* ctx, const uint8_t* pk_x, const ui
     return download(ctx, ok, ctx->out1, n);
 }
 
-int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x,
-                     uint8_t* ok) {
+static int batch_ecdh_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x,
+                           uint8_t* ok, bool ct, const char* fn) {
+    const auto dev = ct ? ecgpu_batch_ecdh_ct_dev : ecgpu_batch_ecdh_dev;
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     SyncScope sync_scope(ctx);
     if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
     size_t L = ecgpu_field_bytes(curve);
-    if (!L) return curve_error(ctx, __func__);
-    if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, __func__);
+    if (!L) return curve_error(ctx, fn);
+    if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, fn);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}}, {{out_x, &ctx->out0, L}, {ok, &ctx->out1, 1}},
                          [&](size_t off, size_t m) {
-                             return ecgpu_batch_ecdh_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
+                             return dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * 2 * L, m,
                                                          (uint8_t*)ctx->out0.p + off * L, (uint8_t*)ctx->out1.p + off);
                          });
     if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
     if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out0, n * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
-    if ((rc = ecgpu_batch_ecdh_dev(ctx, curve, ctx->in0.p, ctx->in1.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
+    if ((rc = dev(ctx, curve, ctx->in0.p, ctx->in1.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return rc;
     if ((rc = download(ctx, out_x, ctx->out0, n * L)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_batch_ecdh(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x, uint8_t* ok) {
+    return batch_ecdh_host(ctx, curve, scalars, points_xy, n, out_x, ok, false, __func__);
+}
+int ecgpu_batch_ecdh_ct(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, size_t n, uint8_t* out_x,
+                        uint8_t* ok) {
+    return batch_ecdh_host(ctx, curve, scalars, points_xy, n, out_x, ok, true, __func__);
 }
 
 int ecgpu_batch_decompress(ecgpu_ctx* ctx, int curve, const uint8_t* xs, const uint8_t* y_is_odd, size_t n, uint8_t* out_xy,

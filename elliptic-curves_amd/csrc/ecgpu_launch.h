@@ -82,6 +82,13 @@ template <class C> size_t var_base_tab_words();         // 32-bit words of table
 template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf,
                                         size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
 
+// ---- group "ct": uniform-schedule variants (ecgpu_ct.h); flags: n bytes of scratch (one verdict byte per element) ----
+template <class C> int ct_base_luts();                  // generator LUTs of 8 affine entries: lut i = {e * 2^(8 i) * G}
+template <class C> void launch_var_base_ct(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf, size_t n,
+                                           uint32_t* tab, size_t slots, uint32_t* proj_out, uint8_t* flags, int* status);
+template <class C> void launch_fixed_base_ct(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* lut, uint32_t* proj_out,
+                                             uint8_t* flags, int* status);
+
 // ---- group "msm": Pippenger pipeline ----
 template <class C> MsmPlan msm_plan(size_t n, int force_c, bool glv);
 template <class C> bool msm_use_glv(size_t n);          // k256: GLV halves for this term count?

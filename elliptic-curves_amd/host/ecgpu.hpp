@@ -187,12 +187,14 @@ struct Curve {
     static ProjectivePoint GENERATOR() { return ProjectivePoint::mul_by_generator(Scalar::from_u64(1)); }
 
     // ---- batch forms (new API; what the GPU is for) --------------------------------------------------
-    static std::vector<ProjectivePoint> batch_mul_by_generator(const std::vector<Scalar>& ks) {
+    // constant_time: the uniform-schedule entry points (ecgpu_batch_*_ct) — the reference's `mul_by_generator` / `Mul` /
+    // `diffie_hellman` proper; false: the variable-time kernels behind the `*_vartime` names (same results)
+    static std::vector<ProjectivePoint> batch_mul_by_generator(const std::vector<Scalar>& ks, bool constant_time = false) {
         size_t n = ks.size();
         std::vector<uint8_t> s(n * L), xy(n * 2 * L), inf(n);
         for (size_t i = 0; i < n; i++) std::memcpy(&s[i * L], ks[i].repr.data(), L);
         Engine& e = Engine::global();
-        e.check(ecgpu_batch_mul_base(e.ctx(), ID, s.data(), n, xy.data(), inf.data()));
+        e.check((constant_time ? ecgpu_batch_mul_base_ct : ecgpu_batch_mul_base)(e.ctx(), ID, s.data(), n, xy.data(), inf.data()));
         return unpack(xy, inf);
     }
     // k_i * G as SEC1 compressed points (tag || x, tag = 02 / 03, a single 00 byte's worth of zeros for the identity):
@@ -211,7 +213,8 @@ struct Curve {
         }
         return out;
     }
-    static std::vector<ProjectivePoint> batch_mul(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks) {
+    static std::vector<ProjectivePoint> batch_mul(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks,
+                                                  bool constant_time = false) {
         size_t n = ks.size();
         if (ps.size() != n) throw Error(ECGPU_ERR_ARG, "batch_mul: length mismatch");
         std::vector<uint8_t> s(n * L), p(n * 2 * L), f(n), xy(n * 2 * L), inf(n);
@@ -223,7 +226,7 @@ struct Curve {
             if (f[i]) std::memset(&p[i * 2 * L], 0, 2 * L);
         }
         Engine& e = Engine::global();
-        e.check(ecgpu_batch_mul(e.ctx(), ID, s.data(), p.data(), f.data(), n, xy.data(), inf.data()));
+        e.check((constant_time ? ecgpu_batch_mul_ct : ecgpu_batch_mul)(e.ctx(), ID, s.data(), p.data(), f.data(), n, xy.data(), inf.data()));
         return unpack(xy, inf);
     }
 
@@ -246,7 +249,8 @@ struct Curve {
         return out;
     }
     // elliptic_curve::ecdh::diffie_hellman(secret, public).raw_secret_bytes()   ({k256,p256,p384}/src/ecdh.rs)
-    static std::vector<FieldBytes> batch_diffie_hellman(const std::vector<Scalar>& secrets, const std::vector<AffinePoint>& publics) {
+    static std::vector<FieldBytes> batch_diffie_hellman(const std::vector<Scalar>& secrets, const std::vector<AffinePoint>& publics,
+                                                        bool constant_time = false) {
         size_t n = secrets.size();
         if (publics.size() != n) throw Error(ECGPU_ERR_ARG, "batch_diffie_hellman: length mismatch");
         std::vector<uint8_t> s(n * L), p(n * 2 * L), x(n * L), ok(n);
@@ -256,7 +260,7 @@ struct Curve {
             std::memcpy(&p[i * 2 * L + L], publics[i].y_.data(), L);
         }
         Engine& e = Engine::global();
-        e.check(ecgpu_batch_ecdh(e.ctx(), ID, s.data(), p.data(), n, x.data(), ok.data()));
+        e.check((constant_time ? ecgpu_batch_ecdh_ct : ecgpu_batch_ecdh)(e.ctx(), ID, s.data(), p.data(), n, x.data(), ok.data()));
         std::vector<FieldBytes> out(n);
         for (size_t i = 0; i < n; i++) std::memcpy(out[i].data(), &x[i * L], L);
         return out;

@@ -14,13 +14,17 @@
 //!         `batch_mul_by_generator_vartime`, `batch_mul_vartime`, `batch_mul_by_generator_and_mul_add_vartime`,
 //!         `batch_verify_prehashed`
 //!
-//! SECRET SCALARS.  Every GPU path is VARIABLE-TIME in its scalars (zero digits are skipped, table entries and buckets
-//! are addressed by scalar bits).  It therefore stands behind the reference's `*_vartime` names ONLY
+//! SECRET SCALARS.  The fast GPU paths are VARIABLE-TIME in their scalars (zero digits are skipped, table entries and
+//! buckets are addressed by scalar bits).  They stand behind the reference's `*_vartime` names ONLY
 //! (`MulVartime` primeorder/src/projective.rs:888-921, `lincomb_vartime`, `mul_by_generator_vartime`): public scalars —
-//! signature verification, MSMs over public data, public-key derivation from non-secret material.  The constant-time
-//! entry points (`Mul`, `mul_by_generator`, `lincomb`: primeorder/src/projective.rs:532-557, tables/lookup.rs:43-65)
-//! are NOT redirected; `ecgpu_batch_ecdh` and `ecgpu_batch_mul_base` take whatever scalars the caller hands them and
-//! the caller owns that decision (see include/ecgpu.h, "Secret scalars").
+//! signature verification, MSMs over public data, public-key derivation from non-secret material.
+//! The constant-time entry points (`Mul`, `mul_by_generator`, `diffie_hellman`: primeorder/src/projective.rs:532-557,
+//! 847-886, tables/lookup.rs:43-65, k256/src/ecdh.rs:56-60) have batch forms of their own over the library's
+//! uniform-schedule kernels — `batch_mul`, `batch_mul_by_generator`, `batch_diffie_hellman` below call
+//! `ecgpu_batch_mul_ct` / `ecgpu_batch_mul_base_ct` / `ecgpu_batch_ecdh_ct`: the reference's constant-time algorithm
+//! itself (fixed digit count, every table entry read and one kept under a mask, complete formulas), with no branch and
+//! no address computed from scalar or point data (include/ecgpu.h, "uniform-schedule variants"; tools/ct_isa_check.py).
+//! The constant-time `lincomb` (:484-496) is not redirected: a bucket method is variable-time by construction.
 //!
 //! Build: `links = "ecgpu"` + a build.rs emitting `cargo:rustc-link-lib=dylib=ecgpu` and
 //! `cargo:rustc-link-search=<repo>/elliptic-curves_amd/lib`.
@@ -195,6 +199,56 @@ pub mod gpu {
         Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
     }
 
+    /// `k[i] * G` — batch form of the constant-time `mul_by_generator` (k256/src/arithmetic/mul.rs:180-197,
+    /// primeorder/src/tables/basepoint.rs:82-99) on the uniform-schedule kernel.
+    pub fn batch_mul_by_generator<C: GpuCurve>(ks: &[Sc<C>]) -> Option<Vec<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let l = field_len::<C>();
+        let scalars = scalars_to_wire::<C>(ks.iter().copied());
+        let (mut xy, mut inf) = (vec![0u8; ks.len() * 2 * l], vec![0u8; ks.len()]);
+        check(unsafe { ecgpu_batch_mul_base_ct(eng.0, C::ID, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) })?;
+        Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
+    }
+
+    /// `k[i] * P[i]` — batch form of the constant-time `impl Mul<Scalar> for ProjectivePoint`
+    /// (primeorder/src/projective.rs:847-886, k256/src/arithmetic/mul.rs:249-274) on the uniform-schedule kernel.
+    pub fn batch_mul<C: GpuCurve>(terms: &[(Proj<C>, Sc<C>)]) -> Option<Vec<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (terms.len(), field_len::<C>());
+        let scalars = scalars_to_wire::<C>(terms.iter().map(|t| t.1));
+        let (pts, pinf) = points_to_wire::<C>(terms.iter().map(|t| t.0));
+        let (mut xy, mut inf) = (vec![0u8; n * 2 * l], vec![0u8; n]);
+        check(unsafe {
+            ecgpu_batch_mul_ct(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr())
+        })?;
+        Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
+    }
+
+    /// `diffie_hellman(secret[i], public[i]).raw_secret_bytes()` (k256/src/ecdh.rs:56-60, p256/src/ecdh.rs; the function
+    /// is `elliptic_curve::ecdh::diffie_hellman`, (public * secret).to_affine().x()) — the x-coordinates, `None` in a slot
+    /// whose product is the identity (cannot happen for a `NonZeroScalar` and a `PublicKey`).
+    pub fn batch_diffie_hellman<C: GpuCurve>(pairs: &[(Sc<C>, Aff<C>)]) -> Option<Vec<Option<FieldBytes<C>>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (pairs.len(), field_len::<C>());
+        let scalars = scalars_to_wire::<C>(pairs.iter().map(|t| t.0));
+        let (pts, _) = points_to_wire::<C>(pairs.iter().map(|t| Proj::<C>::from(t.1)));
+        let (mut x, mut ok) = (vec![0u8; n * l], vec![0u8; n]);
+        check(unsafe { ecgpu_batch_ecdh_ct(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), n, x.as_mut_ptr(), ok.as_mut_ptr()) })?;
+        Some(x.chunks(l).zip(ok).map(|(c, f)| (f != 0).then(|| FieldBytes::<C>::try_from(c).expect("field bytes"))).collect())
+    }
+
     /// `sum_i k[i] * P[i]` — `LinearCombination::lincomb_vartime` (Pippenger instead of Straus; same group element).
     /// One GPU up to NODE_MIN_TERMS terms, all GPUs of the node beyond (ecgpu_group_msm: term shards, one exchange of
     /// per-window partial sums over xGMI, one combining step).
@@ -319,6 +373,25 @@ pub mod gpu {
 //         }
 //
 //     `fn lincomb` (:484-496, constant time) is left alone — see "SECRET SCALARS" above.
+//
+// (1b) primeorder/src/projective.rs:847-886 (`impl Mul<Scalar<C>> for ProjectivePoint<C>`) and k256/src/arithmetic/mul.rs:249-274
+//     are single-element operators and stay on the CPU; their constant-time BATCH forms are new inherent functions beside
+//     them, over the uniform-schedule kernels:
+//
+//         #[cfg(feature = "gpu")]
+//         impl<C: PrimeCurveParams + ecgpu::GpuCurve> ProjectivePoint<C> {
+//             /// `terms[i].1 * terms[i].0` for a whole slice, constant time in the scalars (GPU, uniform schedule).
+//             pub fn batch_mul(terms: &[(Self, Scalar<C>)]) -> Vec<Self> {
+//                 ecgpu::gpu::batch_mul::<C>(terms).unwrap_or_else(|| terms.iter().map(|(p, k)| *p * *k).collect())
+//             }
+//             /// `ks[i] * G` for a whole slice, constant time.
+//             pub fn batch_mul_by_generator(ks: &[Scalar<C>]) -> Vec<Self> {
+//                 ecgpu::gpu::batch_mul_by_generator::<C>(ks).unwrap_or_else(|| ks.iter().map(Self::mul_by_generator).collect())
+//             }
+//         }
+//
+//     and {k256,p256,p384}/src/ecdh.rs gain `pub fn diffie_hellman_batch(pairs: &[(NonZeroScalar, PublicKey)]) ->
+//     Vec<SharedSecret>` on `ecgpu::gpu::batch_diffie_hellman` (fallback: `elliptic_curve::ecdh::diffie_hellman` per pair).
 //
 // (2) k256/src/arithmetic/mul.rs:100-108 — the same three lines at the top of k256's own
 //     `LinearCombination<[(ProjectivePoint, Scalar)]>::lincomb_vartime` (k256 does not use primeorder), with

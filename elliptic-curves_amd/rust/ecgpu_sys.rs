@@ -452,6 +452,60 @@ unsafe extern "C" {
         d_out_x: *mut c_void,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_batch_mul_base_ct(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_batch_mul_base_ct_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        n: usize,
+        d_out_xy: *mut c_void,
+        d_out_inf: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_batch_mul_ct(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        points_xy: *const u8,
+        points_inf: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_batch_mul_ct_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        d_points_xy: *const c_void,
+        d_points_inf: *const c_void,
+        n: usize,
+        d_out_xy: *mut c_void,
+        d_out_inf: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_batch_ecdh_ct(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        points_xy: *const u8,
+        n: usize,
+        out_x: *mut u8,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_batch_ecdh_ct_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        d_points_xy: *const c_void,
+        n: usize,
+        d_out_x: *mut c_void,
+        d_ok: *mut c_void,
+    ) -> c_int;
     pub fn ecgpu_batch_decompress(
         ctx: *mut EcgpuCtx,
         curve: c_int,

@@ -32,9 +32,9 @@
  * itself is total (complete formulas).  There is NO CPU fallback: without a usable gfx950 device
  * ecgpu_init fails with ECGPU_ERR_NO_DEVICE.
  *
- * Secret scalars: EVERY entry point of this library is VARIABLE-TIME in its scalars (zero digits are skipped; comb-table
- * entries, per-point table entries and Pippenger buckets are addressed by scalar bits; the kernels' duration and memory
- * access pattern depend on the scalar).  The library therefore stands behind the reference's `*_vartime` names —
+ * Secret scalars: every entry point whose name does not end in `_ct` / `_ct_dev` is VARIABLE-TIME in its scalars (zero
+ * digits are skipped; comb-table entries, per-point table entries and Pippenger buckets are addressed by scalar bits; the
+ * kernels' duration and memory access pattern depend on the scalar).  Those stand behind the reference's `*_vartime` names —
  * `MulVartime::mul_vartime` (primeorder/src/projective.rs:888-921), `LinearCombination::lincomb_vartime` (:498-510,
  * k256/src/arithmetic/mul.rs:100-108), `MulByGeneratorVartime::{mul_by_generator_vartime,
  * mul_by_generator_and_mul_add_vartime}` (:923-940, k256 mul.rs:205-232,296-310) — and is meant for PUBLIC scalars:
@@ -43,6 +43,9 @@
  * when the scalar is a long-term secret and an attacker can observe the device (timing of a shared GPU, its memory
  * traffic).  ecgpu_batch_mul_base* and ecgpu_batch_ecdh accept whatever scalars they are given: a caller that passes
  * private keys there has decided that its threat model allows it; the results are the same group elements either way.
+ * For secret scalars there are the three uniform-schedule entry points ecgpu_batch_mul_base_ct, ecgpu_batch_mul_ct and
+ * ecgpu_batch_ecdh_ct (below): the reference's constant-time drivers as they are — fixed digit count, all eight table
+ * entries read and one kept under a mask, complete formulas — at 1.5-9x the cost of the variable-time kernels.
  *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
  * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
@@ -389,6 +392,39 @@ int ecgpu_batch_ecdh(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const ui
                      size_t n, uint8_t *out_x, uint8_t *ok);
 int ecgpu_batch_ecdh_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy,
                          size_t n, void *d_out_x, void *d_ok);
+
+/* ---- uniform-schedule ("constant-time shaped") variants for SECRET scalars --------------------------------------------
+ * Same arguments, results and error behaviour as ecgpu_batch_mul_base / ecgpu_batch_mul / ecgpu_batch_ecdh, computed by the
+ * reference's constant-time algorithms restated one to one (elliptic-curves_amd/csrc/ecgpu_ctmul.h):
+ *   ecgpu_batch_mul_base_ct   `ProjectivePoint::mul_by_generator` (k256/src/arithmetic/mul.rs:180-197) /
+ *                             `BasepointTable::mul` (primeorder/src/tables/basepoint.rs:82-99): 8 N + 1 signed radix-16 digits
+ *                             (primeorder/src/tables/radix16.rs:35-61) over LUTs of 2^(8 i) G, even digits into one
+ *                             accumulator, odd digits into a second one, acc + 16 acc2; every LUT is scanned in full
+ *                             (`LookupTable::select`, primeorder/src/tables/lookup.rs:43-65)
+ *   ecgpu_batch_mul_ct        `impl Mul<Scalar> for ProjectivePoint` (primeorder/src/projective.rs:847-886 -> `lincomb`
+ *                             :532-557 with one term; k256/src/arithmetic/mul.rs:112-163,249-274 on the two GLV halves):
+ *                             table [P..8P] by complete additions (lookup.rs:30-38), 65 / 97 (k256: 2 x 33) digits, four
+ *                             complete doublings and one complete addition per digit, no digit skipped, the accumulator
+ *                             starts at the identity
+ *   ecgpu_batch_ecdh_ct       `diffie_hellman(secret, public)` (k256/src/ecdh.rs:56-60 over the `Mul` above): x of
+ *                             ecgpu_batch_mul_ct
+ * What is guaranteed, and checked on the gfx950 ISA of the two kernels by tools/ct_isa_check.py (a register-level taint
+ * analysis from every loaded record to every branch condition and every memory address; tests/test_ct_isa.py): no
+ * conditional branch and no load / store address depends on the contents of a scalar or point record; range and
+ * on-curve verdicts are computed for every element and reported through the usual error codes after the kernel.
+ * What is not: the conversion to affine output that follows branches on "the result is the identity" (k = 0 or
+ * P = identity), as `to_affine` must distinguish that case for the wire format; power and clock side channels of the
+ * device are outside what an ISA-level argument can cover.  Measured cost: DESIGN.md §7. */
+int ecgpu_batch_mul_base_ct(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_batch_mul_base_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, size_t n, void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_mul_ct(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy, const uint8_t *points_inf,
+                       size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_batch_mul_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
+                           size_t n, void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_ecdh_ct(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy, size_t n, uint8_t *out_x,
+                        uint8_t *ok);
+int ecgpu_batch_ecdh_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, size_t n, void *d_out_x,
+                            void *d_ok);
 
 /* Batch point decompression — `DecompressPoint::decompress(x_bytes, y_is_odd)`
  * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;

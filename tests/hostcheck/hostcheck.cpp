@@ -11,6 +11,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_recode.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_fixedmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_varmul.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_ctmul.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_msm_chunk.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_scalar.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_sha256.h"
@@ -299,6 +300,70 @@ int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, s
         proj[i] = var_base_one<C>(a, k);
     }
     normalize<C>(proj, nthreads ? nthreads : 1, out_xy, out_inf);
+    return 0;
+}
+
+// k_fixed_base_ct / k_var_base_ct: the uniform-schedule bodies of ecgpu_ctmul.h (generator LUTs built the way
+// ensure_ct_lut does: bases 2^(8 i) G, eight multiples each, packed affine)
+template <class C>
+struct CtLutLocal {
+    std::vector<uint32_t> w;     // [CT_BASE_LUTS][8][2 N]
+    void load(PackedPoint<2 * C::N>& p, int i, int entry) const {
+        std::memcpy(p.w, &w[((size_t)i * 8 + entry) * (2 * C::N)], 2 * C::N * 4);
+    }
+};
+template <class C>
+void build_ct_lut(CtLutLocal<C>& t) {
+    using G = Group<C>;
+    using F = Field<C>;
+    constexpr int N = C::N, NLUT = CT_BASE_LUTS<C>;
+    auto b = G::curve_b();
+    t.w.resize((size_t)NLUT * 8 * 2 * N);
+    Affine<C> g;
+    g.x = F::from_canonical(C::GX).e;
+    g.y = F::from_canonical(C::GY).e;
+    Proj<C> base = G::from_affine(g);
+    for (int i = 0; i < NLUT; i++) {
+        for (uint32_t e = 1; e <= 8; e++) {
+            Proj<C> cur = table_entry_rule<C>(base, e, 0);
+            auto zi = F::inv(G::m(cur.z));
+            F::pack(&t.w[((size_t)i * 8 + e - 1) * 2 * N], F::mul(G::m(cur.x), zi));
+            F::pack(&t.w[((size_t)i * 8 + e - 1) * 2 * N + N], F::mul(G::m(cur.y), zi));
+        }
+        for (int s = 0; s < 8; s++) base = G::dbl(base, b);
+    }
+}
+template <class C>
+int batch_mul_base_ct(const uint8_t* scalars, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    static CtLutLocal<C> lut;
+    if (lut.w.empty()) build_ct_lut<C>(lut);
+    std::vector<Proj<C>> proj(n);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[C::N];
+        if (!load_scalar<C>(k, scalars + i * WireBytes<C>::value)) return -2;
+        proj[i] = fixed_base_mul_ct<C>(k, lut, Group<C>::curve_b());
+    }
+    normalize<C>(proj, 1, out_xy, out_inf);
+    return 0;
+}
+template <class C>
+int batch_mul_ct(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    using G = Group<C>;
+    std::vector<Proj<C>> proj(n);
+    auto b = G::curve_b();
+    for (size_t i = 0; i < n; i++) {
+        uint32_t k[C::N];
+        if (!load_scalar<C>(k, scalars + i * WireBytes<C>::value)) return -2;
+        Affine<C> a;
+        Proj<C> p = G::identity();
+        if (load_affine<C>(&a, pxy + i * 2 * WireBytes<C>::value, pinf ? pinf[i] : 0)) {
+            if (!G::on_curve(a, b)) return -3;
+            p = G::from_affine(a);
+        }
+        VarTabLocal<C> tab;
+        proj[i] = var_base_mul_ct<C>(p, k, b, tab);
+    }
+    normalize<C>(proj, 1, out_xy, out_inf);
     return 0;
 }
 
@@ -695,6 +760,12 @@ int hc_batch_mul_base(int curve, int w, const uint8_t* s, size_t n, size_t nthre
 int hc_batch_mul(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, size_t nthreads, uint8_t* o,
                  uint8_t* oi) {
     DISPATCH(curve, batch_mul, (s, p, pi, n, nthreads, o, oi))
+}
+int hc_batch_mul_base_ct(int curve, const uint8_t* s, size_t n, uint8_t* o, uint8_t* oi) {
+    DISPATCH(curve, batch_mul_base_ct, (s, n, o, oi))
+}
+int hc_batch_mul_ct(int curve, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o, uint8_t* oi) {
+    DISPATCH(curve, batch_mul_ct, (s, p, pi, n, o, oi))
 }
 // glv != 0: k256 on the GLV halves (MsmSplit<K256Params, true>), otherwise the plain folded scalar
 int hc_msm(int curve, int c, size_t chunk, int glv, const uint8_t* s, const uint8_t* p, const uint8_t* pi, size_t n, uint8_t* o,

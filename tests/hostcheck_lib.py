@@ -105,6 +105,26 @@ def batch_mul(curve, scalars, pxy, pinf=None, nthreads=1):
     return rc, out, inf[:n]
 
 
+def batch_mul_base_ct(curve, scalars):
+    """fixed_base_mul_ct (ecgpu_ctmul.h) over CPU-built generator LUTs."""
+    s = _a(scalars)
+    n = s.size // L[curve]
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    inf = np.zeros(max(n, 1), np.uint8)
+    rc = lib().hc_batch_mul_base_ct(curve, _p(s), ctypes.c_size_t(n), _p(out), _p(inf))
+    return rc, out, inf[:n]
+
+
+def batch_mul_ct(curve, scalars, pxy, pinf=None):
+    """var_base_mul_ct (ecgpu_ctmul.h) with a stack table."""
+    s, p, pi = _a(scalars), _a(pxy), _a(pinf)
+    n = s.size // L[curve]
+    out = np.zeros(n * 2 * L[curve], np.uint8)
+    inf = np.zeros(max(n, 1), np.uint8)
+    rc = lib().hc_batch_mul_ct(curve, _p(s), _p(p), _p(pi), ctypes.c_size_t(n), _p(out), _p(inf))
+    return rc, out, inf[:n]
+
+
 def msm(curve, c, scalars, pxy, pinf=None, chunk=32, glv=None):
     """The Pippenger pipeline on the CPU.  glv: k256 on the GLV halves (True) or the plain folded scalar (False);
     None = both for k256 (the two must agree; the GLV result is returned), plain for the other curves."""

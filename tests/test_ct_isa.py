@@ -1,0 +1,29 @@
+"""The uniform-schedule kernels (csrc/ecgpu_ct.h) on their gfx950 ISA: tools/ct_isa_check.py compiles the translation unit
+to assembly (no GPU needed) and runs a register-level taint analysis from every loaded record to every branch condition
+and every memory address.  The same analysis must flag the variable-time kernels (self-test), otherwise it proves nothing."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "tools", "ct_isa_check.py")
+
+
+def _run(*args):
+    return subprocess.run([sys.executable, TOOL, *args], capture_output=True, text=True, timeout=1500)
+
+
+@pytest.mark.parametrize("curve", ["K256Params", "P256Params", "P384Params"])
+def test_no_branch_or_address_depends_on_scalar_or_point_data(curve):
+    r = _run("--curve", curve)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("-> OK") == 2 and "k_var_base_ct" in r.stdout and "k_fixed_base_ct" in r.stdout, r.stdout
+
+
+def test_checker_flags_the_variable_time_kernels():
+    r = _run("--self-test", "--curve", "P256Params")
+    assert r.returncode == 0, r.stdout + r.stderr              # 0 = both variable-time kernels were reported
+    assert r.stdout.count("VIOLATIONS") == 2, r.stdout
+    assert "load address from tainted register" in r.stdout and "branch on tainted" in r.stdout

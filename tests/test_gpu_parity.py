@@ -623,6 +623,116 @@ def test_ecdh_vs_node_openssl_and_oracle(eng, curve):
     assert list(ok) == [0 if f else 1 for f in winf] and ok[0] == 0 and ok[1:].all()
 
 
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_uniform_schedule_entry_points(eng, curve):
+    """ecgpu_batch_mul_base_ct / _mul_ct / _ecdh_ct (the reference's constant-time `mul_by_generator` / `Mul` /
+    `diffie_hellman` restated one to one, ecgpu_ctmul.h) against the oracle's constant-time drivers, the golden k*G vectors,
+    Node / OpenSSL's ECDH secrets and the variable-time kernels, with the variable-time entry points' error behaviour."""
+    import json
+    import os
+    from gpu_common import GOLDEN
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES[curve]
+    G = pyec.G(c)
+    # generator: golden vectors (where the reference has them), edge + ladder-corner + random scalars
+    ks = edge_scalars(c) + ladder_edge_scalars(c)[:30]
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks) + bytes(rand_scalars(c.cid, 300, 0xC7EC0001 + c.cid))
+    out, inf = eng.mul_by_generator(c.cid, scal, constant_time=True)
+    want, winf = oracle_lib.batch_mul_base(c.cid, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    if curve in CURVES:
+        g = load_golden(curve)["group"]
+        gk = b"".join([pyec.enc_scalar(c, v["k"]) for v in g["add"]] + [bytes.fromhex(v["k"]) for v in g["mul"]])
+        out, inf = eng.mul_by_generator(c.cid, gk, constant_time=True)
+        assert not inf.any() and bytes(out) == b"".join(xy(v) for v in g["add"] + g["mul"])
+        gxy = pyec.enc_point(c, G)[0]
+        out, inf = eng.mul(c.cid, gk, gxy * (len(gk) // c.L), constant_time=True)
+        assert not inf.any() and bytes(out) == b"".join(xy(v) for v in g["add"] + g["mul"])
+    # variable base: edge scalars x {G, -G, identity}, random pairs, a duplicated point
+    n = 400
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xC7EC0002 + c.cid))
+    pts = pts.copy()
+    sc = rand_scalars(c.cid, n, 0xC7EC0003 + c.cid).copy()
+    pinf = np.zeros(n, np.uint8)
+    slot = 0
+    for k in edge_scalars(c):
+        for P in (G, pyec.neg(c, G), pyec.INF):
+            e, f = pyec.enc_point(c, P)
+            sc[slot * c.L: (slot + 1) * c.L] = np.frombuffer(pyec.enc_scalar(c, k), np.uint8)
+            pts[slot * 2 * c.L: (slot + 1) * 2 * c.L] = np.frombuffer(e, np.uint8)
+            pinf[slot] = f
+            slot += 1
+    assert slot < n - 2
+    out, oinf = eng.mul(c.cid, sc, pts, pinf, constant_time=True)
+    want, winf = oracle_lib.batch_mul(c.cid, sc, pts, pinf)                 # the oracle's constant-time `Mul`
+    assert bytes(out) == bytes(want) and bytes(oinf) == bytes(winf)
+    out_v, oinf_v = eng.mul(c.cid, sc, pts, pinf)                           # and the variable-time kernel
+    assert bytes(out) == bytes(out_v) and bytes(oinf) == bytes(oinf_v)
+    out3, _ = eng.mul(c.cid, sc[slot * c.L:], pts[slot * 2 * c.L:], None, constant_time=True)   # NULL flags
+    assert bytes(out3) == bytes(want[slot * 2 * c.L:])
+    # ECDH: Node / OpenSSL's shared secrets, then k = 0 -> ok = 0
+    rows = json.load(open(os.path.join(GOLDEN, "ecdh_node.json")))[curve]
+    k = b"".join(bytes.fromhex(r["d"]) for r in rows)
+    p = b"".join(bytes.fromhex(r["qx"]) + bytes.fromhex(r["qy"]) for r in rows)
+    x, ok = eng.ecdh(c.cid, k, p, constant_time=True)
+    assert ok.all() and bytes(x) == b"".join(bytes.fromhex(r["z"]) for r in rows)
+    ks0 = sc[slot * c.L:].copy()
+    ks0[: c.L] = 0
+    x, ok = eng.ecdh(c.cid, ks0, pts[slot * 2 * c.L:], constant_time=True)
+    w0, wi0 = oracle_lib.batch_mul(c.cid, ks0, pts[slot * 2 * c.L:])
+    assert bytes(x) == bytes(w0.reshape(-1, 2 * c.L)[:, : c.L].copy().reshape(-1)) and ok[0] == 0 and ok[1:].all()
+    # errors: the verdicts of the flag pass surface as the usual codes; empty batches
+    good_k = pyec.enc_scalar(c, 5)
+    gxy = pyec.enc_point(c, G)[0]
+    for bad_k in (c.n, 2 ** (8 * c.L) - 1):
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.mul_by_generator(c.cid, good_k + bad_k.to_bytes(c.L, "big"), constant_time=True)
+        assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.mul(c.cid, good_k + bad_k.to_bytes(c.L, "big"), gxy * 2, constant_time=True)
+        assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+    off = bytearray(gxy); off[-1] ^= 1
+    for bad_p in (bytes(off), c.p.to_bytes(c.L, "big") + gxy[c.L:]):
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.mul(c.cid, good_k * 2, gxy + bad_p, constant_time=True)
+        assert e.value.code == ecgpu.ERR_POINT
+        with pytest.raises(ecgpu.EcgpuError) as e:
+            eng.ecdh(c.cid, good_k * 2, gxy + bad_p, constant_time=True)
+        assert e.value.code == ecgpu.ERR_POINT
+    # an off-curve record under a set identity flag is not an error (its verdict is dropped under the mask), as in the
+    # variable-time entry point, which never looks at it
+    o, f = eng.mul(c.cid, good_k * 2, gxy + bytes(off), np.array([0, 1], np.uint8), constant_time=True)
+    assert f[1] == 1 and f[0] == 0
+    assert eng.mul_by_generator(c.cid, b"", constant_time=True)[0].size == 0
+    assert eng.mul(c.cid, b"", b"", constant_time=True)[0].size == 0
+
+
+def test_uniform_schedule_device_resident_and_queued(eng):
+    """The _dev forms on device-resident p256 / k256 batches (2^14 elements: several waves per SIMD slot, the table scratch
+    reused by the lanes' later elements), synchronous and queued (ecgpu_set_async), equal to the variable-time results."""
+    for curve in ("k256", "p256"):
+        c = pyec.CURVES[curve]
+        n = 1 << 14
+        ks = rand_scalars(c.cid, n, 0xC7EC0010 + c.cid)
+        d_k = eng.to_device(ks)
+        d_pts = eng.dev_alloc(n * 2 * c.L)
+        d_out = eng.dev_alloc(n * 2 * c.L)
+        d_out_ct = eng.dev_alloc(n * 2 * c.L)
+        d_inf = eng.dev_alloc(n)
+        eng.mul_by_generator_dev(c.cid, d_k, n, d_pts, d_inf)
+        eng.mul_by_generator_dev(c.cid, d_k, n, d_out_ct, d_inf, constant_time=True)
+        assert bytes(eng.to_host(d_pts)) == bytes(eng.to_host(d_out_ct))
+        d_k2 = eng.to_device(rand_scalars(c.cid, n, 0xC7EC0011 + c.cid))
+        eng.mul_dev(c.cid, d_k2, d_pts, None, n, d_out, d_inf)
+        eng.set_async(True)
+        eng.mul_dev(c.cid, d_k2, d_pts, None, n, d_out_ct, d_inf, constant_time=True)
+        eng.synchronize()
+        eng.set_async(False)
+        assert bytes(eng.to_host(d_out)) == bytes(eng.to_host(d_out_ct))
+        for b in (d_k, d_k2, d_pts, d_out, d_out_ct, d_inf):
+            b.free()
+
+
 def test_schnorr_bip340_vectors_from_wire_bytes(eng):
     """`VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` entirely on the device (lift_x, SHA-256 tagged hash, s G - e P):
     the 19 BIP340 vectors of k256/src/schnorr.rs, the 32-byte-message ones as one batch, plus random batches against the

@@ -244,6 +244,37 @@ def test_var_base_algorithm(oracle, curve):
 
 
 @pytest.mark.parametrize("curve", CURVES)
+def test_uniform_schedule_bodies(oracle, curve):
+    """fixed_base_mul_ct / var_base_mul_ct (ecgpu_ctmul.h: the reference's constant-time drivers restated for the
+    uniform-schedule kernels) against the oracle's constant-time drivers: edge scalars x {G, -G, identity, random points},
+    the ladder's corner scalars, zero and n - 1."""
+    from gpu_common import ladder_edge_scalars
+    c = pyec.CURVES[curve]
+    rng = random.Random(0xC7 + c.cid)
+    G = pyec.G(c)
+    ks = _scalars(c, rng, 12) + ladder_edge_scalars(c)[:24]
+    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    rc, out, inf = hc.batch_mul_base_ct(c.cid, scal)
+    assert rc == 0
+    want, winf = oracle.batch_mul_base(c.cid, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    assert hc.batch_mul_base_ct(c.cid, c.n.to_bytes(c.L, "big"))[0] == -2
+    pts = [G, pyec.neg(c, G), pyec.INF] + [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(3)]
+    pairs = [(k, P) for k in ks[:8] for P in pts[:4]] + [(k, pts[3 + i % 3]) for i, k in enumerate(ks)]
+    scal = b"".join(pyec.enc_scalar(c, k) for k, _ in pairs)
+    enc = [pyec.enc_point(c, P) for _, P in pairs]
+    pxy = b"".join(e[0] for e in enc)
+    pinf = np.array([e[1] for e in enc], np.uint8)
+    rc, out, inf = hc.batch_mul_ct(c.cid, scal, pxy, pinf)
+    assert rc == 0
+    want, winf = oracle.batch_mul(c.cid, scal, pxy, pinf)           # the oracle's constant-time `Mul` driver
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    for k, P in pairs[:3] + pairs[-3:]:                             # and the independent big-int model
+        got = hc.batch_mul_ct(c.cid, pyec.enc_scalar(c, k), pyec.enc_point(c, P)[0], np.array([pyec.enc_point(c, P)[1]], np.uint8))
+        assert (bytes(got[1]), int(got[2][0])) == pyec.enc_point(c, pyec.mul(c, k, P))
+
+
+@pytest.mark.parametrize("curve", CURVES)
 def test_pippenger_skewed_scalars(oracle, curve):
     """Every term in the same bucket of every window (equal scalars), all-ones scalars, and a half/half mix: the
     chunked accumulation spreads one bucket over many lanes and the partial sums must add up."""
