@@ -1235,7 +1235,7 @@ int ecgpu_ecdsa_recover_batch_dev(ecgpu_ctx* ctx, int curve, const void* d_z, co
     if (n && (!d_z || !d_r || !d_s || !d_recid || !d_out_xy || !d_ok || !aligned16(d_z) || !aligned16(d_r) || !aligned16(d_s) ||
               !aligned16(d_out_xy)))
         return arg_error(ctx, __func__);
-    if (curve == ECGPU_SM2 || curve == ECGPU_BIGN256 || curve == ECGPU_P224)   // not ECDSA curves; p224: no decompression (p = 1 mod 4)
+    if (curve == ECGPU_SM2 || curve == ECGPU_BIGN256)   // not ECDSA curves
         return curve_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return verify_dev<decltype(c)>(ctx, VERIFY_RECOVER, d_z, d_r, d_s, d_recid, n, reject_high_s, d_ok, 0, d_out_xy);
@@ -1324,10 +1324,6 @@ int ecgpu_batch_decompress_dev(ecgpu_ctx* ctx, int curve, const void* d_xs, cons
                                void* d_ok) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     if (n && (!d_xs || !d_y_is_odd || !d_out_xy || !d_ok || !aligned16(d_xs) || !aligned16(d_out_xy))) return arg_error(ctx, __func__);
-    if (curve == ECGPU_P224) {              // p = 1 (mod 4): no square root by one exponentiation
-        ctx->err = "point decompression is not available for p224";
-        return ECGPU_ERR_CURVE;
-    }
     return dispatch(curve, [&](auto c) {
         using C = decltype(c);
         if (n == 0) return (int)ECGPU_OK;

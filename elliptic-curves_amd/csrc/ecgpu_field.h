@@ -780,12 +780,52 @@ struct Field {
             return r;
         }
     }
-    // square root: a^((p+1)/4) (all three primes are 3 mod 4), *ok = whether the result squares back to a.
+    // p = 1 (mod 4) (p224: p - 1 = 2^96 (2^128 - 1)): Tonelli-Shanks in its fixed-schedule form.  With q = 2^128 - 1 and
+    // g = z^q a generator of the subgroup of order 2^96 (z = 11, the smallest non-residue), x = a^((q+1)/2) has
+    // x^2 = a t with t = a^q = g^e in that subgroup, e even exactly when a is a square; the bits of e come out one per
+    // round (the lowest unknown bit is set iff t^(2^(95-i)) = -1; t is then multiplied by g^(-2^i) to clear it), and the
+    // root is x g^(-e/2).  Every lane runs the same 96 rounds (4,560 squarings in all — against 223 for the 3 mod 4 primes —
+    // and at most 190 multiplications): no lane waits for another's iteration count.  The reference delegates to
+    // crypto-bigint (primefield/src/monty.rs:467-469, un-vendored); either root serves, the callers pick by parity.
+    static ECGPU_HD M1 sqrt_sylow(const M1& a, bool* ok) {
+        static_assert(C::ID == CURVE_P224, "Tonelli-Shanks constants exist for p224 only");
+        constexpr int S = C::UC::SYLOW_S;
+        // a^(2^127 - 1): 127 ones
+        M1 x2 = mul(sqr(a), a);
+        M1 x3 = mul(sqr(x2), a);
+        M1 x6 = mul(sqr_n(x3, 3), x3);
+        M1 x12 = mul(sqr_n(x6, 6), x6);
+        M1 x24 = mul(sqr_n(x12, 12), x12);
+        M1 x48 = mul(sqr_n(x24, 24), x24);
+        M1 x96 = mul(sqr_n(x48, 48), x48);
+        M1 x120 = mul(sqr_n(x96, 24), x24);
+        M1 x126 = mul(sqr_n(x120, 6), x6);
+        M1 w = mul(sqr(x126), a);
+        M1 r = mul(w, a);                       // a^(2^127) = a^((q+1)/2)
+        M1 t = mul(r, w);                       // a^(2^128 - 1) = a^q
+        M1 gpow = wrap<1, 1>(p_const(C::UC::SYLOW_GINV));       // g^(-2^i)
+        M1 ghalf = one();                       // g^(-2^(i-1)) (unused in round 0: an odd e means "no root")
+#pragma unroll 1
+        for (int i = 0; i < S; i++) {
+            const M1 u = sqr_n(t, S - 1 - i);
+            const bool bit = !eq(u, one());
+            const M1 tg = mul(t, gpow), rg = mul(r, ghalf);
+            t = wrap<1, 1>(sel(bit, tg, t).e);
+            r = wrap<1, 1>(sel(bit && i > 0, rg, r).e);
+            ghalf = gpow;
+            gpow = sqr(gpow);
+        }
+        *ok = eq(sqr(r), a);
+        return r;
+    }
+    // square root: a^((p+1)/4) (the primes that are 3 mod 4), *ok = whether the result squares back to a.
     // k256/src/arithmetic/field.rs:200-235 and p256/src/arithmetic/field.rs:121-147 (the same addition chains);
     // p384 delegates to crypto-bigint (primefield/src/monty.rs:467-469): a fixed 4-bit window over the exponent.
     static ECGPU_HD M1 sqrt(const M1& a, bool* ok) {
         M1 r;
-        if constexpr (REPR == REPR_U29_K256) {
+        if constexpr (C::ID == CURVE_P224) {
+            return sqrt_sylow(a, ok);
+        } else if constexpr (REPR == REPR_U29_K256) {
             M1 x2 = mul(sqr(a), a);
             M1 x3 = mul(sqr(x2), a);
             M1 x6 = mul(sqr_n(x3, 3), x3);

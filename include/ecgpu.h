@@ -328,7 +328,7 @@ int ecgpu_ecdsa_verify_msg_batch_dev(ecgpu_ctx *ctx, int curve, const void *d_q_
  *   ok[i] = 1 and out_xy[i] = the key (affine x||y) iff 1 <= r, s < n, (reject_high_s == 0 or s <= (n-1)/2: the
  *      `verify_prehash` the crate runs on the recovered key applies the curve's NORMALIZE_S — pass 1 for k256), recid <= 3,
  *      the candidate x is below p and on the curve, and the key is not the identity;  otherwise ok[i] = 0 and a zero record.
- * ECGPU_ERR_CURVE for sm2 / bign256 (not ECDSA) and p224 (no decompression). */
+ * ECGPU_ERR_CURVE for sm2 / bign256 (not ECDSA). */
 int ecgpu_ecdsa_recover_batch(ecgpu_ctx *ctx, int curve, const uint8_t *z, const uint8_t *r,
                               const uint8_t *s, const uint8_t *recid, size_t n, int reject_high_s,
                               uint8_t *out_xy, uint8_t *ok);
@@ -430,7 +430,9 @@ int ecgpu_batch_ecdh_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, co
  * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;
  * BIP340 `decompact` = y_is_odd 0).  xs n*L bytes big-endian, y_is_odd n bytes.  out_xy[i] = (x, y) with
  * y^2 = x^3 + a x + b and the requested parity and ok[i] = 1, or a zero record and ok[i] = 0 when x >= p or
- * no such y exists (the reference's `CtOption::None`).   ECGPU_ERR_CURVE for p224 (p = 1 mod 4: no square root by a single exponentiation). */
+ * no such y exists (the reference's `CtOption::None`).  Every parameter set, p224 included (p = 1 mod 4: the square root
+ * is a fixed-schedule Tonelli-Shanks over the 2^96-element subgroup, ~20 times the work of the other curves' single
+ * exponentiation; primefield/src/monty.rs:467-469). */
 int ecgpu_batch_decompress(ecgpu_ctx *ctx, int curve, const uint8_t *xs, const uint8_t *y_is_odd,
                            size_t n, uint8_t *out_xy, uint8_t *ok);
 int ecgpu_batch_decompress_dev(ecgpu_ctx *ctx, int curve, const void *d_xs, const void *d_y_is_odd,

@@ -200,15 +200,15 @@ int ecref_ecdsa_verify_batch(int curve, const uint8_t *z, const uint8_t *r, cons
  *     u1 = -(r^-1 z), u2 = r^-1 s;  pk = ProjectivePoint::lincomb(&[(G, u1), (R, u2)])
  *     vk = VerifyingKey::from_affine(pk)   (error for the identity);  vk.verify_prehash(prehash, signature)?  — which is
  *     where a curve with NORMALIZE_S (k256) rejects a high s.
- * ok[i] = 1 and out_xy[i] = the recovered key, or ok[i] = 0 and a zero record.  Not offered for p224 (no decompression:
- * p = 1 mod 4), sm2 and bign256 (not ECDSA curves). */
+ * ok[i] = 1 and out_xy[i] = the recovered key, or ok[i] = 0 and a zero record.  Not offered for sm2 and bign256
+ * (not ECDSA curves). */
 int ecref_ecdsa_recover_batch(int curve, const uint8_t *z, const uint8_t *r, const uint8_t *s, const uint8_t *recid, size_t n,
                               int reject_high_s, uint8_t *out_xy, uint8_t *ok) {
-    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384 && curve != ECREF_BP256T1 && curve != ECREF_BP384T1) return ECREF_ERR_CURVE;
+    if (curve != ECREF_K256 && curve != ECREF_P256 && curve != ECREF_P384 && curve != ECREF_P224 && curve != ECREF_P192 && curve != ECREF_P521 && curve != ECREF_BP256 && curve != ECREF_BP384 && curve != ECREF_BP256T1 && curve != ECREF_BP384T1) return ECREF_ERR_CURVE;
     modn_t m;
     modn_init(&m, curve);
     const int nl = m.nl;
-    const size_t L = curve == ECREF_P521 ? 66 : 8 * (size_t)nl;
+    const size_t L = curve == ECREF_P224 ? 28 : curve == ECREF_P521 ? 66 : 8 * (size_t)nl;
     for (size_t i = 0; i < n; i++) {
         uint64_t zw[9], rw[9], sw[9], xw[10], rinv[9], u1[9], u2[9];
         ok[i] = 0;

@@ -555,12 +555,37 @@ static int p224_fe_invert(fe_p224 *out, const fe_p224 *a) {          /* monty.rs
     return 1;
 }
 
-/* p = 1 (mod 4): no single-exponentiation square root; decompression is not offered for this curve (the device
- * library returns an error for it as well). */
+/* sqrt — primefield/src/monty.rs:467-469 -> crypto-bigint ConstMontyForm::sqrt (un-vendored).  p = 1 (mod 4) with
+ * p - 1 = 2^96 * (2^128 - 1): the textbook Tonelli-Shanks loop (Cohen, Algorithm 1.5.1), with z = 11 the smallest
+ * quadratic non-residue.  Either root serves: every caller selects by parity (primeorder/src/affine.rs:183-200). */
+static int p224_fe_eq(const fe_p224 *a, const fe_p224 *b) { fe_p224 d = p224_fe_sub(a, b); return p224_fe_is_zero(&d); }
 static int p224_fe_sqrt(fe_p224 *out, const fe_p224 *a) {
-    (void)a;
-    *out = p224_fe_zero();
-    return 0;
+    if (p224_fe_is_zero(a)) { *out = p224_fe_zero(); return 1; }
+    const fe_p224 one = p224_fe_one();
+    /* q = 2^128 - 1: a^q and a^((q+1)/2) = a^(2^127) by square-and-multiply */
+    fe_p224 t = one, r = *a;
+    for (int i = 0; i < 128; i++) { t = p224_fe_sqr(&t); t = p224_fe_mul(&t, a); }       /* a^(2^128 - 1) */
+    for (int i = 0; i < 127; i++) r = p224_fe_sqr(&r);                                    /* a^(2^127) */
+    fe_p224 z = one;
+    for (int i = 0; i < 10; i++) z = p224_fe_add(&z, &one);                               /* 11 (Montgomery form) */
+    fe_p224 c = one;
+    for (int i = 0; i < 128; i++) { c = p224_fe_sqr(&c); c = p224_fe_mul(&c, &z); }       /* z^q: order 2^96 */
+    int m = 96;
+    while (!p224_fe_eq(&t, &one)) {
+        int i = 0;
+        fe_p224 u = t;
+        while (!p224_fe_eq(&u, &one)) { u = p224_fe_sqr(&u); i++; if (i == m) { *out = p224_fe_zero(); return 0; } }
+        fe_p224 b = c;
+        for (int j = 0; j < m - i - 1; j++) b = p224_fe_sqr(&b);
+        r = p224_fe_mul(&r, &b);
+        c = p224_fe_sqr(&b);
+        t = p224_fe_mul(&t, &c);
+        m = i;
+    }
+    fe_p224 chk = p224_fe_sqr(&r);
+    if (!p224_fe_eq(&chk, a)) { *out = p224_fe_zero(); return 0; }
+    *out = r;
+    return 1;
 }
 
 #define PO_PFX p224

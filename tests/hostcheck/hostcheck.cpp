@@ -783,7 +783,7 @@ int hc_ecdsa_hash_msg(int curve, const uint8_t* msgs, size_t msg_len, size_t n, 
 }
 int hc_ecdsa_recover(int curve, const uint8_t* z, const uint8_t* r, const uint8_t* s, const uint8_t* recid, size_t n, int reject_high_s,
                      uint8_t* out_xy, uint8_t* ok) {
-    if (curve == 3 || curve == 11 || curve == 4) return -1;      // sm2 / bign: not ECDSA; p224: no decompression
+    if (curve == 3 || curve == 11) return -1;                    // sm2 / bign: not ECDSA
     DISPATCH(curve, ecdsa_recover, (z, r, s, recid, n, reject_high_s, out_xy, ok))
 }
 int hc_schnorr_verify(int mode, const uint8_t* e_or_msgs, size_t msg_len, const uint8_t* r_or_sigs, const uint8_t* s, const uint8_t* p,
@@ -805,7 +805,6 @@ int hc_sm3(const uint8_t* msg, size_t len, uint8_t* out32) {
     return 0;
 }
 int hc_decompress(int curve, const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok) {
-    if (curve == 4) return -1;                                   // p224: p = 1 mod 4
     DISPATCH(curve, decompress, (xs, odd, n, out_xy, ok))
 }
 int hc_table_rule(int curve, int w, int j, uint32_t e, uint8_t* out_xy) {

@@ -16,10 +16,20 @@ _lib = None
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_verify.h", "ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h", "ecgpu_hash.h", "ecgpu_sm3.h")]
-    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
+    import fcntl
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_verify.h", "ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_ctmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h", "ecgpu_hash.h", "ecgpu_sm3.h")]
+
+    def fresh():
+        return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)
+    if fresh():
         return
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", LIB, SRC])
+    # pytest-xdist workers arrive here together: one builds (into a temporary name, renamed when complete), the others wait
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not fresh():
+            tmp = LIB + ".tmp.%d" % os.getpid()
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", tmp, SRC])
+            os.replace(tmp, LIB)
 
 
 def lib():

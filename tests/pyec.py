@@ -229,14 +229,36 @@ def ecdsa_verify(c, Q, z, r, s, reject_high_s=False):
     return R is not INF and R[0] % c.n == r
 
 
+def sqrt_mod(a, p):
+    """A square root of a modulo the odd prime p, or None: one exponentiation for p = 3 (mod 4), otherwise Tonelli-Shanks
+    in its discrete-logarithm form (p224: p - 1 = 2^96 (2^128 - 1))."""
+    a %= p
+    if a == 0:
+        return 0
+    if pow(a, (p - 1) // 2, p) != 1:
+        return None
+    if p % 4 == 3:
+        return pow(a, (p + 1) // 4, p)
+    s, q = 0, p - 1
+    while q % 2 == 0:
+        s, q = s + 1, q // 2
+    z = next(c for c in range(2, 200) if pow(c, (p - 1) // 2, p) == p - 1)
+    g, t, e = pow(z, q, p), pow(a, q, p), 0
+    for i in range(1, s):                       # e: t = g^e, e even; bit i from (t g^-e)^(2^(s-1-i))
+        if pow(t * pow(g, -e, p) % p, 1 << (s - 1 - i), p) != 1:
+            e |= 1 << i
+    y = pow(a, (q + 1) // 2, p) * pow(g, -(e // 2), p) % p
+    assert y * y % p == a
+    return y
+
+
 def lift_x(c, x, y_is_odd):
-    """The curve point with this x and the requested y parity, or None (x >= p, or x^3 + a x + b is not a square).
-    Needs p = 3 (mod 4) — every curve here except p224."""
-    if x >= c.p or c.p % 4 != 3:
+    """The curve point with this x and the requested y parity, or None (x >= p, or x^3 + a x + b is not a square)."""
+    if x >= c.p:
         return None
     alpha = (pow(x, 3, c.p) + c.a * x + c.b) % c.p
-    y = pow(alpha, (c.p + 1) // 4, c.p)
-    if y * y % c.p != alpha:
+    y = sqrt_mod(alpha, c.p)
+    if y is None:
         return None
     if (y & 1) != int(bool(y_is_odd)):
         y = (c.p - y) % c.p

@@ -572,7 +572,7 @@ def test_schnorr_bip340_vectors(eng):
     assert one.size == 64
 
 
-@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c != "p224"])      # p224: p = 1 mod 4, no decompression
+@pytest.mark.parametrize("curve", ALL_CURVES)
 def test_decompress_vs_oracle(eng, curve):
     """DecompressPoint::decompress on a batch: residues and non-residues, both parities, x >= p, the generator; then
     compress(k*G) -> decompress round trip over 4096 random points."""
@@ -908,14 +908,14 @@ def test_ecdsa_recover_reference_vectors(eng):
     assert eng.ecdsa_verify(ecgpu.K256, z, r, s, out, reject_high_s=True).all()     # what recover_from_prehash ends with
     out0, ok0 = eng.ecdsa_recover(ecgpu.K256, b"", b"", b"", b"")
     assert out0.size == 0 and ok0.size == 0
-    for cid in (pyec.CURVES["sm2"].cid, pyec.CURVES["p224"].cid, pyec.CURVES["bign256"].cid):
+    for cid in (pyec.CURVES["sm2"].cid, pyec.CURVES["bign256"].cid):
         L = ecgpu.FIELD_BYTES[cid]
         with pytest.raises(ecgpu.EcgpuError) as e:
             eng.ecdsa_recover(cid, bytes(L), bytes(L), bytes(L), b"\0")
         assert e.value.code == ecgpu.ERR_CURVE
 
 
-@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c not in ("p224", "sm2")])
+@pytest.mark.parametrize("curve", [c for c in ALL_CURVES if c != "sm2"])
 def test_ecdsa_recover_vs_oracle_and_model(eng, curve):
     """Recovery ids of the nonce point and the other three, disturbed fields, range failures, ids above 3, candidates off
     the curve, x-reduced candidates, both high-S policies: key for key the oracle's restatement of `recover_from_prehash`
@@ -959,7 +959,7 @@ def test_ecdsa_recover_vs_oracle_and_model(eng, curve):
     assert (gr[good & nonzero] == Qr[good & nonzero]).all() and not (gr[~good] == Qr[~good]).all(axis=1).any()
 
 
-@pytest.mark.parametrize("name", ["k256_der", "p256_der", "p384_der", "p521_der"])
+@pytest.mark.parametrize("name", ["k256_der", "p256_der", "p384_der", "p224_der", "p521_der"])
 def test_ecdsa_recover_wycheproof(eng, name):
     """The reference's Wycheproof blobs through ecgpu_ecdsa_recover_batch: every parsed vector under all four recovery ids; one
     of them gives back the vector's public key exactly when the vector is valid; keys and verdicts equal the oracle's."""
