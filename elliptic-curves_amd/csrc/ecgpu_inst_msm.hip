@@ -5,11 +5,6 @@ namespace ecgpu {
 
 using CurveT = ECGPU_CURVE;
 
-// the latency-scheduled build of the tail kernels lives in ecgpu_inst_msmtail.hip (its own compiler flags)
-extern template void launch_msm_tail<CurveT, 1>(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t* parts, hipEvent_t ev_accumulated);
-extern template void launch_msm_finish_v<CurveT, 1>(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins,
-                                                    uint32_t* out);
-
 template MsmPlan msm_plan<CurveT>(size_t n, int force_c, bool glv);
 template bool msm_use_glv<CurveT>(size_t n);
 template int msm_choose_window<CurveT>(size_t n);

@@ -37,10 +37,6 @@
 #include "ecgpu_launch.h"
 #include "ecgpu_msm_chunk.h"
 
-#ifndef ECGPU_MSM_TAIL_DEFAULT
-#define ECGPU_MSM_TAIL_DEFAULT 0
-#endif
-
 namespace ecgpu {
 
 // ---- prepare ----------------------------------------------------------------------------------------------
@@ -391,9 +387,9 @@ constexpr uint32_t MSM_BIG_PARTIALS = 32;
 // One wave per SIMD at most (a few thousand waves in all): the whole register file, so that nothing spills — at three waves
 // per SIMD 83 registers went to scratch and every lane paid ~100 scratch round trips (0.13 ms for a kernel whose arithmetic
 // is 10 us; profiles/r03/).
-// V: build variant of the latency-bound tail kernels (0: this translation unit's flags, 1: ecgpu_inst_msmtail.hip, scheduled
-// for instruction-level parallelism: these kernels run one wave per SIMD and wait on their own dependency chains)
-template <class C, int V = 0>
+// (A second build of these tail kernels scheduled for instruction-level parallelism, `-amdgpu-sched-strategy=max-ilp`, was
+// measured and dropped: no difference beyond noise, profiles/r03/msm_tail_variants_88130fd.txt.)
+template <class C>
 __global__ void __launch_bounds__(64, 1)
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
@@ -461,7 +457,7 @@ __device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const
 // shift_w = 0 except for the last window (sub-buckets, see msm_digit).  Running-sum trick: walking the
 // segment downwards, `running` is added to `local` once per unit drop of the weight, and the weight of the
 // lowest bucket multiplies the whole segment sum at the end.
-template <class C, int V = 0>
+template <class C>
 __global__ void __launch_bounds__(64)
 k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin, int top_shift,
                       uint32_t* __restrict__ segs) {
@@ -487,7 +483,7 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
 // parts[w][g] = sum of the segment sums segs[w][g * per .. (g + 1) * per): one workgroup per (g, w), a strided pass
 // and an LDS tree.  With the default plan (4 buckets per segment, 256 segments per workgroup) a lane adds one segment:
 // the depth is the 8 levels of the tree, where one workgroup per window used to walk 32 segments per lane first.
-template <class C, int V = 0>
+template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per, uint32_t* __restrict__ parts) {
     using G = Group<C>;
@@ -503,7 +499,7 @@ k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per,
 
 // wins[w] = sum over ranks r and workgroups g of parts[r][w][g] — the one place where the partial results of several
 // GPUs meet (nranks = 1: this GPU's own).  One workgroup per window.
-template <class C, int V = 0>
+template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int nparts, uint32_t* __restrict__ wins) {
     using G = Group<C>;
@@ -520,7 +516,7 @@ k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int 
 }
 
 // out = sum_w 2^(c w) wins[w]   (Horner)
-template <class C, int V = 0>
+template <class C>
 __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -704,20 +700,10 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     return p;
 }
 
-// Which build of the latency-bound tail kernels runs: ECGPU_MSM_TAIL = 0 (this translation unit's flags) / 1 (the build of
-// ecgpu_inst_msmtail.hip, scheduled for instruction-level parallelism); results do not depend on it.
-inline int msm_tail_variant() {
-    static const int v = [] {
-        const char* e = getenv("ECGPU_MSM_TAIL");
-        return e ? atoi(e) : ECGPU_MSM_TAIL_DEFAULT;
-    }();
-    return v;
-}
-
 // Everything between the accumulation and the per-window partial sums: bucket finish, running sums over segments of buckets,
 // the tree over the segment sums.  These kernels hold a few thousand waves at most and each lane walks a chain of dependent
 // point operations: their time is latency, not throughput.
-template <class C, int V>
+template <class C>
 void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t* parts, hipEvent_t ev_accumulated) {
     const size_t ne = p.nsub;
     uint32_t* pts = (uint32_t*)(ws + p.off_points);
@@ -730,7 +716,7 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     const size_t nbk = p.nb * p.nwin;
     (void)hipMemsetAsync(big_list, 0, 4, stream);
-    hipLaunchKernelGGL((k_msm_bucket_finish<C, V>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((k_msm_bucket_finish<C>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
                        (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
     hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
@@ -738,9 +724,9 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
                        p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
     (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
-    hipLaunchKernelGGL((k_msm_reduce_segments<C, V>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
+    hipLaunchKernelGGL((k_msm_reduce_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
-    hipLaunchKernelGGL((k_msm_reduce_windows<C, V>), dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
+    hipLaunchKernelGGL((k_msm_reduce_windows<C>), dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
                        (const uint32_t*)segs, p.nseg, p.per_part, parts);
 }
 
@@ -836,28 +822,18 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
                        (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials);
-    if (msm_tail_variant() == 1)
-        launch_msm_tail<C, 1>(p, stream, ws, parts, ev_accumulated);
-    else
-        launch_msm_tail<C, 0>(p, stream, ws, parts, ev_accumulated);
+    launch_msm_tail<C>(p, stream, ws, parts, ev_accumulated);
 }
 
 // Second half: the window sums over `nranks` sets of partial sums (laid out [rank][nwin][nparts]) and the Horner chain
 // over the windows; the result (projective, internal form) lands in out[0].  `wins` is nwin points of scratch.
-template <class C, int V>
-void launch_msm_finish_v(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
+template <class C>
+void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
     // the tree of k_msm_window_sums is as wide as the parts of all ranks need, not wider (16 parts: 4 levels, not 8)
     int items = nranks * (int)p.nparts, block = 64;
     while (block < items && block < BLOCK) block *= 2;
-    hipLaunchKernelGGL((k_msm_window_sums<C, V>), dim3((unsigned)p.nwin), dim3(block), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
-    hipLaunchKernelGGL((k_msm_combine<C, V>), dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
-}
-template <class C>
-void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
-    if (msm_tail_variant() == 1)
-        launch_msm_finish_v<C, 1>(p, stream, parts_all, nranks, wins, out);
-    else
-        launch_msm_finish_v<C, 0>(p, stream, parts_all, nranks, wins, out);
+    hipLaunchKernelGGL(k_msm_window_sums<C>, dim3((unsigned)p.nwin), dim3(block), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
+    hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
 }
 
 // The whole pipeline on one GPU.

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Start / end of every kernel of ONE k256 MSM step (the last one of a short bench run) relative to the step's first kernel,
+from rocprofv3 --kernel-trace: how the tail kernels of the window groups lie beside the accumulation.
+    python tools/gpu_msm_timeline.py [log2 n] [groups]"""
+import csv
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+groups = sys.argv[2] if len(sys.argv) > 2 else "3"
+out = "/tmp/msm_timeline_%d_%s" % (lg, groups)
+env = dict(os.environ, ECGPU_MSM_GROUPS=groups, TMPDIR="/tmp")
+cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+       "--only", "msm_k256", "--n", str(1 << lg), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+rows = []
+for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("ecgpu::", ""),
+                     r.get("Queue_Id", "?"), r.get("Grid_Size", "?")))
+rows.sort()
+# the last step: from the last k_msm_prepare on
+starts = [i for i, r in enumerate(rows) if r[2].startswith("k_msm_prepare")]
+if not starts:
+    sys.exit("no MSM kernels in the trace")
+# the check of the bench runs more MSMs after the timed steps; take the last timed one = the (warmup + steps)-th prepare
+idx = starts[min(len(starts) - 1, 3)]
+end = starts[starts.index(idx) + 1] if starts.index(idx) + 1 < len(starts) else len(rows)
+t0 = rows[idx][0]
+print("n = 2^%d, ECGPU_MSM_GROUPS = %s: one step, times in ms from the start of k_msm_prepare" % (lg, groups))
+for s, e, name, q, grid in rows[idx:end]:
+    print("  %9.3f .. %9.3f  (%7.3f)  queue %-3s grid %-9s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, grid, name[:60]))
