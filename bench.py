@@ -480,9 +480,9 @@ class Bench:
             if rc.get("gui_cycles"):
                 # clock-independent view: issue cycles executed / cycles the 1024 SIMDs had under the profiler
                 # (GRBM_GUI_ACTIVE sums the 8 XCDs), and the shader clock that cycle count implies for the live duration
-                # both sides from the SAME committed PMC pass (insts_valu_pmc: the count of that pass, before any later scaling)
-                frac_cycles = rc.get("insts_valu_pmc", rc["insts_valu"]) * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * 1024)
-                clock_kernel = rc["gui_cycles"] / 8 * scale * rc.get("insts_scale", 1.0) / ksec / 1e9   # fewer instructions since the pass: fewer cycles
+                # (both sides from the SAME committed PMC pass)
+                frac_cycles = rc["insts_valu"] * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * 1024)
+                clock_kernel = rc["gui_cycles"] / 8 * scale / ksec / 1e9
             traffic = (rc["fetch_bytes"] + rc["write_bytes"]) * scale if rc.get("fetch_bytes") is not None else None
             basis = rc["source"] + ("" if scale == 1 and not args.window else " (scaled from %d units per launch)" % rc["units_per_launch"])
         hbm_gbps = wl["bytes_per_unit"] * n / ksec / 1e9 if ksec else None

@@ -517,7 +517,7 @@ int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n,
 // ECGPU_MSM_SMALL_LOG2 overrides the measured default (tuning knob, -1 disables)
 template <class C>
 size_t msm_small_max() {
-    // measured (tools/gpu_run51.sh): k256 0.75-0.91 ms against 1.21-1.36 ms up to 2^16 terms (1.51 against 1.39 at 2^17),
+    // measured (round 1, tools/gpu_msm_sweep.py is today's form of the sweep): k256 0.75-0.91 ms against 1.21-1.36 ms up to 2^16 terms (1.51 against 1.39 at 2^17),
     // p256 1.23-1.44 against 1.39-1.59 ms, p384 3.3-3.4 against 3.7-4.1 ms up to 2^10 and level beyond
     int lg = C::N > 8 ? 10 : 16;
     if (const char* e = getenv("ECGPU_MSM_SMALL_LOG2")) lg = atoi(e);
@@ -1872,6 +1872,24 @@ int ecgpu_valu_probe(ecgpu_ctx* ctx, int which, double* ops_per_sec) {
         float gms = 0;
         HIP_TRY(ctx, hipEventElapsedTime(&gms, ctx->ev[0], ctx->ev[1]));
         *ops_per_sec = (double)gblocks * BLOCK * per_lane * 64.0 / (gms * 1e-3);
+        return ECGPU_OK;
+    }
+    if (which == 201 || which == 202) {
+        // the per-lane table pattern of the variable-base kernels with known useful bytes (ecgpu_misc.hip k_tabrow_probe):
+        // 201 = every lane of a wave reads the same entry (contiguous 256-byte rows), 202 = a per-lane entry.  2048 workgroups
+        // like a 2^20-element variable-base call, 64 entry reads of 20 rows per lane: returns useful bytes read per second.
+        const int tblocks = 2048, reps = 64;
+        const size_t lanes = (size_t)tblocks * BLOCK;
+        if ((rc = ensure(ctx, ctx->vtab, lanes * 8 * 30 * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->out0, lanes * 4)) != ECGPU_OK) return rc;
+        record(ctx, 0);
+        launch_tabrow_probe(ctx->stream, (uint32_t*)ctx->vtab.p, which == 202, reps, (uint32_t*)ctx->out0.p, tblocks);
+        record(ctx, 1);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        float tms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&tms, ctx->ev[0], ctx->ev[1]));
+        *ops_per_sec = (double)lanes * reps * 20 * 4.0 / (tms * 1e-3);
         return ECGPU_OK;
     }
     const int blocks = 256 * 8, iters = 2048;

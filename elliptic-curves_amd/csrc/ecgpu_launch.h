@@ -112,5 +112,6 @@ void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r
 void launch_valu_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
 void launch_isa_probe(hipStream_t s, int which, uint32_t* out, int blocks, int iters);
 void launch_gather_probe(hipStream_t s, const uint32_t* table, size_t entries, int per_lane, uint32_t* out, int blocks);
+void launch_tabrow_probe(hipStream_t s, uint32_t* tab, int scattered, int reps, uint32_t* out, int blocks);
 
 }  // namespace ecgpu

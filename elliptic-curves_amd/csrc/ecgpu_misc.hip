@@ -183,6 +183,35 @@ __global__ void __launch_bounds__(BLOCK) k_gather_probe(const uint32_t* __restri
     }
     out[t] = acc;
 }
+// The access pattern of the variable-base kernels' per-lane tables (ecgpu_var.h: [wave][entry][row][lane] u32, 8 entries x 30
+// rows for the 10-limb curves), with KNOWN useful bytes: every wave writes its block once (240 row stores of 256 bytes) and
+// then reads `reps` entries of 20 rows each — entry (r & 7) for all lanes (uniform: every load instruction is one
+// contiguous 256-byte row) or a per-lane pseudo-random entry as a digit-dependent ladder does (scattered: the 64 lanes' words
+// of one load instruction lie in up to 8 different rows).  Under rocprofv3 --pmc FETCH_SIZE the first calibrates the counter
+// for this row width, the second measures how many bytes the memory system moves per useful byte when lanes pick different
+// entries (tools/gpu_fetch_calibration.py).
+__global__ void __launch_bounds__(BLOCK, 2) k_tabrow_probe(uint32_t* __restrict__ tab, int scattered, int reps, uint32_t* __restrict__ out) {
+    constexpr int ROWS = 30, PER_ENTRY = ROWS * 64;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t* base = tab + (t / 64) * (size_t)(8 * PER_ENTRY) + (t % 64);
+    for (int e = 0; e < 8; e++)
+        for (int r = 0; r < ROWS; r++) base[(size_t)e * PER_ENTRY + r * 64] = (uint32_t)(t * 2654435761u) + e * 31 + r;
+    uint32_t acc = 0;
+    uint64_t x = 0x9E3779B97F4A7C15ull * (t + 1);
+#pragma unroll 1
+    for (int i = 0; i < reps; i++) {
+        x ^= x >> 27; x *= 0x3C79AC492BA7B653ull; x ^= x >> 33;
+        const int e = scattered ? (int)(x & 7) : (i & 7);
+        const uint32_t* ent = base + (size_t)e * PER_ENTRY;
+#pragma unroll
+        for (int r = 0; r < 20; r++) acc ^= ent[r * 64];
+    }
+    out[t] = acc;
+}
+void launch_tabrow_probe(hipStream_t s, uint32_t* tab, int scattered, int reps, uint32_t* out, int blocks) {
+    hipLaunchKernelGGL(k_tabrow_probe, dim3(blocks), dim3(BLOCK), 0, s, tab, scattered, reps, out);
+}
+
 void launch_gather_probe(hipStream_t s, const uint32_t* table, size_t entries, int per_lane, uint32_t* out, int blocks) {
     hipLaunchKernelGGL(k_gather_probe, dim3(blocks), dim3(BLOCK), 0, s, table, entries, per_lane, out);
 }

@@ -12,7 +12,9 @@
  *   scalars   n * L bytes, big-endian, canonical (< group order n) — `Scalar::to_repr`
  *             (k256/src/arithmetic/scalar.rs:310-316, primefield/src/monty.rs:498-500);
  *             L = 32 (k256, p256, sm2, bp256 = brainpoolP256r1, bp256t1, bign256), 48 (p384, bp384 = brainpoolP384r1, bp384t1), 28 (p224), 24 (p192) or 66 (p521) = `FieldBytesSize`.  Records are packed without
- *             padding (p224: 28-byte scalars, 56-byte points); only the base pointers of device buffers must be 16-byte aligned.
+ *             padding (p224: 28-byte scalars, 56-byte points); only the base pointers of device buffers must be 16-byte aligned
+ *             (which also gives every record the alignment its codec reads with: 4 bytes for p224 / p192, 2 bytes for p521's
+ *             66-byte records — a *_dev pointer into the middle of an array must keep to a whole number of records).
  *   points    n * 2L bytes, big-endian affine x || y — `AffinePoint::{x,y}`
  *             (primeorder/src/affine.rs:106-112) + optional n-byte identity flags
  *             (`AffinePoint::infinity`, k256/src/arithmetic/affine.rs:45-49); NULL flags = none.

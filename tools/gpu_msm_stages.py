@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""The k256 MSM at one GPU's share (2^21 terms) and at the full size (2^24) for every setting of the overlapped tail
-(ECGPU_MSM_GROUPS = 1: tail after the accumulation on the main stream; 2 / 3: window groups, tails on their own streams):
-step time without a profiler, then the per-kernel times under rocprofv3 --kernel-trace.  Every setting runs in a process of
-its own.    python tools/gpu_msm_stages.py [log2 sizes ...]"""
+"""The k256 MSM at one GPU's share (2^21 terms) and at the full size (2^24): step time without a profiler, then the
+per-kernel times under rocprofv3 --kernel-trace.  Every size runs in a process of its own; extra environment settings
+(tuning knobs such as ECGPU_MSM_CHUNK, ECGPU_MSM_SEG) are inherited.    python tools/gpu_msm_stages.py [log2 sizes ...]"""
 import json
 import os
 import subprocess
@@ -19,22 +18,21 @@ def line(out):
 
 
 for lg in sizes:
-    for groups in ("1", "2", "3"):
-        env = dict(os.environ, ECGPU_MSM_GROUPS=groups, TMPDIR="/tmp")
-        r = subprocess.run(BENCH + ["--n", str(1 << lg)], env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
-        rec = line(r.stdout)
-        if not rec:
-            print("n=2^%d groups=%s FAILED\n%s" % (lg, groups, r.stderr[-2000:]))
-            continue
-        print("n=2^%d ECGPU_MSM_GROUPS=%s  %.3f ms/step  check=%s  stages=%s" % (
-            lg, groups, rec["ms_per_step"], rec["check_vs_oracle"], {k: round(v, 3) for k, v in rec["stage_ms"].items()}), flush=True)
-        out = "/tmp/msm_stages_%d_%s" % (lg, groups)
-        cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--"] + BENCH + ["--n", str(1 << lg)]
-        r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
-        rec = line(r.stdout)
-        if rec:
-            print("    under the profiler: %.3f ms/step" % rec["ms_per_step"])
-        st = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "stats", out], capture_output=True, text=True)
-        for l in st.stdout.splitlines():
-            if "k_msm" in l or "k_normalize<K256Params, 0>" in l:
-                print("    " + l)
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(BENCH + ["--n", str(1 << lg)], env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+    rec = line(r.stdout)
+    if not rec:
+        print("n=2^%d FAILED\n%s" % (lg, r.stderr[-2000:]))
+        continue
+    print("n=2^%d  %.3f ms/step  check=%s  stages=%s" % (
+        lg, rec["ms_per_step"], rec["check_vs_oracle"], {k: round(v, 3) for k, v in rec["stage_ms"].items()}), flush=True)
+    out = "/tmp/msm_stages_%d" % lg
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "-o", "t", "--"] + BENCH + ["--n", str(1 << lg)]
+    r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
+    rec = line(r.stdout)
+    if rec:
+        print("    under the profiler: %.3f ms/step" % rec["ms_per_step"])
+    st = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "stats", out], capture_output=True, text=True)
+    for l in st.stdout.splitlines():
+        if "k_msm" in l or "k_normalize<K256Params, 0>" in l:
+            print("    " + l)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Start / end of every kernel of ONE k256 MSM step (the last one of a short bench run) relative to the step's first kernel,
-from rocprofv3 --kernel-trace: how the tail kernels of the window groups lie beside the accumulation.
-    python tools/gpu_msm_timeline.py [log2 n] [groups]"""
+"""Start / end of every kernel of ONE k256 MSM step (of a short bench run) relative to the step's first kernel, from
+rocprofv3 --kernel-trace: which kernel waits for which, and the gaps between them.
+    python tools/gpu_msm_timeline.py [log2 n]"""
 import csv
 import glob
 import os
@@ -10,9 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-groups = sys.argv[2] if len(sys.argv) > 2 else "3"
-out = "/tmp/msm_timeline_%d_%s" % (lg, groups)
-env = dict(os.environ, ECGPU_MSM_GROUPS=groups, TMPDIR="/tmp")
+out = "/tmp/msm_timeline_%d" % lg
+env = dict(os.environ, TMPDIR="/tmp")
 cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, os.path.join(ROOT, "bench.py"),
        "--only", "msm_k256", "--n", str(1 << lg), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
 subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=600)
@@ -30,6 +29,6 @@ if not starts:
 idx = starts[min(len(starts) - 1, 3)]
 end = starts[starts.index(idx) + 1] if starts.index(idx) + 1 < len(starts) else len(rows)
 t0 = rows[idx][0]
-print("n = 2^%d, ECGPU_MSM_GROUPS = %s: one step, times in ms from the start of k_msm_prepare" % (lg, groups))
+print("n = 2^%d: one step, times in ms from the start of k_msm_prepare" % lg)
 for s, e, name, q, grid in rows[idx:end]:
     print("  %9.3f .. %9.3f  (%7.3f)  queue %-3s grid %-9s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, grid, name[:60]))

@@ -35,14 +35,16 @@ def pmc(outdir, tag):
                 k = short(r["Kernel_Name"])
                 if "probe" in k or "ecgpu" not in r["Kernel_Name"]:
                     continue
-                acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+                acc[(k, r["Counter_Name"])].append((int(r.get("Grid_Size") or 0), float(r["Counter_Value"])))
     summary = collections.defaultdict(dict)
-    for (k, c), v in sorted(acc.items()):
-        # the first launches of a kernel in a process may be table construction / warm-up at other sizes: the timed
-        # launches are the last ones, all alike — average the second half
-        tail = v[len(v) // 2:]
-        summary[k][c] = sum(tail) / len(tail)
-        print("%-58s %-22s n=%-3d avg=%.6g" % (k[:58], c, len(v), summary[k][c]))
+    for (k, c), rows in sorted(acc.items()):
+        # a kernel also runs at other sizes in a process (table construction, the one-point normalisation of the bench's
+        # check): the timed launches are the ones of the most frequent grid size (ties: the largest) — average those
+        sizes = collections.Counter(g for g, _ in rows)
+        grid = max(sizes, key=lambda g: (sizes[g], g))
+        v = [x for g, x in rows if g == grid]
+        summary[k][c] = sum(v) / len(v)
+        print("%-58s %-22s n=%-3d grid=%-9d avg=%.6g" % (k[:58], c, len(v), grid, summary[k][c]))
     with open(os.path.join(outdir, "pmc_%s.json" % tag), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
 

@@ -31,24 +31,10 @@ KERNELS = {
     "k_normalize<K256Params, 0>": ("base", "K256Params", "k_normalizeINS_10K256ParamsELi0E", 1 << 20, "fixed_k256"),
     "k_var_base<P256Params>": ("var", "P256Params", "k_var_base", 1 << 20, "var_p256"),
     "k_var_base<P384Params>": ("var", "P384Params", "k_var_base", 1 << 20, "var_p384"),
-    "k_var_base<K256Params>": ("var", "K256Params", "k_var_base", 1 << 20, "var_k256"),
+    "k_var_base<K256Params>": ("var", "K256Params", "k_var_base", 1 << 20, "recover_k256"),   # b R of a G + b R: 2^20 launches per call
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
 }
 HALF_SLOT_EXCEPT = ("_co_",)          # carry-producing / -consuming VOP2 ops were measured at the full cost
-
-# Kernels whose code changed AFTER the PMC pass was taken and that could not be counted again (GPU budget): SQ_INSTS_VALU of
-# the pass is scaled by the static instruction ratio new / old of the blocks the kernel spends its time in, so that
-# `roofline.achieved` does not credit the new build with instructions it no longer executes.  The k256 reduction change at the
-# end of round 2 (ecgpu_field.h k_reduce: three instead of four multiply-adds per folded high column) removed 51 of the 1,775
-# VALU instructions of the fixed-base loop block, 25 of 1,041 in the first-addition block and 15 of 515 in the last one:
-# 16,674 -> 16,226 per scalar; one XYZZ addition per sorted entry in the MSM accumulation (51 of ~1,810); 25 of ~2,800 per
-# point in the normalisation.
-INSTS_SCALE = {
-    "k_fixed_base<K256Params>": 16226.0 / 16674.0,
-    "k_msm_accumulate<K256Params>": 1.0 - 51.0 / 1810.0,
-    "k_normalize<K256Params, 0>": 1.0 - 25.0 / 2800.0,
-}
-
 
 def isa_histogram(group, curve, substr):
     with tempfile.TemporaryDirectory() as td:
@@ -83,10 +69,8 @@ def main():
             continue
         rec["_source"] = os.path.relpath(os.path.abspath(path), ROOT)
         h = isa_histogram(group, curve, substr)
-        scale = INSTS_SCALE.get(name, 1.0)
         out[name] = {
-            "workload": workload, "units_per_launch": units, "insts_valu": rec["SQ_INSTS_VALU"] * scale,
-            "insts_valu_pmc": rec["SQ_INSTS_VALU"], "insts_scale": round(scale, 4),
+            "workload": workload, "units_per_launch": units, "insts_valu": rec["SQ_INSTS_VALU"],
             "slots_per_inst": round(h["slots_per_inst"], 4), "mad_share": round(h["mad_share"], 4),
             "static_valu_instructions": h["static_valu"], "isa_top": h["top"],
             # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB (guide: MI355X_MICROARCH.md, HBM section)
@@ -94,9 +78,7 @@ def main():
             "write_bytes": rec["WRITE_SIZE"] * 1024 if "WRITE_SIZE" in rec else None,
             "gui_cycles": rec.get("GRBM_GUI_ACTIVE"), "sq_busy_cycles": rec.get("SQ_BUSY_CYCLES"),
             "sq_wave_cycles": rec.get("SQ_WAVE_CYCLES"), "waves": rec.get("SQ_WAVES"),
-            "source": rec["_source"] + " + ISA histogram (tools/roofline_consts.py)" +
-                      ("; SQ_INSTS_VALU of that pass x %.4f: static instruction ratio of the hot blocks after the k256 reduction change"
-                       % scale if scale != 1.0 else ""),
+            "source": rec["_source"] + " + ISA histogram (tools/roofline_consts.py)",
         }
         print("%-32s insts %.4g  slots/inst %.3f  mad %.3f  fetch %s write %s" % (
             name, out[name]["insts_valu"], h["slots_per_inst"], h["mad_share"], out[name]["fetch_bytes"], out[name]["write_bytes"]))
