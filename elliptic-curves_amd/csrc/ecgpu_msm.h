@@ -515,11 +515,69 @@ k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int 
     if (threadIdx.x == 0) store_proj<C>(wins, blockIdx.x, acc);
 }
 
-// out = sum_w 2^(c w) wins[w]   (Horner)
+// ---- one Jacobian doubling spread over three lanes of a wave ---------------------------------------------------------------
+// The Horner chain below is ONE dependency chain of c * (nwin - 1) doublings (120 for 128-bit sub-scalars, 240 for 255-bit
+// ones): a single lane issues one instruction every ~5 cycles, so the chain's time is its instruction count.  A doubling's
+// seven or eight field multiplications are only three or four DEPENDENT levels:
+//   a = 0  (dbl-2009-l)   {X^2, Y^2, 2Y Z}  ->  {(Y^2)^2, (X + Y^2)^2, (3 X^2)^2}  ->  {E (D - X3)}
+//   a = -3 (dbl-2001-b)   {Z^2, Y^2, (Y + Z)^2}  ->  {X gamma, (X - delta)(X + delta), gamma^2}  ->  {alpha3^2}  ->  {alpha3 (4 beta - X3)}
+// Lanes 0, 1, 2 of the wave each compute one product of a level (the same instruction stream on per-lane operands: plain
+// SIMT), the three results are handed to every lane through the LDS crossbar (`__shfl`, 9-15 words each) and the cheap
+// linear steps in between are done by all lanes alike, so that every lane holds the whole state again.  Three resp. four
+// multiplication times per doubling instead of seven resp. eight.  Every lane must enter with the same point.
+template <class M>
+__device__ __forceinline__ M msm_lane_bcast(const M& v, int src) {
+    M r;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(v.e.v) / sizeof(v.e.v[0])); i++) r.e.v[i] = (uint32_t)__shfl((int)v.e.v[i], src, 64);
+    return r;
+}
+template <class C, class A, class B, class D>
+__device__ __forceinline__ auto msm_sel3(int lane, const A& a, const B& b, const D& d) {
+    using F = Field<C>;
+    return F::sel(lane == 0, a, F::sel(lane == 1, b, d));
+}
+
+template <class C>
+__device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
+    using G = Group<C>;
+    using F = Field<C>;
+    auto X = G::mj(p.x), Y = G::mj(p.y), Z = G::mj(p.z);
+    Jac<C> o;
+    if constexpr (C::A_IS_ZERO) {
+        const auto p1 = F::mul(msm_sel3<C>(lane, X, Y, F::dbl(Y)), msm_sel3<C>(lane, X, Y, Z));     // X^2 | Y^2 | 2 Y Z
+        const auto aa = msm_lane_bcast(p1, 0), bb = msm_lane_bcast(p1, 1), z3 = msm_lane_bcast(p1, 2);
+        const auto e3 = F::template mul_small<3>(aa);
+        const auto p2 = F::sqr(msm_sel3<C>(lane, bb, F::add(X, bb), e3));                           // bb^2 | (X + bb)^2 | e3^2
+        const auto cc = msm_lane_bcast(p2, 0), g = msm_lane_bcast(p2, 1), f = msm_lane_bcast(p2, 2);
+        const auto d = F::dbl(F::norm(F::sub(g, F::add(aa, cc))));                                  // 2
+        const auto X3 = F::norm(F::sub(f, F::dbl(d)));                                              // 6 -> 1
+        o.x = G::jstore(X3);
+        o.y = G::jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
+        o.z = G::jstore(z3);
+    } else {
+        const auto p1 = F::sqr(msm_sel3<C>(lane, Z, Y, F::add(Y, Z)));                              // delta | gamma | (Y + Z)^2
+        const auto delta = msm_lane_bcast(p1, 0), gamma = msm_lane_bcast(p1, 1), yz = msm_lane_bcast(p1, 2);
+        const auto p2 = F::mul(msm_sel3<C>(lane, X, F::sub(X, delta), gamma), msm_sel3<C>(lane, gamma, F::add(X, delta), gamma));
+        const auto beta = msm_lane_bcast(p2, 0), alpha = msm_lane_bcast(p2, 1), gg = msm_lane_bcast(p2, 2);
+        const auto alpha3 = F::add(F::dbl(alpha), alpha);                                           // 3
+        const auto beta4 = F::dbl(F::dbl(beta));                                                    // 4
+        const auto X3 = F::norm(F::sub(F::sqr(alpha3), F::dbl(beta4)));                             // 10 -> 1
+        const auto gg8 = F::dbl(F::dbl(F::dbl(gg)));                                                // 8
+        o.x = G::jstore(X3);
+        o.y = G::jstore(F::norm(F::sub(F::mul(alpha3, F::sub(beta4, X3)), gg8)));
+        o.z = G::jstore(F::norm(F::sub(yz, F::add(gamma, delta))));
+    }
+    return o;
+}
+
+// out = sum_w 2^(c w) wins[w]   (Horner).  One wave; lanes 0..2 share the doublings (above), every lane carries the same
+// accumulator, lane 0 stores.
 template <class C>
 __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
     using G = Group<C>;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = (int)threadIdx.x;
     // Everything here is wave-uniform, and left alone the compiler moves the whole doubling chain to the
     // scalar ALU (no 32x32+64 multiply-add there: 10x the instructions).  An opaque zero in a VGPR makes the
     // addresses, hence the data, formally divergent, which keeps the arithmetic on the vector ALU.
@@ -530,7 +588,8 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
     Proj<C> acc = load_proj<C>(vw, nwin - 1);
     for (int w = nwin - 2; w >= 0; w--) {
         // c doublings in Jacobian coordinates (2M + 5S resp. 3M + 5S instead of the complete 6M + 2S + .. / 8M + 3S + ..):
-        // (X : Y : Z) -> (X Z : Y Z^2 : Z) and back (X Z : Y : Z^3).  The identity has no Jacobian form here: skipped.
+        // (X : Y : Z) -> (X Z : Y Z^2 : Z) and back (X Z : Y : Z^3).  The identity has no Jacobian form here: skipped
+        // (by every lane: the accumulator is the same in all of them).
         if (!G::is_identity(acc)) {
             Jac<C> j;
             {
@@ -539,12 +598,17 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
                 j.y = Field<C>::mul(Y, Field<C>::sqr(Z)).e;
                 j.z = acc.z;
             }
-            for (int s = 0; s < c; s++) j = G::jac_dbl(j);
+            if constexpr (GenericA<C>::value) {
+                for (int s = 0; s < c; s++) j = G::jac_dbl(j);                  // (any-a curves: the one-lane chain)
+            } else {
+#pragma unroll 1
+                for (int s = 0; s < c; s++) j = msm_jac_dbl_lanes<C>(j, lane);
+            }
             acc = G::jac_to_proj(j);
         }
         acc = G::add(acc, load_proj<C>(vw, w), b);
     }
-    store_proj<C>(out, 0, acc);
+    if (lane == 0) store_proj<C>(out, 0, acc);
 }
 
 // out[0 .. count) = the identity
