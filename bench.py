@@ -68,6 +68,10 @@ WORKLOADS = {
                      imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
     "var_k256": dict(curve="k256", kind="var", n=1 << 20, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=1984 * 136, bytes_per_unit=160, kernel="k_var_base<K256Params>", scaling="weak"),
+    # the uniform-schedule (constant-time) form of configs[2]: the reference's own `ProjectivePoint * Scalar` algorithm — table
+    # [P..8P], 65 radix-16 digits, every table entry read and one kept under a mask, complete formulas (ecgpu_batch_mul_ct)
+    "var_p256_ct": dict(curve="p256", kind="var", ct=True, n=1 << 20, metric="p256 variable-base scalar-muls/sec (uniform schedule)",
+                        unit="scalar-muls/s", imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base_ct<P256Params>", scaling="weak"),
     "msm_p256": dict(curve="p256", kind="msm", n=1 << 24, metric="p256 MSM terms/sec", unit="terms/s",
                      imad_per_unit=int(16.06 * 11 * 136), bytes_per_unit=96 + 16 * 64, kernel="k_msm_accumulate<P256Params>",
                      scaling="strong"),
@@ -89,10 +93,10 @@ WORKLOADS = {
 # one GPU's share of configs[3] on an 8-GPU node (2^24 / 8 terms): the part of the bucket method that does not shrink with n
 # shows here; its per-term rate against the 2^24 rate is the single-GPU projection of the 8-GPU scaling efficiency
 WORKLOADS["msm_k256_2p21"] = dict(WORKLOADS["msm_k256"], n=1 << 21, metric="k256 MSM terms/sec (2^21-term share)")
-SEEDS = {"msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
+SEEDS = {"var_p256_ct": 11, "msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
 # BASELINE configs[2], [3], [4] beside the top-level configs[1], then the two signature workloads of SURVEY.md 8(f) (callers of the
 # path: p256 verification, k256 public-key recovery) so that they are driver-timed too
-DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "msm_k256_2p21", "ecdsa_p256", "recover_k256"]
+DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "msm_k256_2p21", "ecdsa_p256", "recover_k256", "var_p256_ct"]
 NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 ROOFLINE_CONSTS = os.path.join(ROOT, "profiles", "roofline_consts.json")
@@ -370,7 +374,7 @@ class Bench:
             if kind == "fixed":
                 eng.mul_by_generator_dev(cid, d_scal, n, d_out, d_inf)
             elif kind == "var":
-                eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
+                eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf, constant_time=bool(wl.get("ct")))
             elif kind == "ecdsa":
                 eng.ecdsa_verify_dev(cid, d_scal, d_r, d_s, d_pts, n, False, d_ok)
             elif kind == "recover":

@@ -4,6 +4,7 @@ modes, scalar split (GLV / plain), duplicated / cancelling / identity terms, ran
 halves; every result against the oracle (n <= 2^13) or a group identity (larger n).  One-off evidence, not part of the test
 suite:    FUZZ_SECONDS=200 FUZZ_SEED=1 python tools/gpu_fuzz.py"""
 import importlib
+import collections
 import os
 import random
 import sys
@@ -24,7 +25,7 @@ e = ec.Engine(0)
 rng = random.Random(int(os.environ.get("FUZZ_SEED", "20260924")))
 budget = float(os.environ.get("FUZZ_SECONDS", "150"))
 t_end = time.time() + budget
-stats = {"msm_oracle": 0, "msm_property": 0, "msm_shards": 0, "fixed": 0, "var": 0, "verify": 0, "recover": 0, "verify_msg": 0}
+stats = collections.defaultdict(int)
 NAMES = ["k256", "p256", "p384", "sm2", "p224", "p192", "p521", "bp256", "bp384", "bp256t1", "bp384t1", "bign256"]
 DEFAULT_W = {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20,
              "bp256t1": 24, "bp384t1": 20, "bign256": 24}
@@ -180,7 +181,7 @@ while time.time() < t_end:
         v = e.ecdsa_verify(c.cid, bytes(zs), bytes(rr), bytes(ss), Q, reject_high_s=high)
         assert bytes(v) == bytes(oracle_lib.ecdsa_verify(c.cid, bytes(zs), bytes(rr), bytes(ss), Q, reject_high_s=high)), ("verify", c.name, n)
         stats["verify"] += 1
-        if c.name != "p224":
+        if True:                                             # (p224 included since its square root exists: round 3)
             gk, gv = e.ecdsa_recover(c.cid, bytes(zs), bytes(rr), bytes(ss), bytes(ids), reject_high_s=high)
             wk, wv = oracle_lib.ecdsa_recover(c.cid, bytes(zs), bytes(rr), bytes(ss), bytes(ids), reject_high_s=high)
             assert bytes(gk) == bytes(wk) and bytes(gv) == bytes(wv), ("recover", c.name, n)
@@ -196,9 +197,11 @@ while time.time() < t_end:
         if wdt:
             e.set_base_window(c.cid, wdt)
         k = rand_scalars(c.cid, n, rng.randrange(1 << 30))
-        o, f = e.mul_by_generator(c.cid, k)
+        ct = rng.random() < 0.3                              # the uniform-schedule entry point instead
+        o, f = e.mul_by_generator(c.cid, k, constant_time=ct)
         w, wf = oracle_lib.batch_mul_base(c.cid, k)
-        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("fixed", c.name, n, wdt)
+        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("fixed", c.name, n, wdt, ct)
+        stats["fixed_ct"] += 1 if ct else 0
         if wdt:
             e.set_base_window(c.cid, DEFAULT_W[c.name])
         stats["fixed"] += 1
@@ -207,8 +210,28 @@ while time.time() < t_end:
         k = rand_scalars(c.cid, n, rng.randrange(1 << 30))
         P = pool(c)
         pts = P[np.array([rng.randrange(1 << 16) for _ in range(n)])].copy().reshape(-1)
-        o, f = e.mul(c.cid, k, pts)
-        w, wf = oracle_lib.batch_mul(c.cid, k, pts)
-        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("var", c.name, n)
-        stats["var"] += 1
-print("fuzz ok: %s in %.0f s, seed %s" % (stats, budget, os.environ.get("FUZZ_SEED", "20260924")))
+        ct = rng.random() < 0.4
+        inf = None
+        if rng.random() < 0.3:                               # identities among the points, tiny / huge scalars
+            inf = np.zeros(n, np.uint8)
+            k = k.copy()
+            for _ in range(rng.randrange(1, 5)):
+                i = rng.randrange(n)
+                if rng.random() < 0.5:
+                    inf[i] = 1
+                else:
+                    k[i * L:(i + 1) * L] = np.frombuffer(pyec.enc_scalar(c, rng.choice([0, 1, 2, c.n - 1, c.n - 2])), np.uint8)
+        o, f = e.mul(c.cid, k, pts, inf, constant_time=ct)
+        w, wf = oracle_lib.batch_mul(c.cid, k, pts, inf)
+        assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("var", c.name, n, ct)
+        stats["var_ct" if ct else "var"] += 1
+        if rng.random() < 0.3:                               # decompression of the x-coordinates just computed (and of junk)
+            xs = o.reshape(n, 2 * L)[:, :L].copy()
+            odd = np.array([rng.randrange(2) for _ in range(n)], np.uint8)
+            for _ in range(rng.randrange(0, 4)):
+                xs[rng.randrange(n)] = np.frombuffer(bytes(rng.randrange(256) for _ in range(L)), np.uint8)
+            dxy, dok = e.decompress(c.cid, xs.reshape(-1), odd)
+            wxy, wok = oracle_lib.batch_decompress(c.cid, xs.reshape(-1), odd)
+            assert bytes(dxy) == bytes(wxy) and bytes(dok) == bytes(wok), ("decompress", c.name, n)
+            stats["decompress"] += 1
+print("fuzz ok: %s in %.0f s, seed %s" % (dict(sorted(stats.items())), budget, os.environ.get("FUZZ_SEED", "20260924")))
