@@ -300,9 +300,14 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
     (void)N;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nthreads) return;
+    // Both passes are software-pipelined by hand: the loads of the lane's NEXT point are issued before the multiplications of
+    // the current one.  With one wave per SIMD (the launch is sized that way: one inversion per lane) nothing else hides a
+    // load's ~2 us, and the loop-carried product keeps the compiler from hoisting the loads itself.
     typename F::M1 acc = F::one();
+    Fe<C::NL> z_next = load_raw<C>(proj + (t < n ? t : 0) * (3 * NS) + 2 * NS);
     for (size_t j = t; j < n; j += nthreads) {
-        Fe<C::NL> z = load_raw<C>(proj + j * (3 * NS) + 2 * NS);
+        const Fe<C::NL> z = z_next;
+        if (j + nthreads < n) z_next = load_raw<C>(proj + (j + nthreads) * (3 * NS) + 2 * NS);
         const bool ident = F::is_zero(G::m(z));
         {   // running product before this point, and whether the point is the identity, in the spare word
             static_assert(NS > C::NL, "raw form has no spare word");
@@ -317,10 +322,18 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
     typename F::M1 inv = F::inv(acc);
     if (n <= t) return;
     size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
+    Proj<C> p_next = load_proj<C>(proj, last);
+    uint32_t pw_next[NS];
+    load_words_vec<NS>(pw_next, prefix + last * NS);
     for (size_t j = last;; j -= nthreads) {
-        Proj<C> p = load_proj<C>(proj, j);
+        const Proj<C> p = p_next;
         uint32_t pw[NS];
-        load_words_vec<NS>(pw, prefix + j * NS);
+#pragma unroll
+        for (int i = 0; i < NS; i++) pw[i] = pw_next[i];
+        if (j >= nthreads) {
+            p_next = load_proj<C>(proj, j - nthreads);
+            load_words_vec<NS>(pw_next, prefix + (j - nthreads) * NS);
+        }
         if (pw[NS - 1]) {
             if constexpr (MODE == NORM_WIRE) {
                 zero_wire<C>(out_xy + j * (2 * WB), 2);
