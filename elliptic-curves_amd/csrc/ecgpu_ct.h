@@ -27,13 +27,13 @@ __device__ __forceinline__ uint32_t ct_load_point(Proj<C>* p, const uint8_t* xy,
     uint32_t cx[C::N], cy[C::N];
     load_wire<C>(cx, xy + i * (2 * WireBytes<C>::value));
     load_wire<C>(cy, xy + i * (2 * WireBytes<C>::value) + WireBytes<C>::value);
-    const bool in_range = !mp_geq<C::N>(cx, C::P) & !mp_geq<C::N>(cy, C::P);
+    const bool in_range = (int)!mp_geq<C::N>(cx, C::P) & (int)!mp_geq<C::N>(cy, C::P);        // (& on purpose: no short circuit)
     Affine<C> a;
     a.x = F::from_canonical(cx).e;
     a.y = F::from_canonical(cy).e;
-    const bool ok = in_range & G::on_curve(a, b);
+    const bool ok = (int)in_range & (int)G::on_curve(a, b);
     *p = ct_sel_proj<C>(ident, G::identity(), G::from_affine(a));
-    return (ok | ident) ? 0u : CT_FLAG_BAD_POINT;
+    return ((int)ok | (int)ident) ? 0u : CT_FLAG_BAD_POINT;
 }
 
 // out[i] = k[i] * P[i]; one lane per element, the table [P..8P] (projective) in the lane's slot of the HBM scratch that

@@ -27,8 +27,6 @@ __global__ void __launch_bounds__(BLOCK)
 k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                 const uint8_t* __restrict__ q_xy, size_t n, int reject_high_s, uint8_t* __restrict__ u1_out,
                 uint8_t* __restrict__ u2_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
-    using S = ScalarN<C>;
-    using F = Field<C>;
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -52,7 +50,6 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_ecdsa_finish(const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf, const uint8_t* __restrict__ r,
                const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
-    using S = ScalarN<C>;
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,8 +204,6 @@ __global__ void __launch_bounds__(BLOCK)
 k_schnorr_prepare(const uint8_t* __restrict__ e, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                   const uint8_t* __restrict__ p_xy, size_t n, uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out,
                   uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
-    using S = ScalarN<C>;
-    using F = Field<C>;
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -237,8 +232,6 @@ k_schnorr_prepare_raw(const uint8_t* __restrict__ pk_x, const uint8_t* __restric
                       const uint8_t* __restrict__ sigs, size_t n, uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out,
                       uint8_t* __restrict__ q_out, uint8_t* __restrict__ r_out, uint8_t* __restrict__ valid) {
     using S = ScalarN<C>;
-    using F = Field<C>;
-    using G = Group<C>;
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     static_assert(N == 8 && C::A_IS_ZERO, "BIP340 is defined over secp256k1");
@@ -290,7 +283,6 @@ k_extract_x(const uint8_t* __restrict__ xy, const uint8_t* __restrict__ inf, siz
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t x[N];
     copy_wire<C>(out_x + i * WB, xy + i * (2 * WB));
     ok[i] = inf[i] ? 0 : 1;
 }
@@ -303,8 +295,6 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_odd, size_t n, uint8_t* __restrict__ out_xy,
              uint8_t* __restrict__ ok_out) {
-    using F = Field<C>;
-    using G = Group<C>;
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
