@@ -325,6 +325,30 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
+        if constexpr (C::ID == CURVE_BIGN256) {
+            // bign-curve256v1: p = 2^256 - 189 in sparse form with SIGNED columns: u p = -189 u + u 2^256, i.e. -189 u into
+            // column i (with u = c_i / 189 mod 2^28 it clears the low 28 bits) and + 16 u into column i + 9
+            // (2^256 = 2^4 * 2^(9 * 28)): two multiply-adds per row instead of the ten of the limb form.  The sign bit is why
+            // the product limit of this parameter set is 11 (tools/gen_field_consts.py).
+            static_assert(UB == 28 && UN == 10, "bign256: 10 x 28 limbs");
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                const int64_t ci = (int64_t)c[i];
+                const int64_t u = (int64_t)(((uint32_t)ci * PC::PINV) & PMASK);
+                const int64_t t = ci + u * (int64_t)(int32_t)opaque_const(0u - 189u);
+                c[i + 1] = (uint64_t)((int64_t)c[i + 1] + (t >> UB));
+                c[i + 9] = (uint64_t)((int64_t)c[i + 9] + u * (int64_t)(int32_t)opaque_const(16u));
+            }
+            E r;
+            int64_t v = (int64_t)c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = (int64_t)c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
         if constexpr (!PC::P0_IS_MINUS_ONE && !PC::P0_IS_ONE) {
             // general p (brainpool): u = c_i * (-p^-1) mod 2^B, then c += u * p over all limbs; the low bits of c_i cancel
             // (model: tools/field_model.py umont_mul_general)

@@ -301,8 +301,53 @@ def p384_mont_mul(a, b, c_extra=None):
     return r
 
 
+BIGN_P = 2 ** 256 - 189                          # bignp256/src/arithmetic/field.rs:60-66
+
+
+def bign_mont_mul(a, b, c_extra=None):
+    """bign-curve256v1 on 10 x 28 limbs (R = 2^280) with SIGNED column accumulators and the Montgomery rows in sparse form:
+    u p = -189 u + u 2^256 with u = c_i / 189 mod 2^28 — -189 u clears the low 28 bits of column i, + 16 u goes into column
+    i + 9 (2^256 = 2^4 2^252).  Two multiply-adds per row instead of ten; product limit 11 (10 x 11 x LB^2 < 2^63)."""
+    mask = (1 << 28) - 1
+    pinv = pow(189, -1, 1 << 28)                  # = -p^-1 mod 2^28
+    c = [0] * 21
+    for x, y in ((a, b),) + ((c_extra,) if c_extra is not None else ()):
+        for i in range(10):
+            for j in range(10):
+                c[i + j] = chk_s64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    for i in range(10):
+        u = (c[i] * pinv) & mask
+        t = chk_s64(c[i] - 189 * u)
+        assert t & mask == 0
+        c[i + 1] = chk_s64(c[i + 1] + (t >> 28))
+        c[i + 9] = chk_s64(c[i + 9] + 16 * u)
+    r = [0] * 10
+    v = c[10]
+    for k in range(9):
+        r[k] = v & mask
+        v = chk_s64(c[11 + k] + (v >> 28))
+    r[9] = chk32(v)
+    return r
+
+
 def selftest(trials=300, seed=1):
     rng = random.Random(seed)
+    # bign256: adversarial magnitudes at the product limit 11 (a single product 11 x 1, and the fused pair 5 x 1 + 6 x 1)
+    rinv = pow(1 << 280, -1, BIGN_P)
+    for ma, mb in ((11, 1), (1, 11), (3, 3), (2, 5)):
+        a = [ma * P_LB - 1] * 9 + [32 * ma - 1]
+        b = [mb * P_LB - 1] * 9 + [32 * mb - 1]
+        r = bign_mont_mul(a, b)
+        assert from_limbs(r, 28) % BIGN_P == from_limbs(a, 28) * from_limbs(b, 28) * rinv % BIGN_P
+    a, b, x, y = ([m * P_LB - 1] * 9 + [32 * m - 1] for m in (5, 1, 6, 1))
+    r = bign_mont_mul(a, b, (x, y))
+    assert from_limbs(r, 28) % BIGN_P == (from_limbs(a, 28) * from_limbs(b, 28) + from_limbs(x, 28) * from_limbs(y, 28)) * rinv % BIGN_P
+    for _ in range(trials):
+        a = [rng.randrange(P_LB) for _ in range(9)] + [rng.randrange(32)]
+        b = [rng.randrange(P_LB) for _ in range(9)] + [rng.randrange(32)]
+        r = bign_mont_mul(a, b)
+        assert from_limbs(r, 28) % BIGN_P == from_limbs(a, 28) * from_limbs(b, 28) * rinv % BIGN_P
+        assert all(0 <= v < (1 << 28) for v in r[:9]) and 0 <= r[9] < 64
     # k256: adversarial maxima at the magnitude-product limit 7 (e.g. 7 x 1, 3 x 2) and random values
     for ma, mb in ((7, 1), (1, 7), (3, 2), (2, 3), (1, 1), (2, 2)):
         assert ma * mb <= 7
