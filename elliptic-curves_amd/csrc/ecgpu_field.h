@@ -325,6 +325,48 @@ struct Field {
             r.v[UN - 1] = (uint32_t)v;
             return r;
         }
+        if constexpr (C::ID == CURVE_SM2 || C::ID == CURVE_P224 || C::ID == CURVE_P192) {
+            // Sparse rows on unsigned, BIASED columns (p_columns_init): u p as a few power-of-two terms, the negative ones as
+            // signed multiply-adds that cannot take their column below zero because it started from the bias.
+            //   sm2   p = 2^256 - 2^224 - 2^96 + 2^64 - 1:  -u (clears), + u 2^8 -> i+2, - u 2^12 -> i+3, + u (2^32 - 1) -> i+8
+            //   p224  p = 2^224 - 2^96 + 1 (p = 1 mod 2^27, u = -c_i):  +u (clears), - u 2^15 -> i+3, + u 2^8 -> i+8
+            //   p192  p = 2^192 - 2^64 - 1:  -u (clears), - u 2^12 -> i+2, + u 2^10 -> i+7
+            // 3 / 2 / 2 multiply-adds per row instead of 9 / 6 / 7 for the limb form (model with overflow and sign checks:
+            // tools/field_model.py sparse_mont_mul).
+            static_assert(HasBias<PC>::value, "sparse rows need the column biases");
+#pragma unroll
+            for (int i = 0; i < UN; i++) {
+                uint32_t u;
+                if constexpr (C::ID == CURVE_P224) {
+                    u = (0u - (uint32_t)c[i]) & PMASK;
+                    c[i + 1] += (c[i] + u) >> UB;
+                } else {
+                    u = (uint32_t)c[i] & PMASK;
+                    c[i + 1] += c[i] >> UB;
+                }
+                const int64_t su = (int64_t)u;
+                if constexpr (C::ID == CURVE_SM2) {
+                    c[i + 2] += (uint64_t)u * opaque_const(1u << 8);
+                    c[i + 3] = (uint64_t)((int64_t)c[i + 3] + su * (int64_t)(int32_t)opaque_const(0u - (1u << 12)));
+                    c[i + 8] += (uint64_t)u * opaque_const(0xFFFFFFFFu);
+                } else if constexpr (C::ID == CURVE_P224) {
+                    c[i + 3] = (uint64_t)((int64_t)c[i + 3] + su * (int64_t)(int32_t)opaque_const(0u - (1u << 15)));
+                    c[i + 8] += (uint64_t)u * opaque_const(1u << 8);
+                } else {
+                    c[i + 2] = (uint64_t)((int64_t)c[i + 2] + su * (int64_t)(int32_t)opaque_const(0u - (1u << 12)));
+                    c[i + 7] += (uint64_t)u * opaque_const(1u << 10);
+                }
+            }
+            E r;
+            uint64_t v = c[UN];
+#pragma unroll
+            for (int k = 0; k < UN - 1; k++) {
+                r.v[k] = (uint32_t)v & PMASK;
+                v = c[UN + 1 + k] + (v >> UB);
+            }
+            r.v[UN - 1] = (uint32_t)v;
+            return r;
+        }
         if constexpr (C::ID == CURVE_BIGN256) {
             // bign-curve256v1: p = 2^256 - 189 in sparse form with SIGNED columns: u p = -189 u + u 2^256, i.e. -189 u into
             // column i (with u = c_i / 189 mod 2^28 it clears the low 28 bits) and + 16 u into column i + 9
@@ -415,11 +457,22 @@ struct Field {
         r.v[UN - 1] = (uint32_t)v;
         return r;
     }
-    static ECGPU_HD void p_columns(uint64_t* c, const uint32_t* a, const uint32_t* b, bool accumulate) {
-        if (!accumulate) {
+    // the columns start from zero — or, for the parameter sets whose sparse reduction rows have negative terms (sm2, p224,
+    // p192), from biases that keep every column non-negative and sum to a multiple of p (ecgpu_field_consts.h BIAS;
+    // tools/field_model.py sparse_bias)
+    template <class T, class = void>
+    struct HasBias : std::false_type {};
+    template <class T>
+    struct HasBias<T, std::void_t<decltype(T::SPARSE_BIAS)>> : std::true_type {};
+    static ECGPU_HD void p_columns_init(uint64_t* c) {
 #pragma unroll
-            for (int k = 0; k < 2 * UN + 1; k++) c[k] = 0;
+        for (int k = 0; k < 2 * UN + 1; k++) {
+            if constexpr (HasBias<PC>::value) c[k] = PC::BIAS[k];
+            else c[k] = 0;
         }
+    }
+    static ECGPU_HD void p_columns(uint64_t* c, const uint32_t* a, const uint32_t* b, bool accumulate) {
+        if (!accumulate) p_columns_init(c);
 #pragma unroll
         for (int i = 0; i < UN; i++) {
 #pragma unroll
@@ -428,8 +481,7 @@ struct Field {
     }
     static ECGPU_HD void p_columns_sqr(uint64_t* c, const uint32_t* a) {
         uint32_t a2[UN];
-#pragma unroll
-        for (int k = 0; k < 2 * UN + 1; k++) c[k] = 0;
+        p_columns_init(c);
 #pragma unroll
         for (int j = 0; j < UN; j++) a2[j] = a[j] << 1;
 #pragma unroll

@@ -2,6 +2,7 @@
 every lazily reduced element is checked at run time against the magnitude its type declares (the run-time
 twin of the static_asserts in ecgpu_field.h; mirrors the reference's debug-build magnitude checker)."""
 import ctypes
+import fcntl
 import os
 import subprocess
 
@@ -16,8 +17,17 @@ LIB = os.path.join(HERE, "hostcheck", "libhostcheck_bounds.so")
 
 @pytest.fixture(scope="module")
 def bounds_lib():
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DECGPU_BOUNDS_CHECK", "-Wno-unknown-pragmas",
-                           "-o", LIB, os.path.join(HERE, "hostcheck", "hostcheck.cpp")])
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    csrc = os.path.join(os.path.dirname(HERE), "elliptic-curves_amd", "csrc")
+    # pytest-xdist workers arrive here together: one builds (temporary name, renamed when complete), the others wait
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
+            tmp = "%s.%d.tmp" % (LIB, os.getpid())
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DECGPU_BOUNDS_CHECK", "-Wno-unknown-pragmas",
+                                   "-o", tmp, src])
+            os.replace(tmp, LIB)
     old = hc._lib
     hc._lib = ctypes.CDLL(LIB)
     yield

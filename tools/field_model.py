@@ -301,6 +301,74 @@ def p384_mont_mul(a, b, c_extra=None):
     return r
 
 
+# ------------------------------------------------------------------------------------------------
+# sparse Montgomery rows on UNSIGNED columns with a bias (sm2, p224, p192)
+# ------------------------------------------------------------------------------------------------
+# u p is written as a few power-of-two terms; the negative ones would take an unsigned column below zero, so every column that
+# receives one starts from a bias instead of zero, and the biases together are a multiple k p of the modulus (plus its
+# canonical rest in the low limbs): the value being reduced is a b + k p, the result is unchanged mod p, and k p / R is
+# negligible against p.  SPARSE[name] = (p, limbs, bits, p0 is one?, [(column offset, coefficient)], bias per negative column)
+SM2_P = 2 ** 256 - 2 ** 224 - 2 ** 96 + 2 ** 64 - 1
+P192_P = 2 ** 192 - 2 ** 64 - 1
+SPARSE = {
+    # u p = -u + u 2^64 - u 2^96 + u 2^224 (2^32 - 1)
+    "SM2U": (SM2_P, 10, 28, False, [(2, 1 << 8), (3, -(1 << 12)), (8, (1 << 32) - 1)], 1 << 44),
+    # u p = +u - u 2^96 + u 2^224            (p = 1 mod 2^27: u = -c_i)
+    "P224U": (2 ** 224 - 2 ** 96 + 1, 9, 27, True, [(3, -(1 << 15)), (8, 1 << 8)], 1 << 46),
+    # u p = -u - u 2^64 + u 2^192
+    "P192U": (P192_P, 8, 26, False, [(2, -(1 << 12)), (7, 1 << 10)], 1 << 42),
+}
+
+
+def sparse_bias(name):
+    """bias per column (2 nl + 1 of them): b on every column that receives a negative term, plus the canonical limbs of
+    k p - (those) so that the biases sum to a multiple of p"""
+    p, nl, bits, p0_one, terms, b = SPARSE[name]
+    neg = sorted({i + off for i in range(nl) for off, coef in terms if coef < 0})
+    target = sum(b << (bits * j) for j in neg)
+    k = -(-target // p)
+    rest = to_limbs(k * p - target, nl, bits)
+    bias = [0] * (2 * nl + 1)
+    for j in neg:
+        bias[j] += b
+    for j in range(nl):
+        bias[j] += rest[j]
+    assert sum(v << (bits * j) for j, v in enumerate(bias)) == k * p and all(v < (1 << 64) for v in bias)
+    for off, coef in terms:
+        if coef < 0:
+            assert ((1 << bits) - 1) * -coef < b, "bias too small for the term"
+    return bias
+
+
+def sparse_mont_mul(name, a, b, c_extra=None):
+    p, nl, bits, p0_one, terms, _ = SPARSE[name]
+    mask = (1 << bits) - 1
+    c = list(sparse_bias(name))
+    for x, y in ((a, b),) + ((c_extra,) if c_extra is not None else ()):
+        for i in range(nl):
+            for j in range(nl):
+                c[i + j] = chk64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    for i in range(nl):
+        if p0_one:
+            u = (-c[i]) & mask
+            carry = chk64(c[i] + u) >> bits
+        else:
+            u = c[i] & mask
+            carry = c[i] >> bits
+        c[i + 1] = chk64(c[i + 1] + carry)
+        for off, coef in terms:
+            v = c[i + off] + u * coef
+            assert v >= 0, "column went negative: the bias is too small"
+            c[i + off] = chk64(v)
+    r = [0] * nl
+    v = c[nl]
+    for k in range(nl - 1):
+        r[k] = v & mask
+        v = chk64(c[nl + 1 + k] + (v >> bits))
+    r[nl - 1] = chk32(v)
+    return r
+
+
 BIGN_P = 2 ** 256 - 189                          # bignp256/src/arithmetic/field.rs:60-66
 
 
@@ -332,6 +400,25 @@ def bign_mont_mul(a, b, c_extra=None):
 
 def selftest(trials=300, seed=1):
     rng = random.Random(seed)
+    # sm2 / p224 / p192 sparse rows with bias: adversarial magnitudes at each set's product limit, fused pairs, random values
+    for name, (lb, top1, maxprod, maxmag) in {"SM2U": (P_LB, 32, 24, 15), "P224U": (Q_LB, 512, 30, 28), "P192U": ((1 << 26) + (1 << 17), 2048, 30, 28)}.items():
+        pp, nl, bits = SPARSE[name][0], SPARSE[name][1], SPARSE[name][2]
+        rinv_s = pow(1 << (nl * bits), -1, pp)
+        pairs = [(ma, maxprod // ma) for ma in range(1, maxmag + 1) if maxprod // ma <= maxmag and maxprod // ma >= 1]
+        for ma, mb in pairs:
+            a = [ma * lb - 1] * (nl - 1) + [top1 * ma - 1]
+            b = [mb * lb - 1] * (nl - 1) + [top1 * mb - 1]
+            r = sparse_mont_mul(name, a, b)
+            assert from_limbs(r, bits) % pp == from_limbs(a, bits) * from_limbs(b, bits) * rinv_s % pp, name
+        a, b, x, y = ([m * lb - 1] * (nl - 1) + [top1 * m - 1] for m in (4, maxprod // 8, 3, maxprod // 8))
+        r = sparse_mont_mul(name, a, b, (x, y))
+        assert from_limbs(r, bits) % pp == (from_limbs(a, bits) * from_limbs(b, bits) + from_limbs(x, bits) * from_limbs(y, bits)) * rinv_s % pp
+        for _ in range(trials):
+            a = [rng.randrange(lb) for _ in range(nl - 1)] + [rng.randrange(top1)]
+            b = [rng.randrange(lb) for _ in range(nl - 1)] + [rng.randrange(top1)]
+            r = sparse_mont_mul(name, a, b)
+            assert from_limbs(r, bits) % pp == from_limbs(a, bits) * from_limbs(b, bits) * rinv_s % pp
+            assert from_limbs(r, bits) < 2 * pp and all(0 <= v < (1 << bits) for v in r[:nl - 1]), name
     # bign256: adversarial magnitudes at the product limit 11 (a single product 11 x 1, and the fused pair 5 x 1 + 6 x 1)
     rinv = pow(1 << 280, -1, BIGN_P)
     for ma, mb in ((11, 1), (1, 11), (3, 3), (2, 5)):
@@ -406,7 +493,7 @@ def selftest(trials=300, seed=1):
         assert r == umont_mul(a, b, Q_NL, Q_B, Q_LIMBS)
         assert from_limbs(r, Q_B) % Q_P == from_limbs(a, Q_B) * from_limbs(b, Q_B) * qinv % Q_P
         assert from_limbs(r, Q_B) < 2 * Q_P
-    # sm2 (dense rows, product limit 24) through the generic routine
+    # sm2 through the generic (dense-row) routine: the value the sparse biased rows below must reproduce modulo p
     s_p = 2 ** 256 - 2 ** 224 - 2 ** 96 + 2 ** 64 - 1
     s_limbs = to_limbs(s_p, 10, 28)
     sinv = pow(P_R, -1, s_p)
