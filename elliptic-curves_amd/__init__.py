@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev", "ecgpu_set_async", "ecgpu_synchronize",
     "ecgpu_ecdsa_recover_batch", "ecgpu_ecdsa_recover_batch_dev",
     "ecgpu_sm2dsa_verify_msg_batch", "ecgpu_sm2dsa_verify_msg_batch_dev",
+    "ecgpu_bign_verify_batch", "ecgpu_bign_verify_batch_dev", "ecgpu_bign_verify_msg_batch", "ecgpu_bign_verify_msg_batch_dev",
     "ecgpu_ecdsa_verify_msg_batch", "ecgpu_ecdsa_verify_msg_batch_dev",
     "ecgpu_group_ecdsa_verify_batch", "ecgpu_group_ecdsa_verify_msg_batch", "ecgpu_group_ecdsa_recover_batch",
     "ecgpu_batch_mul_base_ct", "ecgpu_batch_mul_base_ct_dev", "ecgpu_batch_mul_ct", "ecgpu_batch_mul_ct_dev",
@@ -409,6 +410,28 @@ class Engine:
                                                           ctypes.c_size_t(msg_len), _hp(sg), ctypes.c_size_t(n), _hp(ok)))
         return ok
 
+    def bign_verify(self, h, sigs, q_xy):
+        """Batch bign verification on the prehash (bign256): h = belt-hash(message) as 32 bytes, signatures n*48 (S0 || S1), keys
+        n*64; all little-endian."""
+        hh, sg, qq = _host(h), _host(sigs), _host(q_xy)
+        n = hh.size // 32
+        _need("h", hh, n * 32); _need("sigs", sg, n * 48); _need("q_xy", qq, n * 64)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_bign_verify_batch(self._ctx, _hp(hh), _hp(sg), _hp(qq), ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
+    def bign_verify_msg(self, q_xy, msgs, msg_len, sigs):
+        """Batch bign verification of messages (bign256): keys n*64, messages n*msg_len, signatures n*48; belt-hash runs on the
+        device."""
+        qq, sg = _host(q_xy), _host(sigs)
+        mm = _host(msgs) if msg_len else None
+        n = qq.size // 64
+        _need("q_xy", qq, n * 64); _need("sigs", sg, n * 48); _need("msgs", mm, n * msg_len)
+        ok = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_bign_verify_msg_batch(self._ctx, _hp(qq), _hp(mm), ctypes.c_size_t(msg_len), _hp(sg),
+                                                        ctypes.c_size_t(n), _hp(ok)))
+        return ok
+
     def ecdh(self, curve, scalars, points_xy, constant_time=False):
         """x-coordinates of k_i * P_i (ECDH shared secrets): returns (x uint8[n*L], ok uint8[n]).
         constant_time: the uniform-schedule entry point (ecgpu_batch_ecdh_ct) for secret scalars."""
@@ -539,6 +562,13 @@ class Engine:
         self._chk(self._lib.ecgpu_sm2dsa_verify_msg_batch_dev(self._ctx, _dp(d_distid), ctypes.c_size_t(distid_len), _dp(d_q_xy),
                                                               _dp(d_msgs), ctypes.c_size_t(msg_len), _dp(d_sigs), ctypes.c_size_t(n),
                                                               _dp(d_ok)))
+
+    def bign_verify_dev(self, d_h, d_sigs, d_q_xy, n, d_ok):
+        self._chk(self._lib.ecgpu_bign_verify_batch_dev(self._ctx, _dp(d_h), _dp(d_sigs), _dp(d_q_xy), ctypes.c_size_t(n), _dp(d_ok)))
+
+    def bign_verify_msg_dev(self, d_q_xy, d_msgs, msg_len, d_sigs, n, d_ok):
+        self._chk(self._lib.ecgpu_bign_verify_msg_batch_dev(self._ctx, _dp(d_q_xy), _dp(d_msgs), ctypes.c_size_t(msg_len), _dp(d_sigs),
+                                                            ctypes.c_size_t(n), _dp(d_ok)))
 
     def ecdsa_recover_dev(self, curve, d_z, d_r, d_s, d_recid, n, reject_high_s, d_out_xy, d_ok):
         self._chk(self._lib.ecgpu_ecdsa_recover_batch_dev(self._ctx, curve, _dp(d_z), _dp(d_r), _dp(d_s), _dp(d_recid),

@@ -782,7 +782,8 @@ int curve_error(ecgpu_ctx* ctx, const char* fn) {
 
 namespace {
 // shared driver of the two verification shapes: prepare -> a*G + b*Q -> normalise -> compare
-enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2, VERIFY_SM2DSA = 3, VERIFY_RECOVER = 4 };
+enum { VERIFY_ECDSA = 0, VERIFY_SCHNORR = 1, VERIFY_SCHNORR_RAW = 2, VERIFY_SM2DSA = 3, VERIFY_RECOVER = 4, VERIFY_BIGN = 5 };
+// mode VERIFY_BIGN: d_h = 32-byte hashes, d_s = 48-byte signatures S0 || S1, d_r unused
 // mode VERIFY_SCHNORR_RAW: d_h = messages (msg_len bytes each), d_s = 64-byte signatures, d_q_xy = 32-byte x-only keys
 // mode VERIFY_RECOVER (public-key recovery): d_q_xy = the recovery id bytes, d_out_xy receives the keys
 template <class C>
@@ -820,6 +821,8 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
                                         (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
     else if (mode == VERIFY_SM2DSA)
         launch_sm2dsa_prepare<C>(ctx->stream, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
+    else if (mode == VERIFY_BIGN)
+        launch_bign_prepare(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_s, (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else if (schnorr)
         launch_schnorr_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
                                   (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
@@ -837,6 +840,9 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     else if (mode == VERIFY_SM2DSA)
         launch_sm2dsa_finish<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p,
                                 (const uint8_t*)d_r, valid, n, (uint8_t*)d_ok);
+    else if (mode == VERIFY_BIGN)
+        launch_bign_finish(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p,
+                           (const uint8_t*)d_s, valid, n, (uint8_t*)d_ok);
     else if (schnorr)
         launch_schnorr_finish<C>(ctx->stream, (const uint8_t*)ctx->ec_xy.p, (const uint8_t*)ctx->ec_inf.p, (const uint8_t*)d_r,
                                  valid, n, (uint8_t*)d_ok);
@@ -1269,6 +1275,27 @@ int ecgpu_sm2dsa_verify_msg_batch_dev(ecgpu_ctx* ctx, const void* d_distid, size
     return verify_dev<Sm2Params>(ctx, VERIFY_SM2DSA, ctx->ec_e.p, ctx->ec_r.p, ctx->ec_s.p, d_q_xy, n, 0, d_ok);
 }
 
+int ecgpu_bign_verify_batch_dev(ecgpu_ctx* ctx, const void* d_h, const void* d_sigs, const void* d_q_xy, size_t n, void* d_ok) {
+    // bign on the prehash: R = ((S1 + H) mod q) G + (S0 + 2^128) Q, ok = (S0 == belt-hash(OID || x(R) || H)[..16]).  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_h || !d_sigs || !d_q_xy || !d_ok || !aligned16(d_h) || !aligned16(d_sigs) || !aligned16(d_q_xy)))
+        return arg_error(ctx, __func__);
+    return verify_dev<Bign256Params>(ctx, VERIFY_BIGN, d_h, nullptr, d_sigs, d_q_xy, n, 0, d_ok);
+}
+
+int ecgpu_bign_verify_msg_batch_dev(ecgpu_ctx* ctx, const void* d_q_xy, const void* d_msgs, size_t msg_len, const void* d_sigs, size_t n,
+                                    void* d_ok) {
+    // VerifyingKey::verify(msg, sig): H = belt-hash(msg) on the device, then the prehash path.  See ecgpu_ecdsa.h.
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_q_xy || !d_sigs || !d_ok || (msg_len && !d_msgs) || !aligned16(d_q_xy) || !aligned16(d_sigs)))
+        return arg_error(ctx, __func__);
+    if (n == 0) return ECGPU_OK;
+    int rc;
+    if ((rc = ensure(ctx, ctx->ec_e, n * 32)) != ECGPU_OK) return rc;
+    launch_bign_hash_msg(ctx->stream, (const uint8_t*)d_msgs, msg_len, n, (uint8_t*)ctx->ec_e.p);
+    return verify_dev<Bign256Params>(ctx, VERIFY_BIGN, ctx->ec_e.p, nullptr, d_sigs, d_q_xy, n, 0, d_ok);
+}
+
 int ecgpu_schnorr_verify_batch_dev(ecgpu_ctx* ctx, const void* d_e, const void* d_r, const void* d_s, const void* d_p_xy,
                                    size_t n, void* d_ok) {
     // BIP340 over secp256k1: R = s G - e P, ok = R finite, y(R) even, x(R) == r.  See ecgpu_ecdsa.h.
@@ -1639,6 +1666,48 @@ int ecgpu_sm2dsa_verify_msg_batch(ecgpu_ctx* ctx, const uint8_t* distid, size_t 
     if ((rc = ecgpu_sm2dsa_verify_msg_batch_dev(ctx, ctx->ec_id.p, distid_len, ctx->in1.p, ctx->in0.p, msg_len, ctx->in3.p, n, ctx->out1.p)) !=
         ECGPU_OK)
         return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_bign_verify_batch(ecgpu_ctx* ctx, const uint8_t* h, const uint8_t* sigs, const uint8_t* q_xy, size_t n, uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
+    if (n && (!h || !sigs || !q_xy || !ok)) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{h, &ctx->in0, 32}, {sigs, &ctx->in3, 48}, {q_xy, &ctx->in1, 64}}, {{ok, &ctx->out1, 1}},
+                         [&](size_t off, size_t m) {
+                             return ecgpu_bign_verify_batch_dev(ctx, (uint8_t*)ctx->in0.p + off * 32, (uint8_t*)ctx->in3.p + off * 48,
+                                                                (uint8_t*)ctx->in1.p + off * 64, m, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in0, h, n * 32)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, sigs, n * 48)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 64)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_bign_verify_batch_dev(ctx, ctx->in0.p, ctx->in3.p, ctx->in1.p, n, ctx->out1.p)) != ECGPU_OK) return rc;
+    return download(ctx, ok, ctx->out1, n);
+}
+
+int ecgpu_bign_verify_msg_batch(ecgpu_ctx* ctx, const uint8_t* q_xy, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n,
+                                uint8_t* ok) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
+    if (n && (!q_xy || !sigs || !ok || (msg_len && !msgs))) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{q_xy, &ctx->in1, 64}, {msg_len ? msgs : nullptr, &ctx->in0, msg_len}, {sigs, &ctx->in3, 48}},
+                         {{ok, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_bign_verify_msg_batch_dev(ctx, (uint8_t*)ctx->in1.p + off * 64,
+                                                                    msg_len ? (uint8_t*)ctx->in0.p + off * msg_len : nullptr, msg_len,
+                                                                    (uint8_t*)ctx->in3.p + off * 48, m, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in1, q_xy, n * 64)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in0, msgs, n * msg_len)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in3, sigs, n * 48)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_bign_verify_msg_batch_dev(ctx, ctx->in1.p, ctx->in0.p, msg_len, ctx->in3.p, n, ctx->out1.p)) != ECGPU_OK) return rc;
     return download(ctx, ok, ctx->out1, n);
 }
 

@@ -16,6 +16,7 @@
 #include "ecgpu_sha256.h"
 #include "ecgpu_hash.h"
 #include "ecgpu_sm3.h"
+#include "ecgpu_belt.h"
 #include "ecgpu_verify.h"
 
 namespace ecgpu {
@@ -192,6 +193,63 @@ k_sm2dsa_hash_msg(const uint8_t* __restrict__ distid, size_t distid_len, const u
     store_be_vec<N>(e_out + i * 32, ew);
     store_be_vec<N>(r_out + i * 32, rw);
     store_be_vec<N>(s_out + i * 32, sw);
+}
+
+// ---- bign verification on the prehash: bignp256/src/ecdsa/verifying.rs:100-147 (STB 34.101.45-2013 §7.2) ---------------------------
+//     the 48-byte signature is S0 (16 bytes) || S1 (32 bytes), little-endian; reject S0 = 0, S1 = 0, S1 >= q (`Signature::from_bytes`)
+//     R = ((S1 + H) mod q) G + (S0 + 2^128) Q;  reject R = O;  t = the first 16 bytes of belt-hash(OID(h) || <R>_2l || H);
+//     accept iff S0 == t.   <R>_2l is the x coordinate of R as 32 little-endian bytes: the bign256 wire record.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_bign_prepare(const uint8_t* __restrict__ h, const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ q_xy, size_t n,
+               uint8_t* __restrict__ a_out, uint8_t* __restrict__ b_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    static_assert(N == 8 && WB == 32 && WireLe<C>::value, "bign-curve256v1: 32-byte little-endian records");
+    static_assert(BLOCK == 256, "k_bign_finish / k_bign_hash_msg stage the 256-byte S-box with one byte per lane");
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t hw[N], s0w[4], s1w[N], cx[N], cy[N], a[N], b[N];
+    load_wire<C>(hw, h + i * WB);
+    load_words_vec<4>(s0w, reinterpret_cast<const uint32_t*>(sigs + i * 48));
+    load_wire<C>(s1w, sigs + i * 48 + 16);
+    load_wire<C>(cx, q_xy + i * (2 * WB));
+    load_wire<C>(cy, q_xy + i * (2 * WB) + WB);
+    const bool ok = bign_prepare_words<C>(hw, s0w, s1w, cx, cy, a, b);                          // ecgpu_verify.h
+    store_wire<C>(a_out + i * WB, a);
+    store_wire<C>(b_out + i * WB, b);
+    store_wire<C>(q_out + i * (2 * WB), cx);
+    store_wire<C>(q_out + i * (2 * WB) + WB, cy);
+    valid[i] = ok ? 1 : 0;
+}
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_bign_finish(const uint8_t* __restrict__ h, const uint8_t* __restrict__ r_xy, const uint8_t* __restrict__ r_inf,
+              const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ valid, size_t n, uint8_t* __restrict__ ok_out) {
+    constexpr int WB = WireBytes<C>::value;
+    __shared__ uint8_t sbox[256];                                   // the S-box where byte-indexed lookups are cheap
+    sbox[threadIdx.x] = Belt::H[threadIdx.x];
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s0w[4], t[8];
+    load_words_vec<4>(s0w, reinterpret_cast<const uint32_t*>(sigs + i * 48));
+    const HashPiece pc[3] = {{Belt::OID, sizeof(Belt::OID)}, {r_xy + i * (2 * WB), (size_t)WB}, {h + i * WB, (size_t)WB}};
+    Belt::hash_pieces<3>(sbox, t, pc);
+    const bool eq = ((t[0] ^ s0w[0]) | (t[1] ^ s0w[1]) | (t[2] ^ s0w[2]) | (t[3] ^ s0w[3])) == 0u;
+    ok_out[i] = (valid[i] && r_inf[i] == 0 && eq) ? 1 : 0;
+}
+// H = belt-hash(message) per element (`hash_msg`, bignp256/src/ecdsa/verifying.rs:87-91); the prehash kernels do the rest
+static __global__ void __launch_bounds__(BLOCK)
+k_bign_hash_msg(const uint8_t* __restrict__ msgs, size_t msg_len, size_t n, uint8_t* __restrict__ h_out) {
+    __shared__ uint8_t sbox[256];
+    sbox[threadIdx.x] = Belt::H[threadIdx.x];
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t hw[8];
+    const HashPiece pc[1] = {{msgs + i * msg_len, msg_len}};
+    Belt::hash_pieces<1>(sbox, hw, pc);
+    store_words_vec<8>(reinterpret_cast<uint32_t*>(h_out + i * 32), hw);
 }
 
 // ---- Schnorr (BIP340) verification: k256/src/schnorr/verifying.rs:76-99 ---------------------------------------------

@@ -106,6 +106,12 @@ template <class C> void launch_msm_finish(const MsmPlan& p, hipStream_t s, const
 // ---- curve-independent ----
 void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,
                                 size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out, uint8_t* r_out, uint8_t* valid);
+// bign verification (bign-curve256v1 only; ecgpu_ecdsa.h)
+void launch_bign_prepare(hipStream_t s, const uint8_t* h, const uint8_t* sigs, const uint8_t* q_xy, size_t n, uint8_t* a, uint8_t* b,
+                         uint8_t* q_out, uint8_t* valid);
+void launch_bign_finish(hipStream_t s, const uint8_t* h, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* sigs,
+                        const uint8_t* valid, size_t n, uint8_t* ok);
+void launch_bign_hash_msg(hipStream_t s, const uint8_t* msgs, size_t msg_len, size_t n, uint8_t* h_out);
 void launch_sm2dsa_hash_msg(hipStream_t s, const uint8_t* distid, size_t distid_len, const uint8_t* q_xy, const uint8_t* msgs,
                             size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* e_out, uint8_t* r_out, uint8_t* s_out);
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status);

@@ -228,6 +228,20 @@ void launch_sm2dsa_hash_msg(hipStream_t s, const uint8_t* distid, size_t distid_
                        q_xy, msgs, msg_len, sigs, n, e_out, r_out, s_out);
 }
 
+void launch_bign_prepare(hipStream_t s, const uint8_t* h, const uint8_t* sigs, const uint8_t* q_xy, size_t n, uint8_t* a, uint8_t* b,
+                         uint8_t* q_out, uint8_t* valid) {
+    hipLaunchKernelGGL(k_bign_prepare<Bign256Params>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, h, sigs, q_xy, n, a,
+                       b, q_out, valid);
+}
+void launch_bign_finish(hipStream_t s, const uint8_t* h, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* sigs,
+                        const uint8_t* valid, size_t n, uint8_t* ok) {
+    hipLaunchKernelGGL(k_bign_finish<Bign256Params>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, h, r_xy, r_inf, sigs,
+                       valid, n, ok);
+}
+void launch_bign_hash_msg(hipStream_t s, const uint8_t* msgs, size_t msg_len, size_t n, uint8_t* h_out) {
+    hipLaunchKernelGGL(k_bign_hash_msg, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, msgs, msg_len, n, h_out);
+}
+
 void launch_k256_glv(hipStream_t s, const uint8_t* scalars, size_t n, uint8_t* r1, uint8_t* r2, int* status) {
     hipLaunchKernelGGL(k_k256_glv, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, scalars, n, r1, r2, status);
 }

@@ -96,6 +96,32 @@ ECGPU_HD bool sm2dsa_finish_words(const uint32_t* ew, const uint32_t* x, bool id
     return eq;
 }
 
+// bign on the prehash (bignp256/src/ecdsa/verifying.rs:100-147 with `Signature::from_bytes`, bignp256/src/ecdsa.rs:72-88): the
+// 48-byte signature is S0 (16 bytes) || S1 (32 bytes), both little-endian; S0 = 0, S1 = 0 or S1 >= q do not parse.
+//     a = (S1 + H) mod q   (H = the 32 hash bytes as a little-endian integer, reduced: `Scalar::reduce`),   b = S0 + 2^128
+// for R = a G + b Q.  (b needs no reduction: 2^129 < q.)
+template <class C>
+ECGPU_HD bool bign_prepare_words(const uint32_t* hw, const uint32_t* s0w, const uint32_t* s1w, uint32_t* cx, uint32_t* cy, uint32_t* a,
+                                 uint32_t* b) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N;
+    static_assert(N == 8, "bign signatures are defined here for l = 128 (bign-curve256v1)");
+    bool ok = (s0w[0] | s0w[1] | s0w[2] | s0w[3]) != 0u && !S::is_zero(s1w) && S::in_range(s1w);
+    uint32_t hr[N], sum[N], d[N];
+    S::reduce_once(hr, hw);                                  // H < 2^256 < 2 q
+    const uint32_t carry = mp_add<N>(sum, s1w, hr);
+    const uint32_t borrow = mp_sub<N>(d, sum, C::ORDER);
+    const bool use_d = carry || !borrow;                     // S1 + H >= q (S1 is below q when ok)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        a[j] = use_d ? d[j] : sum[j];
+        b[j] = j < 4 ? s0w[j] : (j == 4 ? 1u : 0u);
+    }
+    ok = verify_point_ok<C>(cx, cy) && ok;
+    verify_blank<C>(ok, a, b, cx, cy);
+    return ok;
+}
+
 // -e mod n of a challenge word array (e is reduced first)
 template <class C>
 ECGPU_HD void schnorr_neg_challenge(uint32_t* ne, const uint32_t* ew) {

@@ -335,6 +335,21 @@ pub mod gpu {
         Some(ok.into_iter().map(|b| b != 0).collect())
     }
 
+    /// Batch form of `bignp256::ecdsa::VerifyingKey::from_bytes(pk)?.verify(msg, &sig)` for messages of one length
+    /// (bignp256/src/ecdsa/verifying.rs:100-169): both belt-hash computations run on the device.  `keys` = affine x || y
+    /// (64 bytes each, little-endian like `FIELD_ENDIANNESS`), `sigs` = `Signature::to_bytes()` (48 bytes each).
+    pub fn bign_batch_verify(keys: &[[u8; 64]], msgs: &[u8], msg_len: usize, sigs: &[[u8; 48]]) -> Option<Vec<bool>> {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let n = keys.len();
+        assert!(sigs.len() == n && msgs.len() == n * msg_len);
+        let mut ok = vec![0u8; n];
+        check(unsafe {
+            ecgpu_bign_verify_msg_batch(eng.0, keys.as_ptr() as *const u8, msgs.as_ptr(), msg_len, sigs.as_ptr() as *const u8, n,
+                                        ok.as_mut_ptr())
+        })?;
+        Some(ok.into_iter().map(|b| b != 0).collect())
+    }
+
     /// Batch form of `VerifyingKey::<C>::recover_from_prehash` (ecdsa 0.17.0 recovery.rs; the reference's vectors:
     /// k256/src/ecdsa.rs:190-262): `recovery_id[i]` = `RecoveryId::to_byte()`.  `None` per element where the reference
     /// returns `Err` (id does not parse, candidate x >= p or off the curve, identity key, high s under NORMALIZE_S).

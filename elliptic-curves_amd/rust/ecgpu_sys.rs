@@ -416,6 +416,40 @@ unsafe extern "C" {
         n: usize,
         d_ok: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_bign_verify_batch(
+        ctx: *mut EcgpuCtx,
+        h: *const u8,
+        sigs: *const u8,
+        q_xy: *const u8,
+        n: usize,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_bign_verify_batch_dev(
+        ctx: *mut EcgpuCtx,
+        d_h: *const c_void,
+        d_sigs: *const c_void,
+        d_q_xy: *const c_void,
+        n: usize,
+        d_ok: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_bign_verify_msg_batch(
+        ctx: *mut EcgpuCtx,
+        q_xy: *const u8,
+        msgs: *const u8,
+        msg_len: usize,
+        sigs: *const u8,
+        n: usize,
+        ok: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_bign_verify_msg_batch_dev(
+        ctx: *mut EcgpuCtx,
+        d_q_xy: *const c_void,
+        d_msgs: *const c_void,
+        msg_len: usize,
+        d_sigs: *const c_void,
+        n: usize,
+        d_ok: *mut c_void,
+    ) -> c_int;
     pub fn ecgpu_schnorr_verify_raw_batch(
         ctx: *mut EcgpuCtx,
         pk_x: *const u8,

@@ -376,6 +376,29 @@ int ecgpu_sm2dsa_verify_msg_batch(ecgpu_ctx *ctx, const uint8_t *distid, size_t 
 int ecgpu_sm2dsa_verify_msg_batch_dev(ecgpu_ctx *ctx, const void *d_distid, size_t distid_len, const void *d_q_xy,
                                       const void *d_msgs, size_t msg_len, const void *d_sigs, size_t n, void *d_ok);
 
+/* Batch bign verification on the prehash — `PrehashVerifier::verify_prehash` of bignp256::ecdsa::VerifyingKey
+ * (bignp256/src/ecdsa/verifying.rs:100-155; STB 34.101.45-2013 §7.2), curve bign256 only.  Everything is little-endian, as
+ * the crate's `FIELD_ENDIANNESS` (bignp256/src/lib.rs:90).  Per element
+ *   h     32 bytes = belt-hash(message), as `verify_prehash` takes it (reduced mod q like `Scalar::reduce`)
+ *   sigs  48 bytes S0 (16) || S1 (32) — `Signature::from_bytes`, bignp256/src/ecdsa.rs:72-88
+ *   q_xy  the public key's affine point, 64 bytes
+ *   ok[i] = 1 iff S0 != 0, 0 < S1 < q, Q is a valid non-identity curve point, R = ((S1 + H) mod q) G + (S0 + 2^128) Q is
+ *         finite (the `lincomb` at verifying.rs:119-122) and S0 equals the first 16 bytes of
+ *         belt-hash(OID(belt-hash) || x(R) as 32 bytes || h), hashed on the device (csrc/ecgpu_belt.h).
+ * The reference's vector: bignp256/tests/ecdsa.rs:21-46. */
+int ecgpu_bign_verify_batch(ecgpu_ctx *ctx, const uint8_t *h, const uint8_t *sigs, const uint8_t *q_xy, size_t n,
+                            uint8_t *ok);
+int ecgpu_bign_verify_batch_dev(ecgpu_ctx *ctx, const void *d_h, const void *d_sigs, const void *d_q_xy, size_t n,
+                                void *d_ok);
+
+/* bign verification of messages — `VerifyingKey::from_bytes(pk)?.verify(msg, &signature)` (bignp256/src/ecdsa/verifying.rs:
+ * 157-169): h = belt-hash(msg) (`hash_msg`, :87-91) on the device, then the verification above.
+ *   q_xy n*64 bytes, msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*48 bytes. */
+int ecgpu_bign_verify_msg_batch(ecgpu_ctx *ctx, const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len,
+                                const uint8_t *sigs, size_t n, uint8_t *ok);
+int ecgpu_bign_verify_msg_batch_dev(ecgpu_ctx *ctx, const void *d_q_xy, const void *d_msgs, size_t msg_len,
+                                    const void *d_sigs, size_t n, void *d_ok);
+
 /* The same verification from wire bytes — `VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)`
  * (k256/src/schnorr/verifying.rs:76-99,149-160): pk_x n*32 bytes (x-only keys, lifted on the device with even y),
  * msgs n*msg_len bytes (one uniform length per call, 0 allowed), sigs n*64 bytes (r || s).  The challenge

@@ -104,6 +104,11 @@ int ecref_sm2dsa_verify_batch(const uint8_t *e, const uint8_t *r, const uint8_t 
 int ecref_sm2dsa_verify_msg_batch(const uint8_t *distid, size_t distid_len, const uint8_t *q_xy,
                                   const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n,
                                   uint8_t *ok);
+/* belt-hash (STB 34.101.31-2020 §7.8) and bign verification on the prehash / of messages (bignp256/src/ecdsa/verifying.rs:100-169);
+ * all records little-endian: h 32 bytes, sigs 48 bytes S0 || S1, q_xy 64 bytes.  Pinned by bignp256/tests/ecdsa.rs:21-46. */
+void ecref_belt_hash(const uint8_t *msg, size_t len, uint8_t out[32]);
+int ecref_bign_verify_batch(const uint8_t *h, const uint8_t *sigs, const uint8_t *q_xy, size_t n, uint8_t *ok);
+int ecref_bign_verify_msg_batch(const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n, uint8_t *ok);
 int ecref_sm3(const uint8_t *msg, size_t len, uint8_t *out32);
 
 /* ECDSA verification of messages: the curve's `DigestAlgorithm` digest (SHA-256 / 384 / 224 / 512), `bits2field`, then

@@ -376,6 +376,137 @@ int ecref_sm2dsa_verify_msg_batch(const uint8_t *distid, size_t distid_len, cons
     return ECREF_OK;
 }
 
+/* ---- belt-hash (STB 34.101.31-2020 §7.8; the reference uses the un-vendored crates belt-hash / belt-block, bignp256/Cargo.toml)
+ * and bign verification, bignp256/src/ecdsa/verifying.rs:100-169.  The standard's algorithm restated byte by byte; pinned by the
+ * reference's own signature vector (bignp256/tests/ecdsa.rs:21-46): that signature only verifies if the hash is right. */
+static const uint8_t BELT_H[256] = {
+    0xB1,0x94,0xBA,0xC8,0x0A,0x08,0xF5,0x3B,0x36,0x6D,0x00,0x8E,0x58,0x4A,0x5D,0xE4,0x85,0x04,0xFA,0x9D,0x1B,0xB6,0xC7,0xAC,0x25,0x2E,0x72,0xC2,0x02,0xFD,0xCE,0x0D,
+    0x5B,0xE3,0xD6,0x12,0x17,0xB9,0x61,0x81,0xFE,0x67,0x86,0xAD,0x71,0x6B,0x89,0x0B,0x5C,0xB0,0xC0,0xFF,0x33,0xC3,0x56,0xB8,0x35,0xC4,0x05,0xAE,0xD8,0xE0,0x7F,0x99,
+    0xE1,0x2B,0xDC,0x1A,0xE2,0x82,0x57,0xEC,0x70,0x3F,0xCC,0xF0,0x95,0xEE,0x8D,0xF1,0xC1,0xAB,0x76,0x38,0x9F,0xE6,0x78,0xCA,0xF7,0xC6,0xF8,0x60,0xD5,0xBB,0x9C,0x4F,
+    0xF3,0x3C,0x65,0x7B,0x63,0x7C,0x30,0x6A,0xDD,0x4E,0xA7,0x79,0x9E,0xB2,0x3D,0x31,0x3E,0x98,0xB5,0x6E,0x27,0xD3,0xBC,0xCF,0x59,0x1E,0x18,0x1F,0x4C,0x5A,0xB7,0x93,
+    0xE9,0xDE,0xE7,0x2C,0x8F,0x0C,0x0F,0xA6,0x2D,0xDB,0x49,0xF4,0x6F,0x73,0x96,0x47,0x06,0x07,0x53,0x16,0xED,0x24,0x7A,0x37,0x39,0xCB,0xA3,0x83,0x03,0xA9,0x8B,0xF6,
+    0x92,0xBD,0x9B,0x1C,0xE5,0xD1,0x41,0x01,0x54,0x45,0xFB,0xC9,0x5E,0x4D,0x0E,0xF2,0x68,0x20,0x80,0xAA,0x22,0x7D,0x64,0x2F,0x26,0x87,0xF9,0x34,0x90,0x40,0x55,0x11,
+    0xBE,0x32,0x97,0x13,0x43,0xFC,0x9A,0x48,0xA0,0x2A,0x88,0x5F,0x19,0x4B,0x09,0xA1,0x7E,0xCD,0xA4,0xD0,0x15,0x44,0xAF,0x8C,0xA5,0x84,0x50,0xBF,0x66,0xD2,0xE8,0x8A,
+    0xA2,0xD7,0x46,0x52,0x42,0xA8,0xDF,0xB3,0x69,0x74,0xC5,0x51,0xEB,0x23,0x29,0x21,0xD4,0xEF,0xD9,0xB4,0x3A,0x62,0x28,0x75,0x91,0x14,0x10,0xEA,0x77,0x6C,0xDA,0x1D};
+
+static uint32_t belt_word(const uint8_t *b) { return (uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16 | (uint32_t)b[3] << 24; }
+static void belt_put(uint8_t *b, uint32_t w) { b[0] = (uint8_t)w; b[1] = (uint8_t)(w >> 8); b[2] = (uint8_t)(w >> 16); b[3] = (uint8_t)(w >> 24); }
+static uint32_t belt_g(uint32_t u, int r) {
+    uint32_t v = (uint32_t)BELT_H[u & 0xff] | (uint32_t)BELT_H[(u >> 8) & 0xff] << 8 | (uint32_t)BELT_H[(u >> 16) & 0xff] << 16 | (uint32_t)BELT_H[u >> 24] << 24;
+    return (v << r) | (v >> (32 - r));
+}
+/* y = belt-block(x) under the 32-byte key theta (§7.1.3: eight rounds, round keys K_1 .. K_56 = theta_1 .. theta_8 repeated) */
+static void belt_block(uint8_t y[16], const uint8_t x[16], const uint8_t theta[32]) {
+    uint32_t K[57], a = belt_word(x), b = belt_word(x + 4), c = belt_word(x + 8), d = belt_word(x + 12), e, t;
+    for (int j = 1; j <= 56; j++) K[j] = belt_word(theta + 4 * ((j - 1) % 8));
+    for (uint32_t i = 1; i <= 8; i++) {
+        b ^= belt_g(a + K[7 * i - 6], 5);
+        c ^= belt_g(d + K[7 * i - 5], 21);
+        a -= belt_g(b + K[7 * i - 4], 13);
+        e = belt_g(b + c + K[7 * i - 3], 21) ^ i;
+        b += e;
+        c -= e;
+        d += belt_g(c + K[7 * i - 2], 13);
+        b ^= belt_g(a + K[7 * i - 1], 21);
+        c ^= belt_g(d + K[7 * i], 5);
+        t = a; a = b; b = t;
+        t = c; c = d; d = t;
+        t = b; b = c; c = t;
+    }
+    belt_put(y, b); belt_put(y + 4, d); belt_put(y + 8, a); belt_put(y + 12, c);
+}
+/* sigma1(u1 || u2 || u3 || u4) = belt-block(u3 ^ u4, u1 || u2) ^ u3 ^ u4 */
+static void belt_sigma1(uint8_t out[16], const uint8_t u[64]) {
+    uint8_t t[16];
+    for (int j = 0; j < 16; j++) t[j] = u[32 + j] ^ u[48 + j];
+    belt_block(out, t, u);
+    for (int j = 0; j < 16; j++) out[j] ^= t[j];
+}
+/* sigma2(u) = (belt-block(u1, sigma1(u) || u4) ^ u1) || (belt-block(u2, (sigma1(u) ^ 1^128) || u3) ^ u2) */
+static void belt_sigma2(uint8_t out[32], const uint8_t u[64]) {
+    uint8_t s1[16], th[32];
+    belt_sigma1(s1, u);
+    memcpy(th, s1, 16);
+    memcpy(th + 16, u + 48, 16);
+    belt_block(out, u, th);
+    for (int j = 0; j < 16; j++) { out[j] ^= u[j]; th[j] = (uint8_t)~s1[j]; }
+    memcpy(th + 16, u + 32, 16);
+    belt_block(out + 16, u + 16, th);
+    for (int j = 0; j < 16; j++) out[16 + j] ^= u[16 + j];
+}
+void ecref_belt_hash(const uint8_t *msg, size_t len, uint8_t out[32]) {
+    uint8_t u[64], s[16] = {0}, t[16], h[32];
+    memcpy(h, BELT_H, 32);
+    for (size_t off = 0; off < len; off += 32) {
+        size_t m = len - off < 32 ? len - off : 32;
+        memset(u, 0, 32);
+        memcpy(u, msg + off, m);
+        memcpy(u + 32, h, 32);
+        belt_sigma1(t, u);
+        for (int j = 0; j < 16; j++) s[j] ^= t[j];
+        belt_sigma2(h, u);
+    }
+    memset(u, 0, 16);
+    for (int j = 0; j < 8; j++) u[j] = (uint8_t)(((uint64_t)len * 8) >> (8 * j));
+    memcpy(u + 16, s, 16);
+    memcpy(u + 32, h, 32);
+    belt_sigma2(out, u);
+}
+
+static const uint64_t ORDER_BIGN256[4] = {0x7E5ABF99263D6607ull, 0xD95C8ED60DFB4DFCull, 0xFFFFFFFFFFFFFFFFull, 0xFFFFFFFFFFFFFFFFull};   /* bignp256/src/lib.rs:74 */
+static const uint8_t BELT_OID[11] = {0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51};                                 /* bignp256/src/ecdsa.rs:58-60 */
+static void from_le32(uint64_t w[4], const uint8_t *b, size_t len) {
+    memset(w, 0, 32);
+    for (size_t j = 0; j < len; j++) w[j / 8] |= (uint64_t)b[j] << (8 * (j % 8));
+}
+static void to_le32(uint8_t b[32], const uint64_t w[4]) {
+    for (int j = 0; j < 32; j++) b[j] = (uint8_t)(w[j / 8] >> (8 * (j % 8)));
+}
+/* ok[i] = `VerifyingKey::from_bytes(Q_i)?.verify_prehash(h_i, &Signature::from_bytes(sig_i)?)`:
+ *   Signature::from_bytes (bignp256/src/ecdsa.rs:72-88): S0 = the first 16 bytes, S1 = the other 32, little-endian; S1 >= q, S0 = 0 or
+ *   S1 = 0 do not parse;  verifying.rs:100-147: R = ((S1 + H) mod q) G + (S0 + 2^128) Q, reject R = O,
+ *   t = belt-hash(OID || x(R) || h), accept iff S0 == t[..16]. */
+int ecref_bign_verify_batch(const uint8_t *h, const uint8_t *sigs, const uint8_t *q_xy, size_t n, uint8_t *ok) {
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *sig = sigs + 48 * i;
+        uint64_t s0[4], s1[4], hw[4];
+        ok[i] = 0;
+        from_le32(s0, sig, 16);
+        from_le32(s1, sig + 16, 32);
+        from_le32(hw, h + 32 * i, 32);
+        if (is_zero(s0, 4) || is_zero(s1, 4) || geq(s1, ORDER_BIGN256, 4)) continue;
+        if (geq(hw, ORDER_BIGN256, 4)) sub_n(hw, ORDER_BIGN256, 4);          /* Scalar::reduce: H < 2^256 < 2q */
+        uint64_t carry = 0;
+        for (int j = 0; j < 4; j++) {                                         /* left = S1 + H mod q */
+            u128 c = (u128)s1[j] + hw[j] + carry;
+            s1[j] = (uint64_t)c;
+            carry = (uint64_t)(c >> 64);
+        }
+        if (carry || geq(s1, ORDER_BIGN256, 4)) sub_n(s1, ORDER_BIGN256, 4);
+        s0[2] += 1;                                                           /* right = S0 + 2^128 (< q) */
+        uint8_t a[32], b[32], xy[64], inf = 0, msg[11 + 32 + 32], t[32];
+        to_le32(a, s1);
+        to_le32(b, s0);
+        if (ecref_mul_base_and_mul_add_vartime(ECREF_BIGN256, a, b, q_xy + 64 * i, 0, xy, &inf) != ECREF_OK) continue;   /* key not on the curve */
+        if (inf) continue;
+        memcpy(msg, BELT_OID, 11);
+        memcpy(msg + 11, xy, 32);
+        memcpy(msg + 43, h + 32 * i, 32);
+        ecref_belt_hash(msg, sizeof msg, t);
+        ok[i] = memcmp(t, sig, 16) == 0;
+    }
+    return ECREF_OK;
+}
+/* ok[i] = `VerifyingKey::from_bytes(Q_i)?.verify(msg_i, &sig_i)` (verifying.rs:157-169): h = belt-hash(msg), then the above */
+int ecref_bign_verify_msg_batch(const uint8_t *q_xy, const uint8_t *msgs, size_t msg_len, const uint8_t *sigs, size_t n, uint8_t *ok) {
+    for (size_t i = 0; i < n; i++) {
+        uint8_t h[32];
+        ecref_belt_hash(msgs + msg_len * i, msg_len, h);
+        ecref_bign_verify_batch(h, sigs + 48 * i, q_xy + 64 * i, 1, ok + i);
+    }
+    return ECREF_OK;
+}
+
 /* BIP340 Schnorr verification over secp256k1 — `VerifyingKey::verify_raw`, k256/src/schnorr/verifying.rs:76-99, without
  * the hash: e is the challenge tagged_hash("BIP0340/challenge", r || pk || m) as 32 bytes (reduced mod n here like
  * `<Scalar as Reduce<FieldBytes>>::reduce`), (r, s) the signature halves parsed as in k256/src/schnorr.rs:132-150

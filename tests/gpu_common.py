@@ -346,6 +346,87 @@ def sm2dsa_cases(seed, nvalid=10):
     return cases
 
 
+# the reference's bign test vector (bignp256/tests/ecdsa.rs:21-35, from STB 34.101.45 via met-10145-10-01.pdf §6.2): public key
+# (x || y, little-endian), message, signature S0 || S1
+BIGN_KAT = {
+    "public_key": "BD1A5650179D79E03FCEE49D4C2BD5DDF54CE46D0CF11E4FF87BF7A890857FD07AC6A60361E8C8173491686D461B2826190C2EDA5909054A9AB84D2AB9D99A90",
+    "message": "B194BAC80A08F53B366D008E58",
+    "signature": "19D32B7E01E25BAE4A70EB6BCA42602CCA6A13944451BCC5D4C54CFD8737619C328B8A58FB9C68FD17D569F7D06495FB",
+}
+
+
+def bign_cases(seed, nvalid=8):
+    """(h, sig, q bytes, expected) tuples for bign verification on the prehash: the reference's vector (h = belt-hash of its
+    message by the model), signatures made by the big-int model, and every way of breaking one."""
+    import random
+    c = pyec.CURVES["bign256"]
+    rng = random.Random(seed)
+    G = pyec.G(c)
+    le = lambda v, n=32: v.to_bytes(n, "little")
+    cases = []
+    pk = bytes.fromhex(BIGN_KAT["public_key"])
+    h = pyec.belt_hash(bytes.fromhex(BIGN_KAT["message"]))
+    sig = bytes.fromhex(BIGN_KAT["signature"])
+    cases.append((h, sig, pk, True))
+    cases.append((bytes([h[0] ^ 1]) + h[1:], sig, pk, False))
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n - 1)
+        Q = pyec.mul(c, d, G)
+        q = le(Q[0]) + le(Q[1])
+        hv = rng.randrange(1 << 256) if i % 3 else rng.randrange(c.n, 1 << 256)           # also hashes >= q (Scalar::reduce)
+        h = le(hv)
+        sig = pyec.bign_sign(c, d, h, rng.randrange(1, c.n))
+        s0, s1 = int.from_bytes(sig[:16], "little"), int.from_bytes(sig[16:], "little")
+        cases.append((h, sig, q, True))
+        cases.append((le(hv ^ 2), sig, q, False))
+        cases.append((h, le(s0 ^ (1 << rng.randrange(128)), 16) + sig[16:], q, False))
+        cases.append((h, sig[:16] + le((s1 + 1) % c.n or 1), q, False))
+        nQ = pyec.neg(c, Q)
+        cases.append((h, sig, le(nQ[0]) + le(nQ[1]), False))
+        if i < 3:
+            cases.append((h, bytes(16) + sig[16:], q, False))                              # S0 = 0 does not parse
+            cases.append((h, sig[:16] + bytes(32), q, False))                              # S1 = 0
+            cases.append((h, sig[:16] + le(c.n), q, False))                                # S1 = q
+            cases.append((h, sig[:16] + le(s1 + c.n) if s1 + c.n < 1 << 256 else sig[:16] + le((1 << 256) - 1), q, False))   # S1 >= q
+            bad = bytearray(q); bad[0] ^= 1
+            cases.append((h, sig, bytes(bad), False))                                      # key off the curve
+            cases.append((h, sig, le(Q[0] + c.p if Q[0] + c.p < 1 << 256 else c.p) + le(Q[1]), False))   # coordinate >= p
+            cases.append((h, sig, bytes(64), False))
+            # R = ((S1 + H) mod q) G + (S0 + 2^128) Q = O: rejected whatever S0 is
+            s1o = (-(s0 + 2 ** 128) * d - hv) % c.n
+            if s1o:
+                cases.append((h, sig[:16] + le(s1o), q, False))
+    return cases
+
+
+def bign_msg_cases(seed, msg_len, nvalid=6):
+    """(q bytes, msg, sig, expected) tuples for bign verification of MESSAGES of one length: the model's signatures over
+    belt-hash(msg) and broken ones (another message, another key, disturbed halves)."""
+    import random
+    c = pyec.CURVES["bign256"]
+    rng = random.Random(seed)
+    G = pyec.G(c)
+    le = lambda v, n=32: v.to_bytes(n, "little")
+    cases = []
+    if msg_len == 13:
+        cases.append((bytes.fromhex(BIGN_KAT["public_key"]), bytes.fromhex(BIGN_KAT["message"]), bytes.fromhex(BIGN_KAT["signature"]), True))
+    for i in range(nvalid):
+        d = rng.randrange(1, c.n - 1)
+        Q = pyec.mul(c, d, G)
+        q = le(Q[0]) + le(Q[1])
+        msg = bytes(rng.randrange(256) for _ in range(msg_len))
+        sig = pyec.bign_sign(c, d, pyec.belt_hash(msg), rng.randrange(1, c.n))
+        cases.append((q, msg, sig, True))
+        if msg_len:
+            other = bytearray(msg); other[rng.randrange(msg_len)] ^= 1 << rng.randrange(8)
+            cases.append((q, bytes(other), sig, False))
+        Q2 = pyec.mul(c, d + 1, G)
+        cases.append((le(Q2[0]) + le(Q2[1]), msg, sig, False))
+        flip = bytearray(sig); flip[rng.randrange(48)] ^= 1 << rng.randrange(8)
+        cases.append((q, msg, bytes(flip), pyec.bign_verify(c, Q, pyec.belt_hash(msg), bytes(flip))))
+    return cases
+
+
 def sm2dsa_msg_cases(seed, distid, msg_len, nvalid=8):
     """(q bytes, msg, sig bytes, expected) tuples for SM2DSA verification of MESSAGES under one distinguishing identifier:
     signatures made by the big-int model over e = SM3(Z || M) (hashlib's SM3), and the ways of breaking one — another

@@ -17,6 +17,7 @@
 #include "../../elliptic-curves_amd/csrc/ecgpu_sha256.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_hash.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_sm3.h"
+#include "../../elliptic-curves_amd/csrc/ecgpu_belt.h"
 #include "../../elliptic-curves_amd/csrc/ecgpu_verify.h"
 
 using namespace ecgpu;
@@ -675,6 +676,45 @@ int sm2dsa_verify_msg(const uint8_t* distid, size_t distid_len, const uint8_t* q
     return 0;
 }
 
+// k_bign_prepare -> a G + b Q -> k_bign_finish (little-endian records: the words as they lie)
+int bign_verify(const uint8_t* h, const uint8_t* sigs, const uint8_t* q, size_t n, uint8_t* ok_out) {
+    using C = Bign256Params;
+    constexpr int N = 8;
+    static BaseTable<C> table;
+    if (table.w != 8) build_table<C>(table, 8);
+    auto le = [](uint32_t* w, const uint8_t* b, int nw) {
+        for (int j = 0; j < nw; j++) w[j] = (uint32_t)b[4 * j] | (uint32_t)b[4 * j + 1] << 8 | (uint32_t)b[4 * j + 2] << 16 | (uint32_t)b[4 * j + 3] << 24;
+    };
+    for (size_t i = 0; i < n; i++) {
+        uint32_t hw[N], s0w[4], s1w[N], cx[N], cy[N], a[N], b[N], x[N], y[N], t[8];
+        le(hw, h + 32 * i, N);
+        le(s0w, sigs + 48 * i, 4);
+        le(s1w, sigs + 48 * i + 16, N);
+        le(cx, q + 64 * i, N);
+        le(cy, q + 64 * i + 32, N);
+        const bool valid = bign_prepare_words<C>(hw, s0w, s1w, cx, cy, a, b);
+        const bool finite = sum_affine_x<C>(table, a, b, cx, cy, x, y);
+        uint8_t xb[32];
+        for (int j = 0; j < 32; j++) xb[j] = (uint8_t)(x[j / 4] >> (8 * (j % 4)));
+        const HashPiece pc[3] = {{Belt::OID, sizeof(Belt::OID)}, {xb, 32}, {h + 32 * i, 32}};
+        Belt::hash_pieces<3>(Belt::H, t, pc);
+        const bool eq = t[0] == s0w[0] && t[1] == s0w[1] && t[2] == s0w[2] && t[3] == s0w[3];
+        ok_out[i] = valid && finite && eq;
+    }
+    return 0;
+}
+int bign_verify_msg(const uint8_t* q, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* ok_out) {
+    for (size_t i = 0; i < n; i++) {
+        uint32_t hw[8];
+        const HashPiece pc[1] = {{msgs + i * msg_len, msg_len}};
+        Belt::hash_pieces<1>(Belt::H, hw, pc);
+        uint8_t h[32];
+        for (int j = 0; j < 32; j++) h[j] = (uint8_t)(hw[j / 4] >> (8 * (j % 4)));
+        bign_verify(h, sigs + 48 * i, q + 64 * i, 1, ok_out + i);
+    }
+    return 0;
+}
+
 template <class C>
 int decompress(const uint8_t* xs, const uint8_t* odd, size_t n, uint8_t* out_xy, uint8_t* ok_out) {
     constexpr int N = C::N, WB = WireBytes<C>::value;
@@ -796,6 +836,19 @@ int hc_sm2dsa_verify(const uint8_t* e, const uint8_t* r, const uint8_t* s, const
 int hc_sm2dsa_verify_msg(const uint8_t* distid, size_t distid_len, const uint8_t* q, const uint8_t* msgs, size_t msg_len,
                          const uint8_t* sigs, size_t n, uint8_t* ok) {
     return sm2dsa_verify_msg(distid, distid_len, q, msgs, msg_len, sigs, n, ok);
+}
+int hc_bign_verify(const uint8_t* h, const uint8_t* sigs, const uint8_t* q, size_t n, uint8_t* ok) { return bign_verify(h, sigs, q, n, ok); }
+int hc_bign_verify_msg(const uint8_t* q, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* ok) {
+    return bign_verify_msg(q, msgs, msg_len, sigs, n, ok);
+}
+// belt-hash of an arbitrary message, optionally as two pieces split at `cut`, through the device-side absorber
+int hc_belt_hash(const uint8_t* msg, size_t len, size_t cut, uint8_t* out32) {
+    uint32_t d[8];
+    if (cut > len) cut = len;
+    const HashPiece pc[2] = {{msg, cut}, {msg + cut, len - cut}};
+    Belt::hash_pieces<2>(Belt::H, d, pc);
+    for (int j = 0; j < 32; j++) out32[j] = (uint8_t)(d[j / 4] >> (8 * (j % 4)));
+    return 0;
 }
 // SM3 of an arbitrary message through the device-side absorber
 int hc_sm3(const uint8_t* msg, size_t len, uint8_t* out32) {

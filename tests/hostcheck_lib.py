@@ -17,7 +17,7 @@ _lib = None
 
 def build():
     import fcntl
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_verify.h", "ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_ctmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h", "ecgpu_hash.h", "ecgpu_sm3.h")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("ecgpu_verify.h", "ecgpu_field.h", "ecgpu_params.h", "ecgpu_field_consts.h", "ecgpu_point.h", "ecgpu_recode.h", "ecgpu_varmul.h", "ecgpu_ctmul.h", "ecgpu_msm_chunk.h", "ecgpu_modinv.h", "ecgpu_fixedmul.h", "ecgpu_scalar.h", "ecgpu_sha256.h", "ecgpu_hash.h", "ecgpu_sm3.h", "ecgpu_belt.h")]
 
     def fresh():
         return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps)
@@ -193,6 +193,30 @@ def ecdsa_hash_msg(curve, msgs, msg_len):
     out = np.zeros(n * L[curve], np.uint8)
     rc = lib().hc_ecdsa_hash_msg(curve, _p(M), ctypes.c_size_t(msg_len), ctypes.c_size_t(n), _p(out))
     return None if rc != 0 else bytes(out)
+
+
+def belt_hash(msg, cut=0):
+    M = _a(msg) if len(msg) else np.zeros(1, np.uint8)
+    out = np.zeros(32, np.uint8)
+    assert lib().hc_belt_hash(_p(M), ctypes.c_size_t(len(msg)), ctypes.c_size_t(cut), _p(out)) == 0
+    return bytes(out)
+
+
+def bign_verify(h, sigs, q):
+    H, SG, Q = _a(h), _a(sigs), _a(q)
+    n = H.size // 32
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_bign_verify(_p(H), _p(SG), _p(Q), ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
+
+
+def bign_verify_msg(q, msgs, msg_len, sigs):
+    Q, SG = _a(q), _a(sigs)
+    M = _a(msgs) if msg_len else np.zeros(1, np.uint8)
+    n = Q.size // 64
+    ok = np.zeros(n, np.uint8)
+    assert lib().hc_bign_verify_msg(_p(Q), _p(M), ctypes.c_size_t(msg_len), _p(SG), ctypes.c_size_t(n), _p(ok)) == 0
+    return ok
 
 
 def sm3(msg):

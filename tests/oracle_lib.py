@@ -175,6 +175,30 @@ def sm2dsa_verify_msg(distid, q_xy, msgs, msg_len, sigs):
     return ok
 
 
+def belt_hash(msg):
+    m = _arr(msg) if len(msg) else None
+    out = np.zeros(32, np.uint8)
+    lib().ecref_belt_hash(_buf(m), ctypes.c_size_t(len(msg)), _buf(out))
+    return bytes(out)
+
+
+def bign_verify(h, sigs, q_xy):
+    hh, sg, qq = _arr(h), _arr(sigs), _arr(q_xy)
+    n = hh.size // 32
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_bign_verify_batch(_buf(hh), _buf(sg), _buf(qq), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
+def bign_verify_msg(q_xy, msgs, msg_len, sigs):
+    qq, sg = _arr(q_xy), _arr(sigs)
+    mm = _arr(msgs) if msg_len else None
+    n = qq.size // 64
+    ok = np.zeros(n, np.uint8)
+    _chk(lib().ecref_bign_verify_msg_batch(_buf(qq), _buf(mm), ctypes.c_size_t(msg_len), _buf(sg), ctypes.c_size_t(n), _buf(ok)))
+    return ok
+
+
 def schnorr_verify_raw(pk_x, msgs, msg_len, sigs):
     pk, sg = _arr(pk_x), _arr(sigs)
     mm = _arr(msgs) if msg_len else None

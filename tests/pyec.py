@@ -341,3 +341,84 @@ def sm2_za(c, ident, Q):
     f = lambda v: (v % c.p).to_bytes(32, "big")
     data = (8 * len(ident)).to_bytes(2, "big") + ident + f(c.a) + f(c.b) + f(c.gx) + f(c.gy) + f(Q[0]) + f(Q[1])
     return hashlib.new("sm3", data).digest()
+
+
+# ---- belt-hash (STB 34.101.31-2020 §7.8) and bign signatures (STB 34.101.45-2013 §7), the independent model -----------------
+
+BELT_H = bytes.fromhex(
+    "B194BAC80A08F53B366D008E584A5DE48504FA9D1BB6C7AC252E72C202FDCE0D5BE3D61217B96181FE6786AD716B890B5CB0C0FF33C356B835C405AED8E07F99"
+    "E12BDC1AE28257EC703FCCF095EE8DF1C1AB76389FE678CAF7C6F860D5BB9C4FF33C657B637C306ADD4EA7799EB23D313E98B56E27D3BCCF591E181F4C5AB793"
+    "E9DEE72C8F0C0FA62DDB49F46F73964706075316ED247A3739CBA38303A98BF692BD9B1CE5D141015445FBC95E4D0EF2682080AA227D642F2687F93490405511"
+    "BE32971343FC9A48A02A885F194B09A17ECDA4D01544AF8CA58450BF66D2E88AA2D7465242A8DFB36974C551EB232921D4EFD9B43A622875911410EA776CDA1D")
+BELT_OID = bytes([0x06, 0x09, 0x2A, 0x70, 0x00, 0x02, 0x00, 0x22, 0x65, 0x1F, 0x51])     # bignp256/src/ecdsa.rs:58-60
+assert len(BELT_H) == 256 and sorted(BELT_H) == list(range(256))                          # the S-box is a permutation
+_M32 = 0xFFFFFFFF
+
+
+def _belt_g(u, r):
+    v = BELT_H[u & 255] | BELT_H[(u >> 8) & 255] << 8 | BELT_H[(u >> 16) & 255] << 16 | BELT_H[(u >> 24) & 255] << 24
+    return ((v << r) | (v >> (32 - r))) & _M32
+
+
+def belt_block(x, key):
+    """belt-block encryption of the 16-byte block x under the 32-byte key (§7.1.3)."""
+    a, b, c, d = (int.from_bytes(x[4 * i:4 * i + 4], "little") for i in range(4))
+    k = [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)]
+    K = lambda j: k[(j - 1) % 8]
+    for i in range(1, 9):
+        b ^= _belt_g((a + K(7 * i - 6)) & _M32, 5)
+        c ^= _belt_g((d + K(7 * i - 5)) & _M32, 21)
+        a = (a - _belt_g((b + K(7 * i - 4)) & _M32, 13)) & _M32
+        e = _belt_g((b + c + K(7 * i - 3)) & _M32, 21) ^ i
+        b = (b + e) & _M32
+        c = (c - e) & _M32
+        d = (d + _belt_g((c + K(7 * i - 2)) & _M32, 13)) & _M32
+        b ^= _belt_g((a + K(7 * i - 1)) & _M32, 21)
+        c ^= _belt_g((d + K(7 * i)) & _M32, 5)
+        a, b = b, a
+        c, d = d, c
+        b, c = c, b
+    return b"".join(v.to_bytes(4, "little") for v in (b, d, a, c))
+
+
+def _bxor(p, q):
+    return bytes(i ^ j for i, j in zip(p, q))
+
+
+def _belt_sigma1(u):
+    t = _bxor(u[32:48], u[48:64])
+    return _bxor(belt_block(t, u[0:32]), t)
+
+
+def _belt_sigma2(u):
+    s1 = _belt_sigma1(u)
+    return (_bxor(belt_block(u[0:16], s1 + u[48:64]), u[0:16]) +
+            _bxor(belt_block(u[16:32], _bxor(s1, b"\xff" * 16) + u[32:48]), u[16:32]))
+
+
+def belt_hash(msg):
+    s, h = bytes(16), BELT_H[:32]
+    for off in range(0, len(msg), 32):
+        x = msg[off:off + 32].ljust(32, b"\0")
+        s = _bxor(s, _belt_sigma1(x + h))
+        h = _belt_sigma2(x + h)
+    return _belt_sigma2((8 * len(msg)).to_bytes(16, "little") + s + h)
+
+
+def bign_sign(c, d, h, k):
+    """48-byte signature S0 || S1 of the 32-byte hash h under private key d with nonce k (STB 34.101.45 §7.1 steps 4-8)."""
+    R = mul(c, k, G(c))
+    s0 = belt_hash(BELT_OID + R[0].to_bytes(32, "little") + h)[:16]
+    s1 = (k - int.from_bytes(h, "little") - (int.from_bytes(s0, "little") + 2 ** 128) * d) % c.n
+    return s0 + s1.to_bytes(32, "little")
+
+
+def bign_verify(c, Q, h, sig):
+    """bignp256/src/ecdsa/verifying.rs:100-147 with Signature::from_bytes (ecdsa.rs:72-88)."""
+    s0, s1 = int.from_bytes(sig[:16], "little"), int.from_bytes(sig[16:48], "little")
+    if s0 == 0 or s1 == 0 or s1 >= c.n or Q is INF or Q[0] >= c.p or Q[1] >= c.p or not on_curve(c, Q):
+        return False
+    R = add(c, mul(c, (s1 + int.from_bytes(h, "little")) % c.n, G(c)), mul(c, (s0 + 2 ** 128) % c.n, Q))
+    if R is INF:
+        return False
+    return belt_hash(BELT_OID + R[0].to_bytes(32, "little") + h)[:16] == sig[:16]

@@ -892,6 +892,45 @@ def test_sm2dsa_verify_messages_vs_reference_vector_oracle_and_model(eng):
     assert e.value.code == ecgpu.ERR_ARG
 
 
+def test_bign_verify_vs_reference_vector_oracle_and_model(eng):
+    """ecgpu_bign_verify_batch / ecgpu_bign_verify_msg_batch (bignp256/src/ecdsa/verifying.rs:100-169, belt-hash on the device):
+    the reference's own signature vector (bignp256/tests/ecdsa.rs:21-46) verifies at both levels and a changed message does not;
+    model-made signatures (hashes on both sides of q, S1 + H on both sides of q) and every way of breaking one — S0 = 0, S1 = 0,
+    S1 >= q, key off the curve / out of range / all zero, R = O — verdict for verdict against the expectation and the oracle;
+    message lengths on every side of the 32-byte block boundary; batches above the pipeline threshold of the host-pointer
+    entries; device-resident buffers; the empty batch."""
+    from gpu_common import BIGN_KAT as K, bign_cases, bign_msg_cases
+    pk, sig, msg = bytes.fromhex(K["public_key"]), bytes.fromhex(K["signature"]), bytes.fromhex(K["message"])
+    assert eng.bign_verify_msg(pk, msg, len(msg), sig)[0] == 1
+    assert eng.bign_verify_msg(pk, msg[:-1] + b"\x59", len(msg), sig)[0] == 0
+    assert eng.bign_verify(pyec.belt_hash(msg), sig, pk)[0] == 1
+    cases = bign_cases(0xB16C)
+    h, sg, q = (b"".join(c[k] for c in cases) for k in range(3))
+    exp = bytes(int(c[3]) for c in cases)
+    assert sum(exp) >= 9 and exp.count(0) > 40
+    got = eng.bign_verify(h, sg, q)
+    assert bytes(got) == exp == bytes(oracle_lib.bign_verify(h, sg, q))
+    reps = ((1 << 19) + 333) // len(exp) + 1
+    assert bytes(eng.bign_verify(h * reps, sg * reps, q * reps)) == exp * reps
+    n = len(exp)
+    d_h, d_s, d_q, d_ok = eng.to_device(h), eng.to_device(sg), eng.to_device(q), eng.dev_alloc(n)
+    eng.bign_verify_dev(d_h, d_s, d_q, n, d_ok)
+    assert bytes(eng.to_host(d_ok, n)) == exp
+    for msg_len in (0, 1, 13, 31, 32, 33, 64, 77, 150):
+        mc = bign_msg_cases(0xB170 + msg_len, msg_len)
+        q, m, sg = (b"".join(c[k] for c in mc) for k in range(3))
+        exp = bytes(int(c[3]) for c in mc)
+        got = eng.bign_verify_msg(q, m, msg_len, sg)
+        assert bytes(got) == exp == bytes(oracle_lib.bign_verify_msg(q, m, msg_len, sg)), msg_len
+    reps = ((1 << 19) + 777) // len(exp) + 1
+    assert bytes(eng.bign_verify_msg(q * reps, m * reps, msg_len, sg * reps)) == exp * reps
+    n = len(exp)
+    d_q, d_m, d_s, d_ok2 = eng.to_device(q), eng.to_device(m), eng.to_device(sg), eng.dev_alloc(n)
+    eng.bign_verify_msg_dev(d_q, d_m, msg_len, d_s, n, d_ok2)
+    assert bytes(eng.to_host(d_ok2, n)) == exp
+    assert eng.bign_verify(b"", b"", b"").size == 0 and eng.bign_verify_msg(b"", b"", 5, b"").size == 0
+
+
 # ---- ECDSA public-key recovery (ecgpu_ecdsa_recover_batch) ------------------------------------------------------------------
 def test_ecdsa_recover_reference_vectors(eng):
     """The reference's recovery vectors (k256/src/ecdsa.rs:190-211 RECOVERY_TEST_VECTORS, :233-261 the Ethereum example)

@@ -460,6 +460,32 @@ def test_sm2dsa_verify_logic_on_cpu(oracle):
     assert bytes(got) == bytes(exp) == bytes(oracle.sm2dsa_verify(e, r, s, q))
 
 
+def test_bign_verify_logic_on_cpu(oracle):
+    """k_bign_prepare / k_bign_finish / k_bign_hash_msg's per-element code on the CPU (ecgpu_verify.h `bign_prepare_words`,
+    ecgpu_belt.h): belt-hash against the model and the oracle around the 32-byte block boundaries and across piece boundaries,
+    the reference's signature vector (bignp256/tests/ecdsa.rs:21-46) at both levels, model-made signatures and broken ones."""
+    from gpu_common import BIGN_KAT as K, bign_cases, bign_msg_cases
+    for n in (0, 1, 13, 31, 32, 33, 63, 64, 65, 75, 96, 200):
+        m = bytes((11 * i + n) & 0xff for i in range(n))
+        want = pyec.belt_hash(m)
+        assert oracle.belt_hash(m) == want
+        for cut in (0, 1, n // 2, n):
+            assert hc.belt_hash(m, cut) == want, (n, cut)
+    pk, sig, msg = bytes.fromhex(K["public_key"]), bytes.fromhex(K["signature"]), bytes.fromhex(K["message"])
+    assert hc.bign_verify_msg(pk, msg, len(msg), sig)[0] == 1 and oracle.bign_verify_msg(pk, msg, len(msg), sig)[0] == 1
+    assert hc.bign_verify_msg(pk, msg[:-1] + b"\x59", len(msg), sig)[0] == 0
+    cases = bign_cases(0xB16A, nvalid=4)
+    h, sg, q = (b"".join(c[k] for c in cases) for k in range(3))
+    exp = bytes(int(c[3]) for c in cases)
+    assert sum(exp) >= 5 and exp.count(0) > 20
+    assert bytes(hc.bign_verify(h, sg, q)) == exp == bytes(oracle.bign_verify(h, sg, q))
+    for msg_len in (0, 13, 40):
+        mc = bign_msg_cases(0xB16B + msg_len, msg_len, nvalid=2)
+        q, m, sg = (b"".join(c[k] for c in mc) for k in range(3))
+        exp = bytes(int(c[3]) for c in mc)
+        assert bytes(hc.bign_verify_msg(q, m, msg_len, sg)) == exp == bytes(oracle.bign_verify_msg(q, m, msg_len, sg))
+
+
 def test_schnorr_verify_logic_on_cpu(oracle):
     """k_schnorr_prepare / k_schnorr_prepare_raw / k_schnorr_finish on the CPU: the BIP340 vectors of k256/src/schnorr.rs with
     the challenge given and from wire bytes (lift_x + tagged SHA-256 in the same code the device runs)."""
