@@ -12,7 +12,8 @@
 //
 // What "uniform schedule" means here, and what tools/ct_isa_check.py verifies on the gfx950 ISA of the two kernels:
 //   * the number of digits is fixed (8 N + 1 radix-16 digits of `Radix16Decomposition`, 33 per GLV half), zero digits are
-//     not skipped, the accumulator starts at the identity and every step is a COMPLETE addition / doubling;
+//     not skipped, the accumulator starts at the identity, every digit step is a COMPLETE addition and the doublings between have no exceptional
+//     case (complete ones for k256, Jacobian ones with the identity patched under a mask elsewhere: ct_dbl4);
 //   * a table entry is picked by reading ALL EIGHT entries and keeping one under a mask (`v_bfi_b32` under an opaque mask), the sign of a digit
 //     by a masked negation: no memory address and no branch condition is computed from scalar (or point) data — the only
 //     conditional branches are the bounds checks on the lane index and the loop counters;
@@ -100,6 +101,36 @@ ECGPU_HD void ct_table_scan(const TabIO& tab, const uint32_t* xabs, Proj<C>* t) 
     }
 }
 
+// The four doublings between two digits.  a = 0 (k256): the complete doubling (6M + 2S) four times, as the reference does.
+// The other curves: through Jacobian coordinates — (X : Y : Z) -> (X Z, Y Z^2, Z), four times dbl-2001-b / dbl-2007-bl
+// (3M + 5S against 8M + 3S for the complete doubling), back with (X Z : Y : Z^3) — 7.3 M-equivalents instead of 10.5 per
+// doubling, 6-7 for the two conversions.  The Jacobian doubling has no exceptional case on these curves (every finite point
+// has odd order) and keeps (t^2, t^3, 0) at infinity; the one point the conversion cannot express, the identity (0 : Y : 0) ->
+// (0, 0, 0), is replaced by (1, 1, 0) under a mask, so the schedule stays the same for every accumulator value.  The digit
+// addition stays the complete one: it is where P + P, P - P and the identity occur.
+template <class C>
+ECGPU_HD Proj<C> ct_dbl4(const Proj<C>& acc, const Fe<C::NL>& b) {
+    using G = Group<C>;
+    using F = Field<C>;
+    if constexpr (C::A_IS_ZERO) {
+        Proj<C> r = acc;
+#pragma unroll 1
+        for (int s = 0; s < 4; s++) r = G::dbl(r, b);
+        return r;
+    } else {
+        const auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
+        const uint32_t inf = ct_mask(F::is_zero(Z));
+        const Fe<C::NL> one = F::one().e;
+        typename G::J j;
+        j.x = ct_sel_fe<C>(inf, one, F::mul(X, Z).e);
+        j.y = ct_sel_fe<C>(inf, one, F::mul(Y, F::sqr(Z)).e);
+        j.z = acc.z;
+#pragma unroll 1
+        for (int s = 0; s < 4; s++) j = G::jac_dbl(j);
+        return G::jac_to_proj(j);
+    }
+}
+
 // p: the point in homogeneous coordinates ((0 : 1 : 0) for the identity), k: N words < n.
 template <class C, class TabIO>
 ECGPU_HD Proj<C> var_base_mul_ct_plain(const Proj<C>& p, const uint32_t* k, const Fe<C::NL>& b, TabIO& tab) {
@@ -111,10 +142,7 @@ ECGPU_HD Proj<C> var_base_mul_ct_plain(const Proj<C>& p, const uint32_t* k, cons
     Proj<C> acc = G::identity();
 #pragma unroll 1
     for (int di = 8 * N; di >= 0; di--) {
-        if (di != 8 * N) {
-#pragma unroll 1
-            for (int s = 0; s < 4; s++) acc = G::dbl(acc, b);
-        }
+        if (di != 8 * N) acc = ct_dbl4<C>(acc, b);
         bool neg;
         const uint32_t xabs = ct_abs_digit(digits.digit(di), &neg);
         Proj<C> t;
@@ -152,10 +180,7 @@ ECGPU_HD Proj<K256Params> var_base_mul_ct_glv(const Proj<K256Params>& p, const u
     Proj<C> acc = G::identity();
 #pragma unroll 1
     for (int di = 32; di >= 0; di--) {
-        if (di != 32) {
-#pragma unroll 1
-            for (int s = 0; s < 4; s++) acc = G::dbl(acc, b);
-        }
+        if (di != 32) acc = ct_dbl4<C>(acc, b);
         bool neg[2];
         uint32_t xabs[2];
         xabs[0] = ct_abs_digit(d1.digit(di), &neg[0]);
