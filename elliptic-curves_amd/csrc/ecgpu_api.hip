@@ -317,7 +317,7 @@ int ensure_table(ecgpu_ctx* ctx) {
 }
 
 // ---- generator LUTs of the uniform-schedule fixed-base kernel (ecgpu_ctmul.h) ----------------------------------------
-// [CT_BASE_LUTS][8][2] packed elements: lut i = {e * 2^(8 i) * G, e = 1..8} — `BasepointTable::new`
+// [CT_BASE_LUTS][CT_BASE_ENTRIES][2] packed elements: lut i = {e * 2^(W i) * G, e = 1..2^(W-1)}, W = CT_BASE_W — `BasepointTable::new`
 // (primeorder/src/tables/basepoint.rs:41-76) with affine entries.  17 KB for k256: built with the comb-table kernels
 // (bases 2^(8 i) G, eight multiples each, one normalisation), shared per device under the registry key width -1.
 void release_ct_lut(ecgpu_ctx* ctx, int id) {
@@ -337,7 +337,7 @@ int ensure_ct_lut(ecgpu_ctx* ctx) {
     if (ctx->ct_lut[C::ID]) return ECGPU_OK;
     constexpr int N = C::N, NS = Field<C>::NS;
     const int nlut = ct_base_luts<C>();
-    const size_t entries = (size_t)nlut * 8;
+    const size_t entries = (size_t)nlut * CT_BASE_ENTRIES;
     TableRegistry& reg = table_registry(ctx->device);
     std::lock_guard<std::mutex> lock(reg.mu);
     SharedTable& st = reg.tabs[std::make_tuple(ctx->device, (int)C::ID, -1)];
@@ -356,8 +356,8 @@ int ensure_ct_lut(ecgpu_ctx* ctx) {
             ctx->err = "generator LUTs: hipMalloc failed";
             return fail(ECGPU_ERR_OOM);
         }
-        launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, 8, nlut);                          // 2^(8 i) G
-        launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, 4, nlut);   // e = 1..8
+        launch_window_bases<C>(ctx->stream, (uint32_t*)ctx->bases.p, CT_BASE_W, nlut);                  // 2^(W i) G
+        launch_table_entries<C>(ctx->stream, (const uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p, CT_BASE_W, nlut);   // e = 1..32
         launch_normalize<C>(ctx->stream, true, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, entries, nullptr, nullptr, d);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -57,13 +57,17 @@ k_var_base_ct(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
     }
 }
 
-// the generator LUTs: [CT_BASE_LUTS][8][2] packed elements, read at wave-uniform addresses (every lane scans the same
-// eight entries of the same LUT)
+// the generator LUTs: [CT_BASE_LUTS][CT_BASE_ENTRIES][2] packed elements, read at wave-uniform addresses (every lane scans the
+// same entries of the same LUT): scalar loads, the entry words arrive in scalar registers (ct_pick_words_uniform).
+// Measured alternatives (profiles/r03/ct_generator_scan_variants.txt): the window's LUT staged in LDS by the workgroup and
+// scanned with broadcast reads + half-slot v_cndmask (a quarter fewer vector instructions, but k256 no faster and p384 slower:
+// the reads' latency is exposed at two or three waves per SIMD, and issuing them ten at a time is slower still).
 template <class C>
 struct CtLutHbm {
+    static constexpr bool UNIFORM = true;
     const uint32_t* lut;
     __device__ void load(PackedPoint<2 * C::N>& p, int i, int entry) const {
-        load_words_vec<2 * C::N>(p.w, lut + ((size_t)i * 8 + entry) * (2 * C::N));
+        load_words_vec<2 * C::N>(p.w, lut + ((size_t)i * CT_BASE_ENTRIES + entry) * (2 * C::N));
     }
 };
 

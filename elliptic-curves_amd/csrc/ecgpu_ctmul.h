@@ -8,13 +8,14 @@
 //   * k256 `ProjectivePoint * Scalar`   k256/src/arithmetic/mul.rs:112-163 (`lincomb`: GLV halves, signs folded into the
 //                                       tables, 33 digits each)
 //   * `mul_by_generator`                k256/src/arithmetic/mul.rs:180-197, primeorder/src/tables/basepoint.rs:82-99
-//                                       (LUTs of 2^(8 i) G, even nibbles into acc, odd nibbles into acc2, acc + 16 acc2)
+//                                       (LUTs of multiples of 2^(W i) G scanned in full — W = 6 here, 4 there: "generator" below)
 //
 // What "uniform schedule" means here, and what tools/ct_isa_check.py verifies on the gfx950 ISA of the two kernels:
-//   * the number of digits is fixed (8 N + 1 radix-16 digits of `Radix16Decomposition`, 33 per GLV half), zero digits are
+//   * the number of digits is fixed (8 N + 1 radix-16 digits of `Radix16Decomposition`, 33 per GLV half; one 6-bit digit per
+//     generator LUT), zero digits are
 //     not skipped, the accumulator starts at the identity, every digit step is a COMPLETE addition and the doublings between have no exceptional
 //     case (complete ones for k256, Jacobian ones with the identity patched under a mask elsewhere: ct_dbl4);
-//   * a table entry is picked by reading ALL EIGHT entries and keeping one under a mask (`v_bfi_b32` under an opaque mask), the sign of a digit
+//   * a table entry is picked by reading ALL entries (8; 32 of a generator LUT) and keeping one under a mask (`v_bfi_b32` under an opaque mask), the sign of a digit
 //     by a masked negation: no memory address and no branch condition is computed from scalar (or point) data — the only
 //     conditional branches are the bounds checks on the lane index and the loop counters;
 //   * range / on-curve verdicts are written as one flag byte per element and folded into the status word by a second
@@ -43,6 +44,54 @@ ECGPU_HD uint32_t ct_mask(bool flag) {
 }
 // a where the mask is set, b elsewhere (one v_bfi_b32)
 ECGPU_HD uint32_t ct_pick(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
+// sel[w] = (x == want) ? e[w] : sel[w] for NW words — the inner statement of a table scan.  The portable form is ct_pick under
+// one mask: three 32-bit logic instructions per word once the compiler is through with it (and, and, or: 1.5 issue slots).  On
+// the device the same selection is written as v_cndmask_b32 in its 32-bit encoding, half a slot per word, in groups of up to
+// eight words behind one v_cmp (an asm statement takes at most 30 operands).  All operands are vector registers: with vcc as
+// the condition the instruction has no constant-bus slot left for a scalar source on gfx9-family targets (tried: the assembler
+// refuses `v_cndmask_b32 v, s, v, vcc`) — ct_pick_words_uniform below is the form for scalar sources.
+// No branch, no address: nothing here for a compiler to turn into control flow, and nothing tools/ct_isa_check.py objects to.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NW, int W0 = 0>
+__device__ __forceinline__ void ct_pick_words(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) {
+    if constexpr (NW - W0 >= 8) {
+        asm("v_cmp_ne_u32 vcc, %8, %9\n\tv_cndmask_b32 %0, %10, %0, vcc\n\tv_cndmask_b32 %1, %11, %1, vcc\n\t"
+                     "v_cndmask_b32 %2, %12, %2, vcc\n\tv_cndmask_b32 %3, %13, %3, vcc\n\tv_cndmask_b32 %4, %14, %4, vcc\n\t"
+                     "v_cndmask_b32 %5, %15, %5, vcc\n\tv_cndmask_b32 %6, %16, %6, vcc\n\tv_cndmask_b32 %7, %17, %7, vcc"
+                     : "+v"(sel[W0]), "+v"(sel[W0 + 1]), "+v"(sel[W0 + 2]), "+v"(sel[W0 + 3]), "+v"(sel[W0 + 4]), "+v"(sel[W0 + 5]),
+                       "+v"(sel[W0 + 6]), "+v"(sel[W0 + 7])
+                     : "s"(want), "v"(x), "v"(e[W0]), "v"(e[W0 + 1]), "v"(e[W0 + 2]), "v"(e[W0 + 3]), "v"(e[W0 + 4]), "v"(e[W0 + 5]),
+                       "v"(e[W0 + 6]), "v"(e[W0 + 7])
+                     : "vcc");
+        ct_pick_words<NW, W0 + 8>(sel, e, x, want);
+    } else if constexpr (NW - W0 >= 2) {
+        asm("v_cmp_ne_u32 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %0, vcc\n\tv_cndmask_b32 %1, %5, %1, vcc"
+                     : "+v"(sel[W0]), "+v"(sel[W0 + 1])
+                     : "s"(want), "v"(x), "v"(e[W0]), "v"(e[W0 + 1])
+                     : "vcc");
+        ct_pick_words<NW, W0 + 2>(sel, e, x, want);
+    } else if constexpr (NW - W0 == 1) {
+        asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(sel[W0]) : "s"(want), "v"(x), "v"(e[W0]) : "vcc");
+    }
+}
+// the same with the entry words in SCALAR registers (a generator LUT read at wave-uniform addresses through the scalar cache):
+// one v_bfi_b32 per word — a full issue slot, but its one constant-bus operand is free for the scalar source.
+template <int NW>
+__device__ __forceinline__ void ct_pick_words_uniform(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) {
+    const uint32_t hit = ct_mask(x == want);
+#pragma unroll
+    for (int w = 0; w < NW; w++) asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(sel[w]) : "v"(hit), "s"(e[w]));
+}
+#else
+template <int NW, int W0 = 0>
+inline void ct_pick_words(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) {
+    const uint32_t hit = ct_mask(x == want);
+    for (int w = W0; w < NW; w++) sel[w] = ct_pick(hit, e[w], sel[w]);
+}
+template <int NW>
+inline void ct_pick_words_uniform(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) { ct_pick_words<NW>(sel, e, x, want); }
+#endif
 
 template <class C>
 ECGPU_HD Fe<C::NL> ct_sel_fe(uint32_t m, const Fe<C::NL>& a, const Fe<C::NL>& b) {
@@ -90,14 +139,18 @@ ECGPU_HD void ct_table_scan(const TabIO& tab, const uint32_t* xabs, Proj<C>* t) 
     using G = Group<C>;
 #pragma unroll
     for (int h = 0; h < H; h++) t[h] = G::identity();
-#pragma unroll 1
+#pragma unroll 2
     for (int j = 0; j < 8; j++) {
         Proj<C> e;
         e.x = tab.get_el(j, 0);
         e.y = tab.get_el(j, 1);
         e.z = tab.get_el(j, 2);
 #pragma unroll
-        for (int h = 0; h < H; h++) t[h] = ct_sel_proj<C>(xabs[h] == (uint32_t)(j + 1), e, t[h]);
+        for (int h = 0; h < H; h++) {
+            ct_pick_words<C::NL>(t[h].x.v, e.x.v, xabs[h], (uint32_t)(j + 1));
+            ct_pick_words<C::NL>(t[h].y.v, e.y.v, xabs[h], (uint32_t)(j + 1));
+            ct_pick_words<C::NL>(t[h].z.v, e.z.v, xabs[h], (uint32_t)(j + 1));
+        }
     }
 }
 
@@ -201,14 +254,25 @@ ECGPU_HD Proj<C> var_base_mul_ct(const Proj<C>& p, const uint32_t* k, const Fe<C
 }
 
 // ---- generator ----------------------------------------------------------------------------------------------------
-// LUT i (i < CT_BASE_LUTS) holds e * 2^(8 i) * G, e = 1..8, affine, packed: `BasepointTable::new`
-// (primeorder/src/tables/basepoint.rs:41-76; k256/src/arithmetic/tables.rs:11-18) with affine instead of projective
-// entries (the additions are mixed complete ones, 11M instead of 12M, and an entry is 2 instead of 3 elements to scan).
-// A zero digit has no affine entry: the addition is carried out against entry 1 and its result dropped under a mask.
+// The reference (`BasepointTable`, primeorder/src/tables/basepoint.rs:41-99; k256/src/arithmetic/mul.rs:180-197) keeps 33 LUTs of
+// e 2^(8 i) G, e = 1..8, and adds one entry per nibble into two accumulators: 65 complete additions and four doublings.  The
+// same idea with a wider window does less: one LUT PER WINDOW of W = 6 bits (LUT i = e 2^(6 i) G, e = 1..32, affine, packed),
+// 43 instead of 65 additions for a 256-bit scalar and no doublings at all; scanning 32 entries instead of 8 costs 32 x 17
+// select instructions per window against the ~1,800 of the addition it saves a third of (W = 5: 52 windows, W = 7: 37 windows
+// of 64 entries — both cost more; first version, W = 4 as the reference: k256 4.6 ms per 2^20, profiles/r03/ct_rates_and_counters.txt).
+// The additions are mixed complete ones (11M, entries of 2 instead of 3 elements).  A zero digit has no affine entry: the addition
+// is carried out against entry 1 and its result dropped under a mask.
 template <class C>
-constexpr int CT_BASE_LUTS = 4 * C::N + 1;          // 33 for 256-bit scalars, 49 for 384-bit ones (basepoint.rs: 1 + bytes)
+constexpr int ct_scalar_bits() {                     // bit length of the group order
+    int b = 32;
+    while (b > 1 && !((C::ORDER[C::N - 1] >> (b - 1)) & 1u)) b--;
+    return 32 * (C::N - 1) + b;
+}
+template <class C>
+constexpr int CT_BASE_LUTS = ct_scalar_bits<C>() / CT_BASE_W + 1;     // 43 for 256-bit orders, 65 for 384, 87 for 521
 
-// Lut: void load(PackedPoint<2N>&, int lut, int entry) const — entry (entry + 1) * 2^(8 lut) * G
+// Lut: void load(PackedPoint<2N>&, int lut, int entry) const — entry (entry + 1) * 2^(W lut) * G;  UNIFORM: the loads are at
+// wave-uniform addresses, the words arrive in scalar registers
 template <class C, class Lut>
 ECGPU_HD Proj<C> ct_lut_add(const Proj<C>& acc, const Lut& lut, int i, int digit, const Fe<C::NL>& b) {
     using G = Group<C>;
@@ -218,13 +282,12 @@ ECGPU_HD Proj<C> ct_lut_add(const Proj<C>& acc, const Lut& lut, int i, int digit
     const uint32_t xabs = ct_abs_digit(digit, &neg);
     PackedPoint<2 * N> sel;
     lut.load(sel, i, 0);                            // entry 1: also what a zero digit adds (and drops)
-#pragma unroll 1
-    for (int j = 1; j < 8; j++) {
+#pragma unroll 2                                    // two entries' loads in flight
+    for (int j = 1; j < CT_BASE_ENTRIES; j++) {
         PackedPoint<2 * N> e;
         lut.load(e, i, j);
-        const uint32_t hit = ct_mask(xabs == (uint32_t)(j + 1));
-#pragma unroll
-        for (int w = 0; w < 2 * N; w++) sel.w[w] = ct_pick(hit, e.w[w], sel.w[w]);
+        if constexpr (Lut::UNIFORM) ct_pick_words_uniform<2 * N>(sel.w, e.w, xabs, (uint32_t)(j + 1));
+        else ct_pick_words<2 * N>(sel.w, e.w, xabs, (uint32_t)(j + 1));
     }
     Affine<C> q;
     q.x = F::unpack(sel.w).e;
@@ -236,19 +299,14 @@ ECGPU_HD Proj<C> ct_lut_add(const Proj<C>& acc, const Lut& lut, int i, int digit
 template <class C, class Lut>
 ECGPU_HD Proj<C> fixed_base_mul_ct(const uint32_t* k, const Lut& lut, const Fe<C::NL>& b) {
     using G = Group<C>;
-    constexpr int N = C::N, NLUT = CT_BASE_LUTS<C>;
-    Radix16Msb<N> digits;
+    using Digits = SignedWindowsMsb<C::N, CT_BASE_W, ct_scalar_bits<C>()>;
+    static_assert(Digits::COUNT == CT_BASE_LUTS<C>, "one LUT per window");
+    Digits digits;
     digits.init(k);
-    Proj<C> acc = ct_lut_add<C>(G::identity(), lut, NLUT - 1, digits.digit(8 * N), b);
-    Proj<C> acc2 = G::identity();
+    Proj<C> acc = G::identity();
 #pragma unroll 1
-    for (int i = NLUT - 2; i >= 0; i--) {
-        acc2 = ct_lut_add<C>(acc2, lut, i, digits.digit(2 * i + 1), b);
-        acc = ct_lut_add<C>(acc, lut, i, digits.digit(2 * i), b);
-    }
-#pragma unroll 1
-    for (int s = 0; s < 4; s++) acc2 = G::dbl(acc2, b);
-    return G::add(acc, acc2, b);
+    for (int i = CT_BASE_LUTS<C> - 1; i >= 0; i--) acc = ct_lut_add<C>(acc, lut, i, digits.digit(i), b);
+    return acc;
 }
 
 }  // namespace ecgpu

@@ -18,6 +18,11 @@
 
 namespace ecgpu {
 
+// window width of the uniform-schedule generator LUTs (ecgpu_ctmul.h `fixed_base_mul_ct`; built by ensure_ct_lut in ecgpu_api.hip)
+constexpr int CT_BASE_W = 6;
+constexpr int CT_BASE_ENTRIES = 1 << (CT_BASE_W - 1);
+
+
 enum CurveId : int { CURVE_K256 = 0, CURVE_P256 = 1, CURVE_P384 = 2, CURVE_SM2 = 3, CURVE_P224 = 4, CURVE_P192 = 5, CURVE_P521 = 6, CURVE_BP256 = 7, CURVE_BP384 = 8, CURVE_BP256T1 = 9, CURVE_BP384T1 = 10, CURVE_BIGN256 = 11 };
 
 // in-register field representations (ecgpu_field.h)

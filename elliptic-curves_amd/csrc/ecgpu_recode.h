@@ -124,6 +124,38 @@ struct Radix16Msb {
     }
 };
 
+// The same trick for windows of W bits: k' = k + sum_{j < FULL} 2^(W j + W - 1) recentres every full window at once, digit j =
+// window_j(k') - 2^(W-1) in [-2^(W-1), 2^(W-1) - 1] for j < FULL = BITS / W, and window FULL holds what is left of k' (the top
+// BITS mod W bits plus the carry: at most 2^(W-1)) as an unsigned digit.  No step depends on the value of a digit.
+template <int NL, int W, int BITS>
+struct SignedWindowsMsb {
+    ECGPU_CONST int FULL = BITS / W, COUNT = FULL + 1, HALF = 1 << (W - 1);
+    static_assert(BITS <= 32 * NL && W >= 2 && W <= 16, "window geometry");
+    struct HalfWords {
+        uint32_t w[NL + 1];
+        constexpr HalfWords() : w{} {
+            for (int j = 0; j < FULL; j++) w[(W * j + W - 1) / 32] |= 1u << ((W * j + W - 1) % 32);
+        }
+    };
+    ECGPU_CONST HalfWords HW{};
+    uint32_t kp[NL + 1];
+    ECGPU_HD void init(const uint32_t* k) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            c += (uint64_t)k[i] + HW.w[i];
+            kp[i] = (uint32_t)c;
+            c >>= 32;
+        }
+        kp[NL] = (uint32_t)c;
+    }
+    // i = 0 .. FULL (a public loop counter)
+    ECGPU_HD int digit(int i) const {
+        const uint32_t raw = get_bits<NL + 1>(kp, W * i, W);
+        return i < FULL ? (int)raw - HALF : (int)raw;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // secp256k1 scalar arithmetic mod n on 8x32 limbs + GLV decomposition
 // ---------------------------------------------------------------------------------------------

@@ -305,12 +305,13 @@ int batch_mul(const uint8_t* scalars, const uint8_t* pxy, const uint8_t* pinf, s
 }
 
 // k_fixed_base_ct / k_var_base_ct: the uniform-schedule bodies of ecgpu_ctmul.h (generator LUTs built the way
-// ensure_ct_lut does: bases 2^(8 i) G, eight multiples each, packed affine)
+// ensure_ct_lut does: bases 2^(W i) G, 2^(W-1) multiples each, packed affine)
 template <class C>
 struct CtLutLocal {
-    std::vector<uint32_t> w;     // [CT_BASE_LUTS][8][2 N]
+    static constexpr bool UNIFORM = false;
+    std::vector<uint32_t> w;     // [CT_BASE_LUTS][CT_BASE_ENTRIES][2 N]
     void load(PackedPoint<2 * C::N>& p, int i, int entry) const {
-        std::memcpy(p.w, &w[((size_t)i * 8 + entry) * (2 * C::N)], 2 * C::N * 4);
+        std::memcpy(p.w, &w[((size_t)i * CT_BASE_ENTRIES + entry) * (2 * C::N)], 2 * C::N * 4);
     }
 };
 template <class C>
@@ -319,19 +320,19 @@ void build_ct_lut(CtLutLocal<C>& t) {
     using F = Field<C>;
     constexpr int N = C::N, NLUT = CT_BASE_LUTS<C>;
     auto b = G::curve_b();
-    t.w.resize((size_t)NLUT * 8 * 2 * N);
+    t.w.resize((size_t)NLUT * CT_BASE_ENTRIES * 2 * N);
     Affine<C> g;
     g.x = F::from_canonical(C::GX).e;
     g.y = F::from_canonical(C::GY).e;
     Proj<C> base = G::from_affine(g);
     for (int i = 0; i < NLUT; i++) {
-        for (uint32_t e = 1; e <= 8; e++) {
+        for (uint32_t e = 1; e <= (uint32_t)CT_BASE_ENTRIES; e++) {
             Proj<C> cur = table_entry_rule<C>(base, e, 0);
             auto zi = F::inv(G::m(cur.z));
-            F::pack(&t.w[((size_t)i * 8 + e - 1) * 2 * N], F::mul(G::m(cur.x), zi));
-            F::pack(&t.w[((size_t)i * 8 + e - 1) * 2 * N + N], F::mul(G::m(cur.y), zi));
+            F::pack(&t.w[((size_t)i * CT_BASE_ENTRIES + e - 1) * 2 * N], F::mul(G::m(cur.x), zi));
+            F::pack(&t.w[((size_t)i * CT_BASE_ENTRIES + e - 1) * 2 * N + N], F::mul(G::m(cur.y), zi));
         }
-        for (int s = 0; s < 8; s++) base = G::dbl(base, b);
+        for (int s = 0; s < CT_BASE_W; s++) base = G::dbl(base, b);
     }
 }
 template <class C>

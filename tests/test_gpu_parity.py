@@ -635,7 +635,7 @@ def test_uniform_schedule_entry_points(eng, curve):
     c = pyec.CURVES[curve]
     G = pyec.G(c)
     # generator: golden vectors (where the reference has them), edge + ladder-corner + random scalars
-    ks = edge_scalars(c) + ladder_edge_scalars(c)[:30]
+    ks = edge_scalars(c) + ladder_edge_scalars(c)[:30] + comb_corner_scalars(c, 6)       # 6-bit generator windows: +-32 runs, carries
     scal = b"".join(pyec.enc_scalar(c, k) for k in ks) + bytes(rand_scalars(c.cid, 300, 0xC7EC0001 + c.cid))
     out, inf = eng.mul_by_generator(c.cid, scal, constant_time=True)
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)

@@ -248,12 +248,13 @@ def test_uniform_schedule_bodies(oracle, curve):
     """fixed_base_mul_ct / var_base_mul_ct (ecgpu_ctmul.h: the reference's constant-time drivers restated for the
     uniform-schedule kernels) against the oracle's constant-time drivers: edge scalars x {G, -G, identity, random points},
     the ladder's corner scalars, zero and n - 1."""
-    from gpu_common import ladder_edge_scalars
+    from gpu_common import comb_corner_scalars, ladder_edge_scalars
     c = pyec.CURVES[curve]
     rng = random.Random(0xC7 + c.cid)
     G = pyec.G(c)
     ks = _scalars(c, rng, 12) + ladder_edge_scalars(c)[:24]
-    scal = b"".join(pyec.enc_scalar(c, k) for k in ks)
+    gen_ks = ks + comb_corner_scalars(c, 6)[:40]                    # the generator LUTs are per 6-bit window: digit strings of +-32, carries
+    scal = b"".join(pyec.enc_scalar(c, k) for k in gen_ks)
     rc, out, inf = hc.batch_mul_base_ct(c.cid, scal)
     assert rc == 0
     want, winf = oracle.batch_mul_base(c.cid, scal)
