@@ -73,7 +73,9 @@ while time.time() < t_end:
     c = pyec.CURVES[rng.choice(NAMES)]
     L = c.L
     kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var", "sig"])
-    if kind == "sig" and c.name in ("sm2", "bign256"):
+    if kind == "sig" and c.name == "bign256":
+        kind = "bign"
+    if kind == "sig" and c.name == "sm2":
         kind = "var"
     if kind == "msm":
         big = rng.random() < 0.25
@@ -191,6 +193,38 @@ while time.time() < t_end:
             vm = e.ecdsa_verify_msg(c.cid, Q, msgs, msg_len, sg, reject_high_s=high)
             assert bytes(vm) == bytes(v) == bytes(oracle_lib.ecdsa_verify_msg(c.cid, Q, msgs, msg_len, sg, reject_high_s=high)), ("verify_msg", c.name, n, msg_len)
             stats["verify_msg"] += 1
+    elif kind == "bign":
+        # bign signatures over engine-computed keys and nonce points, a third of them disturbed somewhere: verification on the
+        # prehash and from the messages (belt-hash on the device) against the oracle, verdict for verdict
+        n = rng.randrange(1, 300)
+        ds = bytes(rand_scalars(c.cid, n, rng.randrange(1 << 30)))
+        ks = bytes(rand_scalars(c.cid, n, rng.randrange(1 << 30)))
+        Q = bytes(e.mul_by_generator(c.cid, ds)[0])
+        R = bytes(e.mul_by_generator(c.cid, ks)[0])
+        msg_len = rng.choice([0, 1, 13, 31, 32, 33, 64, 65, 200])
+        msgs = bytes(rng.randrange(256) for _ in range(n * msg_len))
+        hs, sigs = bytearray(), bytearray()
+        for i in range(n):
+            h = oracle_lib.belt_hash(msgs[i * msg_len:(i + 1) * msg_len])
+            s0 = oracle_lib.belt_hash(pyec.BELT_OID + R[64 * i:64 * i + 32] + h)[:16]
+            d, k = int.from_bytes(ds[32 * i:32 * i + 32], "little"), int.from_bytes(ks[32 * i:32 * i + 32], "little")
+            s1 = (k - int.from_bytes(h, "little") - (int.from_bytes(s0, "little") + 2 ** 128) * d) % c.n
+            sig = bytearray(s0 + s1.to_bytes(32, "little"))
+            flip = rng.randrange(9)
+            if flip == 0:
+                sig[rng.randrange(48)] ^= 1 << rng.randrange(8)
+            elif flip == 1:
+                sig[16:] = rng.choice([0, c.n, c.n + 1, (1 << 256) - 1]).to_bytes(32, "little")
+            elif flip == 2:
+                sig[:16] = bytes(16)
+            hs += h
+            sigs += sig
+        v = e.bign_verify(bytes(hs), bytes(sigs), Q)
+        assert bytes(v) == bytes(oracle_lib.bign_verify(bytes(hs), bytes(sigs), Q)), ("bign", n)
+        vm = e.bign_verify_msg(Q, msgs, msg_len, bytes(sigs))
+        assert bytes(vm) == bytes(v) == bytes(oracle_lib.bign_verify_msg(Q, msgs, msg_len, bytes(sigs))), ("bign_msg", n, msg_len)
+        assert 0 < int(v.sum()) or n < 4
+        stats["bign_verify"] += 1
     elif kind == "fixed":
         n = rng.randrange(1, 3000)
         wdt = rng.choice([0, 0, rng.randrange(4, 17)])
