@@ -46,8 +46,8 @@
  * traffic).  ecgpu_batch_mul_base* and ecgpu_batch_ecdh accept whatever scalars they are given: a caller that passes
  * private keys there has decided that its threat model allows it; the results are the same group elements either way.
  * For secret scalars there are the three uniform-schedule entry points ecgpu_batch_mul_base_ct, ecgpu_batch_mul_ct and
- * ecgpu_batch_ecdh_ct (below): the reference's constant-time drivers as they are — fixed digit count, all eight table
- * entries read and one kept under a mask, complete formulas — at 1.5-9x the cost of the variable-time kernels.
+ * ecgpu_batch_ecdh_ct (below): the reference's constant-time drivers — fixed digit count, every table entry read and one
+ * kept under a mask, complete additions — at 1.2-7x the cost of the variable-time kernels.
  *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
  * create one context per thread / per GPU for concurrency.  The host-pointer forms of the per-unit batch calls
@@ -420,17 +420,18 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const
 
 /* ---- uniform-schedule ("constant-time shaped") variants for SECRET scalars --------------------------------------------
  * Same arguments, results and error behaviour as ecgpu_batch_mul_base / ecgpu_batch_mul / ecgpu_batch_ecdh, computed by the
- * reference's constant-time algorithms restated one to one (elliptic-curves_amd/csrc/ecgpu_ctmul.h):
+ * reference's constant-time algorithms (elliptic-curves_amd/csrc/ecgpu_ctmul.h):
  *   ecgpu_batch_mul_base_ct   `ProjectivePoint::mul_by_generator` (k256/src/arithmetic/mul.rs:180-197) /
- *                             `BasepointTable::mul` (primeorder/src/tables/basepoint.rs:82-99): 8 N + 1 signed radix-16 digits
- *                             (primeorder/src/tables/radix16.rs:35-61) over LUTs of 2^(8 i) G, even digits into one
- *                             accumulator, odd digits into a second one, acc + 16 acc2; every LUT is scanned in full
- *                             (`LookupTable::select`, primeorder/src/tables/lookup.rs:43-65)
+ *                             `BasepointTable::mul` (primeorder/src/tables/basepoint.rs:82-99), with 6-bit windows where the
+ *                             reference has nibbles: one LUT of the 32 multiples e 2^(6 i) G per window, one signed digit
+ *                             and one complete mixed addition per window (43 for a 256-bit scalar), no doublings; every
+ *                             LUT is scanned in full (`LookupTable::select`, primeorder/src/tables/lookup.rs:43-65)
  *   ecgpu_batch_mul_ct        `impl Mul<Scalar> for ProjectivePoint` (primeorder/src/projective.rs:847-886 -> `lincomb`
  *                             :532-557 with one term; k256/src/arithmetic/mul.rs:112-163,249-274 on the two GLV halves):
  *                             table [P..8P] by complete additions (lookup.rs:30-38), 65 / 97 (k256: 2 x 33) digits, four
- *                             complete doublings and one complete addition per digit, no digit skipped, the accumulator
- *                             starts at the identity
+ *                             doublings (complete ones on k256; Jacobian ones, which have no exceptional case on a
+ *                             prime-order curve, with the identity patched under a mask elsewhere) and one complete
+ *                             addition per digit, no digit skipped, the accumulator starts at the identity
  *   ecgpu_batch_ecdh_ct       `diffie_hellman(secret, public)` (k256/src/ecdh.rs:56-60 over the `Mul` above): x of
  *                             ecgpu_batch_mul_ct
  * What is guaranteed, and checked on the gfx950 ISA of the two kernels by tools/ct_isa_check.py (a register-level taint
