@@ -50,7 +50,7 @@ ECGPU_HD uint32_t ct_pick(uint32_t m, uint32_t a, uint32_t b) { return (a & m) |
 // the device the same selection is written as v_cndmask_b32 in its 32-bit encoding, half a slot per word, in groups of up to
 // eight words behind one v_cmp (an asm statement takes at most 30 operands).  All operands are vector registers: with vcc as
 // the condition the instruction has no constant-bus slot left for a scalar source on gfx9-family targets (tried: the assembler
-// refuses `v_cndmask_b32 v, s, v, vcc`) — ct_pick_words_uniform below is the form for scalar sources.
+// refuses `v_cndmask_b32 v, s, v, vcc`) — the generator scan (ct_lut_scan_uniform) uses v_bfi_b32 for scalar sources.
 // No branch, no address: nothing here for a compiler to turn into control flow, and nothing tools/ct_isa_check.py objects to.
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int NW, int W0 = 0>
@@ -75,22 +75,12 @@ __device__ __forceinline__ void ct_pick_words(uint32_t* sel, const uint32_t* e, 
         asm("v_cmp_ne_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %0, vcc" : "+v"(sel[W0]) : "s"(want), "v"(x), "v"(e[W0]) : "vcc");
     }
 }
-// the same with the entry words in SCALAR registers (a generator LUT read at wave-uniform addresses through the scalar cache):
-// one v_bfi_b32 per word — a full issue slot, but its one constant-bus operand is free for the scalar source.
-template <int NW>
-__device__ __forceinline__ void ct_pick_words_uniform(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) {
-    const uint32_t hit = ct_mask(x == want);
-#pragma unroll
-    for (int w = 0; w < NW; w++) asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(sel[w]) : "v"(hit), "s"(e[w]));
-}
 #else
 template <int NW, int W0 = 0>
 inline void ct_pick_words(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) {
     const uint32_t hit = ct_mask(x == want);
     for (int w = W0; w < NW; w++) sel[w] = ct_pick(hit, e[w], sel[w]);
 }
-template <int NW>
-inline void ct_pick_words_uniform(uint32_t* sel, const uint32_t* e, uint32_t x, uint32_t want) { ct_pick_words<NW>(sel, e, x, want); }
 #endif
 
 template <class C>
@@ -273,6 +263,35 @@ constexpr int CT_BASE_LUTS = ct_scalar_bits<C>() / CT_BASE_W + 1;     // 43 for 
 
 // Lut: void load(PackedPoint<2N>&, int lut, int entry) const — entry (entry + 1) * 2^(W lut) * G;  UNIFORM: the loads are at
 // wave-uniform addresses, the words arrive in scalar registers
+#if defined(__HIP_DEVICE_COMPILE__)
+// The scan of a LUT that arrives through the scalar cache is bound by the latency of its loads, not by its instructions
+// (profiles/r03/ct_generator_scan_variants.txt), and scalar loads return out of order: the only wait there is waits for ALL of
+// them.  So the load of entry j + 1 is issued right AFTER the wait for entry j and flies under the selection of entry j: the
+// first word of entry j is selected, then the next index is passed through an empty asm statement that names that word as an
+// input (the load cannot be scheduled above the selection it seems to depend on), then the other words are selected.
+template <class C, class Lut>
+__device__ __forceinline__ void ct_lut_scan_uniform(PackedPoint<2 * C::N>& sel, const Lut& lut, int i, uint32_t xabs) {
+    constexpr int NW = 2 * C::N;
+    PackedPoint<NW> e[2];
+    lut.load(sel, i, 0);
+    lut.load(e[1], i, 1);
+#pragma unroll
+    for (int j = 1; j < CT_BASE_ENTRIES; j++) {
+        const uint32_t hit = ct_mask(xabs == (uint32_t)(j + 1));
+        const uint32_t* cur = e[j & 1].w;
+        asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(sel.w[0]) : "v"(hit), "s"(cur[0]));
+        if (j + 1 < CT_BASE_ENTRIES) {
+            int jn = j + 1;
+            asm volatile("" : "+s"(jn) : "v"(sel.w[0]));
+            lut.load(e[(j + 1) & 1], i, jn);
+            __builtin_amdgcn_sched_barrier(0);      // ... and not sunk below the selections that follow
+        }
+#pragma unroll
+        for (int w = 1; w < NW; w++) asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(sel.w[w]) : "v"(hit), "s"(cur[w]));
+    }
+}
+#endif
+
 template <class C, class Lut>
 ECGPU_HD Proj<C> ct_lut_add(const Proj<C>& acc, const Lut& lut, int i, int digit, const Fe<C::NL>& b) {
     using G = Group<C>;
@@ -281,13 +300,19 @@ ECGPU_HD Proj<C> ct_lut_add(const Proj<C>& acc, const Lut& lut, int i, int digit
     bool neg;
     const uint32_t xabs = ct_abs_digit(digit, &neg);
     PackedPoint<2 * N> sel;
-    lut.load(sel, i, 0);                            // entry 1: also what a zero digit adds (and drops)
-#pragma unroll 2                                    // two entries' loads in flight
-    for (int j = 1; j < CT_BASE_ENTRIES; j++) {
-        PackedPoint<2 * N> e;
-        lut.load(e, i, j);
-        if constexpr (Lut::UNIFORM) ct_pick_words_uniform<2 * N>(sel.w, e.w, xabs, (uint32_t)(j + 1));
-        else ct_pick_words<2 * N>(sel.w, e.w, xabs, (uint32_t)(j + 1));
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Lut::UNIFORM) {
+        ct_lut_scan_uniform<C>(sel, lut, i, xabs);
+    } else
+#endif
+    {
+        lut.load(sel, i, 0);                        // entry 1: also what a zero digit adds (and drops)
+#pragma unroll 2
+        for (int j = 1; j < CT_BASE_ENTRIES; j++) {
+            PackedPoint<2 * N> e;
+            lut.load(e, i, j);
+            ct_pick_words<2 * N>(sel.w, e.w, xabs, (uint32_t)(j + 1));
+        }
     }
     Affine<C> q;
     q.x = F::unpack(sel.w).e;
