@@ -93,7 +93,12 @@ WORKLOADS = {
 # one GPU's share of configs[3] on an 8-GPU node (2^24 / 8 terms): the part of the bucket method that does not shrink with n
 # shows here; its per-term rate against the 2^24 rate is the single-GPU projection of the 8-GPU scaling efficiency
 WORKLOADS["msm_k256_2p21"] = dict(WORKLOADS["msm_k256"], n=1 << 21, metric="k256 MSM terms/sec (2^21-term share)")
-SEEDS = {"var_p256_ct": 11, "msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
+# the same two MSM workloads with SEVERAL MSMs in flight (ecgpu_set_msm_lanes on an asynchronous context: rotating internal streams
+# and workspaces; N = 1 only): throughput of independent back-to-back MSMs, the time of a single one does not change
+# (profiles/r03/msm_lanes.txt: two lanes are best at 2^21 terms, three at 2^24)
+WORKLOADS["msm_k256_lanes"] = dict(WORKLOADS["msm_k256"], lanes=3, metric="k256 MSM terms/sec, three MSMs in flight")
+WORKLOADS["msm_k256_2p21_lanes"] = dict(WORKLOADS["msm_k256_2p21"], lanes=2, metric="k256 MSM terms/sec (2^21-term share), two MSMs in flight")
+SEEDS = {"msm_k256_lanes": 4, "msm_k256_2p21_lanes": 10, "var_p256_ct": 11, "msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
 # BASELINE configs[2], [3], [4] beside the top-level configs[1], then the two signature workloads of SURVEY.md 8(f) (callers of the
 # path: p256 verification, k256 public-key recovery) so that they are driver-timed too
 DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "msm_k256_2p21", "ecdsa_p256", "recover_k256", "var_p256_ct"]
@@ -362,6 +367,11 @@ class Bench:
         # timed region; the per-call HIP events are then read for the last timed step.  The other kinds keep the
         # synchronous calls and read every step's events.
         queued = kind in ("fixed", "var") and not args.sync_calls
+        lanes = int(wl.get("lanes", 1)) if kind == "msm" and exchange is None else 1
+        if lanes > 1:
+            queued = True
+            lane_out = [(d_out, d_inf)] + [(torch.empty_like(d_out), torch.empty_like(d_inf)) for _ in range(lanes - 1)]
+        nstep = [0]
 
         def read_events():
             main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
@@ -380,7 +390,11 @@ class Bench:
             elif kind == "recover":
                 eng.ecdsa_recover_dev(cid, d_scal, d_r, d_s, d_recid, n, True, d_out, d_ok)
             elif exchange is None:
-                eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
+                nstep[0] += 1
+                if lanes > 1:                              # several MSMs in flight: each writes buffers of its own
+                    eng.lincomb_dev(cid, d_scal, d_pts, None, n, *lane_out[nstep[0] % lanes])
+                else:
+                    eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
             else:
                 # sharded MSM: local pipeline down to the per-window partial sums, ONE exchange step (RCCL all-gather of
                 # the parts over xGMI), window sums over all ranks + the Horner chain on every rank
@@ -395,6 +409,12 @@ class Bench:
         main_ms.clear(); stages.clear()
         if queued:
             eng.set_async(True)
+        if lanes > 1:
+            eng.set_msm_lanes(lanes)
+            for _ in range(lanes):                       # the lanes' streams and workspaces exist before the clock starts
+                step()
+            eng.synchronize()
+            nstep[0] = 0
         self.fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -405,6 +425,8 @@ class Bench:
         elapsed = time.perf_counter() - t0
         if queued:
             read_events()
+            if lanes > 1:
+                eng.set_msm_lanes(1)
             eng.set_async(False)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
@@ -497,7 +519,9 @@ class Bench:
             "config": {"workload": name, "curve": wl["curve"], "units_per_gpu": n, "units_total": units_per_step,
                        "window_bits": args.window or "default", "parallelism": "shard%d" % world,
                        **({"dry_run": "ranks share one GPU, %s exchange" % self.backend} if os.environ.get("ECGPU_BENCH_SHARE_GPU") else {})},
-            "calls": "queued (ecgpu_set_async), drained inside the timed region; kernel_ms from the HIP events of the last timed step" if queued
+            "calls": "%d MSMs in flight (ecgpu_set_async + ecgpu_set_msm_lanes), drained inside the timed region; kernel_ms = the last "
+                     "accumulation kernel with the other lanes' kernels beside it" % lanes if lanes > 1
+                     else "queued (ecgpu_set_async), drained inside the timed region; kernel_ms from the HIP events of the last timed step" if queued
                      else "synchronous, kernel_ms averaged over the HIP events of every timed step",
             "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms,
                          "achieved": achieved / 1e12 if achieved else None, "peak": NOMINAL_PEAK / 1e12, "unit": "TIMAD32-slots/s",
@@ -639,7 +663,8 @@ NOTES = {
            "cores busy ~1.2 s on slices of the same seeded workload after a single-thread pilot; one = single-thread rate",
     "check": "last timed step vs the oracle: batch workloads 256 sampled outputs byte for byte AND the sum of ALL outputs == "
              "(sum k_i [s_i]) G; MSMs == (sum k_i s_i mod n) G exactly; signatures: every verdict / every recovered key",
-    "calls": "fixed / variable base: batches queued (ecgpu_set_async) and drained inside the timed region; others synchronous",
+    "calls": "fixed / variable base: batches queued (ecgpu_set_async) and drained inside the timed region; others synchronous; "
+             "*_lanes_ms: the same MSMs with two (2^21) / three (2^24) in flight (ecgpu_set_msm_lanes: rotating streams + workspaces), per MSM",
 }
 
 
@@ -710,6 +735,12 @@ def main():
         r = b.run(name, cpu_leg)
         if r is not None:
             full[name] = r
+    lanes = {}
+    if not single and b.world == 1 and not args.no_extras:       # the two MSM sizes again with two MSMs in flight (top-level keys only)
+        for name in ("msm_k256_lanes", "msm_k256_2p21_lanes"):
+            r = b.run(name, False)
+            if r is not None:
+                lanes[name] = r
     e2e = group = None
     if not single and not args.no_extras:
         if b.world == 1:
@@ -748,6 +779,9 @@ def main():
             full["msm_k256_2p21"]["share_of_2p24_rate"] = share   # per-term rate of a 2^21-term share / per-term rate at 2^24
             full["msm_k256_2p21"]["projected_8gpu_efficiency"] = share
             rec["msm_k256_2p21_ms"] = full["msm_k256_2p21"]["ms_per_step"]
+        for name, r in lanes.items():                            # throughput with two MSMs in flight per GPU (ecgpu_set_msm_lanes)
+            rec[name + "_ms"] = r["ms_per_step"]
+            rec[name + "_check"] = r["check_vs_oracle"]
         rec["configs"] = {k: compact(v) for k, v in full.items()}
         if group:
             rec["configs"]["group_msm_k256"] = group

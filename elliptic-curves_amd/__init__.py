@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "ecgpu_sm2dsa_verify_batch", "ecgpu_sm2dsa_verify_batch_dev", "ecgpu_set_async", "ecgpu_synchronize",
     "ecgpu_ecdsa_recover_batch", "ecgpu_ecdsa_recover_batch_dev",
     "ecgpu_sm2dsa_verify_msg_batch", "ecgpu_sm2dsa_verify_msg_batch_dev",
-    "ecgpu_bign_verify_batch", "ecgpu_bign_verify_batch_dev", "ecgpu_bign_verify_msg_batch", "ecgpu_bign_verify_msg_batch_dev",
+    "ecgpu_set_msm_lanes", "ecgpu_bign_verify_batch", "ecgpu_bign_verify_batch_dev", "ecgpu_bign_verify_msg_batch", "ecgpu_bign_verify_msg_batch_dev",
     "ecgpu_ecdsa_verify_msg_batch", "ecgpu_ecdsa_verify_msg_batch_dev",
     "ecgpu_group_ecdsa_verify_batch", "ecgpu_group_ecdsa_verify_msg_batch", "ecgpu_group_ecdsa_recover_batch",
     "ecgpu_batch_mul_base_ct", "ecgpu_batch_mul_base_ct_dev", "ecgpu_batch_mul_ct", "ecgpu_batch_mul_ct_dev",
@@ -268,6 +268,11 @@ class Engine:
 
     def synchronize(self):
         self._chk(self._lib.ecgpu_synchronize(self._ctx))
+
+    def set_msm_lanes(self, lanes=2):
+        """Two MSMs in flight on an asynchronous context (alternating internal streams and workspaces); their outputs are
+        ordered by synchronize() only (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_set_msm_lanes(self._ctx, int(lanes)))
 
     def last_timing(self, name="total"):
         ms = ctypes.c_double(0)

@@ -78,6 +78,18 @@ struct ecgpu_ctx {
     // accumulates on the device until ecgpu_synchronize (or a host-pointer call) collects it into `deferred`
     bool async = false, pending = false;
     int deferred = 0;
+    // MSM lanes (ecgpu_set_msm_lanes): in asynchronous mode consecutive MSMs alternate between two internal streams, each with
+    // a workspace of its own, so that the sort and the reduction tail of one MSM (bandwidth- and latency-bound) run beside the
+    // accumulation of the other (issue-bound)
+    struct MsmLane {
+        hipStream_t s = nullptr;
+        DevBuf ws, proj, prefix;
+        hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr;
+    };
+    int msm_lanes = 1;
+    unsigned msm_seq = 0;
+    MsmLane lane[4];
+    int lane_last = -1;          // the lane of the last MSM queued on one (ecgpu_last_timing "accumulate" reads its events)
 };
 
 namespace {
@@ -95,6 +107,21 @@ int ensure(ecgpu_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return ECGPU_OK;
     if (b.p) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 4096;
+    HIP_TRY(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ECGPU_OK;
+}
+
+// the same for a buffer that is used on another stream of the context (an MSM lane)
+int ensure_on(ecgpu_ctx* ctx, hipStream_t stream, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return ECGPU_OK;
+    if (b.p) {
+        HIP_TRY(ctx, hipStreamSynchronize(stream));
         HIP_TRY(ctx, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -155,6 +182,8 @@ int finish(ecgpu_ctx* ctx) {
 
 // asynchronous mode: wait for the queued work, move its status flags into ctx->deferred, clear the device word
 int drain(ecgpu_ctx* ctx) {
+    for (auto& l : ctx->lane)                  // queued MSMs on the lanes: their status flags land in the same word
+        if (l.s) HIP_TRY(ctx, hipStreamSynchronize(l.s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -200,6 +229,7 @@ void resolve_timing(ecgpu_ctx* ctx) {
 // yet) when ecgpu_last_timing asks
 void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*, std::pair<int, int>>> spans) {
     ctx->spans.clear();
+    ctx->lane_last = -1;
     for (auto& s : spans) ctx->spans.emplace_back(s.first, s.second);
     if (!ctx->async) resolve_timing(ctx);
 }
@@ -557,9 +587,33 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
                              {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
         return rc;
     }
+    MsmPlan plan = msm_plan<C>(n, ctx->msm_c, msm_use_glv<C>(n));
+    if (ctx->async && ctx->msm_lanes > 1) {
+        // one of the lanes: everything of this MSM on the lane's stream and in the lane's buffers, ordered after what the
+        // context's stream holds now (the inputs); its output is ordered by ecgpu_synchronize only
+        ctx->lane_last = (int)(ctx->msm_seq % (unsigned)ctx->msm_lanes);
+        ecgpu_ctx::MsmLane& l = ctx->lane[ctx->msm_seq++ % (unsigned)ctx->msm_lanes];
+        ctx->spans.clear();
+        ctx->timing.clear();
+        if (!l.s) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_in, hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreate(&l.ev_a));
+            HIP_TRY(ctx, hipEventCreate(&l.ev_b));
+        }
+        if ((rc = ensure_on(ctx, l.s, l.ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
+        if ((rc = ensure_on(ctx, l.s, l.proj, 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure_on(ctx, l.s, l.prefix, NS * 4)) != ECGPU_OK) return rc;
+        HIP_TRY(ctx, hipEventRecord(l.ev_in, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(l.s, l.ev_in, 0));
+        launch_msm<C>(plan, l.s, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, l.ws.p, (uint32_t*)l.proj.p,
+                      ctx->d_status, l.ev_a, l.ev_b);
+        launch_normalize<C>(l.s, false, (const uint32_t*)l.proj.p, (uint32_t*)l.prefix.p, 1, (uint8_t*)d_out_xy, (uint8_t*)d_out_inf,
+                            nullptr);
+        return finish(ctx);
+    }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
-    MsmPlan plan = msm_plan<C>(n, ctx->msm_c, msm_use_glv<C>(n));
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_msm<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
@@ -923,6 +977,14 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
                       &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
     if (ctx->ct_flags.p) (void)hipFree(ctx->ct_flags.p);
+    for (auto& l : ctx->lane) {
+        if (l.s) (void)hipStreamSynchronize(l.s);
+        for (DevBuf* b : {&l.ws, &l.proj, &l.prefix})
+            if (b->p) (void)hipFree(b->p);
+        for (hipEvent_t e : {l.ev_in, l.ev_a, l.ev_b})
+            if (e) (void)hipEventDestroy(e);
+        if (l.s) (void)hipStreamDestroy(l.s);
+    }
     for (int id = 0; id < 12; id++) {                            // the last context of the device frees the shared tables
         release_table(ctx, id);
         release_ct_lut(ctx, id);
@@ -1014,6 +1076,14 @@ int ecgpu_set_msm_window(ecgpu_ctx* ctx, int window_bits) {
     return ECGPU_OK;
 }
 
+int ecgpu_set_msm_lanes(ecgpu_ctx* ctx, int lanes) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (lanes < 1 || lanes > 4) return arg_error(ctx, __func__);
+    int rc = ctx->async ? drain(ctx) : ECGPU_OK;       // nothing in flight on a lane while the mode changes
+    ctx->msm_lanes = lanes;
+    return rc;
+}
+
 int ecgpu_set_async(ecgpu_ctx* ctx, int on) {
     if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
     int rc = ecgpu_synchronize(ctx);          // what was queued so far is reported here
@@ -1041,6 +1111,15 @@ int ecgpu_synchronize(ecgpu_ctx* ctx) {
 int ecgpu_last_timing(const ecgpu_ctx* ctx_in, const char* name, double* ms) {
     if (!ctx_in || !name || !ms) return ECGPU_ERR_ARG;
     ecgpu_ctx* ctx = const_cast<ecgpu_ctx*>(ctx_in);
+    if (ctx->lane_last >= 0 && ctx->timing.empty() && ctx->spans.empty() && std::string(name) == "accumulate") {
+        // the last MSM went to a lane: the duration of its accumulation kernel with whatever ran beside it
+        ecgpu_ctx::MsmLane& l = ctx->lane[ctx->lane_last];
+        float t = 0;
+        if (!check_ctx(ctx) || !l.s || hipStreamSynchronize(l.s) != hipSuccess || hipEventElapsedTime(&t, l.ev_a, l.ev_b) != hipSuccess)
+            return ECGPU_ERR_HIP;
+        *ms = t;
+        return ECGPU_OK;
+    }
     if (!ctx->spans.empty()) {                 // asynchronous call: its events are complete once the stream has drained
         if (!check_ctx(ctx) || hipStreamSynchronize(ctx->stream) != hipSuccess) return ECGPU_ERR_HIP;
         resolve_timing(ctx);

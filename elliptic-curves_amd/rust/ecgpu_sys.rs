@@ -55,6 +55,7 @@ unsafe extern "C" {
     pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
     pub fn ecgpu_set_async(ctx: *mut EcgpuCtx, on: c_int) -> c_int;
     pub fn ecgpu_synchronize(ctx: *mut EcgpuCtx) -> c_int;
+    pub fn ecgpu_set_msm_lanes(ctx: *mut EcgpuCtx, lanes: c_int) -> c_int;
     pub fn ecgpu_batch_mul_base(
         ctx: *mut EcgpuCtx,
         curve: c_int,

@@ -147,6 +147,15 @@ int ecgpu_set_msm_window(ecgpu_ctx *ctx, int window_bits);
 int ecgpu_set_async(ecgpu_ctx *ctx, int on);
 int ecgpu_synchronize(ecgpu_ctx *ctx);
 
+/* MSM lanes: with lanes = 2 .. 4 on an asynchronous context, consecutive ecgpu_msm_dev calls rotate over that many internal
+ * streams, each with a workspace of its own, so that several independent MSMs are in flight: the sort and the reduction tail of
+ * one (bandwidth- and latency-bound) run beside the accumulation of the other (issue-bound) — 8-12 % more MSMs per second on
+ * one GPU (profiles/r03/msm_lanes.txt); the time of a single MSM does not change.  A lane starts after the work queued on
+ * the context's stream at the time of the call (its inputs); its OUTPUT is ordered by ecgpu_synchronize only, not by later
+ * calls on the context, and every MSM in flight needs output buffers of its own.  lanes = 1 (the default) restores one
+ * stream.  Other entry points and synchronous contexts are unaffected.  Returns ECGPU_ERR_ARG for other values. */
+int ecgpu_set_msm_lanes(ecgpu_ctx *ctx, int lanes);
+
 /* ---- host-pointer entry points (copy in, compute on the GPU, copy out) ------------------------ */
 
 /* out[i] = k[i] * G.

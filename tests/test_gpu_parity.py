@@ -733,6 +733,57 @@ def test_uniform_schedule_device_resident_and_queued(eng):
             b.free()
 
 
+def test_msm_lanes_several_in_flight(eng):
+    """ecgpu_set_msm_lanes(2 .. 4) on an asynchronous context: consecutive MSMs rotate over that many internal streams and
+    workspaces.  Eight queued MSMs of different sizes (both sorts, GLV and plain, two curves) on points that an earlier QUEUED
+    generator multiplication produces (the lane must start after it) equal their synchronous results; a bad scalar in one of
+    them surfaces at synchronize(); lanes = 1 restores the single stream; other values are refused."""
+    ecgpu = ecgpu_module()
+    jobs = []
+    for curve, n in (("k256", 5000), ("p256", 3000), ("k256", 1 << 17), ("k256", 77), ("p256", 1 << 16), ("k256", 20000),
+                     ("p256", 1), ("k256", 1 << 18)):
+        c = pyec.CURVES[curve]
+        d_s = eng.to_device(rand_scalars(c.cid, n, 0x1A9E0 + n))
+        d_k = eng.to_device(rand_scalars(c.cid, n, 0x1A9E1 + n))
+        d_p, d_f = eng.dev_alloc(n * 2 * c.L), eng.dev_alloc(n)
+        outs = [(eng.dev_alloc(2 * c.L), eng.dev_alloc(16)) for _ in range(2)]
+        jobs.append((c, n, d_s, d_k, d_p, d_f, outs))
+    want = []
+    for c, n, d_s, d_k, d_p, d_f, outs in jobs:                          # synchronous reference
+        eng.mul_by_generator_dev(c.cid, d_s, n, d_p, d_f)
+        eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[0])
+        want.append((bytes(eng.to_host(outs[0][0], 2 * c.L)), int(eng.to_host(outs[0][1], 1)[0])))
+    eng.set_async(True)
+    for nl in (2, 3, 4):
+        eng.set_msm_lanes(nl)
+        for c, n, d_s, d_k, d_p, d_f, outs in jobs:                      # points re-made by queued work, then the MSM on a lane
+            eng.to_device(np.zeros(16, np.uint8), outs[1][0])
+            eng.mul_by_generator_dev(c.cid, d_s, n, d_p, d_f)
+            eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[1])
+        eng.synchronize()
+        for (c, n, d_s, d_k, d_p, d_f, outs), w in zip(jobs, want):
+            assert (bytes(eng.to_host(outs[1][0], 2 * c.L)), int(eng.to_host(outs[1][1], 1)[0])) == w, (nl, c.name, n)
+    eng.set_msm_lanes(2)
+    # a scalar >= n in a queued lane MSM: the error is deferred to synchronize()
+    c, n, d_s, d_k, d_p, d_f, outs = jobs[0]
+    bad = np.frombuffer(bytes(rand_scalars(c.cid, n, 5)), np.uint8).copy()
+    bad[: c.L] = 0xFF
+    d_bad = eng.to_device(bad)
+    eng.lincomb_dev(c.cid, d_bad, d_p, None, n, *outs[1])
+    eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[0])
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.synchronize()
+    assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+    assert bytes(eng.to_host(outs[0][0], 2 * c.L)) == want[0][0]
+    with pytest.raises(ecgpu.EcgpuError):
+        eng.set_msm_lanes(5)
+    eng.set_msm_lanes(1)
+    eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[1])
+    eng.synchronize()
+    eng.set_async(False)
+    assert bytes(eng.to_host(outs[1][0], 2 * c.L)) == want[0][0]
+
+
 def test_schnorr_bip340_vectors_from_wire_bytes(eng):
     """`VerifyingKey::from_bytes(pk)?.verify_raw(msg, sig)` entirely on the device (lift_x, SHA-256 tagged hash, s G - e P):
     the 19 BIP340 vectors of k256/src/schnorr.rs, the 32-byte-message ones as one batch, plus random batches against the
