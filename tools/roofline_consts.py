@@ -33,6 +33,7 @@ KERNELS = {
     "k_var_base<P384Params>": ("var", "P384Params", "k_var_base", 1 << 20, "var_p384"),
     "k_var_base<K256Params>": ("var", "K256Params", "k_var_base", 1 << 20, "recover_k256"),   # b R of a G + b R: 2^20 launches per call
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
+    "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
 }
 HALF_SLOT_EXCEPT = ("_co_",)          # carry-producing / -consuming VOP2 ops were measured at the full cost
 
@@ -49,7 +50,9 @@ def isa_histogram(group, curve, substr):
         ops = [l.split()[0] for l in m.group(2).splitlines() if re.match(r"^\s+v_", l)]
         c = collections.Counter(ops)
         total = sum(c.values())
-        half = sum(v for k, v in c.items() if k.endswith("_e32") and not any(x in k for x in HALF_SLOT_EXCEPT))
+        # (inline-asm instructions print without an encoding suffix: the v_cmp / v_cndmask of ecgpu_ctmul.h are 32-bit encodings)
+        half = sum(v for k, v in c.items() if (k.endswith("_e32") or k in ("v_cndmask_b32", "v_cmp_ne_u32"))
+                   and not any(x in k for x in HALF_SLOT_EXCEPT))
         mad = sum(v for k, v in c.items() if k.startswith("v_mad_u64_u32"))
         return {"static_valu": total, "slots_per_inst": (total - half / 2) / total, "mad_share": mad / total,
                 "top": dict(c.most_common(8))}
