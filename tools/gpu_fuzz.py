@@ -72,7 +72,7 @@ kind = c = n = None
 while time.time() < t_end:
     c = pyec.CURVES[rng.choice(NAMES)]
     L = c.L
-    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var", "sig"])
+    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var", "sig", "lanes"])
     if kind == "sig" and c.name == "bign256":
         kind = "bign"
     if kind == "sig" and c.name == "sm2":
@@ -113,6 +113,34 @@ while time.time() < t_end:
             w, wf = oracle_lib.msm(c.cid, k.reshape(-1), pts.reshape(-1), inf, vartime=True)
             assert bytes(o) == bytes(w) and f == wf, ("msm oracle", c.name, n, cb, dict(os.environ))
             stats["msm_oracle"] += 1
+    elif kind == "lanes":
+        # several MSMs in flight (ecgpu_set_msm_lanes on an asynchronous context) == the same MSMs one at a time
+        msm_knobs(c)
+        e.set_msm_window(0)
+        P = pool(c)
+        nj = rng.randrange(2, 7)
+        jobs, want = [], []
+        for _ in range(nj):
+            n = rng.choice([rng.randrange(1, 200), rng.randrange(200, 1 << 13), rng.randrange(1 << 13, 1 << 17)])
+            d_k = e.to_device(rand_scalars(c.cid, n, rng.randrange(1 << 30)))
+            d_p = e.to_device(P[np.array([rng.randrange(1 << 16) for _ in range(n)])].copy().reshape(-1))
+            d_o, d_f = e.dev_alloc(2 * L), e.dev_alloc(16)
+            e.lincomb_dev(c.cid, d_k, d_p, None, n, d_o, d_f)
+            want.append((bytes(e.to_host(d_o, 2 * L)), int(e.to_host(d_f, 1)[0])))
+            e.to_device(np.zeros(2 * L, np.uint8), d_o)
+            jobs.append((n, d_k, d_p, d_o, d_f))
+        e.set_async(True)
+        e.set_msm_lanes(rng.randrange(2, 5))
+        for n, d_k, d_p, d_o, d_f in jobs:
+            e.lincomb_dev(c.cid, d_k, d_p, None, n, d_o, d_f)
+        e.synchronize()
+        e.set_msm_lanes(1)
+        e.set_async(False)
+        for (n, d_k, d_p, d_o, d_f), w in zip(jobs, want):
+            assert (bytes(e.to_host(d_o, 2 * L)), int(e.to_host(d_f, 1)[0])) == w, ("lanes", c.name, n, dict(os.environ))
+            for b in (d_k, d_p, d_o, d_f):
+                b.free()
+        stats["msm_lanes"] += 1
     elif kind == "shards":
         # the two halves of a multi-GPU MSM on random, unequal shards (some empty) == the one-call MSM
         n = rng.randrange(1, 1 << 15)
