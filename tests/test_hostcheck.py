@@ -473,6 +473,10 @@ def test_bign_verify_logic_on_cpu(oracle):
         for cut in (0, 1, n // 2, n):
             assert hc.belt_hash(m, cut) == want, (n, cut)
     pk, sig, msg = bytes.fromhex(K["public_key"]), bytes.fromhex(K["signature"]), bytes.fromhex(K["message"])
+    # the standard's own known answers for the same 13-byte message and for one block encryption (STB 34.101.31 annex A; the
+    # document is not in the image — these two are quoted from it as a second pin beside the reference's signature vector)
+    assert hc.belt_hash(msg).hex().upper() == "ABEF9725D4C5A83597A367D14494CC2542F20F659DDFECC961A3EC550CBA8C75"
+    assert pyec.belt_block(pyec.BELT_H[:16], pyec.BELT_H[128:160]).hex().upper() == "69CCA1C93557C9E3D66BC3E0FA88FA6E"
     assert hc.bign_verify_msg(pk, msg, len(msg), sig)[0] == 1 and oracle.bign_verify_msg(pk, msg, len(msg), sig)[0] == 1
     assert hc.bign_verify_msg(pk, msg[:-1] + b"\x59", len(msg), sig)[0] == 0
     cases = bign_cases(0xB16A, nvalid=4)
