@@ -779,9 +779,11 @@ def main():
             full["msm_k256_2p21"]["share_of_2p24_rate"] = share   # per-term rate of a 2^21-term share / per-term rate at 2^24
             full["msm_k256_2p21"]["projected_8gpu_efficiency"] = share
             rec["msm_k256_2p21_ms"] = full["msm_k256_2p21"]["ms_per_step"]
-        for name, r in lanes.items():                            # throughput with two MSMs in flight per GPU (ecgpu_set_msm_lanes)
+        for name, r in lanes.items():                            # throughput with several MSMs in flight per GPU (ecgpu_set_msm_lanes)
             rec[name + "_ms"] = r["ms_per_step"]
             rec[name + "_check"] = r["check_vs_oracle"]
+        if len(lanes) == 2:                                      # per-term rate of a 2^21-term share over the 2^24 rate, both with MSMs in flight
+            rec["msm_k256_2p21_lanes_share"] = lanes["msm_k256_lanes"]["ms_per_step"] / (8.0 * lanes["msm_k256_2p21_lanes"]["ms_per_step"])
         rec["configs"] = {k: compact(v) for k, v in full.items()}
         if group:
             rec["configs"]["group_msm_k256"] = group
