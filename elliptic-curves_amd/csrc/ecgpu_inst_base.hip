@@ -21,41 +21,34 @@ template <> void launch_table_entries<CurveT>(hipStream_t s, const uint32_t* bas
     size_t total = ((size_t)1 << tlog) * nwin;
     hipLaunchKernelGGL(k_table_entries<CurveT>, dim3(grid_for(total)), dim3(BLOCK), 0, s, bases, entries, w, nwin, tlog);
 }
-// Normalisation: k_normalize_wg (one inversion per 256 x K points, running products in registers) for every batch size;
-// ECGPU_NORM_WG=0 selects the first kernel (one inversion per lane amortised over K = ceil(n / 65536) <= 64 points, about one
-// wave per SIMD; ECGPU_NORM_K overrides its K) — kept for A/B measurements (profiles/r04/normalize_wg.txt).
-static bool normalize_wg_enabled() {
-    const char* e = getenv("ECGPU_NORM_WG");
-    return !(e && e[0] == '0');
-}
-template <int MODE>
-static void launch_normalize_mode(hipStream_t s, const uint32_t* proj, uint32_t* prefix, size_t n, uint8_t* out_xy, uint8_t* out_inf,
-                                  uint32_t* out_limbs) {
+// One inversion per lane, amortised over K points (Montgomery's trick).  The inversion is a serial chain of ~45k
+// instructions whatever K is, so the kernel is fastest when there is about one wave per SIMD (1024 of them):
+// K = ceil(n / 65536), capped at 64 for large batches.
+template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
+                                          uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
     if (n == 0) return;
-    if (normalize_wg_enabled()) {
-        const size_t nthreads = (n + NormWg<CurveT>::K - 1) / NormWg<CurveT>::K;
-        hipLaunchKernelGGL((k_normalize_wg<CurveT, MODE>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, n, nthreads, out_xy,
-                           out_inf, out_limbs);
-        return;
-    }
     size_t k = (n + 65535) / 65536;
     if (k > 64) k = 64;
     if (const char* e = getenv("ECGPU_NORM_K")) {          // tuning knob: points per lane
         long v = atol(e);
         if (v >= 1 && v <= 1024) k = (size_t)v;
     }
-    const size_t nthreads = (n + k - 1) / k;
-    hipLaunchKernelGGL((k_normalize<CurveT, MODE>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads, out_xy,
-                       out_inf, out_limbs);
-}
-template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
-                                          uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
-    if (out_internal) launch_normalize_mode<NORM_PACKED>(s, proj, prefix, n, out_xy, out_inf, out_limbs);
-    else launch_normalize_mode<NORM_WIRE>(s, proj, prefix, n, out_xy, out_inf, out_limbs);
+    size_t nthreads = (n + k - 1) / k;
+    if (out_internal)
+        hipLaunchKernelGGL((k_normalize<CurveT, NORM_PACKED>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                           out_xy, out_inf, out_limbs);
+    else
+        hipLaunchKernelGGL((k_normalize<CurveT, NORM_WIRE>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                           out_xy, out_inf, out_limbs);
 }
 template <> void launch_normalize_compressed<CurveT>(hipStream_t s, const uint32_t* proj, uint32_t* prefix, size_t n,
                                                      uint8_t* out_x, uint8_t* out_tag) {
-    launch_normalize_mode<NORM_COMPRESSED>(s, proj, prefix, n, out_x, out_tag, (uint32_t*)nullptr);
+    if (n == 0) return;
+    size_t k = (n + 65535) / 65536;
+    if (k > 64) k = 64;
+    size_t nthreads = (n + k - 1) / k;
+    hipLaunchKernelGGL((k_normalize<CurveT, NORM_COMPRESSED>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                       out_x, out_tag, (uint32_t*)nullptr);
 }
 template <> void launch_fixed_base<CurveT>(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
                                            int nwin, uint32_t* proj_out, int* status) {

@@ -371,138 +371,6 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
     }
 }
 
-// ---- normalisation with ONE inversion per 256 x K points (round 4) ------------------------------------------------------
-// k_normalize above runs one inversion per LANE: at 2^20 points that is K = 16 points per lane at one wave per SIMD, the lane's
-// time is the inversion's ~12k dependent instructions + 16 serial iterations, each behind its own loads, and the running
-// products make a round trip through HBM (`prefix`: 96 B per point of the kernel's 290 MB).  Here Montgomery's trick has two
-// levels: a lane multiplies the Z of its K points (K = 8 for the 9/10-limb fields: the K running products stay in
-// REGISTERS, no scratch array), the workgroup's 256 lane products meet in LDS, ONE wave takes four of them per lane, inverts
-// their product — 64 inversions in lockstep, the cost of one — and hands every lane its own inverse back; the second pass is
-// the old one without the prefix loads.  One inversion per 4 K points instead of per K points at TWICE the waves per SIMD:
-// the per-point passes are throughput-bound again and the inversion is 1/4 of the waves' business.
-// The inverting wave rotates with the workgroup index so that the inverters of co-resident workgroups sit on different SIMDs.
-template <class C>
-struct NormWg {
-    static constexpr int K = C::NL <= 10 ? 8 : 4;     // points per lane (K x NL registers of running products)
-    static constexpr int W = BLOCK / 64;              // lane products per inverting lane
-};
-// pass 3 of k_normalize_wg for point J of the lane, then J - 1 ... 0 (a compile-time recursion: the running products are
-// indexed by constants and stay in registers; a `#pragma unroll` loop was unrolled by two only and read them from scratch)
-template <class C, int MODE, int J>
-struct NormWgBack {
-    using F = Field<C>;
-    using G = Group<C>;
-    using M1 = typename F::M1;
-    static __device__ __forceinline__ void run(const uint32_t* __restrict__ proj, size_t n, size_t nthreads, size_t t, uint32_t skip,
-                                               const M1 (&pre)[NormWg<C>::K], M1& inv, Proj<C>& p_next, uint8_t* __restrict__ out_xy,
-                                               uint8_t* __restrict__ out_inf, uint32_t* __restrict__ out_packed) {
-        constexpr int N = C::N, WB = WireBytes<C>::value;
-        (void)N;
-        const size_t idx = t + (size_t)J * nthreads;
-        const Proj<C> p = p_next;
-        if constexpr (J > 0) p_next = load_proj<C>(proj, idx - nthreads < n ? idx - nthreads : t);
-        if (idx < n) {
-            if ((skip >> J) & 1) {
-                if constexpr (MODE == NORM_WIRE) {
-                    zero_wire<C>(out_xy + idx * (2 * WB), 2);
-                    if (out_inf) out_inf[idx] = 1;
-                } else if constexpr (MODE == NORM_COMPRESSED) {
-                    zero_wire<C>(out_xy + idx * WB, 1);
-                    out_inf[idx] = 0;
-                }
-            } else {
-                const M1 zinv = F::mul(pre[J], inv);
-                inv = F::mul(inv, G::m(p.z));
-                const M1 x = F::mul(G::m(p.x), zinv), y = F::mul(G::m(p.y), zinv);
-                if constexpr (MODE == NORM_PACKED) {
-                    store_packed_affine<C>(out_packed + idx * (2 * N), x.e, y.e);
-                } else if constexpr (MODE == NORM_COMPRESSED) {
-                    uint32_t w[N];
-                    F::to_canonical(w, x);
-                    store_wire<C>(out_xy + idx * WB, w);
-                    F::to_canonical(w, y);
-                    out_inf[idx] = (uint8_t)(2u + (w[0] & 1u));
-                } else {
-                    uint32_t w[N];
-                    F::to_canonical(w, x);
-                    store_wire<C>(out_xy + idx * (2 * WB), w);
-                    F::to_canonical(w, y);
-                    store_wire<C>(out_xy + idx * (2 * WB) + WB, w);
-                    if (out_inf) out_inf[idx] = 0;
-                }
-            }
-        }
-        if constexpr (J > 0) NormWgBack<C, MODE, J - 1>::run(proj, n, nthreads, t, skip, pre, inv, p_next, out_xy, out_inf, out_packed);
-    }
-};
-template <class C, int MODE>
-__global__ void __launch_bounds__(BLOCK, 2) k_normalize_wg(const uint32_t* __restrict__ proj, size_t n, size_t nthreads,
-                                                           uint8_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf,
-                                                           uint32_t* __restrict__ out_packed) {
-    using F = Field<C>;
-    using G = Group<C>;
-    using M1 = typename F::M1;
-    constexpr int N = C::N, NL = C::NL, NS = F::NS, WB = WireBytes<C>::value, K = NormWg<C>::K, W = NormWg<C>::W;
-    (void)N;
-    __shared__ uint32_t xch[NL][BLOCK];               // the lanes' products, then their inverses (limb-major: no bank conflicts)
-    const uint32_t tid = threadIdx.x;
-    const size_t t = (size_t)blockIdx.x * BLOCK + tid;
-    const bool lane_live = t < nthreads;              // (no early return: every lane meets the barriers)
-    // pass 1: running products in registers.  Point j of the lane is record t + j * nthreads; `skip` bit j: not a point of
-    // the batch, or the identity (Z = 0), which takes no part in the product.
-    Fe<NL> z[K];
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        const size_t idx = t + (size_t)j * nthreads;
-        z[j] = load_raw<C>(proj + ((lane_live && idx < n) ? idx : 0) * (3 * NS) + 2 * NS);
-    }
-    M1 pre[K];
-    M1 acc = F::one();
-    uint32_t skip = 0;
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        const size_t idx = t + (size_t)j * nthreads;
-        pre[j] = acc;
-        const bool use = lane_live && idx < n && !F::is_zero(G::m(z[j]));
-        if (use) acc = F::mul(acc, G::m(z[j]));
-        else skip |= 1u << j;
-    }
-    // pass 2: the workgroup's lane products -> their inverses
-#pragma unroll
-    for (int i = 0; i < NL; i++) xch[i][tid] = acc.e.v[i];
-    __syncthreads();
-    if ((tid >> 6) == (blockIdx.x & (W - 1))) {
-        const uint32_t l = tid & 63;
-        M1 p[W], q[W];
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-#pragma unroll
-            for (int i = 0; i < NL; i++) p[w].e.v[i] = xch[i][l + 64 * w];
-        }
-        q[0] = p[0];
-#pragma unroll
-        for (int w = 1; w < W; w++) q[w] = F::mul(q[w - 1], p[w]);
-        M1 inv = F::inv(q[W - 1]);                    // (never zero: identities were left out)
-#pragma unroll
-        for (int w = W - 1; w >= 1; w--) {
-            const M1 r = F::mul(inv, q[w - 1]);
-            inv = F::mul(inv, p[w]);
-#pragma unroll
-            for (int i = 0; i < NL; i++) xch[i][l + 64 * w] = r.e.v[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NL; i++) xch[i][l] = inv.e.v[i];
-    }
-    __syncthreads();
-    if (!lane_live) return;
-    M1 inv;
-#pragma unroll
-    for (int i = 0; i < NL; i++) inv.e.v[i] = xch[i][tid];
-    // pass 3: from the lane's last point down; the record of the next point is requested before the arithmetic of this one
-    Proj<C> p_next = load_proj<C>(proj, (t + (size_t)(K - 1) * nthreads < n) ? t + (size_t)(K - 1) * nthreads : t);
-    NormWgBack<C, MODE, K - 1>::run(proj, n, nthreads, t, skip, pre, inv, p_next, out_xy, out_inf, out_packed);
-}
-
 // ---- fixed base: out[i] = k[i] * G -----------------------------------------------------------------
 // One lane per scalar; the algorithm and the reference citations are in ecgpu_fixedmul.h.
 template <class C>
