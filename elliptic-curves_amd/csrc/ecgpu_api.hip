@@ -607,9 +607,7 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
         HIP_TRY(ctx, hipEventRecord(l.ev_in, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(l.s, l.ev_in, 0));
         launch_msm<C>(plan, l.s, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, l.ws.p, (uint32_t*)l.proj.p,
-                      ctx->d_status, l.ev_a, l.ev_b);
-        launch_normalize<C>(l.s, false, (const uint32_t*)l.proj.p, (uint32_t*)l.prefix.p, 1, (uint8_t*)d_out_xy, (uint8_t*)d_out_inf,
-                            nullptr);
+                      ctx->d_status, l.ev_a, l.ev_b, (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);   // (the last kernel writes the wire record)
         return finish(ctx);
     }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
@@ -617,9 +615,8 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_msm<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
-                  ctx->msm_ws.p, (uint32_t*)ctx->proj.p, ctx->d_status, ctx->ev[3], ctx->ev[4]);
-    record(ctx, 1);
-    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+                  ctx->msm_ws.p, (uint32_t*)ctx->proj.p, ctx->d_status, ctx->ev[3], ctx->ev[4], (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);
+    record(ctx, 1);     // (the conversion to affine happens inside the last kernel of the chain: "normalize" is an empty span)
     record(ctx, 2);
     rc = finish(ctx);
     collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
@@ -663,9 +660,9 @@ int msm_finish_dev(ecgpu_ctx* ctx, const void* d_parts_all, int nranks, size_t p
     if ((rc = ensure(ctx, ctx->bases, (size_t)plan.nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
-    launch_msm_finish<C>(plan, ctx->stream, (const uint32_t*)d_parts_all, nranks, (uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p);
+    launch_msm_finish<C>(plan, ctx->stream, (const uint32_t*)d_parts_all, nranks, (uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p,
+                         (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);
     record(ctx, 1);
-    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
     record(ctx, 2);
     rc = finish(ctx);
     collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}});

@@ -208,12 +208,12 @@ __device__ __forceinline__ void load_scalar(uint32_t* k, const uint8_t* scalars,
 
 // affine point record -> internal form; returns false for the identity.  Flags coordinates >= p
 // and off-curve points (AffinePoint::from_coordinates, primeorder/src/affine.rs:100-109).
+// (cx, cy: the canonical coordinate words as read — for the plain-residue field of k256 they ARE the packed storage form)
 template <class C>
-__device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, const uint8_t* inf, size_t i,
-                                            const Fe<C::NL>& b, int* status) {
+__device__ __forceinline__ bool load_affine_words(Affine<C>* a, uint32_t* cx, uint32_t* cy, const uint8_t* xy, const uint8_t* inf,
+                                                  size_t i, const Fe<C::NL>& b, int* status) {
     using F = Field<C>;
     if (inf != nullptr && inf[i]) return false;
-    uint32_t cx[C::N], cy[C::N];
     load_wire<C>(cx, xy + i * (2 * WireBytes<C>::value));
     load_wire<C>(cy, xy + i * (2 * WireBytes<C>::value) + WireBytes<C>::value);
     bool ok = !mp_geq<C::N>(cx, C::P) && !mp_geq<C::N>(cy, C::P);
@@ -222,6 +222,12 @@ __device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, con
     ok = ok && Group<C>::on_curve(*a, b);
     if (!ok) atomicOr(status, ST_BAD_POINT);
     return true;
+}
+template <class C>
+__device__ __forceinline__ bool load_affine(Affine<C>* a, const uint8_t* xy, const uint8_t* inf, size_t i,
+                                            const Fe<C::NL>& b, int* status) {
+    uint32_t cx[C::N], cy[C::N];
+    return load_affine_words<C>(a, cx, cy, xy, inf, i, b, status);
 }
 
 // ---- basepoint table construction -------------------------------------------------------------------

@@ -23,6 +23,10 @@ struct MsmPlan {
     // by the remaining sort_bits_b bits inside the partitions.  sort_bits_b = 0: single-level sort.
     int sort_bits_b = 0;
     size_t npart = 0, ntiles2 = 0;
+    // packed form of the two-level sort (round 4): ONE 32-bit word per entry between the levels — index | sign << idx_bits |
+    // low bucket bits << (idx_bits + 1) — and level B as one workgroup per partition; needs idx_bits + 1 + sort_bits_b <= 32
+    bool sort_packed = false;
+    int idx_bits = 0;
     size_t off_tmpidx = 0, off_tmpkey = 0, off_count_a = 0, off_offset_a = 0, off_cursor = 0;
     size_t max_big = 0;            // upper bound on the number of buckets that have more than MSM_BIG_PARTIALS partial sums
     // sub-terms: MsmSplit<C>::SUB per term (k256: the two GLV halves), sub-term h of term i at index h * npad + i
@@ -96,12 +100,13 @@ template <class C> int msm_choose_window(size_t n);
 template <class C> size_t msm_max_terms();              // sorted entries are sub-term index | sign << 31
 template <class C> void launch_msm(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,
                                    const uint8_t* inf, size_t n, void* workspace, uint32_t* out, int* status,
-                                   hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
+                                   hipEvent_t ev_sorted, hipEvent_t ev_accumulated, uint8_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 template <class C> void launch_msm_parts(const MsmPlan& p, hipStream_t s, const uint8_t* scalars, const uint8_t* xy,
                                          const uint8_t* inf, size_t n, void* workspace, uint32_t* parts, int* status,
                                          hipEvent_t ev_sorted, hipEvent_t ev_accumulated);
+// out_xy != nullptr: the result as a wire record (x || y, identity flag) straight from the last kernel; otherwise projective in out[0]
 template <class C> void launch_msm_finish(const MsmPlan& p, hipStream_t s, const uint32_t* parts_all, int nranks, uint32_t* wins,
-                                          uint32_t* out);
+                                          uint32_t* out, uint8_t* out_xy = nullptr, uint8_t* out_inf = nullptr);
 
 // ---- curve-independent ----
 void launch_schnorr_prepare_raw(hipStream_t s, const uint8_t* pk_x, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs,

@@ -78,9 +78,15 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
             S::split(k, sub, flip);
             Fe<C::NL> b = G::curve_b();
             Affine<C> a;
-            finite = load_affine<C>(&a, points_xy, points_inf, ii, b, status);
+            uint32_t cx[N], cy[N];
+            finite = load_affine_words<C>(&a, cx, cy, points_xy, points_inf, ii, b, status);
             if (finite) {
-                store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
+                if constexpr (F::REPR == REPR_U29_K256) {     // plain residues: the canonical words read ARE the packed form
+                    store_words_vec<N>(pts + ii * (2 * N), cx);
+                    store_words_vec<N>(pts + ii * (2 * N) + N, cy);
+                } else {
+                    store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
+                }
                 if constexpr (S::SUB == 2)
                     store_packed_affine<C>(pts + (npad + ii) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
             }
@@ -330,6 +336,203 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
     }
 }
 
+// ---- two-level sort, packed form (round 4) ---------------------------------------------------------------------------------
+// The same two levels with ONE 32-bit word per entry between them and no global atomics in level B:
+//   level A  (k_msm_sort_a) partitions a window's entries by the top bits_a bits of the bucket and writes
+//            packed = index | sign << idx_bits | (bucket & (2^bits_b - 1)) << (idx_bits + 1)
+//            — 4 bytes per entry instead of a 4-byte index + a 2-byte code (idx_bits = ceil(log2(entries per window)); the
+//            plan uses this form whenever idx_bits + 1 + bits_b <= 32).  A lane takes 8 CONSECUTIVE entries: their codes are
+//            one 16-byte load and their validity bits one byte, instead of 8 halfword loads + 8 looks at the mask words;
+//   level B  (k_msm_sort_b) is ONE workgroup per (partition, window): it counts the partition's entries per bucket in an LDS
+//            histogram (pass 1), turns the counts into the window's `counts` / `offsets` rows itself (the partition's start
+//            comes from level A's scan), and scatters tile by tile through the LDS staging buffer with LDS cursors (pass 2).
+//            No separate counting launch, no scan over 2^15 counters, no cursor copy, no global atomic per (tile, key).
+// A partition is ~65,536 entries (256 KiB) at 2^24 terms.  A degenerate input puts a whole window into ONE partition, i.e.
+// one workgroup streams it (a few ms more for 2^24 equal scalars); its lanes then all want the same LDS counter, so a
+// partition above MSM_SORTB_HEAVY entries ranks with one LDS atomic per distinct key and wave (msm_lds_rank<true>).
+constexpr uint32_t MSM_SORTB_HEAVY = 1u << 18;
+constexpr int MSM_SORTP_MAX_BITS_A = 9;        // level-A keys: <= 512 (k_msm_prepare holds nwin x 2^bits_a counters in LDS)
+constexpr int MSM_SORTP_MAX_BITS_B = 8;        // level-B keys: <= 256
+
+// rank of this lane's entry among the entries of its key counted so far in cnt[] (LDS); AGG: the lanes of a wave that
+// share a key are counted with one atomic per distinct key (loop over the distinct keys of the wave)
+template <bool AGG>
+__device__ __forceinline__ uint32_t msm_lds_rank(uint32_t* cnt, uint32_t key, bool live) {
+    if constexpr (!AGG) {
+        return live ? atomicAdd(&cnt[key], 1u) : 0u;
+    } else {
+        uint32_t rank = 0;
+        const int lane = (int)(threadIdx.x & 63);
+        unsigned long long todo = __ballot(live);
+        while (todo) {                                   // wave-uniform
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lk = (uint32_t)__shfl((int)key, leader, 64);
+            const bool same = live && key == lk;
+            const unsigned long long m = __ballot(same);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cnt[lk], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (same) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            todo &= ~m;
+        }
+        return rank;
+    }
+}
+
+// loc[0 .. nkeys) = exclusive prefix sums of cnt[0 .. nkeys), nkeys <= blockDim.x (a multiple of 64, <= 1024); returns the
+// total.  Every thread calls it; cnt must be final (barrier before), loc is valid on return (barrier inside).
+__device__ __forceinline__ uint32_t msm_block_scan(const uint32_t* cnt, uint32_t* loc, uint32_t nkeys, uint32_t* wtot) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const uint32_t mine = tid < nkeys ? cnt[tid] : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((int)(tid & 63) >= d) incl += v;
+    }
+    if ((tid & 63) == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t k = 0; k < nwaves; k++) {
+        const uint32_t v = wtot[k];
+        if (k < wave) before += v;
+        total += v;
+    }
+    if (tid < nkeys) loc[tid] = before + incl - mine;
+    __syncthreads();
+    return total;
+}
+
+// grid (ceil(n / 8192), nwin), 1024 lanes.  cursor[w][key]: the run starts (level A's scan), advanced by one global
+// atomicAdd per (tile, key) as in k_msm_sort2.
+static __global__ void __launch_bounds__(1024, 8)
+k_msm_sort_a(const uint16_t* __restrict__ digits, const unsigned long long* __restrict__ vmask, size_t n, int bits_b, int idx_bits,
+             uint32_t npart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ out) {
+    __shared__ uint32_t cnt[1 << MSM_SORTP_MAX_BITS_A], loc[1 << MSM_SORTP_MAX_BITS_A], gbase[1 << MSM_SORTP_MAX_BITS_A], wtot[16];
+    __shared__ uint32_t stage[MSM_SORT2_TILE];
+    __shared__ uint16_t stage_k[MSM_SORT2_TILE];
+    const size_t w = blockIdx.y;
+    const uint32_t tid = threadIdx.x;
+    const size_t i0 = (size_t)blockIdx.x * MSM_SORT2_TILE + (size_t)tid * MSM_SORT2_PER_LANE;   // n is a multiple of 64
+    const bool in = i0 < n;
+    uint32_t cw[4] = {0, 0, 0, 0};
+    uint32_t vb = 0;
+    if (in) {
+        const uint4 dv = *reinterpret_cast<const uint4*>(digits + w * n + i0);
+        cw[0] = dv.x; cw[1] = dv.y; cw[2] = dv.z; cw[3] = dv.w;
+        vb = reinterpret_cast<const uint8_t*>(vmask + w * (n / 64))[i0 >> 3];
+    }
+    if (tid < npart) cnt[tid] = 0;
+    __syncthreads();
+    const uint32_t mask_b = (1u << bits_b) - 1;
+    uint32_t key[MSM_SORT2_PER_LANE], rank[MSM_SORT2_PER_LANE];
+#pragma unroll
+    for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+        const uint32_t c16 = (cw[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+        key[u] = (c16 & 0x7FFFu) >> bits_b;
+        rank[u] = msm_lds_rank<false>(cnt, key[u], (vb >> u) & 1u);
+    }
+    __syncthreads();
+    const uint32_t mine = tid < npart ? cnt[tid] : 0u;
+    uint32_t gb = 0;
+    if (mine) gb = atomicAdd(&cursor[w * npart + tid], mine);          // flies under the scan and the staging
+    const uint32_t total = msm_block_scan(cnt, loc, npart, wtot);
+#pragma unroll
+    for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+        if (!((vb >> u) & 1u)) continue;
+        const uint32_t c16 = (cw[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+        const uint32_t slot = loc[key[u]] + rank[u];
+        stage[slot] = (uint32_t)(i0 + u) | ((c16 >> 15) << idx_bits) | ((c16 & mask_b) << (idx_bits + 1));
+        stage_k[slot] = (uint16_t)key[u];
+    }
+    if (mine) gbase[tid] = gb;
+    __syncthreads();
+    uint32_t* ow = out + w * n;
+    for (uint32_t slot = tid; slot < total; slot += 1024) {
+        const uint32_t k = stage_k[slot];
+        ow[gbase[k] + (slot - loc[k])] = stage[slot];
+    }
+}
+
+// grid (npart, nwin); blockDim 256 or 1024.  in: level A's output; part_offsets / part_counts [nwin][npart]: level A's
+// scan / histogram.  Writes counts / offsets [nwin][npart << bits_b] and sorted[w][.] = index | sign << 31.
+template <bool HEAVY>
+__device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src, uint32_t np, uint32_t lo, int bits_b, int idx_bits,
+                                                uint32_t* __restrict__ counts_row, uint32_t* __restrict__ offsets_row,
+                                                uint32_t* __restrict__ sorted_w, uint32_t* hist, uint32_t* cur, uint32_t* cnt,
+                                                uint32_t* loc, uint32_t* wtot, uint32_t* stage) {
+    const uint32_t tid = threadIdx.x, T = blockDim.x, tile = T * MSM_SORT2_PER_LANE;
+    const uint32_t nkeys = 1u << bits_b, kshift = (uint32_t)idx_bits + 1, idx_mask = (1u << idx_bits) - 1;
+    if (tid < nkeys) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < np; base += tile) {                 // pass 1: the partition's histogram
+        uint32_t v[MSM_SORT2_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = base + (uint32_t)u * T + tid;
+            v[u] = src[i < np ? i : np - 1];                           // (no exec-masked load: the dead lanes re-read the last entry)
+        }
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = base + (uint32_t)u * T + tid;
+            (void)msm_lds_rank<HEAVY>(hist, v[u] >> kshift, i < np);
+        }
+    }
+    __syncthreads();
+    (void)msm_block_scan(hist, loc, nkeys, wtot);
+    if (tid < nkeys) {
+        counts_row[tid] = hist[tid];
+        offsets_row[tid] = lo + loc[tid];
+        cur[tid] = lo + loc[tid];
+    }
+    for (uint32_t base = 0; base < np; base += tile) {                 // pass 2: tile by tile through the staging buffer
+        if (tid < nkeys) cnt[tid] = 0;
+        __syncthreads();                                               // (also: cur[] of the previous tile is final)
+        uint32_t v[MSM_SORT2_PER_LANE], rank[MSM_SORT2_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = base + (uint32_t)u * T + tid;
+            v[u] = src[i < np ? i : np - 1];                           // (no exec-masked load: the dead lanes re-read the last entry)
+        }
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = base + (uint32_t)u * T + tid;
+            rank[u] = msm_lds_rank<HEAVY>(cnt, v[u] >> kshift, i < np);
+        }
+        __syncthreads();
+        const uint32_t total = msm_block_scan(cnt, loc, nkeys, wtot);
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = base + (uint32_t)u * T + tid;
+            if (i < np) stage[loc[v[u] >> kshift] + rank[u]] = v[u];
+        }
+        __syncthreads();
+        for (uint32_t slot = tid; slot < total; slot += T) {
+            const uint32_t p = stage[slot], k = p >> kshift;
+            sorted_w[cur[k] + (slot - loc[k])] = (p & idx_mask) | (((p >> idx_bits) & 1u) << 31);
+        }
+        __syncthreads();
+        if (tid < nkeys) cur[tid] += cnt[tid];
+    }
+}
+static __global__ void __launch_bounds__(1024, 8)
+k_msm_sort_b(const uint32_t* __restrict__ in, size_t n, int bits_b, int idx_bits, uint32_t npart,
+             const uint32_t* __restrict__ part_offsets, const uint32_t* __restrict__ part_counts, uint32_t* __restrict__ counts,
+             uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t hist[1 << MSM_SORTP_MAX_BITS_B], cur[1 << MSM_SORTP_MAX_BITS_B], cnt[1 << MSM_SORTP_MAX_BITS_B],
+        loc[1 << MSM_SORTP_MAX_BITS_B], wtot[16];
+    __shared__ uint32_t stage[MSM_SORT2_TILE];
+    const size_t w = blockIdx.y, p = blockIdx.x;
+    const uint32_t lo = part_offsets[w * npart + p], np = part_counts[w * npart + p];
+    const size_t nb = (size_t)npart << bits_b, row = w * nb + (p << bits_b);
+    if (np > MSM_SORTB_HEAVY)
+        msm_sort_b_body<true>(in + w * n + lo, np, lo, bits_b, idx_bits, counts + row, offsets + row, sorted + w * n, hist, cur, cnt, loc,
+                              wtot, stage);
+    else
+        msm_sort_b_body<false>(in + w * n + lo, np, lo, bits_b, idx_bits, counts + row, offsets + row, sorted + w * n, hist, cur, cnt,
+                               loc, wtot, stage);
+}
+
 // ---- accumulate: the hot loop --------------------------------------------------------------------------------------
 template <class C>
 struct MsmPointsHbm {
@@ -573,8 +776,11 @@ __device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
 
 // out = sum_w 2^(c w) wins[w]   (Horner).  One wave; lanes 0..2 share the doublings (above), every lane carries the same
 // accumulator, lane 0 stores.
+// out_xy != nullptr: the result leaves the kernel as a wire record (affine x || y + identity flag, what k_normalize<C, NORM_WIRE>
+// writes for one point) instead of a projective point in `out` — one launch and one load round trip less at the end of the chain.
 template <class C>
-__global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__ wins, int c, int nwin, uint32_t* __restrict__ out,
+                                                    uint8_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf) {
     using G = Group<C>;
     if (blockIdx.x != 0) return;
     const int lane = (int)threadIdx.x;
@@ -608,7 +814,27 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
         }
         acc = G::add(acc, load_proj<C>(vw, w), b);
     }
-    if (lane == 0) store_proj<C>(out, 0, acc);
+    if (out_xy == nullptr) {
+        if (lane == 0) store_proj<C>(out, 0, acc);
+        return;
+    }
+    // `to_affine` (k256 projective.rs:64-75, primeorder projective.rs:74-86) on the one point; every lane computes, lane 0 stores
+    using F = Field<C>;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    const bool ident = G::is_identity(acc);
+    uint32_t wx[N], wy[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) wx[i] = wy[i] = 0;
+    if (!ident) {
+        const typename F::M1 zinv = F::inv(G::m(acc.z));
+        F::to_canonical(wx, F::mul(G::m(acc.x), zinv));
+        F::to_canonical(wy, F::mul(G::m(acc.y), zinv));
+    }
+    if (lane == 0) {
+        store_wire<C>(out_xy, wx);
+        store_wire<C>(out_xy + WB, wy);
+        if (out_inf) out_inf[0] = ident ? 1 : 0;
+    }
 }
 
 // out[0 .. count) = the identity
@@ -736,10 +962,23 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
         if (const char* e = getenv("ECGPU_MSM_SORT2")) two = atoi(e) != 0;
         if (two && p.c - 1 > MSM_SORT2_BITS_A) {
             p.sort_bits_b = p.c - 1 - MSM_SORT2_BITS_A;
+            // packed form: as many low bucket bits as fit beside the index and the sign (fewer low bits = more level-A keys)
+            int idx_bits = 1;
+            while (((size_t)1 << idx_bits) < ne) idx_bits++;
+            int bb = p.sort_bits_b;
+            if (bb > 31 - idx_bits) bb = 31 - idx_bits;
+            if (bb > MSM_SORTP_MAX_BITS_B) bb = MSM_SORTP_MAX_BITS_B;
+            bool packed = bb >= 1 && p.c - 1 - bb <= MSM_SORTP_MAX_BITS_A;
+            if (const char* e = getenv("ECGPU_MSM_SORT_PACKED")) packed = packed && atoi(e) != 0;   // 0: the round-3 kernels (A/B runs)
+            if (packed) {
+                p.sort_packed = true;
+                p.idx_bits = idx_bits;
+                p.sort_bits_b = bb;
+            }
             p.npart = p.nb >> p.sort_bits_b;
             p.ntiles2 = (ne + MSM_SORT2_TILE - 1) / MSM_SORT2_TILE;
             p.off_tmpidx = o;  o = align(o + (size_t)p.nwin * ne * 4);
-            p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * ne * 2);
+            if (!p.sort_packed) { p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * ne * 2); }
             p.off_count_a = o;  o = align(o + (size_t)p.nwin * p.npart * 4);
             p.off_offset_a = o; o = align(o + (size_t)p.nwin * p.npart * 4);
             p.off_cursor = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
@@ -840,7 +1079,7 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     const size_t prep_lds = p.sort_bits_b ? (size_t)p.nwin * p.npart * 4 : 0;
     if (p.sort_bits_b) {
         (void)hipMemsetAsync(counts_a0, 0, (size_t)p.nwin * p.npart * 4, stream);
-        (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
+        if (!p.sort_packed) (void)hipMemsetAsync(counts, 0, (size_t)p.nwin * p.nb * 4, stream);
     }
     if constexpr (MsmHasGlv<C>::value) {
         if (p.glv)
@@ -850,7 +1089,21 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     if (!p.glv)
         hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
                            p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart, reps);
-    if (p.sort_bits_b) {
+    if (p.sort_packed) {
+        uint32_t* tmp = (uint32_t*)(ws + p.off_tmpidx);
+        uint32_t* counts_a = (uint32_t*)(ws + p.off_count_a);
+        uint32_t* offsets_a = (uint32_t*)(ws + p.off_offset_a);
+        uint32_t* cursor = (uint32_t*)(ws + p.off_cursor);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart);
+        (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
+        hipLaunchKernelGGL(k_msm_sort_a, dim3((unsigned)p.ntiles2, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint16_t*)digits,
+                           (const unsigned long long*)vmask, ne, p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, cursor, tmp);
+        // level B: one workgroup per (partition, window); small partitions (small MSMs) get 256 lanes
+        const unsigned tb = ne / p.npart >= 4096 ? 1024u : 256u;
+        hipLaunchKernelGGL(k_msm_sort_b, dim3((unsigned)p.npart, (unsigned)p.nwin), dim3(tb), 0, stream, (const uint32_t*)tmp, ne,
+                           p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, (const uint32_t*)offsets_a, (const uint32_t*)counts_a, counts,
+                           offsets, sorted);
+    } else if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
         uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);
         uint32_t* counts_a = (uint32_t*)(ws + p.off_count_a);
@@ -890,25 +1143,27 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
 }
 
 // Second half: the window sums over `nranks` sets of partial sums (laid out [rank][nwin][nparts]) and the Horner chain
-// over the windows; the result (projective, internal form) lands in out[0].  `wins` is nwin points of scratch.
+// over the windows; the result lands in out[0] (projective, internal form) or, if out_xy is given, in out_xy / out_inf as a
+// wire record.  `wins` is nwin points of scratch.
 template <class C>
-void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out) {
+void launch_msm_finish(const MsmPlan& p, hipStream_t stream, const uint32_t* parts_all, int nranks, uint32_t* wins, uint32_t* out,
+                       uint8_t* out_xy, uint8_t* out_inf) {
     // the tree of k_msm_window_sums is as wide as the parts of all ranks need, not wider (16 parts: 4 levels, not 8)
     int items = nranks * (int)p.nparts, block = 64;
     while (block < items && block < BLOCK) block *= 2;
     hipLaunchKernelGGL(k_msm_window_sums<C>, dim3((unsigned)p.nwin), dim3(block), 0, stream, parts_all, nranks, p.nwin, (int)p.nparts, wins);
-    hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out);
+    hipLaunchKernelGGL(k_msm_combine<C>, dim3(1), dim3(64), 0, stream, (const uint32_t*)wins, p.c, p.nwin, out, out_xy, out_inf);
 }
 
 // The whole pipeline on one GPU.
 template <class C>
 void launch_msm(const MsmPlan& p, hipStream_t stream, const uint8_t* d_scalars, const uint8_t* d_xy,
                 const uint8_t* d_inf, size_t n, void* workspace, uint32_t* out, int* d_status, hipEvent_t ev_sorted,
-                hipEvent_t ev_accumulated) {
+                hipEvent_t ev_accumulated, uint8_t* out_xy, uint8_t* out_inf) {
     uint8_t* ws = (uint8_t*)workspace;
     uint32_t* parts = (uint32_t*)(ws + p.off_parts);
     launch_msm_parts<C>(p, stream, d_scalars, d_xy, d_inf, n, workspace, parts, d_status, ev_sorted, ev_accumulated);
-    launch_msm_finish<C>(p, stream, parts, 1, (uint32_t*)(ws + p.off_wins), out);
+    launch_msm_finish<C>(p, stream, parts, 1, (uint32_t*)(ws + p.off_wins), out, out_xy, out_inf);
 }
 
 }  // namespace ecgpu
