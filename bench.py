@@ -48,6 +48,7 @@ import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -249,6 +250,42 @@ def cpu_plumbing_record():
             "check_vs_model": bool(ok)}
 
 
+def group_msm_in_child(args, world, timeout=300.0):
+    """Rank 0, N > 1: `bench.py --group-msm-child N` in a process of its own — all N GPUs from one process through
+    ecgpu_group_msm_dev — with a deadline; -> its record, or {"skipped": reason}."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-msm-child", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.n:
+        cmd += ["--n", str(args.n)]
+    if args.no_check:
+        cmd += ["--no-check"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")
+           and not k.startswith("TORCHELASTIC")}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "ecgpu_group_msm child still running after %.0f s (killed)" % timeout}
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        tail = [ln for ln in (p.stderr or "").strip().splitlines() if ln.strip()]
+        return {"skipped": "ecgpu_group_msm child exit %s: %s" % (p.returncode, (tail[-1] if tail else "no output")[:300])}
+    return json.loads(lines[-1])
+
+
+def group_msm_child_main(args):
+    import torch
+    b = Bench.__new__(Bench)
+    b.torch, b.dist, b.args = torch, None, args
+    b.world, b.rank, b.device = args.group_msm_child, 0, "cuda:0"
+    torch.cuda.set_device(0)
+    b.ecgpu = importlib.import_module("elliptic-curves_amd")
+    b.eng = b.ecgpu.Engine(0)
+    b.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        return b.group_msm()
+    finally:
+        b.eng.close()
+
+
 class Bench:
     def __init__(self, args):
         import torch
@@ -263,7 +300,7 @@ class Bench:
             args.gpus = self.world
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a gfx950 GPU; there is no CPU path")
-        # Dry-run knobs for a one-GPU box (tools/gpu_run.sh recipe `bench2`): ECGPU_BENCH_SHARE_GPU=1 puts every rank on
+        # Dry-run knobs for a one-GPU box (tools/gpu_run.sh recipes `bench2` / `benchN`): ECGPU_BENCH_SHARE_GPU=1 puts every rank on
         # device 0 and ECGPU_BENCH_BACKEND=gloo moves the (tiny) exchange through the host, so that the N > 1 code path —
         # term shards, parts / finish around the all-gather, the collective check — can be exercised where RCCL cannot run
         # (it refuses two ranks on one device).  The driver's launch uses neither: one GPU per rank, RCCL.
@@ -272,20 +309,26 @@ class Bench:
             local_rank = 0
         torch.cuda.set_device(local_rank)
         self.device = "cuda:%d" % local_rank
-        if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=torch.device(self.device))
-            else:
-                dist.init_process_group(self.backend)
         self.ecgpu = importlib.import_module("elliptic-curves_amd")
+        self.exchange_kind, self.exchange_reason, self.group = "none", "one rank", None
+        if self.world > 1:
+            # The first contact with RCCL on N GPUs happens in the driver's ONE scaling run, so it must not be able to lose that
+            # run: the control plane (barriers, max-over-ranks timing, the check's gathers) is gloo, RCCL is tried in a child
+            # process per rank first and becomes the data path only if every canary and the group's first collective are
+            # healthy; otherwise the 41 KiB records travel through gloo and the line says so (sharded.init_exchange).
+            ex = self.ecgpu.init_exchange(torch, dist, local_rank, prefer=self.backend)
+            self.exchange_kind, self.exchange_reason, self.group = ex.kind, ex.reason, ex.group
         self.eng = self.ecgpu.Engine(local_rank)
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
         self.peak = None
 
     def fence(self):
         if self.world > 1:
-            self.dist.barrier()
+            self.torch.cuda.synchronize()
+            if self.group is not None:
+                self.dist.barrier(group=self.group)          # RCCL: a device-side barrier (tens of microseconds)
+            else:
+                self.dist.barrier()                          # gloo (fallback / dry runs)
         self.torch.cuda.synchronize()
 
     def valu_peak(self):
@@ -359,7 +402,7 @@ class Bench:
         exchange = None
         if kind == "msm" and world > 1:
             plan_terms = (n_total + world - 1) // world              # the largest shard: every rank plans the same windows
-            exchange = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device)
+            exchange = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device, group=self.group)
         torch.cuda.synchronize()     # inputs were written on torch's stream; make sure they are there whatever stream the engine uses
 
         main_ms, stages = [], {}
@@ -429,7 +472,7 @@ class Bench:
                 eng.set_msm_lanes(1)
             eng.set_async(False)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device if self.backend == "nccl" else "cpu")
+            t = torch.tensor([elapsed], dtype=torch.float64)           # (the control plane is gloo: a host tensor)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
@@ -518,6 +561,7 @@ class Bench:
             "scaling": wl["scaling"], "vs_baseline": None, "dtype": "u32 limbs (v_mad_u64_u32)", "data": "synthetic",
             "config": {"workload": name, "curve": wl["curve"], "units_per_gpu": n, "units_total": units_per_step,
                        "window_bits": args.window or "default", "parallelism": "shard%d" % world,
+                       **({"exchange": self.exchange_kind, "exchange_reason": self.exchange_reason} if world > 1 else {}),
                        **({"dry_run": "ranks share one GPU, %s exchange" % self.backend} if os.environ.get("ECGPU_BENCH_SHARE_GPU") else {})},
             "calls": "%d MSMs in flight (ecgpu_set_async + ecgpu_set_msm_lanes), drained inside the timed region; kernel_ms = the last "
                      "accumulation kernel with the other lanes' kernels beside it" % lanes if lanes > 1
@@ -639,7 +683,8 @@ class Bench:
                 oracle_lib.build()
                 w, wf = oracle_lib.batch_mul_base(cid, np.frombuffer((dot % ecgpu.GROUP_ORDERS[cid]).to_bytes(L, "big"), np.uint8))
                 ok = bytes(w) == bytes(out) and int(wf[0]) == int(inf)
-            return {"value": n_total / dt, "unit": "terms/s", "ms_per_step": dt * 1e3, "exchange": grp.exchange, "check_vs_oracle": ok,
+            return {"value": n_total / dt, "unit": "terms/s", "ms_per_step": dt * 1e3, "exchange": grp.exchange,
+                    "exchange_reason": grp.exchange_reason, "check_vs_oracle": ok,
                     "calls": "synchronous ecgpu_group_msm_dev from one process, result (65 bytes) downloaded inside the call"}
         finally:
             grp.close()
@@ -718,7 +763,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="default run: skip the PCIe-inclusive host-pointer MSM (N = 1) / the single-process group MSM (N > 1)")
     ap.add_argument("--cpu-plumbing", action="store_true",
                     help="BASELINE configs[0] alone: 1024 k256 generator multiplications on the CPU reference path (no GPU needed)")
+    ap.add_argument("--group-msm-child", type=int, default=0, help=argparse.SUPPRESS)     # internal: see group_msm_in_child
     args = ap.parse_args()
+    if args.group_msm_child:
+        print(json.dumps(group_msm_child_main(args)), flush=True)
+        return None
     if args.cpu_plumbing:
         rec = cpu_plumbing_record()
         print(json.dumps(rec), flush=True)
@@ -747,7 +796,9 @@ def main():
             e2e = b.e2e_msm()
         else:
             if b.rank == 0:
-                group = b.group_msm()
+                # in a child process with a deadline: the library's own RCCL communicator (ncclCommInitAll over all GPUs from
+                # one process) meets this hardware for the first time here, and a hang must not cost the line above
+                group = group_msm_in_child(args, b.world)
             b.fence()
     if rec is not None and single:
         print(json.dumps(rec), flush=True)                       # profiling / sweep runs: the full record of one workload

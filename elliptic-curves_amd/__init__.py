@@ -59,6 +59,8 @@ ABI_SYMBOLS = [
     "ecgpu_group_ecdsa_verify_batch", "ecgpu_group_ecdsa_verify_msg_batch", "ecgpu_group_ecdsa_recover_batch",
     "ecgpu_batch_mul_base_ct", "ecgpu_batch_mul_base_ct_dev", "ecgpu_batch_mul_ct", "ecgpu_batch_mul_ct_dev",
     "ecgpu_batch_ecdh_ct", "ecgpu_batch_ecdh_ct_dev",
+    "ecgpu_lincomb_ct", "ecgpu_lincomb_ct_dev", "ecgpu_msm_compressed", "ecgpu_msm_compressed_dev",
+    "ecgpu_batch_mul_compressed", "ecgpu_batch_mul_compressed_dev", "ecgpu_wipe", "ecgpu_group_exchange_reason",
 ]
 
 
@@ -111,6 +113,8 @@ def load_library():
     lib.ecgpu_copy_to_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     lib.ecgpu_group_last_error.restype = ctypes.c_char_p
     lib.ecgpu_group_exchange.restype = ctypes.c_char_p
+    lib.ecgpu_group_exchange_reason.restype = ctypes.c_char_p
+    lib.ecgpu_group_exchange_reason.argtypes = [ctypes.c_void_p]
     lib.ecgpu_group_last_error.argtypes = [ctypes.c_void_p]
     lib.ecgpu_group_exchange.argtypes = [ctypes.c_void_p]
     lib.ecgpu_group_destroy.restype = None
@@ -337,6 +341,44 @@ class Engine:
         self._chk(self._lib.ecgpu_msm(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
         return out, int(inf[0])
 
+    def lincomb_ct(self, curve, scalars, points_xy, points_inf=None):
+        """sum_i k_i P_i by the uniform-schedule entry point (ecgpu_lincomb_ct: `LinearCombination::lincomb` in its constant-time
+        form) — for secret scalars; `lincomb` (the bucket method) is the one for public data."""
+        L = _field_bytes(curve)
+        s, p, pi = _host(scalars), _host(points_xy), _host(points_inf)
+        n = s.size // L
+        _need("scalars", s, n * L); _need("points_xy", p, n * 2 * L); _need("points_inf", pi, n)
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_lincomb_ct(self._ctx, curve, _hp(s), _hp(p), _hp(pi), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
+    def lincomb_compressed(self, curve, scalars, points_x, points_tag):
+        """sum_i k_i P_i with SEC1-compressed points: points_x n*L bytes, points_tag n bytes (0x02 / 0x03, 0x00 = identity)."""
+        L = _field_bytes(curve)
+        s, x, t = _host(scalars), _host(points_x), _host(points_tag)
+        n = s.size // L
+        _need("scalars", s, n * L); _need("points_x", x, n * L); _need("points_tag", t, n)
+        out = np.zeros(2 * L, np.uint8)
+        inf = np.zeros(1, np.uint8)
+        self._chk(self._lib.ecgpu_msm_compressed(self._ctx, curve, _hp(s), _hp(x), _hp(t), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, int(inf[0])
+
+    def mul_compressed(self, curve, scalars, points_x, points_tag):
+        """k_i * P_i with SEC1-compressed points (see lincomb_compressed); returns (xy uint8[n*2L], inf uint8[n])."""
+        L = _field_bytes(curve)
+        s, x, t = _host(scalars), _host(points_x), _host(points_tag)
+        n = s.size // L
+        _need("scalars", s, n * L); _need("points_x", x, n * L); _need("points_tag", t, n)
+        out = np.zeros(n * 2 * L, np.uint8)
+        inf = np.zeros(n, np.uint8)
+        self._chk(self._lib.ecgpu_batch_mul_compressed(self._ctx, curve, _hp(s), _hp(x), _hp(t), ctypes.c_size_t(n), _hp(out), _hp(inf)))
+        return out, inf
+
+    def wipe(self):
+        """ecgpu_wipe: zero every staging / scratch buffer of the context on the device."""
+        self._chk(self._lib.ecgpu_wipe(self._ctx))
+
     def mul_by_generator_and_mul_add(self, curve, a_scalars, b_scalars, points_xy, points_inf=None):
         L = _field_bytes(curve)
         a, b, p, pi = _host(a_scalars), _host(b_scalars), _host(points_xy), _host(points_inf)
@@ -543,6 +585,18 @@ class Engine:
         self._chk(self._lib.ecgpu_msm_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
                                           ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
 
+    def lincomb_ct_dev(self, curve, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf):
+        self._chk(self._lib.ecgpu_lincomb_ct_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
+                                                 ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
+    def lincomb_compressed_dev(self, curve, d_scalars, d_points_x, d_points_tag, n, d_out_xy, d_out_inf):
+        self._chk(self._lib.ecgpu_msm_compressed_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_x), _dp(d_points_tag),
+                                                     ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
+    def mul_compressed_dev(self, curve, d_scalars, d_points_x, d_points_tag, n, d_out_xy, d_out_inf=None):
+        self._chk(self._lib.ecgpu_batch_mul_compressed_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_x), _dp(d_points_tag),
+                                                           ctypes.c_size_t(n), _dp(d_out_xy), _dp(d_out_inf)))
+
     # an MSM spread over several GPUs: local half -> all-gather of the parts -> combining half (include/ecgpu.h)
     def msm_parts_bytes(self, curve, plan_terms):
         return int(self._lib.ecgpu_msm_parts_bytes(self._ctx, curve, ctypes.c_size_t(plan_terms)))
@@ -598,6 +652,7 @@ class Group:
             raise EcgpuError(rc, "ecgpu_group_init failed")
         self.size = int(self._lib.ecgpu_group_size(self._g))
         self.exchange = self._lib.ecgpu_group_exchange(self._g).decode()
+        self.exchange_reason = self._lib.ecgpu_group_exchange_reason(self._g).decode()
 
     def close(self):
         if getattr(self, "_g", None):
@@ -702,4 +757,4 @@ def version():
     return load_library().ecgpu_version().decode()
 
 
-from .sharded import RecordExchange, TensorExchange, lincomb_sharded, shard_range  # noqa: E402,F401
+from .sharded import Exchange, RecordExchange, TensorExchange, init_exchange, lincomb_sharded, run_nccl_probe, shard_range  # noqa: E402,F401

@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <atomic>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -46,7 +48,12 @@ struct SharedTable {
 struct TableRegistry {
     std::mutex mu;                                               // held while a table is built: a second context of the device waits
     std::map<std::tuple<int, int, int>, SharedTable> tabs;       // (device, curve id, comb width)
+    std::set<std::tuple<int, int, int>> nofit;                   // widths whose allocation was refused: later contexts go straight to
+                                                                 // the width that worked (forgotten when a table of the device is freed)
 };
+// test-only fault injection (tests/test_gpu_multidevice.py through the exported ecgpu_testhook_table_max_mb; no environment
+// variable: the production path cannot be steered from outside the process): comb tables above this many MiB are refused
+std::atomic<size_t> g_test_table_max_mb{0};
 TableRegistry& table_registry(int device) {                      // one per device: the GPUs of a group build in parallel
     static TableRegistry* r = new TableRegistry[64];             // never destroyed: contexts may outlive static destructors
     return r[device & 63];
@@ -71,6 +78,8 @@ struct ecgpu_ctx {
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r, ec_e, ec_s, ec_id;   // signature verification scratch
     DevBuf ct_flags;             // one verdict byte per element of a uniform-schedule batch
+    DevBuf cx_xy, cx_inf;        // x || y + flag records decoded from compressed input (ecgpu_msm_compressed, ecgpu_batch_mul_compressed)
+    bool keep_status = false;    // the status word already holds the verdicts of a first stage of the call: do not clear it
     hipEvent_t ev[6] = {};
     std::map<std::string, double> timing;
     std::vector<std::pair<std::string, std::pair<int, int>>> spans;   // event pairs of the last call not yet turned into `timing`
@@ -84,8 +93,9 @@ struct ecgpu_ctx {
     struct MsmLane {
         hipStream_t s = nullptr;
         DevBuf ws, proj, prefix;
-        hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr;
+        hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr, ev_done = nullptr;
     };
+    bool lanes_pending = false;  // an MSM was queued on a lane since the last other call: that call first waits for the lanes (ev_done)
     int msm_lanes = 1;
     unsigned msm_seq = 0;
     MsmLane lane[4];
@@ -156,7 +166,12 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK);
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int reset_status(ecgpu_ctx* ctx) {
-    if (ctx->async) return ECGPU_OK;          // flags accumulate until ecgpu_synchronize
+    if (ctx->lanes_pending) {                 // MSMs in flight on the lanes: later work of the context is ordered after them
+        for (auto& l : ctx->lane)
+            if (l.s && l.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.ev_done, 0));
+        ctx->lanes_pending = false;
+    }
+    if (ctx->async || ctx->keep_status) return ECGPU_OK;          // flags accumulate until ecgpu_synchronize / the call's end
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     return ECGPU_OK;
 }
@@ -212,6 +227,30 @@ struct SyncScope {
     }
 };
 
+// The uniform-schedule entry points are meant for secret scalars, and the reference keeps such values in zeroize-on-drop
+// types (`NonZeroScalar`, `SharedSecret`).  Whatever path such a call leaves by, the context's scratch that held values derived
+// from its secrets — k P in projective form, the running products of the batch inversion, the affine products of an ECDH —
+// is zeroed behind its last kernel (stream-ordered), and `staging` also clears the copies a host-pointer call made of the
+// caller's scalars and results.  The caller's own buffers are the caller's to wipe; ecgpu_wipe does the same on request.
+enum : int { WIPE_SCRATCH = 1, WIPE_EC = 2, WIPE_STAGING = 4 };
+void wipe_scratch(ecgpu_ctx* ctx, int what) {
+    auto clear = [&](std::initializer_list<DevBuf*> bufs) {
+        for (DevBuf* b : bufs)
+            if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, ctx->stream);
+    };
+    if (what & WIPE_SCRATCH) clear({&ctx->proj, &ctx->prefix});
+    if (what & WIPE_EC) clear({&ctx->ec_xy, &ctx->ec_inf});
+    if (what & WIPE_STAGING) clear({&ctx->in0, &ctx->in3, &ctx->out0, &ctx->out1});
+}
+struct CtWipe {
+    ecgpu_ctx* ctx;
+    int what;
+    CtWipe(ecgpu_ctx* c, int what_) : ctx(c), what(what_) {}
+    ~CtWipe() {
+        if (what) wipe_scratch(ctx, what);
+    }
+};
+
 void record(ecgpu_ctx* ctx, int i) { (void)hipEventRecord(ctx->ev[i], ctx->stream); }
 
 void resolve_timing(ecgpu_ctx* ctx) {
@@ -246,6 +285,7 @@ void release_table(ecgpu_ctx* ctx, int id) {
     if (it != reg.tabs.end() && it->second.d == t.d && --it->second.refs == 0) {
         (void)hipFree(it->second.d);
         reg.tabs.erase(it);
+        reg.nofit.clear();                    // memory came back: widths refused earlier may fit now
     }
     t = Table();
 }
@@ -268,9 +308,9 @@ int build_table(ecgpu_ctx* ctx, int w, SharedTable* out) {
     if ((rc = ensure(ctx, ctx->proj, slab * half * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->prefix, slab * half * NS * 4)) != ECGPU_OK) return rc;
     uint32_t* d = nullptr;
-    if (const char* e = getenv("ECGPU_TEST_TABLE_MAX_MB")) {     // fault injection for the fallback path (tests): pretend larger tables do not fit
-        if (entries * 2 * N * 4 > (size_t)atol(e) << 20) {
-            ctx->err = "basepoint table: allocation refused by ECGPU_TEST_TABLE_MAX_MB";
+    if (const size_t cap_mb = g_test_table_max_mb.load()) {     // fault injection for the fallback path (ecgpu_testhook_table_max_mb)
+        if (entries * 2 * N * 4 > cap_mb << 20) {
+            ctx->err = "basepoint table: allocation refused by the test hook";
             return ECGPU_ERR_OOM;
         }
     }
@@ -324,13 +364,16 @@ int ensure_table(ecgpu_ctx* ctx) {
     std::lock_guard<std::mutex> lock(reg.mu);
     int rc = ECGPU_ERR_OOM;
     for (int w = want;; w -= 2) {
-        SharedTable& st = reg.tabs[std::make_tuple(ctx->device, (int)C::ID, w)];
+        const auto key = std::make_tuple(ctx->device, (int)C::ID, w);
+        if (w - 2 >= 16 && reg.nofit.count(key)) continue;       // an earlier context of the device was refused this width
+        SharedTable& st = reg.tabs[key];
         if (!st.d) {
             rc = build_table<C>(ctx, w, &st);
             if (rc != ECGPU_OK) {
-                reg.tabs.erase(std::make_tuple(ctx->device, (int)C::ID, w));
+                reg.tabs.erase(key);
                 (void)hipGetLastError();                         // an out-of-memory error is not sticky
                 int rc2 = drop_build_scratch(ctx);
+                if (rc == ECGPU_ERR_OOM) reg.nofit.insert(key);
                 if (rc == ECGPU_ERR_OOM && rc2 == ECGPU_OK && w - 2 >= 16) continue;
                 if (rc == ECGPU_ERR_OOM) ctx->err = "basepoint comb table does not fit in device memory (even at 16-bit windows)";
                 return rc;
@@ -348,8 +391,8 @@ int ensure_table(ecgpu_ctx* ctx) {
 
 // ---- generator LUTs of the uniform-schedule fixed-base kernel (ecgpu_ctmul.h) ----------------------------------------
 // [CT_BASE_LUTS][CT_BASE_ENTRIES][2] packed elements: lut i = {e * 2^(W i) * G, e = 1..2^(W-1)}, W = CT_BASE_W — `BasepointTable::new`
-// (primeorder/src/tables/basepoint.rs:41-76) with affine entries.  17 KB for k256: built with the comb-table kernels
-// (bases 2^(8 i) G, eight multiples each, one normalisation), shared per device under the registry key width -1.
+// (primeorder/src/tables/basepoint.rs:41-76) with affine entries.  43 LUTs of 32 entries = 88 KB for k256: built with the
+// comb-table kernels (bases 2^(6 i) G, 32 multiples each, one normalisation), shared per device under the registry key width -1.
 void release_ct_lut(ecgpu_ctx* ctx, int id) {
     if (!ctx->ct_lut[id]) return;
     TableRegistry& reg = table_registry(ctx->device);
@@ -472,6 +515,7 @@ int mul_base_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out
     int rc;
     if ((rc = ensure_ct_lut<C>(ctx)) != ECGPU_OK) return rc;
     if (n == 0) return ECGPU_OK;
+    CtWipe wipe(ctx, WIPE_SCRATCH);
     if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ct_flags, n + 16)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
@@ -492,6 +536,7 @@ int mul_var_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_points_x
     constexpr int NS = Field<C>::NS;
     if (n == 0) return ECGPU_OK;
     int rc;
+    CtWipe wipe(ctx, WIPE_SCRATCH);
     size_t tstride = var_base_slots<C>(n);
     if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
@@ -600,6 +645,7 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
             HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_in, hipEventDisableTiming));
             HIP_TRY(ctx, hipEventCreate(&l.ev_a));
             HIP_TRY(ctx, hipEventCreate(&l.ev_b));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
         }
         if ((rc = ensure_on(ctx, l.s, l.ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
         if ((rc = ensure_on(ctx, l.s, l.proj, 3 * NS * 4)) != ECGPU_OK) return rc;
@@ -608,6 +654,11 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
         HIP_TRY(ctx, hipStreamWaitEvent(l.s, l.ev_in, 0));
         launch_msm<C>(plan, l.s, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, l.ws.p, (uint32_t*)l.proj.p,
                       ctx->d_status, l.ev_a, l.ev_b, (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);   // (the last kernel writes the wire record)
+        // Any OTHER entry point called later on this context waits for this event first (reset_status): it may read the
+        // output or reuse the inputs.  Further MSMs do not — they go to the next lane — and neither does work the caller
+        // queues on the stream itself: for that, inputs and outputs belong to the lane until ecgpu_synchronize.
+        HIP_TRY(ctx, hipEventRecord(l.ev_done, l.s));
+        ctx->lanes_pending = true;
         return finish(ctx);
     }
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
@@ -622,6 +673,77 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
                          {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
     return rc;
+}
+
+// ---- `LinearCombination::lincomb` in its constant-time form (primeorder/src/projective.rs:484-496 -> :532-557; k256
+// mul.rs:84-98 -> :112-163): one uniform-schedule multiplication per term (k_var_base_ct: the reference's table, digits and
+// additions for that term) and a tree of complete additions over the products, 256 per workgroup and level.  The reference
+// interleaves the terms on one accumulator (Straus); the group element is the same and the schedule here depends on n only.
+template <class C>
+int lincomb_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void* d_inf, size_t n, void* d_out_xy,
+                   void* d_out_inf) {
+    constexpr int NS = Field<C>::NS, WB = WireBytes<C>::value;
+    int rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    if (n == 0) {                              // the empty sum
+        HIP_TRY(ctx, hipMemsetAsync(d_out_xy, 0, 2 * WB, ctx->stream));
+        if (d_out_inf) HIP_TRY(ctx, hipMemsetAsync(d_out_inf, 1, 1, ctx->stream));
+        return finish(ctx);
+    }
+    CtWipe wipe(ctx, WIPE_SCRATCH);
+    const size_t tstride = var_base_slots<C>(n);
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->ct_flags, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->prefix, ((n + BLOCK - 1) / BLOCK + 1) * 3 * NS * 4)) != ECGPU_OK) return rc;
+    record(ctx, 0);
+    launch_var_base_ct<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
+                          (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, (uint8_t*)ctx->ct_flags.p, ctx->d_status);
+    (void)hipEventRecord(ctx->ev[3], ctx->stream);
+    launch_proj_sum<C>(ctx->stream, (uint32_t*)ctx->proj.p, n, (uint32_t*)ctx->prefix.p);
+    record(ctx, 1);
+    if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
+    record(ctx, 2);
+    rc = finish(ctx);
+    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"accumulate", {0, 3}}, {"reduce", {3, 1}}});
+    return rc;
+}
+
+// ---- compressed points into the path: x + SEC1 tag records are decoded on the device (k_decompress_tagged: one square root
+// per point) into the context's scratch, then the ordinary pipeline runs on the x || y records; a record that decodes to no
+// point ends the call with ECGPU_ERR_POINT like an off-curve x || y record would
+template <class C>
+int decode_compressed(ecgpu_ctx* ctx, const void* d_x, const void* d_tag, size_t n) {
+    constexpr int WB = WireBytes<C>::value;
+    int rc;
+    if ((rc = ensure(ctx, ctx->cx_xy, n * 2 * WB + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->cx_inf, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
+    if (n)
+        launch_decompress_tagged<C>(ctx->stream, (const uint8_t*)d_x, (const uint8_t*)d_tag, n, (uint8_t*)ctx->cx_xy.p,
+                                    (uint8_t*)ctx->cx_inf.p, ctx->d_status);
+    return ECGPU_OK;
+}
+struct KeepStatus {            // the second stage of a two-stage call must not clear the first stage's verdicts
+    ecgpu_ctx* ctx;
+    explicit KeepStatus(ecgpu_ctx* c) : ctx(c) { ctx->keep_status = true; }
+    ~KeepStatus() { ctx->keep_status = false; }
+};
+template <class C>
+int msm_compressed_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_x, const void* d_tag, size_t n, void* d_out_xy,
+                       void* d_out_inf) {
+    int rc;
+    if ((rc = decode_compressed<C>(ctx, d_x, d_tag, n)) != ECGPU_OK) return rc;
+    KeepStatus keep(ctx);
+    return msm_dev<C>(ctx, d_scalars, ctx->cx_xy.p, ctx->cx_inf.p, n, d_out_xy, d_out_inf);
+}
+template <class C>
+int mul_var_compressed_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_x, const void* d_tag, size_t n, void* d_out_xy,
+                           void* d_out_inf) {
+    int rc;
+    if ((rc = decode_compressed<C>(ctx, d_x, d_tag, n)) != ECGPU_OK) return rc;
+    KeepStatus keep(ctx);
+    return mul_var_dev<C>(ctx, d_scalars, ctx->cx_xy.p, ctx->cx_inf.p, n, d_out_xy, d_out_inf);
 }
 
 // ---- an MSM whose terms are spread over several GPUs: local half / combining half ------------------------
@@ -973,12 +1095,13 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
                       &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
                       &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
-    if (ctx->ct_flags.p) (void)hipFree(ctx->ct_flags.p);
+    for (DevBuf* b : {&ctx->ct_flags, &ctx->cx_xy, &ctx->cx_inf})
+        if (b->p) (void)hipFree(b->p);
     for (auto& l : ctx->lane) {
         if (l.s) (void)hipStreamSynchronize(l.s);
         for (DevBuf* b : {&l.ws, &l.proj, &l.prefix})
             if (b->p) (void)hipFree(b->p);
-        for (hipEvent_t e : {l.ev_in, l.ev_a, l.ev_b})
+        for (hipEvent_t e : {l.ev_in, l.ev_a, l.ev_b, l.ev_done})
             if (e) (void)hipEventDestroy(e);
         if (l.s) (void)hipStreamDestroy(l.s);
     }
@@ -1105,6 +1228,24 @@ int ecgpu_synchronize(ecgpu_ctx* ctx) {
     return status_error(ctx, st);
 }
 
+int ecgpu_wipe(ecgpu_ctx* ctx) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    for (auto& l : ctx->lane)
+        if (l.s) HIP_TRY(ctx, hipStreamSynchronize(l.s));
+    for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3, &ctx->out0, &ctx->out1,
+                      &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy, &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e,
+                      &ctx->ec_s, &ctx->ec_id, &ctx->ct_flags, &ctx->cx_xy, &ctx->cx_inf})
+        if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->cap, ctx->stream));
+    for (auto& l : ctx->lane)
+        for (DevBuf* b : {&l.ws, &l.proj, &l.prefix})
+            if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->cap, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ECGPU_OK;
+}
+
+// test-only (not in include/ecgpu.h): comb tables above `mb` MiB are refused as if the allocation had failed; 0 switches it off
+void ecgpu_testhook_table_max_mb(size_t mb) { g_test_table_max_mb.store(mb); }
+
 int ecgpu_last_timing(const ecgpu_ctx* ctx_in, const char* name, double* ms) {
     if (!ctx_in || !name || !ms) return ECGPU_ERR_ARG;
     ecgpu_ctx* ctx = const_cast<ecgpu_ctx*>(ctx_in);
@@ -1178,6 +1319,38 @@ int ecgpu_msm_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* 
     if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return arg_error(ctx, __func__);
     return dispatch(curve, [&](auto c) {
         return msm_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_lincomb_ct_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_xy, const void* d_points_inf,
+                         size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy)) return arg_error(ctx, __func__);
+    if (n && (!d_scalars || !d_points_xy || !aligned16(d_scalars) || !aligned16(d_points_xy))) return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return lincomb_ct_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_msm_compressed_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_x, const void* d_points_tag,
+                             size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_out_xy || !aligned16(d_out_xy)) return arg_error(ctx, __func__);
+    if (n && (!d_scalars || !d_points_x || !d_points_tag || !aligned16(d_scalars) || !aligned16(d_points_x)))
+        return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return msm_compressed_dev<decltype(c)>(ctx, d_scalars, d_points_x, d_points_tag, n, d_out_xy, d_out_inf);
+    });
+}
+
+int ecgpu_batch_mul_compressed_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void* d_points_x,
+                                   const void* d_points_tag, size_t n, void* d_out_xy, void* d_out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (n && (!d_scalars || !d_points_x || !d_points_tag || !d_out_xy || !aligned16(d_scalars) || !aligned16(d_points_x) ||
+              !aligned16(d_out_xy)))
+        return arg_error(ctx, __func__);
+    return dispatch(curve, [&](auto c) {
+        return mul_var_compressed_dev<decltype(c)>(ctx, d_scalars, d_points_x, d_points_tag, n, d_out_xy, d_out_inf);
     });
 }
 
@@ -1399,6 +1572,7 @@ static int ecdh_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const void
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, __func__);
     int rc;
+    CtWipe wipe(ctx, ct ? WIPE_EC : 0);             // (declared first: runs after the x extraction below has been queued)
     if ((rc = ensure(ctx, ctx->ec_xy, n * 2 * L + 16)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
     rc = ct ? ecgpu_batch_mul_ct_dev(ctx, curve, d_scalars, d_points_xy, nullptr, n, ctx->ec_xy.p, ctx->ec_inf.p)
@@ -1453,6 +1627,7 @@ static int batch_mul_base_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, fn);
     if (n && (!scalars || !out_xy)) return arg_error(ctx, fn);
+    CtWipe wipe(ctx, ct ? WIPE_STAGING : 0);          // (after everything below, before SyncScope restores the mode)
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}}, {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}},
@@ -1506,6 +1681,7 @@ static int batch_mul_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, con
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, fn);
     if (n && (!scalars || !points_xy || !out_xy)) return arg_error(ctx, fn);
+    CtWipe wipe(ctx, ct ? WIPE_STAGING : 0);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}, {points_inf, &ctx->in2, 1}},
@@ -1581,6 +1757,97 @@ int ecgpu_msm(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* 
         return rc;
     if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
     return download(ctx, out_inf, ctx->out1, 1);
+}
+
+int ecgpu_lincomb_ct(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_xy, const uint8_t* points_inf, size_t n,
+                     uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (!out_xy || (n && (!scalars || !points_xy))) return arg_error(ctx, __func__);
+    CtWipe wipe(ctx, WIPE_STAGING);
+    int rc;
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_xy, n * 2 * L)) != ECGPU_OK) return rc;
+    if (points_inf && (rc = upload(ctx, ctx->in2, points_inf, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_lincomb_ct_dev(ctx, curve, ctx->in0.p, ctx->in1.p, points_inf ? ctx->in2.p : nullptr, n, ctx->out0.p,
+                                   ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, 1);
+}
+
+int ecgpu_msm_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_x, const uint8_t* points_tag,
+                         size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (!out_xy || (n && (!scalars || !points_x || !points_tag))) return arg_error(ctx, __func__);
+    int rc;
+    const size_t pipe_chunk = msm_pipe_chunk();
+    if (n >= 2 * pipe_chunk) {          // as ecgpu_msm: one partial MSM per chunk under the upload of the next, then a point sum
+        const size_t nparts = (n + pipe_chunk - 1) / pipe_chunk;
+        if ((rc = ensure(ctx, ctx->out0, (nparts + 1) * 2 * L + 64)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->out1, nparts + 32)) != ECGPU_OK) return rc;
+        uint8_t* part_xy = (uint8_t*)ctx->out0.p + (2 * L + 15) / 16 * 16;
+        uint8_t* part_inf = (uint8_t*)ctx->out1.p + 16;
+        return dispatch(curve, [&](auto c) -> int {
+            using C = decltype(c);
+            int r = pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_x, &ctx->in1, L}, {points_tag, &ctx->in2, 1}}, {},
+                              [&](size_t off, size_t m) {
+                                  const size_t j = off / pipe_chunk;
+                                  return msm_compressed_dev<C>(ctx, (uint8_t*)ctx->in0.p + off * L, (uint8_t*)ctx->in1.p + off * L,
+                                                               (uint8_t*)ctx->in2.p + off, m, part_xy + j * 2 * L, part_inf + j);
+                              },
+                              pipe_chunk);
+            if (r != ECGPU_OK) return r;
+            if ((r = point_sum_dev<C>(ctx, part_xy, part_inf, nparts, ctx->out0.p, ctx->out1.p)) != ECGPU_OK) return r;
+            if ((r = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return r;
+            return download(ctx, out_inf, ctx->out1, 1);
+        });
+    }
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_x, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, points_tag, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_msm_compressed_dev(ctx, curve, ctx->in0.p, ctx->in1.p, ctx->in2.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, 1);
+}
+
+int ecgpu_batch_mul_compressed(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, const uint8_t* points_x, const uint8_t* points_tag,
+                               size_t n, uint8_t* out_xy, uint8_t* out_inf) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    SyncScope sync_scope(ctx);
+    if (sync_scope.rc != ECGPU_OK) return sync_scope.rc;
+    size_t L = ecgpu_field_bytes(curve);
+    if (!L) return curve_error(ctx, __func__);
+    if (n && (!scalars || !points_x || !points_tag || !out_xy)) return arg_error(ctx, __func__);
+    int rc;
+    if (n >= PIPE_MIN)
+        return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_x, &ctx->in1, L}, {points_tag, &ctx->in2, 1}},
+                         {{out_xy, &ctx->out0, 2 * L}, {out_inf, &ctx->out1, 1}}, [&](size_t off, size_t m) {
+                             return ecgpu_batch_mul_compressed_dev(ctx, curve, (uint8_t*)ctx->in0.p + off * L,
+                                                                   (uint8_t*)ctx->in1.p + off * L, (uint8_t*)ctx->in2.p + off, m,
+                                                                   (uint8_t*)ctx->out0.p + off * 2 * L, (uint8_t*)ctx->out1.p + off);
+                         });
+    if ((rc = upload(ctx, ctx->in0, scalars, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in1, points_x, n * L)) != ECGPU_OK) return rc;
+    if ((rc = upload(ctx, ctx->in2, points_tag, n)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out0, n * 2 * L + 16)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->out1, n + 16)) != ECGPU_OK) return rc;
+    if ((rc = ecgpu_batch_mul_compressed_dev(ctx, curve, ctx->in0.p, ctx->in1.p, ctx->in2.p, n, ctx->out0.p, ctx->out1.p)) != ECGPU_OK)
+        return rc;
+    if ((rc = download(ctx, out_xy, ctx->out0, n * 2 * L)) != ECGPU_OK) return rc;
+    return download(ctx, out_inf, ctx->out1, n);
 }
 
 int ecgpu_batch_mul_base_and_mul_add(ecgpu_ctx* ctx, int curve, const uint8_t* a_scalars, const uint8_t* b_scalars,
@@ -1844,6 +2111,7 @@ static int batch_ecdh_host(ecgpu_ctx* ctx, int curve, const uint8_t* scalars, co
     size_t L = ecgpu_field_bytes(curve);
     if (!L) return curve_error(ctx, fn);
     if (n && (!scalars || !points_xy || !out_x || !ok)) return arg_error(ctx, fn);
+    CtWipe wipe(ctx, ct ? WIPE_STAGING : 0);
     int rc;
     if (n >= PIPE_MIN)
         return pipelined(ctx, n, {{scalars, &ctx->in0, L}, {points_xy, &ctx->in1, 2 * L}}, {{out_x, &ctx->out0, L}, {ok, &ctx->out1, 1}},

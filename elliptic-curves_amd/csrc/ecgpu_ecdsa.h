@@ -365,4 +365,34 @@ k_decompress(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ y_is_od
     ok_out[i] = ok ? 1 : 0;
 }
 
+// SEC1-compressed points INTO the scalar-multiplication entry points (ecgpu_msm_compressed, ecgpu_batch_mul_compressed): record i
+// is x (one wire element) + a tag byte — 0x02 / 0x03: the point with that x and even / odd y (`FromSec1Point` ->
+// `DecompressPoint::decompress`, primeorder/src/affine.rs:183-200,352-366; k256/src/arithmetic/affine.rs:261-280), 0x00: the
+// identity (`Sec1Point::identity`, the one-byte encoding).  out_xy / out_inf are the x || y + flag records the path takes.  Any
+// other tag, x >= p, or an x with no point on the curve raises ST_BAD_POINT — the reference's `CtOption::None`, which ends a
+// `lincomb` over decoded keys before it starts.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_decompress_tagged(const uint8_t* __restrict__ xs, const uint8_t* __restrict__ tags, size_t n, uint8_t* __restrict__ out_xy,
+                    uint8_t* __restrict__ out_inf, int* status) {
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t tag = tags[i];
+    uint32_t cx[N], cy[N];
+    load_wire<C>(cx, xs + i * WB);
+    bool ok;
+    if (tag == 0u) {                                        // the identity: x must be absent / zero; a zero record goes on
+        ok = mp_is_zero<N>(cx);
+#pragma unroll
+        for (int k = 0; k < N; k++) cx[k] = cy[k] = 0;
+    } else {
+        ok = (tag == 2u || tag == 3u) && decompress_words<C>(cx, tag == 3u, cy);          // ecgpu_verify.h
+    }
+    if (!ok) atomicOr(status, ST_BAD_POINT);
+    store_wire<C>(out_xy + i * (2 * WB), cx);
+    store_wire<C>(out_xy + i * (2 * WB) + WB, cy);
+    out_inf[i] = tag == 0u ? 1 : 0;
+}
+
 }  // namespace ecgpu

@@ -72,6 +72,7 @@ struct Member {
 struct ecgpu_group {
     std::vector<Member> m;
     bool use_rccl = false;
+    std::string why;                   // how the exchange was chosen (ecgpu_group_exchange_reason)
     Rccl rccl;
     std::string err;
     std::mutex err_mu;                 // fail() may be called from several per-device worker threads at once
@@ -155,18 +156,29 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
     (void)hipGetLastError();
     const char* mode = getenv("ECGPU_GROUP_EXCHANGE");
     const bool want_rccl = !(mode && std::strcmp(mode, "peer") == 0);
-    if (want_rccl && distinct && g->rccl.load()) {
+    const bool must_rccl = mode && std::strcmp(mode, "rccl") == 0;
+    if (!want_rccl) {
+        g->why = "peer: ECGPU_GROUP_EXCHANGE=peer";
+    } else if (!distinct) {
+        g->why = "peer: duplicate devices in the group (RCCL wants one communicator rank per device)";
+    } else if (!g->rccl.load()) {
+        const char* de = dlerror();
+        g->why = std::string("peer: librccl could not be loaded (") + (de ? de : "no such library") + ")";
+    } else {
         std::vector<nccl_comm_t> comms(ndev, nullptr);
-        if (g->rccl.comm_init_all(comms.data(), ndev, devices) == 0) {
+        const int nrc = g->rccl.comm_init_all(comms.data(), ndev, devices);
+        if (nrc == 0) {
             g->use_rccl = true;
             for (int r = 0; r < ndev; r++) g->m[r].comm = comms[r];
+            g->why = "rccl: ncclCommInitAll over " + std::to_string(ndev) + (ndev == 1 ? " device" : " devices");
+        } else {
+            g->why = std::string("peer: ncclCommInitAll failed (") +
+                     (g->rccl.error_string ? g->rccl.error_string(nrc) : ("code " + std::to_string(nrc)).c_str()) + ")";
+            (void)hipGetLastError();
         }
-        if (mode && std::strcmp(mode, "rccl") == 0 && !g->use_rccl) {
-            ecgpu_group_destroy(g);
-            return ECGPU_ERR_HIP;
-        }
-    } else if (mode && std::strcmp(mode, "rccl") == 0) {
-        ecgpu_group_destroy(g);                                     // asked for RCCL explicitly and it is not to be had
+    }
+    if (must_rccl && !g->use_rccl) {                                // asked for RCCL explicitly and it is not to be had
+        ecgpu_group_destroy(g);
         return ECGPU_ERR_HIP;
     }
     *out = g;
@@ -194,6 +206,8 @@ ecgpu_ctx* ecgpu_group_ctx(ecgpu_group* g, int i) { return g && i >= 0 && i < (i
 const char* ecgpu_group_last_error(const ecgpu_group* g) { return g ? g->err.c_str() : "null group"; }
 
 const char* ecgpu_group_exchange(const ecgpu_group* g) { return g && g->use_rccl ? "rccl" : "peer"; }
+
+const char* ecgpu_group_exchange_reason(const ecgpu_group* g) { return g ? g->why.c_str() : "null group"; }
 
 int ecgpu_group_set_msm_window(ecgpu_group* g, int window_bits) {
     if (!g) return ECGPU_ERR_ARG;
@@ -231,27 +245,51 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
         if ((rc = grow(g, g->m[r], &g->m[r].d_parts, &g->m[r].parts_cap, bytes)) != ECGPU_OK) return rc;
         if ((r == 0 || g->use_rccl) && (rc = grow(g, g->m[r], &g->m[r].d_all, &g->m[r].all_cap, bytes * nd)) != ECGPU_OK) return rc;
     }
-    // local halves + the exchange step, one thread per GPU
+    // local halves, one thread per GPU
     rc = for_each_member(g, [&](int r) -> int {
         Member& mb = g->m[r];
-        int e = ecgpu_msm_parts_dev(mb.ctx, curve, d_scalars[r], d_points_xy[r], d_points_inf ? d_points_inf[r] : nullptr,
-                                    n_per_device[r], plan_terms, mb.d_parts);          // returns with the parts written
-        if (e != ECGPU_OK) return e;
-        if (g->use_rccl) {
+        return ecgpu_msm_parts_dev(mb.ctx, curve, d_scalars[r], d_points_xy[r], d_points_inf ? d_points_inf[r] : nullptr,
+                                   n_per_device[r], plan_terms, mb.d_parts);           // returns with the parts written
+    });
+    if (rc != ECGPU_OK) return rc;
+    // the exchange step.  RCCL first where the group has it; a collective that fails is not the end of the call: the parts
+    // are still in every GPU's d_parts, so the peer copies below move them, and the group stays on peer copies from then on.
+    if (g->use_rccl) {
+        int nrc_seen = 0;
+        std::mutex nrc_mu;
+        rc = for_each_member(g, [&](int r) -> int {
+            Member& mb = g->m[r];
             if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
-            if (g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream) != 0) return ECGPU_ERR_HIP;
+            const int nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
+            if (nrc != 0) {
+                std::lock_guard<std::mutex> lock(nrc_mu);
+                nrc_seen = nrc;
+                return ECGPU_ERR_HIP;
+            }
             return hipStreamSynchronize(mb.stream) == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
+        });
+        if (rc != ECGPU_OK) {
+            g->use_rccl = false;
+            g->why = std::string("peer: ncclAllGather failed (") +
+                     (nrc_seen && g->rccl.error_string ? g->rccl.error_string(nrc_seen) : "HIP error on the exchange stream") + ")";
+            g->err.clear();
+            (void)hipGetLastError();
         }
+    }
+    if (!g->use_rccl) {
         // device-to-device copies are asynchronous with respect to the host: an explicit stream + synchronisation, so that
         // the combining half (on member 0's own stream) starts after every part has landed
-        if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
-        uint8_t* dst = (uint8_t*)g->m[0].d_all + (size_t)r * bytes;
-        hipError_t he = mb.device == g->m[0].device
-                            ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
-                            : hipMemcpyPeerAsync(dst, g->m[0].device, mb.d_parts, mb.device, bytes, mb.stream);
-        if (he == hipSuccess) he = hipStreamSynchronize(mb.stream);
-        return he == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
-    });
+        rc = for_each_member(g, [&](int r) -> int {
+            Member& mb = g->m[r];
+            if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
+            uint8_t* dst = (uint8_t*)g->m[0].d_all + (size_t)r * bytes;
+            hipError_t he = mb.device == g->m[0].device
+                                ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
+                                : hipMemcpyPeerAsync(dst, g->m[0].device, mb.d_parts, mb.device, bytes, mb.stream);
+            if (he == hipSuccess) he = hipStreamSynchronize(mb.stream);
+            return he == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
+        });
+    }
     if (rc != ECGPU_OK) return rc == ECGPU_ERR_HIP && g->err.empty() ? fail(g, rc, "exchange of the partial sums failed") : rc;
     // the combining half, once
     Member& m0 = g->m[0];

@@ -98,6 +98,10 @@ template <> void launch_decompress<CurveT>(hipStream_t s, const uint8_t* xs, con
                                            uint8_t* out_xy, uint8_t* ok) {
     hipLaunchKernelGGL(k_decompress<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xs, y_is_odd, n, out_xy, ok);
 }
+template <> void launch_decompress_tagged<CurveT>(hipStream_t s, const uint8_t* xs, const uint8_t* tags, size_t n, uint8_t* out_xy,
+                                                  uint8_t* out_inf, int* status) {
+    hipLaunchKernelGGL(k_decompress_tagged<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xs, tags, n, out_xy, out_inf, status);
+}
 template <> void launch_ecdsa_finish<CurveT>(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                              const uint8_t* valid, size_t n, uint8_t* ok) {
     hipLaunchKernelGGL(k_ecdsa_finish<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, r_xy, r_inf, r, valid, n, ok);

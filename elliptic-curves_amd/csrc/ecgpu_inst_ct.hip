@@ -6,6 +6,10 @@ namespace ecgpu {
 
 using CurveT = ECGPU_CURVE;
 
+// ecgpu_lincomb_ct adds the products of k_var_base_ct with the tree kernel of the base group; instantiated here as well so
+// that the translation unit tools/ct_isa_check.py compiles holds every kernel of the uniform-schedule entry points
+template __global__ void k_proj_sum_level<CurveT>(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ out);
+
 template <> int ct_base_luts<CurveT>() { return CT_BASE_LUTS<CurveT>; }
 template <> void launch_var_base_ct<CurveT>(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf, size_t n,
                                             uint32_t* tab, size_t slots, uint32_t* proj_out, uint8_t* flags, int* status) {

@@ -73,6 +73,8 @@ template <class C> void launch_schnorr_finish(hipStream_t s, const uint8_t* r_xy
 template <class C> void launch_extract_x(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint8_t* out_x, uint8_t* ok);
 template <class C> void launch_decompress(hipStream_t s, const uint8_t* xs, const uint8_t* y_is_odd, size_t n, uint8_t* out_xy,
                                           uint8_t* ok);
+template <class C> void launch_decompress_tagged(hipStream_t s, const uint8_t* xs, const uint8_t* tags, size_t n, uint8_t* out_xy,
+                                                 uint8_t* out_inf, int* status);
 template <class C> void launch_ecdsa_finish(hipStream_t s, const uint8_t* r_xy, const uint8_t* r_inf, const uint8_t* r,
                                             const uint8_t* valid, size_t n, uint8_t* ok);
 
@@ -87,7 +89,7 @@ template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, c
                                         size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
 
 // ---- group "ct": uniform-schedule variants (ecgpu_ct.h); flags: n bytes of scratch (one verdict byte per element) ----
-template <class C> int ct_base_luts();                  // generator LUTs of 8 affine entries: lut i = {e * 2^(8 i) * G}
+template <class C> int ct_base_luts();                  // generator LUTs: one per 6-bit window (CT_BASE_W), 32 affine entries each: lut i = {e * 2^(6 i) * G, e = 1..32}
 template <class C> void launch_var_base_ct(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf, size_t n,
                                            uint32_t* tab, size_t slots, uint32_t* proj_out, uint8_t* flags, int* status);
 template <class C> void launch_fixed_base_ct(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* lut, uint32_t* proj_out,

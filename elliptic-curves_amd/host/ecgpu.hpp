@@ -129,27 +129,33 @@ struct Curve {
 
         // Group::mul_by_generator
         static ProjectivePoint mul_by_generator(const Scalar& k) { return batch_mul_by_generator({k})[0]; }
-        static ProjectivePoint mul_by_generator_vartime(const Scalar& k) { return mul_by_generator(k); }
+        static ProjectivePoint mul_by_generator_vartime(const Scalar& k) { return batch_mul_by_generator({k}, false)[0]; }
         // impl Mul<Scalar> / MulVartime
         ProjectivePoint operator*(const Scalar& k) const { return batch_mul({*this}, {k})[0]; }
-        ProjectivePoint mul_vartime(const Scalar& k) const { return *this * k; }
+        ProjectivePoint mul_vartime(const Scalar& k) const { return batch_mul({*this}, {k}, false)[0]; }
         // impl Add via Sum of two
         ProjectivePoint operator+(const ProjectivePoint& o) const { return sum({*this, o}); }
 
         // LinearCombination<[(ProjectivePoint, Scalar)]>::lincomb / lincomb_vartime
+        // `lincomb` is the reference's constant-time name: the uniform-schedule entry point (one constant-time multiplication
+        // per term + a tree of complete additions); `lincomb_vartime` is the bucket method, for public scalars
         static ProjectivePoint lincomb(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms) {
+            return lincomb_impl(terms, true);
+        }
+        static ProjectivePoint lincomb_vartime(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms) {
+            return lincomb_impl(terms, false);
+        }
+        static ProjectivePoint lincomb_impl(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms, bool constant_time) {
             std::vector<uint8_t> s, p, f;
             pack(terms, s, p, f);
             AffinePoint out;
             Engine& e = Engine::global();
             uint8_t xy[2 * L];
-            e.check(ecgpu_msm(e.ctx(), ID, s.data(), p.data(), f.data(), terms.size(), xy, &out.infinity));
+            e.check((constant_time ? ecgpu_lincomb_ct : ecgpu_msm)(e.ctx(), ID, s.data(), p.data(), f.data(), terms.size(), xy,
+                                                                   &out.infinity));
             std::memcpy(out.x_.data(), xy, L);
             std::memcpy(out.y_.data(), xy + L, L);
             return ProjectivePoint{out};
-        }
-        static ProjectivePoint lincomb_vartime(const std::vector<std::pair<ProjectivePoint, Scalar>>& terms) {
-            return lincomb(terms);
         }
         // MulByGeneratorVartime::mul_by_generator_and_mul_add_vartime: a*G + b*P
         static ProjectivePoint mul_by_generator_and_mul_add_vartime(const Scalar& a, const Scalar& b,
@@ -187,9 +193,17 @@ struct Curve {
     static ProjectivePoint GENERATOR() { return ProjectivePoint::mul_by_generator(Scalar::from_u64(1)); }
 
     // ---- batch forms (new API; what the GPU is for) --------------------------------------------------
-    // constant_time: the uniform-schedule entry points (ecgpu_batch_*_ct) — the reference's `mul_by_generator` / `Mul` /
-    // `diffie_hellman` proper; false: the variable-time kernels behind the `*_vartime` names (same results)
-    static std::vector<ProjectivePoint> batch_mul_by_generator(const std::vector<Scalar>& ks, bool constant_time = false) {
+    // The names the reference uses for its constant-time operations (`mul_by_generator`, `Mul`, `diffie_hellman`) default to
+    // the uniform-schedule entry points (ecgpu_batch_*_ct); the variable-time kernels (same results, 1.2-7x faster, for
+    // PUBLIC scalars) stand behind the `*_vartime` names below, as in include/ecgpu.h and the Rust shim.
+    static std::vector<ProjectivePoint> batch_mul_by_generator_vartime(const std::vector<Scalar>& ks) { return batch_mul_by_generator(ks, false); }
+    static std::vector<ProjectivePoint> batch_mul_vartime(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks) {
+        return batch_mul(ps, ks, false);
+    }
+    static std::vector<FieldBytes> batch_diffie_hellman_vartime(const std::vector<Scalar>& secrets, const std::vector<AffinePoint>& publics) {
+        return batch_diffie_hellman(secrets, publics, false);
+    }
+    static std::vector<ProjectivePoint> batch_mul_by_generator(const std::vector<Scalar>& ks, bool constant_time = true) {
         size_t n = ks.size();
         std::vector<uint8_t> s(n * L), xy(n * 2 * L), inf(n);
         for (size_t i = 0; i < n; i++) std::memcpy(&s[i * L], ks[i].repr.data(), L);
@@ -214,7 +228,7 @@ struct Curve {
         return out;
     }
     static std::vector<ProjectivePoint> batch_mul(const std::vector<ProjectivePoint>& ps, const std::vector<Scalar>& ks,
-                                                  bool constant_time = false) {
+                                                  bool constant_time = true) {
         size_t n = ks.size();
         if (ps.size() != n) throw Error(ECGPU_ERR_ARG, "batch_mul: length mismatch");
         std::vector<uint8_t> s(n * L), p(n * 2 * L), f(n), xy(n * 2 * L), inf(n);
@@ -250,7 +264,7 @@ struct Curve {
     }
     // elliptic_curve::ecdh::diffie_hellman(secret, public).raw_secret_bytes()   ({k256,p256,p384}/src/ecdh.rs)
     static std::vector<FieldBytes> batch_diffie_hellman(const std::vector<Scalar>& secrets, const std::vector<AffinePoint>& publics,
-                                                        bool constant_time = false) {
+                                                        bool constant_time = true) {
         size_t n = secrets.size();
         if (publics.size() != n) throw Error(ECGPU_ERR_ARG, "batch_diffie_hellman: length mismatch");
         std::vector<uint8_t> s(n * L), p(n * 2 * L), x(n * L), ok(n);

@@ -24,7 +24,12 @@
 //! `ecgpu_batch_mul_ct` / `ecgpu_batch_mul_base_ct` / `ecgpu_batch_ecdh_ct`: the reference's constant-time algorithm
 //! itself (fixed digit count, every table entry read and one kept under a mask, complete formulas), with no branch and
 //! no address computed from scalar or point data (include/ecgpu.h, "uniform-schedule variants"; tools/ct_isa_check.py).
-//! The constant-time `lincomb` (:484-496) is not redirected: a bucket method is variable-time by construction.
+//! The constant-time `lincomb` (:484-496; k256 mul.rs:84-98) goes to `ecgpu_lincomb_ct` (`lincomb` below): one
+//! uniform-schedule multiplication per term and a tree of complete additions — never to the bucket method, which is
+//! variable-time by construction.
+//! Memory hygiene on these paths: the wire copies of secret scalars and of shared secrets live in `Zeroizing` buffers here,
+//! and the library zeroes its own device-side staging and scratch after every `_ct` call (include/ecgpu.h, ecgpu_wipe) —
+//! the counterpart of the reference's zeroize-on-drop `NonZeroScalar` / `SharedSecret`.
 //!
 //! Build: `links = "ecgpu"` + a build.rs emitting `cargo:rustc-link-lib=dylib=ecgpu` and
 //! `cargo:rustc-link-search=<repo>/elliptic-curves_amd/lib`.
@@ -41,6 +46,7 @@ use elliptic_curve::{
     CurveArithmetic, FieldBytes, PrimeField,
 };
 use sys::*;
+use zeroize::Zeroizing;
 
 /// One GPU: the analogue of `static BASEPOINT_TABLE: LazyLock<..>` (k256/src/arithmetic/tables.rs:18,
 /// primeorder/src/tables/basepoint.rs:29-31) — created on first use, holds the device-resident comb tables.
@@ -72,6 +78,8 @@ pub static NODE: LazyLock<Option<Mutex<Node>>> = LazyLock::new(|| {
 
 /// Below this many terms a sum stays on the CPU (a launch costs ~1 ms end to end).
 pub const GPU_MIN_TERMS: usize = 1 << 10;
+/// The same threshold for the constant-time `lincomb` (n uniform-schedule multiplications, ~20 ns each at full occupancy).
+pub const GPU_MIN_TERMS_CT: usize = 1 << 8;
 /// From this many terms on an MSM is spread over all GPUs of the node.
 pub const NODE_MIN_TERMS: usize = 1 << 22;
 
@@ -111,6 +119,19 @@ where
     C::FieldBytesSize: ModulusSize,
 {
     ks.flat_map(|k| k.to_repr().as_ref().to_vec()).collect()
+}
+
+/// The same for SECRET scalars: the wire copy is wiped when it goes out of scope.
+fn secret_scalars_to_wire<C: GpuCurve>(ks: impl Iterator<Item = Sc<C>>) -> Zeroizing<Vec<u8>>
+where
+    C::FieldBytesSize: ModulusSize,
+{
+    let mut out = Zeroizing::new(Vec::new());
+    for k in ks {
+        let repr = Zeroizing::new(k.to_repr());
+        out.extend_from_slice(repr.as_ref());
+    }
+    out
 }
 
 fn points_to_wire<C: GpuCurve>(ps: impl Iterator<Item = Proj<C>>) -> (Vec<u8>, Vec<u8>)
@@ -208,7 +229,7 @@ pub mod gpu {
     {
         let eng = ENGINE.as_ref()?.lock().ok()?;
         let l = field_len::<C>();
-        let scalars = scalars_to_wire::<C>(ks.iter().copied());
+        let scalars = secret_scalars_to_wire::<C>(ks.iter().copied());
         let (mut xy, mut inf) = (vec![0u8; ks.len() * 2 * l], vec![0u8; ks.len()]);
         check(unsafe { ecgpu_batch_mul_base_ct(eng.0, C::ID, scalars.as_ptr(), ks.len(), xy.as_mut_ptr(), inf.as_mut_ptr()) })?;
         Some(xy.chunks(2 * l).zip(inf).map(|(c, f)| point_from_wire::<C>(c, f)).collect())
@@ -223,9 +244,9 @@ pub mod gpu {
     {
         let eng = ENGINE.as_ref()?.lock().ok()?;
         let (n, l) = (terms.len(), field_len::<C>());
-        let scalars = scalars_to_wire::<C>(terms.iter().map(|t| t.1));
+        let scalars = secret_scalars_to_wire::<C>(terms.iter().map(|t| t.1));
         let (pts, pinf) = points_to_wire::<C>(terms.iter().map(|t| t.0));
-        let (mut xy, mut inf) = (vec![0u8; n * 2 * l], vec![0u8; n]);
+        let (mut xy, mut inf) = (Zeroizing::new(vec![0u8; n * 2 * l]), vec![0u8; n]);    // k P for a secret k: wiped on drop
         check(unsafe {
             ecgpu_batch_mul_ct(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), inf.as_mut_ptr())
         })?;
@@ -235,18 +256,69 @@ pub mod gpu {
     /// `diffie_hellman(secret[i], public[i]).raw_secret_bytes()` (k256/src/ecdh.rs:56-60, p256/src/ecdh.rs; the function
     /// is `elliptic_curve::ecdh::diffie_hellman`, (public * secret).to_affine().x()) — the x-coordinates, `None` in a slot
     /// whose product is the identity (cannot happen for a `NonZeroScalar` and a `PublicKey`).
-    pub fn batch_diffie_hellman<C: GpuCurve>(pairs: &[(Sc<C>, Aff<C>)]) -> Option<Vec<Option<FieldBytes<C>>>>
+    /// The x-coordinates come back in zeroize-on-drop wrappers (`SharedSecret` is one, elliptic-curve ecdh.rs): the caller
+    /// builds `SharedSecret::from(bytes)` from each and drops the vector.
+    pub fn batch_diffie_hellman<C: GpuCurve>(pairs: &[(Sc<C>, Aff<C>)]) -> Option<Vec<Option<Zeroizing<FieldBytes<C>>>>>
     where
         C::FieldBytesSize: ModulusSize,
         Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
     {
         let eng = ENGINE.as_ref()?.lock().ok()?;
         let (n, l) = (pairs.len(), field_len::<C>());
-        let scalars = scalars_to_wire::<C>(pairs.iter().map(|t| t.0));
+        let scalars = secret_scalars_to_wire::<C>(pairs.iter().map(|t| t.0));
         let (pts, _) = points_to_wire::<C>(pairs.iter().map(|t| Proj::<C>::from(t.1)));
-        let (mut x, mut ok) = (vec![0u8; n * l], vec![0u8; n]);
+        let (mut x, mut ok) = (Zeroizing::new(vec![0u8; n * l]), vec![0u8; n]);
         check(unsafe { ecgpu_batch_ecdh_ct(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), n, x.as_mut_ptr(), ok.as_mut_ptr()) })?;
-        Some(x.chunks(l).zip(ok).map(|(c, f)| (f != 0).then(|| FieldBytes::<C>::try_from(c).expect("field bytes"))).collect())
+        Some(x.chunks(l).zip(ok).map(|(c, f)| (f != 0).then(|| Zeroizing::new(FieldBytes::<C>::try_from(c).expect("field bytes")))).collect())
+    }
+
+    /// `sum_i k[i] * P[i]` — `LinearCombination::lincomb`, the CONSTANT-TIME form (primeorder/src/projective.rs:484-496,
+    /// k256/src/arithmetic/mul.rs:84-98): `ecgpu_lincomb_ct`, one uniform-schedule multiplication per term and a tree of
+    /// complete additions.  Costs n constant-time multiplications (no bucket method): worth it from a few hundred terms
+    /// (`GPU_MIN_TERMS_CT`), where the reference's Straus loop over n per-term tables has left the CPU caches.
+    pub fn lincomb<C: GpuCurve>(terms: &[(Proj<C>, Sc<C>)]) -> Option<Proj<C>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C> + AffineCoordinates<FieldRepr = FieldBytes<C>>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (terms.len(), field_len::<C>());
+        let scalars = secret_scalars_to_wire::<C>(terms.iter().map(|t| t.1));
+        let (pts, pinf) = points_to_wire::<C>(terms.iter().map(|t| t.0));
+        let (mut xy, mut inf) = (Zeroizing::new(vec![0u8; 2 * l]), 0u8);
+        check(unsafe { ecgpu_lincomb_ct(eng.0, C::ID, scalars.as_ptr(), pts.as_ptr(), pinf.as_ptr(), n, xy.as_mut_ptr(), &mut inf) })?;
+        Some(point_from_wire::<C>(&xy, inf))
+    }
+
+    /// `sum_i k[i] * P[i]` over SEC1-COMPRESSED public keys (33-byte `tag || x` encodings as they arrive on the wire:
+    /// `PublicKey::from_sec1_bytes`, `FromSec1Point` -> `DecompressPoint::decompress`, primeorder/src/affine.rs:183-200,
+    /// k256/src/arithmetic/affine.rs:261-280): the square roots run on the device (`ecgpu_msm_compressed`).  `None` in the
+    /// outer `Option` = no GPU; `Some(None)` = some encoding is not a point of the curve (the reference's `CtOption::None`).
+    pub fn lincomb_vartime_sec1<C: GpuCurve>(keys: &[&[u8]], ks: &[Sc<C>]) -> Option<Option<Proj<C>>>
+    where
+        C::FieldBytesSize: ModulusSize,
+        Aff<C>: FromSec1Point<C>,
+    {
+        let eng = ENGINE.as_ref()?.lock().ok()?;
+        let (n, l) = (keys.len(), field_len::<C>());
+        assert!(ks.len() == n);
+        let (mut xs, mut tags) = (vec![0u8; n * l], vec![0u8; n]);
+        for (i, k) in keys.iter().enumerate() {
+            match k.len() {
+                1 if k[0] == 0 => {}                                            // the identity: tag 0, x = 0
+                m if m == l + 1 => {
+                    tags[i] = k[0];
+                    xs[i * l..(i + 1) * l].copy_from_slice(&k[1..]);
+                }
+                _ => return Some(None),                                         // uncompressed / hybrid forms: the caller's CPU path
+            }
+        }
+        let scalars = scalars_to_wire::<C>(ks.iter().copied());
+        let (mut xy, mut inf) = (vec![0u8; 2 * l], 0u8);
+        match unsafe { ecgpu_msm_compressed(eng.0, C::ID, scalars.as_ptr(), xs.as_ptr(), tags.as_ptr(), n, xy.as_mut_ptr(), &mut inf) } {
+            ECGPU_ERR_POINT => Some(None),
+            rc => check(rc).map(|_| Some(point_from_wire::<C>(&xy, inf))),
+        }
     }
 
     /// `sum_i k[i] * P[i]` — `LinearCombination::lincomb_vartime` (Pippenger instead of Straus; same group element).
@@ -387,7 +459,15 @@ pub mod gpu {
 //             }
 //         }
 //
-//     `fn lincomb` (:484-496, constant time) is left alone — see "SECRET SCALARS" above.
+//     and at the top of `fn lincomb` (:484-496, the CONSTANT-TIME form), the uniform-schedule entry point — never the
+//     bucket method:
+//
+//         #[cfg(feature = "gpu")]
+//         if points_and_scalars.len() >= ecgpu::GPU_MIN_TERMS_CT {
+//             if let Some(sum) = ecgpu::gpu::lincomb::<C>(points_and_scalars) {
+//                 return sum;
+//             }
+//         }
 //
 // (1b) primeorder/src/projective.rs:847-886 (`impl Mul<Scalar<C>> for ProjectivePoint<C>`) and k256/src/arithmetic/mul.rs:249-274
 //     are single-element operators and stay on the CPU; their constant-time BATCH forms are new inherent functions beside
@@ -411,7 +491,7 @@ pub mod gpu {
 // (2) k256/src/arithmetic/mul.rs:100-108 — the same three lines at the top of k256's own
 //     `LinearCombination<[(ProjectivePoint, Scalar)]>::lincomb_vartime` (k256 does not use primeorder), with
 //     `ecgpu::gpu::lincomb_vartime::<Secp256k1>`; the array form at :75-82 forwards to the slice form above
-//     GPU_MIN_TERMS.
+//     GPU_MIN_TERMS.  k256's constant-time `fn lincomb` (:84-98) gets the `ecgpu::gpu::lincomb::<Secp256k1>` lines of (1).
 //
 // (3) k256/src/arithmetic/mul.rs:205-232 (`mul_by_generator_vartime`) and :303-310
 //     (`mul_by_generator_and_mul_add_vartime`) are single-element calls: they stay on the CPU (a launch for one scalar

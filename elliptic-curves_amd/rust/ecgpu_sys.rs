@@ -56,6 +56,7 @@ unsafe extern "C" {
     pub fn ecgpu_set_async(ctx: *mut EcgpuCtx, on: c_int) -> c_int;
     pub fn ecgpu_synchronize(ctx: *mut EcgpuCtx) -> c_int;
     pub fn ecgpu_set_msm_lanes(ctx: *mut EcgpuCtx, lanes: c_int) -> c_int;
+    pub fn ecgpu_wipe(ctx: *mut EcgpuCtx) -> c_int;
     pub fn ecgpu_batch_mul_base(
         ctx: *mut EcgpuCtx,
         curve: c_int,
@@ -211,6 +212,7 @@ unsafe extern "C" {
     pub fn ecgpu_group_ctx(group: *mut EcgpuGroup, i: c_int) -> *mut EcgpuCtx;
     pub fn ecgpu_group_last_error(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_exchange(group: *const EcgpuGroup) -> *const c_char;
+    pub fn ecgpu_group_exchange_reason(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_set_msm_window(group: *mut EcgpuGroup, window_bits: c_int) -> c_int;
     pub fn ecgpu_group_msm(
         group: *mut EcgpuGroup,
@@ -540,6 +542,66 @@ unsafe extern "C" {
         n: usize,
         d_out_x: *mut c_void,
         d_ok: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_lincomb_ct(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        points_xy: *const u8,
+        points_inf: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_lincomb_ct_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        d_points_xy: *const c_void,
+        d_points_inf: *const c_void,
+        n: usize,
+        d_out_xy: *mut c_void,
+        d_out_inf: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_msm_compressed(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        points_x: *const u8,
+        points_tag: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_msm_compressed_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        d_points_x: *const c_void,
+        d_points_tag: *const c_void,
+        n: usize,
+        d_out_xy: *mut c_void,
+        d_out_inf: *mut c_void,
+    ) -> c_int;
+    pub fn ecgpu_batch_mul_compressed(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        scalars: *const u8,
+        points_x: *const u8,
+        points_tag: *const u8,
+        n: usize,
+        out_xy: *mut u8,
+        out_inf: *mut u8,
+    ) -> c_int;
+    pub fn ecgpu_batch_mul_compressed_dev(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        d_scalars: *const c_void,
+        d_points_x: *const c_void,
+        d_points_tag: *const c_void,
+        n: usize,
+        d_out_xy: *mut c_void,
+        d_out_inf: *mut c_void,
     ) -> c_int;
     pub fn ecgpu_batch_decompress(
         ctx: *mut EcgpuCtx,

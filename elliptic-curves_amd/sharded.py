@@ -14,7 +14,20 @@ Either way the payload is far below a megabyte: the step is latency- not bandwid
 
 The compute steps are injected, so the same host logic is exercised on CPU by the gloo tests (with the
 oracle standing in for the GPU) and on the GPU box by bench.py / the -m gpu tests (with Engine methods).
+
+First contact with RCCL must not be able to lose a run (bench.py --gpus N is launched ONCE by the driver on hardware this
+code has never seen): `init_exchange` below brings the process group up on gloo (the control plane: barriers, the agreement
+on the exchange path), tries RCCL in a throw-away CHILD process per rank first (`python sharded.py --nccl-probe`: its own
+rendezvous port, one all-gather, a deadline) and only when every rank's canary came back healthy creates the nccl group the
+data path uses.  A canary that crashes, reports wrong bytes or hangs past its deadline is killed, and the job runs its
+exchange through gloo (the records are tens of KiB) with the reason on record — a measured scaling curve with a slower
+exchange instead of a crash.
 """
+import os
+import subprocess
+import sys
+import time
+
 import numpy as np
 
 
@@ -120,3 +133,115 @@ class RecordExchange:
             # collective: wait for the gathered bytes
             self.torch.cuda.current_stream(self.all.device).synchronize()
         return self.all
+
+
+# ---- bringing the exchange up: gloo control plane, RCCL canary, fallback ------------------------------------------------------
+
+PROBE_BYTES = 64 << 10          # one parts record of a k256 MSM is 41 KiB
+
+
+def _nccl_probe_main():
+    """The canary (child process): RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT from the environment, one
+    all_gather_into_tensor over nccl (= RCCL on ROCm) on this rank's GPU, contents checked.  Exit status 0 = healthy."""
+    from datetime import timedelta
+
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("ECGPU_PROBE_DEVICE", os.environ.get("LOCAL_RANK", rank)))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=int(os.environ.get("ECGPU_PROBE_TIMEOUT", "60"))))
+    mine = torch.full((PROBE_BYTES,), rank + 1, dtype=torch.uint8, device=dev)
+    every = torch.zeros((world * PROBE_BYTES,), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(every, mine)
+    torch.cuda.synchronize()
+    got = every.view(world, PROBE_BYTES)[:, ::4096].cpu().numpy()
+    ok = all((got[r] == r + 1).all() for r in range(world))
+    dist.destroy_process_group()
+    print("NCCL_PROBE_OK" if ok else "NCCL_PROBE_BAD_BYTES", flush=True)
+    return 0 if ok else 3
+
+
+def run_nccl_probe(local_device, port_offset=1, timeout=None):
+    """Runs the canary for this rank; -> (healthy: bool, reason: str).  Never raises, never outlives `timeout` seconds."""
+    timeout = float(timeout if timeout is not None else os.environ.get("ECGPU_NCCL_PROBE_TIMEOUT", "150"))
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["ECGPU_PROBE_DEVICE"] = str(local_device)
+    env["ECGPU_PROBE_TIMEOUT"] = str(int(max(20, timeout - 30)))
+    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+        env.pop(k, None)
+    if os.environ.get("ECGPU_NCCL_PROBE_FAIL"):            # fault injection for the dry runs / tests: crash | hang
+        mode = os.environ["ECGPU_NCCL_PROBE_FAIL"]
+        cmd = [sys.executable, "-c", "import time, sys; time.sleep(3600)" if mode == "hang" else "import sys; sys.exit('injected canary failure')"]
+    else:
+        cmd = [sys.executable, os.path.abspath(__file__), "--nccl-probe"]
+    t0 = time.time()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        return False, "canary could not be started: %s" % e
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        try:
+            p.communicate(timeout=10)
+        except Exception:
+            pass
+        return False, "RCCL canary still running after %.0f s (killed)" % timeout
+    if p.returncode == 0 and "NCCL_PROBE_OK" in out:
+        return True, "RCCL canary healthy in %.1f s" % (time.time() - t0)
+    tail = [ln for ln in (err or out or "").strip().splitlines() if ln.strip()]
+    return False, "RCCL canary exit %s: %s" % (p.returncode, (tail[-1] if tail else "no output")[:300])
+
+
+class Exchange:
+    """What init_exchange returns: `group` for RecordExchange / TensorExchange (None = the default gloo group), `kind`
+    ("rccl" | "gloo-fallback" | "gloo-forced"), `reason` (one line for the bench record)."""
+
+    def __init__(self, kind, reason, group):
+        self.kind, self.reason, self.group = kind, reason, group
+
+
+def init_exchange(torch, dist, local_device, prefer="nccl", probe=True):
+    """Initialises torch.distributed for a one-process-per-GPU job so that it cannot be lost to the collective library:
+    default group = gloo (always); the data-path group is nccl only if every rank's canary was healthy AND the group's own
+    first collective completes; otherwise the exchange stays on gloo.  Call once per process, after torch.cuda.set_device."""
+    from datetime import timedelta
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", timeout=timedelta(seconds=600))
+    if prefer != "nccl":
+        return Exchange("gloo-forced", "exchange backend forced to %s" % prefer, None)
+    ok, reason = run_nccl_probe(local_device) if probe else (True, "canary skipped")
+    vote = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)                     # gloo: every rank learns whether ALL canaries were healthy
+    if int(vote.item()) != 1:
+        reasons = [None] * dist.get_world_size()
+        dist.all_gather_object(reasons, reason)
+        bad = [(r, x) for r, x in enumerate(reasons) if "healthy" not in x and "skipped" not in x]
+        return Exchange("gloo-fallback", "rank %d: %s" % bad[0] if bad else reason, None)
+    try:
+        group = dist.new_group(backend="nccl", timeout=timedelta(seconds=180), device_id=torch.device("cuda", local_device))
+        t = torch.full((1024,), dist.get_rank() + 1, dtype=torch.uint8, device="cuda:%d" % local_device)
+        every = torch.zeros((dist.get_world_size() * 1024,), dtype=torch.uint8, device="cuda:%d" % local_device)
+        dist.all_gather_into_tensor(every, t, group=group)
+        torch.cuda.synchronize()
+        good = bool((every.view(-1, 1024)[:, 0].cpu() == torch.arange(1, dist.get_world_size() + 1, dtype=torch.uint8)).all())
+    except Exception as e:                                           # raised errors only: a hang here is what the canary is for
+        good, group, reason = False, None, "nccl group in the main process failed: %s" % str(e).splitlines()[0][:300]
+    vote = torch.tensor([1 if good else 0], dtype=torch.int32)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if int(vote.item()) != 1:
+        return Exchange("gloo-fallback", reason if not good else "another rank's nccl group failed", None)
+    return Exchange("rccl", reason, group)
+
+
+if __name__ == "__main__":
+    if "--nccl-probe" in sys.argv:
+        sys.exit(_nccl_probe_main())

@@ -45,8 +45,8 @@
  * when the scalar is a long-term secret and an attacker can observe the device (timing of a shared GPU, its memory
  * traffic).  ecgpu_batch_mul_base* and ecgpu_batch_ecdh accept whatever scalars they are given: a caller that passes
  * private keys there has decided that its threat model allows it; the results are the same group elements either way.
- * For secret scalars there are the three uniform-schedule entry points ecgpu_batch_mul_base_ct, ecgpu_batch_mul_ct and
- * ecgpu_batch_ecdh_ct (below): the reference's constant-time drivers — fixed digit count, every table entry read and one
+ * For secret scalars there are the uniform-schedule entry points ecgpu_batch_mul_base_ct, ecgpu_batch_mul_ct,
+ * ecgpu_batch_ecdh_ct and ecgpu_lincomb_ct (below): the reference's constant-time drivers — fixed digit count, every table entry read and one
  * kept under a mask, complete additions — at 1.2-7x the cost of the variable-time kernels.
  *
  * Threading: a context may be used from one thread at a time (calls serialise on its stream);
@@ -151,10 +151,22 @@ int ecgpu_synchronize(ecgpu_ctx *ctx);
  * streams, each with a workspace of its own, so that several independent MSMs are in flight: the sort and the reduction tail of
  * one (bandwidth- and latency-bound) run beside the accumulation of the other (issue-bound) — 8-12 % more MSMs per second on
  * one GPU (profiles/r03/msm_lanes.txt); the time of a single MSM does not change.  A lane starts after the work queued on
- * the context's stream at the time of the call (its inputs); its OUTPUT is ordered by ecgpu_synchronize only, not by later
- * calls on the context, and every MSM in flight needs output buffers of its own.  lanes = 1 (the default) restores one
- * stream.  Other entry points and synchronous contexts are unaffected.  Returns ECGPU_ERR_ARG for other values. */
+ * the context's stream at the time of the call (its inputs).  Ordering rules while MSMs are in flight on the lanes:
+ *   - every MSM in flight needs output buffers of its own, and its INPUT buffers must stay untouched until it has finished;
+ *   - any other entry point called later on this context (a batch call, ecgpu_point_sum_dev, ecgpu_copy_to_host, ...) first
+ *     waits for all lanes, so it may read an MSM's output or overwrite its inputs;
+ *   - a further ecgpu_msm_dev does NOT wait (that is the point), and neither does work the caller enqueues itself on the
+ *     context's stream (ecgpu_set_stream): for those, inputs and outputs belong to the lanes until ecgpu_synchronize.
+ * lanes = 1 (the default) restores one stream.  Synchronous contexts are unaffected.  Returns ECGPU_ERR_ARG for other values. */
 int ecgpu_set_msm_lanes(ecgpu_ctx *ctx, int lanes);
+
+/* Zeroes every staging and scratch buffer the context owns on the device (inputs copied in by host-pointer calls, projective
+ * results, batch-inversion products, signature scratch, MSM workspaces) and waits for it.  The uniform-schedule (`_ct`) entry
+ * points do this by themselves for what they touch — the reference keeps secret scalars and shared secrets in
+ * zeroize-on-drop types (`NonZeroScalar`, `SharedSecret`) —; a caller that has passed secrets through a variable-time name
+ * (private keys to ecgpu_batch_mul_base) calls this before it lets go of the context.  Buffers the CALLER allocated
+ * (ecgpu_dev_alloc, ecgpu_host_alloc, torch tensors) are the caller's to wipe.  Basepoint tables are public data and stay. */
+int ecgpu_wipe(ecgpu_ctx *ctx);
 
 /* ---- host-pointer entry points (copy in, compute on the GPU, copy out) ------------------------ */
 
@@ -268,6 +280,10 @@ int ecgpu_group_size(const ecgpu_group *group);
 ecgpu_ctx *ecgpu_group_ctx(ecgpu_group *group, int i);              /* borrowed: member i's context */
 const char *ecgpu_group_last_error(const ecgpu_group *group);
 const char *ecgpu_group_exchange(const ecgpu_group *group);         /* "rccl" or "peer" */
+/* why: "rccl: ncclCommInitAll over 8 devices", "peer: ECGPU_GROUP_EXCHANGE=peer", "peer: duplicate devices in the group",
+ * "peer: librccl could not be loaded (...)", "peer: ncclCommInitAll failed (...)", "peer: ncclAllGather failed (...)": a
+ * group whose RCCL exchange fails at run time falls back to peer copies for that call and all later ones */
+const char *ecgpu_group_exchange_reason(const ecgpu_group *group);
 int ecgpu_group_set_msm_window(ecgpu_group *group, int window_bits);
 /* `lincomb` over all GPUs of the group, host buffers (every GPU uploads its own shard over its own PCIe link). */
 int ecgpu_group_msm(ecgpu_group *group, int curve, const uint8_t *scalars, const uint8_t *points_xy,
@@ -443,6 +459,13 @@ int ecgpu_batch_ecdh_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const
  *                             addition per digit, no digit skipped, the accumulator starts at the identity
  *   ecgpu_batch_ecdh_ct       `diffie_hellman(secret, public)` (k256/src/ecdh.rs:56-60 over the `Mul` above): x of
  *                             ecgpu_batch_mul_ct
+ *   ecgpu_lincomb_ct          `LinearCombination::lincomb` (primeorder/src/projective.rs:484-496 -> :532-557;
+ *                             k256/src/arithmetic/mul.rs:84-98 -> :112-163): out = sum_i k_i P_i with one ecgpu_batch_mul_ct
+ *                             multiplication per term and a tree of complete additions over the n products (256 per workgroup
+ *                             and level).  The reference interleaves the terms on one accumulator; the group element is the
+ *                             same, and the instruction and memory schedule here is a function of n alone.  n == 0 gives the
+ *                             identity.  Cost: n uniform-schedule multiplications — for PUBLIC scalars ecgpu_msm (the bucket
+ *                             method) is 50-100x faster from a few thousand terms on
  * What is guaranteed, and checked on the gfx950 ISA of the two kernels by tools/ct_isa_check.py (a register-level taint
  * analysis from every loaded record to every branch condition and every memory address; tests/test_ct_isa.py): no
  * conditional branch and no load / store address depends on the contents of a scalar or point record; range and
@@ -460,6 +483,28 @@ int ecgpu_batch_ecdh_ct(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const
                         uint8_t *ok);
 int ecgpu_batch_ecdh_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, size_t n, void *d_out_x,
                             void *d_ok);
+int ecgpu_lincomb_ct(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_xy, const uint8_t *points_inf,
+                     size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_lincomb_ct_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
+                         size_t n, void *d_out_xy, void *d_out_inf);
+
+/* Compressed points INTO the path (callers hold 33-byte SEC1 keys).  Like ecgpu_msm / ecgpu_batch_mul with
+ * point i given as points_x[i] (L bytes, the curve's wire order) + points_tag[i]: 0x02 / 0x03 = the point with that x and even /
+ * odd y (`FromSec1Point::from_sec1_point` of a compressed encoding -> `DecompressPoint::decompress`,
+ * primeorder/src/affine.rs:183-200,352-366, k256/src/arithmetic/affine.rs:261-280), 0x00 (with x = 0) = the identity
+ * (`Sec1Point::identity`).  The points are decoded on the device — one square root each, which costs about as much as 25 point
+ * additions: at 2^24 k256 terms the decoding takes as long as the MSM itself — and the ordinary pipeline runs on the
+ * result.  Any other tag, x >= p or an x that is on no point of the curve (the reference's `CtOption::None`) fails the call
+ * with ECGPU_ERR_POINT.  Variable-time like the calls they feed; for secret scalars over compressed public keys decode with
+ * ecgpu_batch_decompress_dev and pass the result to ecgpu_batch_mul_ct_dev. */
+int ecgpu_msm_compressed(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_x, const uint8_t *points_tag,
+                         size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_msm_compressed_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_x, const void *d_points_tag,
+                             size_t n, void *d_out_xy, void *d_out_inf);
+int ecgpu_batch_mul_compressed(ecgpu_ctx *ctx, int curve, const uint8_t *scalars, const uint8_t *points_x,
+                               const uint8_t *points_tag, size_t n, uint8_t *out_xy, uint8_t *out_inf);
+int ecgpu_batch_mul_compressed_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_x,
+                                   const void *d_points_tag, size_t n, void *d_out_xy, void *d_out_inf);
 
 /* Batch point decompression — `DecompressPoint::decompress(x_bytes, y_is_odd)`
  * (primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280; SEC1 tag 0x02 / 0x03 = y_is_odd 0 / 1;

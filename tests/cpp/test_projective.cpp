@@ -165,14 +165,16 @@ int run(const char* name, const uint8_t* n_be, int cases) {
         CHECK(flipped[0] != A && flipped[0].x() == A.x());
         auto shared = C::batch_diffie_hellman({a, b}, {B, A});
         CHECK(shared[0] == shared[1]);
-        // the constant-time forms (uniform-schedule kernels) compute the same group elements: `Mul`, `mul_by_generator`,
-        // `diffie_hellman` proper (primeorder/src/projective.rs:847-886, k256/src/arithmetic/mul.rs:180-197, k256/src/ecdh.rs:56-60)
-        auto pub_ct = C::batch_mul_by_generator({a, b}, true);
-        CHECK(pub_ct[0] == pub[0] && pub_ct[1] == pub[1]);
-        auto shared_ct = C::batch_diffie_hellman({a, b}, {B, A}, true);
-        CHECK(shared_ct[0] == shared[0] && shared_ct[1] == shared[1]);
-        auto prod = C::batch_mul({pub[0], pub[1], P::IDENTITY()}, {b, a, a}), prod_ct = C::batch_mul({pub[0], pub[1], P::IDENTITY()}, {b, a, a}, true);
-        CHECK(prod_ct[0] == prod[0] && prod_ct[1] == prod[1] && prod_ct[0] == prod_ct[1] && prod_ct[2].is_identity());
+        // the reference's names are the constant-time forms (uniform-schedule kernels): `Mul`, `mul_by_generator`,
+        // `diffie_hellman` proper (primeorder/src/projective.rs:847-886, k256/src/arithmetic/mul.rs:180-197, k256/src/ecdh.rs:56-60);
+        // the `*_vartime` names compute the same group elements on the variable-time kernels
+        auto pub_vt = C::batch_mul_by_generator_vartime({a, b});
+        CHECK(pub_vt[0] == pub[0] && pub_vt[1] == pub[1]);
+        auto shared_vt = C::batch_diffie_hellman_vartime({a, b}, {B, A});
+        CHECK(shared_vt[0] == shared[0] && shared_vt[1] == shared[1]);
+        auto prod = C::batch_mul({pub[0], pub[1], P::IDENTITY()}, {b, a, a}), prod_vt = C::batch_mul_vartime({pub[0], pub[1], P::IDENTITY()}, {b, a, a});
+        CHECK(prod_vt[0] == prod[0] && prod_vt[1] == prod[1] && prod_vt[0] == prod_vt[1] && prod_vt[2].is_identity());
+        CHECK(P::mul_by_generator_vartime(a) == pub[0] && pub[1].mul_vartime(a) == prod[1]);
     }
     // ECDSA: a signature assembled from the verification equation itself verifies, a disturbed one does not.
     // Choose u1, u2, set R = u1 G + u2 Q, r = x(R) (when x(R) < n), s = r / u2, z = u1 s: then z/s = u1, r/s = u2.

@@ -29,10 +29,14 @@ def main():
     import oracle_lib
     ecgpu = importlib.import_module("elliptic-curves_amd")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    local = int(os.environ.get("LOCAL_RANK", rank))
+    local = 0 if os.environ.get("MGPU_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", rank))     # (one-GPU dry runs: every rank on device 0)
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    dist.init_process_group("nccl", device_id=torch.device(device))
+    # as bench.py: gloo control plane, RCCL for the records only if a canary process and the group's first collective are
+    # healthy (sharded.init_exchange); MGPU_REQUIRE_RCCL=1 (the first-contact test on real multi-GPU boxes) insists on it
+    ex_info = ecgpu.init_exchange(torch, dist, local)
+    if os.environ.get("MGPU_REQUIRE_RCCL") and ex_info.kind != "rccl":
+        raise SystemExit("RCCL exchange not available: %s" % ex_info.reason)
     eng = ecgpu.Engine(local)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     oracle_lib.build()
@@ -54,7 +58,7 @@ def main():
         if n:
             eng.mul_by_generator_dev(cid, d_s, n, d_pts, None)
         plan_terms = max(1, (n_total + world - 1) // world)
-        ex = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device)
+        ex = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device, group=ex_info.group)
         d_out = torch.zeros((1, 2 * L), dtype=torch.uint8, device=device)
         d_inf = torch.zeros((16,), dtype=torch.uint8, device=device)
         eng.msm_parts_dev(cid, d_k if n else None, d_pts if n else None, None, n, plan_terms, ex.mine)
@@ -81,19 +85,19 @@ def main():
             torch.cuda.synchronize()
             ref[: 2 * L] = o1.view(-1)
             ref[2 * L] = f1[0]
-        dist.broadcast(ref, 0)
-        torch.cuda.synchronize()
+        ref_h = ref.cpu()                                    # (the default group is gloo: host tensors)
+        dist.broadcast(ref_h, 0)
+        ref = ref_h.to(device)
         assert got == bytes(ref[: 2 * L + 1].cpu().numpy()), "rank %d: sharded MSM != single-GPU MSM (curve %d, n %d)" % (rank, cid, n_total)
         # (c) every rank holds the same bytes (all-gather of the result records)
         mine = torch.frombuffer(bytearray(got + bytes(15 - (len(got) - 1) % 16)), dtype=torch.uint8).to(device)
-        allr = torch.empty((world * mine.numel(),), dtype=torch.uint8, device=device)
-        dist.all_gather_into_tensor(allr, mine)
-        torch.cuda.synchronize()
-        rows = allr.cpu().numpy().reshape(world, -1)
+        allr = torch.empty((world * mine.numel(),), dtype=torch.uint8)
+        dist.all_gather_into_tensor(allr, mine.cpu())
+        rows = allr.numpy().reshape(world, -1)
         assert all(bytes(rows[r]) == bytes(rows[0]) for r in range(world)), "ranks disagree"
     dist.barrier()
     if rank == 0:
-        print("MGPU_WORKER_OK world=%d" % world, flush=True)
+        print("MGPU_WORKER_OK world=%d exchange=%s (%s)" % (world, ex_info.kind, ex_info.reason), flush=True)
     dist.destroy_process_group()
     eng.close()
 

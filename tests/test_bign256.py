@@ -170,6 +170,18 @@ def test_gpu_vs_oracle(eng):
     assert bytes(dxy) == bytes(oxy) and bytes(dok) == bytes(ook) and bytes(dxy) == bytes(want[64:])
     cx, tag = eng.mul_by_generator_compressed(CID, scal)
     assert bytes(cx[32:]) == bytes(xs) and bytes(tag[1:]) == bytes(2 + odd) and tag[0] == 0
+    # round 4: the constant-time `lincomb` and compressed points into the path, little-endian records
+    for m in (0, 1, 3, 17, n):
+        o, f = eng.lincomb_ct(CID, k2[: 32 * m], want[: 64 * m], winf[:m])
+        wm, wf = oracle_lib.msm(CID, k2[: 32 * m], want[: 64 * m], winf[:m], vartime=False) if m else (np.zeros(64, np.uint8), 1)
+        assert bytes(o) == bytes(wm) and f == wf, m
+    tags = np.concatenate([np.zeros(1, np.uint8), (2 + odd).astype(np.uint8)])          # index 0 is the identity (k = 0): tag 0, x = 0
+    xs_all = np.concatenate([np.zeros(32, np.uint8), xs])
+    o, f = eng.lincomb_compressed(CID, k2, xs_all, tags)
+    wm, wf = oracle_lib.msm(CID, k2, want, winf, vartime=True)
+    assert bytes(o) == bytes(wm) and f == wf
+    out, inf = eng.mul_compressed(CID, k2, xs_all, tags)
+    assert bytes(out) == bytes(w2) and bytes(inf) == bytes(wi2)
     # device field arithmetic, little-endian records
     vals = [rng.randrange(C.p) for _ in range(500)]
     oth = [rng.randrange(C.p) for _ in range(500)]

@@ -58,12 +58,36 @@ def test_nccl_ranks_sharded_msm_equals_single_gpu(world):
     """One process per GPU under torch.distributed.run, RCCL all-gather of the parts: every rank's result == the
     single-GPU MSM == the exact dot product (tests/mgpu_worker.py has the cases)."""
     need_gpus(world)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    port = 29700 + (os.getpid() + world) % 200
+    r = run_workers(world, MGPU_REQUIRE_RCCL="1")
+    assert r.returncode == 0 and "MGPU_WORKER_OK world=%d exchange=rccl" % world in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+
+
+def run_workers(world, **extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra)
+    port = 29700 + (os.getpid() + 7 * world + len(extra)) % 200
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "mgpu_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "MGPU_WORKER_OK world=%d" % world in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+@pytest.mark.parametrize("fault", ["natural", "crash", "hang"])
+def test_two_ranks_fall_back_to_gloo_when_rccl_is_not_to_be_had(fault):
+    """What the driver's one scaling run must survive, reproduced on ONE GPU: two ranks share device 0, so RCCL cannot form
+    its communicator (`natural`: measured in round 4, its init neither fails nor returns — the canary process of
+    sharded.init_exchange is killed at its deadline, which is exactly the case a hung main process could not report), or the
+    canary is made to crash / hang (fault injection: ECGPU_NCCL_PROBE_FAIL).  Either way every rank agrees on the gloo
+    exchange, the sharded MSM results are right on every rank, and the reason is on record."""
+    if device_count() < 1:
+        pytest.skip("needs a GPU")
+    extra = dict(MGPU_SHARE_GPU="1")
+    if fault != "natural":
+        extra.update(ECGPU_NCCL_PROBE_FAIL=fault, ECGPU_NCCL_PROBE_TIMEOUT="25")
+    else:
+        extra.update(ECGPU_NCCL_PROBE_TIMEOUT="45")      # (RCCL with two ranks on one device does not fail, it HANGS: the canary is killed)
+    r = run_workers(2, **extra)
+    assert r.returncode == 0 and "MGPU_WORKER_OK world=2 exchange=gloo-fallback" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
+    if fault == "hang":
+        assert "killed" in r.stdout
 
 
 @pytest.mark.parametrize("mode", ["rccl", "peer"])
@@ -184,27 +208,40 @@ def test_comb_table_is_shared_per_device_and_outlives_its_builder():
 
 
 def test_comb_table_falls_back_to_a_narrower_window_when_it_does_not_fit(monkeypatch):
-    """ECGPU_TEST_TABLE_MAX_MB makes the table allocation refuse anything larger (fault injection: a real out-of-memory
-    needs a full GPU): the width drops two bits at a time, results stay identical; when not even 16 bits fit the call
-    returns ECGPU_ERR_OOM (not ECGPU_ERR_HIP) and the context stays usable."""
+    """The test hook ecgpu_testhook_table_max_mb (an exported symbol that is not in include/ecgpu.h; no environment variable can
+    steer the production path) makes the table allocation refuse anything larger (fault injection: a real out-of-memory needs
+    a full GPU): the width drops two bits at a time, results stay identical, a second context of the device goes straight to
+    the width that worked; when not even 16 bits fit the call returns ECGPU_ERR_OOM (not ECGPU_ERR_HIP) and the context
+    stays usable."""
+    import ctypes
     ecgpu = ecgpu_module()
+    hook = ecgpu.load_library().ecgpu_testhook_table_max_mb
+    hook.restype, hook.argtypes = None, [ctypes.c_size_t]
     c = pyec.CURVES["p192"]
     k = rand_scalars(c.cid, 300, 0xEC0012F7)
     want, winf = oracle_lib.batch_mul_base(c.cid, k)
     e = ecgpu.Engine(0)
     try:
         e.set_base_window(c.cid, 22)          # 2^21 x 9 windows x 48 B = 906 MB; 20: 252 MB; 18: 69 MB; 16: 19 MB
-        monkeypatch.setenv("ECGPU_TEST_TABLE_MAX_MB", "64")
+        hook(64)
         out, inf = e.mul_by_generator(c.cid, k)
         assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
-        monkeypatch.setenv("ECGPU_TEST_TABLE_MAX_MB", "8")
+        e2 = ecgpu.Engine(0)                  # the registry remembers the refused widths: no second attempt at 22 / 20 / 18
+        try:
+            e2.set_base_window(c.cid, 22)
+            out, inf = e2.mul_by_generator(c.cid, k)
+            assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+        finally:
+            e2.close()
+        hook(8)
         e.set_base_window(c.cid, 21)          # 21 -> 19 -> 17: 38 MB; 15 is below the floor
         with pytest.raises(ecgpu.EcgpuError) as ei:
             e.mul_by_generator(c.cid, k)
         assert ei.value.code == ecgpu.ERR_OOM
-        monkeypatch.delenv("ECGPU_TEST_TABLE_MAX_MB")
+        hook(0)
         e.set_base_window(c.cid, 12)
         out, inf = e.mul_by_generator(c.cid, k)
         assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     finally:
+        hook(0)
         e.close()

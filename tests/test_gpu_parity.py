@@ -707,6 +707,163 @@ def test_uniform_schedule_entry_points(eng, curve):
     assert eng.mul(c.cid, b"", b"", constant_time=True)[0].size == 0
 
 
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_lincomb_constant_time_form_vs_oracle(eng, curve):
+    """ecgpu_lincomb_ct = `LinearCombination::lincomb` in its constant-time form (primeorder/src/projective.rs:484-496,532-557;
+    k256/src/arithmetic/mul.rs:84-98,112-163): against the oracle's `lincomb` (vartime = False: the reference's Straus loop) and
+    the bucket method for n in {0, 1, 2, 3, 17, 257, 4000}, with edge scalars, identities, duplicates and cancelling pairs
+    among the terms, NULL flags, the device-pointer form, and the variable-time entry point's error behaviour."""
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES[curve]
+    G = pyec.G(c)
+    nmax = 4000
+    pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, nmax, 0xC7EC0020 + c.cid))
+    pts = pts.copy()
+    sc = rand_scalars(c.cid, nmax, 0xC7EC0021 + c.cid).copy()
+    pinf = np.zeros(nmax, np.uint8)
+    slot = 3                                        # (the first three terms stay random: n = 1, 2, 3 are plain cases)
+    for k in edge_scalars(c)[:12]:
+        for P in (G, pyec.neg(c, G), pyec.INF):
+            e, f = pyec.enc_point(c, P)
+            sc[slot * c.L: (slot + 1) * c.L] = np.frombuffer(pyec.enc_scalar(c, k), np.uint8)
+            pts[slot * 2 * c.L: (slot + 1) * 2 * c.L] = np.frombuffer(e, np.uint8)
+            pinf[slot] = f
+            slot += 1
+    # a duplicated term and a cancelling pair (k P + (n - k) P)
+    sc[(slot + 1) * c.L: (slot + 2) * c.L] = sc[slot * c.L: (slot + 1) * c.L]
+    pts[(slot + 1) * 2 * c.L: (slot + 2) * 2 * c.L] = pts[slot * 2 * c.L: (slot + 1) * 2 * c.L]
+    for n in (0, 1, 2, 3, 17, 257, nmax):
+        s_, p_, f_ = sc[: n * c.L], pts[: n * 2 * c.L], pinf[:n]
+        got, ginf = eng.lincomb_ct(c.cid, s_, p_, f_)
+        want, winf = oracle_lib.msm(c.cid, s_, p_, f_, vartime=False) if n else (np.zeros(2 * c.L, np.uint8), 1)
+        assert bytes(got) == bytes(want) and ginf == winf, "lincomb_ct != oracle lincomb at n = %d" % n
+        vxy, vinf = eng.lincomb(c.cid, s_, p_, f_)                            # the bucket method (variable-time names)
+        assert bytes(got) == bytes(vxy) and ginf == vinf
+    # NULL flags on a stretch without identities
+    lo = slot + 3
+    got, ginf = eng.lincomb_ct(c.cid, sc[lo * c.L:(lo + 300) * c.L], pts[lo * 2 * c.L:(lo + 300) * 2 * c.L], None)
+    want, winf = oracle_lib.msm(c.cid, sc[lo * c.L:(lo + 300) * c.L], pts[lo * 2 * c.L:(lo + 300) * 2 * c.L], None, vartime=False)
+    assert bytes(got) == bytes(want) and ginf == winf
+    # cancellation to the identity: k G + (n - k) G
+    k = 0x1234567
+    two = pyec.enc_scalar(c, k) + pyec.enc_scalar(c, c.n - k)
+    gxy = pyec.enc_point(c, G)[0]
+    got, ginf = eng.lincomb_ct(c.cid, two, gxy * 2)
+    assert ginf == 1 and not got.any()
+    # device-pointer form
+    n = 600
+    d_k, d_p, d_f = eng.to_device(sc[: n * c.L]), eng.to_device(pts[: n * 2 * c.L]), eng.to_device(pinf[:n])
+    d_o, d_oi = eng.dev_alloc(2 * c.L + 64), eng.dev_alloc(16)
+    eng.lincomb_ct_dev(c.cid, d_k, d_p, d_f, n, d_o, d_oi)
+    want, winf = oracle_lib.msm(c.cid, sc[: n * c.L], pts[: n * 2 * c.L], pinf[:n], vartime=False)
+    assert bytes(eng.to_host(d_o, 2 * c.L)) == bytes(want) and int(eng.to_host(d_oi, 1)[0]) == winf
+    for b in (d_k, d_p, d_f, d_o, d_oi):
+        b.free()
+    # errors
+    good_k = pyec.enc_scalar(c, 5)
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.lincomb_ct(c.cid, good_k + c.n.to_bytes(c.L, "little" if c.le else "big"), gxy * 2)
+    assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+    off = bytearray(gxy); off[-1 if not c.le else c.L] ^= 1
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.lincomb_ct(c.cid, good_k * 2, gxy + bytes(off))
+    assert e.value.code == ecgpu.ERR_POINT
+
+
+@pytest.mark.parametrize("curve", ALL_CURVES)
+def test_compressed_points_into_msm_and_batch_mul(eng, curve):
+    """ecgpu_msm_compressed / ecgpu_batch_mul_compressed: x + SEC1 tag records are decoded on the device
+    (`DecompressPoint::decompress`, primeorder/src/affine.rs:183-200, k256/src/arithmetic/affine.rs:261-280) and the ordinary
+    pipeline runs on them — equal to the oracle's decompress-then-lincomb / -mul, including identity records (tag 0x00); an x that
+    is on no point of the curve, x >= p and a tag outside {0, 2, 3} fail the call with ECGPU_ERR_POINT."""
+    ecgpu = ecgpu_module()
+    c = pyec.CURVES[curve]
+    for n in (1, 2, 300, 5000):
+        pts, _ = oracle_lib.batch_mul_base(c.cid, rand_scalars(c.cid, n, 0xC0EC0001 + c.cid + n))
+        P = pts.reshape(n, 2 * c.L)
+        ylow = P[:, c.L] if c.le else P[:, 2 * c.L - 1]                     # the byte that holds y's parity in wire order
+        xs = P[:, : c.L].copy()
+        tags = (2 + (ylow & 1)).astype(np.uint8)
+        sc = rand_scalars(c.cid, n, 0xC0EC0002 + c.cid + n)
+        pin = np.zeros(n, np.uint8)
+        if n >= 300:                                                          # identity records among the terms
+            for i in (5, 77, n - 1):
+                xs[i] = 0; tags[i] = 0; pin[i] = 1
+        got, ginf = eng.lincomb_compressed(c.cid, sc, xs.reshape(-1), tags)
+        want, winf = oracle_lib.msm(c.cid, sc, pts, pin, vartime=True)
+        assert bytes(got) == bytes(want) and ginf == winf, "msm_compressed != oracle at n = %d" % n
+        out, oinf = eng.mul_compressed(c.cid, sc, xs.reshape(-1), tags)
+        wout, woinf = oracle_lib.batch_mul(c.cid, sc, pts, pin, vartime=True)
+        assert bytes(out) == bytes(wout) and bytes(oinf) == bytes(woinf)
+    # the decoded records agree with the oracle's decompression (both parities of one x give P and -P)
+    xs1 = xs[:64].copy().reshape(-1)
+    dec, ok = oracle_lib.batch_decompress(c.cid, xs1, np.ones(64, np.uint8))
+    assert ok[:5].all()
+    one = np.frombuffer(pyec.enc_scalar(c, 1) * 64, np.uint8)
+    out, oinf = eng.mul_compressed(c.cid, one[: 4 * c.L], xs1[: 4 * c.L], np.full(4, 3, np.uint8))
+    assert bytes(out) == bytes(dec[: 4 * 2 * c.L]) and not oinf.any()
+    # failures: a non-residue x, x = p, bad tags, a non-zero x under the identity tag
+    rng = np.random.default_rng(0xC0EC0003 + c.cid)
+    bad_x = None
+    while bad_x is None:
+        cand = rng.integers(0, 256, c.L, dtype=np.uint8)
+        if c.L == 66:
+            cand[0] &= 1
+        _, okc = oracle_lib.batch_decompress(c.cid, cand, np.zeros(1, np.uint8))
+        if not okc[0] and int.from_bytes(bytes(cand), "little" if c.le else "big") < c.p:
+            bad_x = cand
+    good_k = np.frombuffer(pyec.enc_scalar(c, 7) * 2, np.uint8)
+    gx = xs[0]
+    p_bytes = np.frombuffer(c.p.to_bytes(c.L, "little" if c.le else "big"), np.uint8)
+    cases = [(np.concatenate([gx, bad_x]), np.array([2, 2], np.uint8)),
+             (np.concatenate([gx, p_bytes]), np.array([2, 3], np.uint8)),
+             (np.concatenate([gx, gx]), np.array([2, 4], np.uint8)),
+             (np.concatenate([gx, gx]), np.array([2, 1], np.uint8)),
+             (np.concatenate([gx, gx]), np.array([2, 0], np.uint8))]
+    for x2, t2 in cases:
+        for fn in (eng.lincomb_compressed, eng.mul_compressed):
+            with pytest.raises(ecgpu.EcgpuError) as e:
+                fn(c.cid, good_k, x2, t2)
+            assert e.value.code == ecgpu.ERR_POINT
+    with pytest.raises(ecgpu.EcgpuError) as e:
+        eng.lincomb_compressed(c.cid, np.frombuffer((c.n).to_bytes(c.L, "little" if c.le else "big"), np.uint8), gx, np.array([2], np.uint8))
+    assert e.value.code == ecgpu.ERR_SCALAR_RANGE
+    got, ginf = eng.lincomb_compressed(c.cid, b"", b"", b"")
+    assert ginf == 1
+    assert eng.mul_compressed(c.cid, b"", b"", b"")[0].size == 0
+
+
+def test_compressed_points_device_resident_2p18_and_wipe(eng):
+    """The _dev forms at 2^18 k256 / p256 terms (two-level sort, queued on an asynchronous context too) equal the x || y forms;
+    ecgpu_wipe leaves the context usable."""
+    for curve in ("k256", "p256"):
+        c = pyec.CURVES[curve]
+        n = 1 << 18
+        d_s = eng.to_device(rand_scalars(c.cid, n, 0xC0EC0010 + c.cid))
+        d_k = eng.to_device(rand_scalars(c.cid, n, 0xC0EC0011 + c.cid))
+        d_p, d_f = eng.dev_alloc(n * 2 * c.L), eng.dev_alloc(n)
+        eng.mul_by_generator_dev(c.cid, d_s, n, d_p, d_f)
+        P = eng.to_host(d_p).reshape(n, 2 * c.L)
+        d_x = eng.to_device(P[:, : c.L].copy().reshape(-1))
+        d_t = eng.to_device((2 + (P[:, 2 * c.L - 1] & 1)).astype(np.uint8))
+        d_o1, d_o2, d_i1, d_i2 = eng.dev_alloc(2 * c.L + 64), eng.dev_alloc(2 * c.L + 64), eng.dev_alloc(16), eng.dev_alloc(16)
+        eng.lincomb_dev(c.cid, d_k, d_p, None, n, d_o1, d_i1)
+        eng.lincomb_compressed_dev(c.cid, d_k, d_x, d_t, n, d_o2, d_i2)
+        assert bytes(eng.to_host(d_o1, 2 * c.L)) == bytes(eng.to_host(d_o2, 2 * c.L)) and eng.to_host(d_i1, 1)[0] == eng.to_host(d_i2, 1)[0] == 0
+        d_q1, d_q2 = eng.dev_alloc(n * 2 * c.L), eng.dev_alloc(n * 2 * c.L)
+        eng.mul_dev(c.cid, d_k, d_p, None, n, d_q1, d_f)
+        eng.set_async(True)
+        eng.mul_compressed_dev(c.cid, d_k, d_x, d_t, n, d_q2, d_f)
+        eng.synchronize()
+        eng.set_async(False)
+        assert bytes(eng.to_host(d_q1)) == bytes(eng.to_host(d_q2))
+        eng.wipe()
+        eng.lincomb_compressed_dev(c.cid, d_k, d_x, d_t, n, d_o2, d_i2)
+        assert bytes(eng.to_host(d_o1, 2 * c.L)) == bytes(eng.to_host(d_o2, 2 * c.L))
+        for b in (d_s, d_k, d_p, d_f, d_x, d_t, d_o1, d_o2, d_i1, d_i2, d_q1, d_q2):
+            b.free()
+
+
 def test_uniform_schedule_device_resident_and_queued(eng):
     """The _dev forms on device-resident p256 / k256 batches (2^14 elements: several waves per SIMD slot, the table scratch
     reused by the lanes' later elements), synchronous and queued (ecgpu_set_async), equal to the variable-time results."""

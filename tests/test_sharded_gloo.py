@@ -162,3 +162,47 @@ def test_record_exchange_world2_gloo(oracle, tmp_path, curve, n):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert " ok" in o
+
+
+WORKER_INIT = '''
+import importlib, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+ecgpu = importlib.import_module("elliptic-curves_amd")
+os.environ.update(RANK=sys.argv[1], WORLD_SIZE=sys.argv[2], LOCAL_RANK=sys.argv[1], MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}")
+ex = ecgpu.init_exchange(torch, dist, int(sys.argv[1]), prefer=sys.argv[3])
+rank, world = dist.get_rank(), dist.get_world_size()
+assert ex.group is None and dist.get_backend() == "gloo", (ex.kind, ex.reason)
+# the exchange object bench.py builds works on the path that was chosen
+rx = ecgpu.RecordExchange(torch, dist, 48, "cpu", group=ex.group)
+rx.mine[:] = rank + 1
+got = rx.gather().numpy().reshape(world, 48)
+assert all((got[r] == r + 1).all() for r in range(world))
+print("rank", rank, "exchange", ex.kind, "|", ex.reason)
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("prefer,fault,kind", [("nccl", "", "gloo-fallback"), ("nccl", "crash", "gloo-fallback"), ("nccl", "hang", "gloo-fallback"),
+                                               ("gloo", "", "gloo-forced")])
+def test_init_exchange_falls_back_to_gloo_world2(tmp_path, prefer, fault, kind):
+    """sharded.init_exchange (what bench.py --gpus N and tests/mgpu_worker.py bring the job up with): gloo control plane, an
+    RCCL canary in a child process per rank, agreement over gloo.  This container has no GPU, so the real canary fails on its
+    own ("natural"); a crashing and a hanging canary are injected too (the hang is killed at its deadline).  Every rank must
+    end on the gloo exchange with the reason on record, and the job must go on."""
+    port = 35500 + (os.getpid() + len(fault) * 17 + len(prefer)) % 2000
+    script = tmp_path / "worker_init.py"
+    script.write_text(WORKER_INIT.format(root=ROOT, port=port))
+    env = dict(os.environ, ECGPU_NCCL_PROBE_TIMEOUT="40" if not fault else "8")
+    if fault:
+        env["ECGPU_NCCL_PROBE_FAIL"] = fault
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", prefer], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                              env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+        assert "exchange " + kind in o, o
+        if fault == "hang":
+            assert "killed" in o, o

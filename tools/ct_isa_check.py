@@ -2,7 +2,8 @@
 """Static check of the uniform-schedule kernels (csrc/ecgpu_ct.h) on their gfx950 ISA: no conditional branch and no memory
 address may depend on the contents of a scalar or point record.
 
-    python tools/ct_isa_check.py [--curve P256Params ...] [--kernels k_var_base_ct,k_fixed_base_ct] [--keep] [--self-test]
+    python tools/ct_isa_check.py [--curve P256Params ...] [--kernels k_var_base_ct,k_fixed_base_ct,k_proj_sum_level] [--keep] [--self-test]
+(k_proj_sum_level: the tree of complete additions ecgpu_lincomb_ct runs over the products of k_var_base_ct)
 
 How: the translation unit is compiled to assembly (hipcc -S --offload-device-only; no GPU needed) and every selected kernel
 goes through a forward taint analysis over its control-flow graph (register-precise, iterated to a fixed point):
@@ -388,7 +389,7 @@ def check(asm, wanted, verbose=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--curve", action="append")
-    ap.add_argument("--kernels", default="k_var_base_ct,k_fixed_base_ct")
+    ap.add_argument("--kernels", default="k_var_base_ct,k_fixed_base_ct,k_proj_sum_level")
     ap.add_argument("--asm", help="check an existing .s file instead of compiling")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--self-test", action="store_true", help="the variable-time kernels must be flagged")

@@ -7,6 +7,7 @@
 #   pytest[:<expr>]       python -m pytest tests -m gpu [-k <expr>]   (expr with + for spaces: "wycheproof+or+full_size")
 #   bench[:<workload>]    python bench.py [--workload W] --check           -> bench_<W>.json
 #   bench2                bench.py --gpus 2 as a dry run on one GPU (ranks share device 0, gloo exchange): the N > 1 code path
+#   benchN:<N>[:<W>]      the driver's N-rank command as it is, on one GPU: the RCCL canary fails, the run falls back to gloo
 #   benchall              the default bench line (all four GPU configs as sub-records) with --check
 #   prof:<workload>       rocprofv3 --kernel-trace --stats of bench.py --workload W  -> prof_<W>/ + kernel_stats summary
 #   pmc:<workload>        three rocprofv3 --pmc passes (VALU counters, FETCH_SIZE, WRITE_SIZE) of bench.py --workload W
@@ -37,6 +38,13 @@ for recipe in "$@"; do
       ECGPU_BENCH_SHARE_GPU=1 ECGPU_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
         --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > "$OUT/bench2.json" 2> "$OUT/bench2.err"
       tail -c 2500 "$OUT/bench2.json"; tail -5 "$OUT/bench2.err" ;;
+    benchN)   # N ranks of EXACTLY the driver's command on ONE GPU (ranks share device 0): RCCL cannot form a communicator there, so
+              # the canary of sharded.init_exchange fails and the run must go on over the gloo exchange — the first-contact
+              # failure the driver's scaling run has to survive.  benchN:2 = the default line, benchN:8:msm_k256 = one workload.
+      nn=${arg%%:*}; only=""; [[ "$arg" == *:* ]] && only="--only ${arg#*:}"
+      ECGPU_BENCH_SHARE_GPU=1 ECGPU_NCCL_PROBE_TIMEOUT=${PROBE_TIMEOUT:-60} timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$nn" \
+        --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus "$nn" --steps 3 --warmup 1 $only > "$OUT/bench_n$nn.json" 2> "$OUT/bench_n$nn.err"
+      tail -c 2500 "$OUT/bench_n$nn.json"; tail -5 "$OUT/bench_n$nn.err" ;;
     prof)
       w=${arg:-fixed_k256}
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$w" -o "$w" -- python "$ROOT/bench.py" --only "$w" --steps "$STEPS" --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} > "$OUT/prof_$w.log" 2>&1)
