@@ -471,6 +471,12 @@ class Bench:
             if lanes > 1:
                 eng.set_msm_lanes(1)
             eng.set_async(False)
+            if lanes == 1:
+                # the queued steps leave ONE sample of the kernel's duration (the HIP events of the last step); five more steps,
+                # outside the timed region and synchronous, give kernel_ms a minimum and a mean to stand on
+                for _ in range(5):
+                    step()
+                    read_events()
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64)           # (the control plane is gloo: a host tensor)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -536,6 +542,7 @@ class Bench:
             return None
 
         kernel_ms = float(np.mean(main_ms)) if main_ms else None
+        kernel_ms_min = float(np.min(main_ms)) if main_ms else None
         peak = self.valu_peak()
         ksec = kernel_ms * 1e-3 if kernel_ms else None
         rc = roofline_consts(wl["kernel"])
@@ -565,9 +572,14 @@ class Bench:
                        **({"dry_run": "ranks share one GPU, %s exchange" % self.backend} if os.environ.get("ECGPU_BENCH_SHARE_GPU") else {})},
             "calls": "%d MSMs in flight (ecgpu_set_async + ecgpu_set_msm_lanes), drained inside the timed region; kernel_ms = the last "
                      "accumulation kernel with the other lanes' kernels beside it" % lanes if lanes > 1
-                     else "queued (ecgpu_set_async), drained inside the timed region; kernel_ms from the HIP events of the last timed step" if queued
+                     else "queued (ecgpu_set_async), drained inside the timed region; kernel_ms = mean (kernel_ms_min: minimum) over the HIP "
+                          "events of the last timed step and of five synchronous steps after the timed region" if queued
                      else "synchronous, kernel_ms averaged over the HIP events of every timed step",
-            "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms,
+            "roofline": {"bound": "valu-int", "kernel": wl["kernel"], "kernel_ms": kernel_ms, "kernel_ms_min": kernel_ms_min,
+                         "kernel_ms_samples": len(main_ms),
+                         # the WHOLE step priced like SURVEY 8d prices the path (reference algorithm's multiply-adds per unit x units
+                         # / step time / peak): what the workload, not its dominant kernel, makes of the issue roof
+                         "workload_frac_8d": wl["imad_per_unit"] * n / (elapsed / args.steps) / NOMINAL_PEAK,
                          "achieved": achieved / 1e12 if achieved else None, "peak": NOMINAL_PEAK / 1e12, "unit": "TIMAD32-slots/s",
                          "frac": achieved / NOMINAL_PEAK if achieved else None,
                          "mad_frac": mad / NOMINAL_PEAK if mad else None,
@@ -700,7 +712,7 @@ NOTES = {
     "roofline": "bound valu-int (SURVEY 8d: neither HBM nor MFMA bounds the path). peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz "
                 "v_mad_u64_u32 slots/s (MI355X_MICROARCH.md; full-rate issue measured by ecgpu_valu_probe = peak_probe). achieved = "
                 "SQ_INSTS_VALU per launch (rocprofv3 PMC pass under profiles/, roofline_consts.json) x issue slots per instruction "
-                "(ISA histogram) x 64 / kernel_ms (HIP events on the launch stream, this run). frac = achieved/peak; cyc = issue "
+                "(ISA histogram) x 64 / kernel_ms (HIP events on the launch stream, this run). frac = achieved/peak; wfrac = reference algorithm's multiply-adds per unit (SURVEY 8d) x units / STEP time / peak (the whole workload, not its dominant kernel); kmin = minimum kernel_ms; cyc = issue "
                 "cycles / GRBM_GUI_ACTIVE of the PMC pass (no clock in it); algo_x = reference algorithm's IMAD32 (SURVEY 8d) over "
                 "the same time and peak (>1: fewer operations than the reference's algorithm); traffic = FETCH_SIZE + WRITE_SIZE "
                 "bytes per launch",
@@ -720,7 +732,8 @@ def compact(r):
     g = lambda v, d=4: None if v is None else float(("%%.%dg" % d) % v)
     out = {"metric": r["metric"], "value": g(r["value"], 5), "unit": r["unit"], "ms_per_step": g(r["ms_per_step"], 5),
            "units": r["config"]["units_total"], "scaling": r["scaling"],
-           "kernel": rf.get("kernel"), "kernel_ms": g(rf.get("kernel_ms")), "frac": g(rf.get("frac")), "cyc": g(rf.get("frac_cycles_pmc")),
+           "kernel": rf.get("kernel"), "kernel_ms": g(rf.get("kernel_ms")), "kmin": g(rf.get("kernel_ms_min")), "frac": g(rf.get("frac")),
+           "wfrac": g(rf.get("workload_frac_8d")), "cyc": g(rf.get("frac_cycles_pmc")),
            "mad_frac": g(rf.get("mad_frac")), "algo_x": g(rf.get("algorithmic_speedup")), "traffic": g(rf.get("traffic")),
            "stage_ms": {k: g(v, 3) for k, v in r.get("stage_ms", {}).items() if k not in ("main", "total")},
            "check": r.get("check_vs_oracle")}
@@ -805,7 +818,7 @@ def main():
     elif rec is not None:
         # ---- the driver's line: every BASELINE config in one record below 8 KB (the driver keeps the last 8 KB) ----
         rf = rec["roofline"]
-        rec["roofline"] = {k: rf[k] for k in ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "mad_frac",
+        rec["roofline"] = {k: rf[k] for k in ("bound", "kernel", "kernel_ms", "kernel_ms_min", "workload_frac_8d", "achieved", "peak", "unit", "frac", "traffic", "mad_frac",
                                               "frac_cycles_pmc", "peak_probe", "frac_vs_probe", "clock_ghz_kernel", "algorithmic_speedup")}
         rec["roofline"]["hbm_algorithmic_gbps"] = rf["hbm"]["achieved"]
         rec["roofline"]["source"] = "profiles/roofline_consts.json"
@@ -820,7 +833,8 @@ def main():
                 rec[name + "_value"] = r["value"]
                 rec[name + "_unit"] = r["unit"]
                 rec[name + "_ms_per_step"] = r["ms_per_step"]
-                rec[name + "_frac"] = r["roofline"]["frac"]
+                rec[name + "_frac"] = r["roofline"]["frac"]                       # the dominant kernel's executed work / roof
+                rec[name + "_workload_frac"] = r["roofline"]["workload_frac_8d"]  # SURVEY 8d's numerator over the WHOLE step
                 rec[name + "_check"] = r["check_vs_oracle"]
         if "msm_k256" in full and e2e:
             full["msm_k256"].update(e2e)

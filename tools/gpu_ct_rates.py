@@ -7,7 +7,8 @@ tools/ct_isa_check.py — executed-instruction counters of the kernels for input
 
 Counter check: each of {zero scalars, all-ones-pattern scalars (n - 1), random scalars} x {points = G, random points} is run
 in a process of its own under `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS`;
-for k_var_base_ct / k_fixed_base_ct every counter must be IDENTICAL across the classes (no instruction is executed or
+for k_var_base_ct / k_fixed_base_ct — and, for ecgpu_lincomb_ct, the tree of complete additions k_proj_sum_level over the
+products (all its launches summed) — every counter must be IDENTICAL across the classes (no instruction is executed or
 skipped depending on the data), while the variable-time kernels of the same inputs must differ (the check can see a
 difference).  Sizes are fixed so that the launch geometry is the same."""
 import csv
@@ -68,6 +69,7 @@ def child(cls):
         for ct in (True, False):
             eng.mul_by_generator_dev(cid, d_k, N_PMC, d_o, d_f, constant_time=ct)
             eng.mul_dev(cid, d_k, d_p, None, N_PMC, d_o, d_f, constant_time=ct)
+        eng.lincomb_ct_dev(cid, d_k, d_p, None, N_PMC, d_o, d_f)          # k_var_base_ct once more + the only k_proj_sum_level launches
     eng.close()
 
 
@@ -80,7 +82,11 @@ def counters(cls):
     for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("ecgpu::", "")
-            if not (k.startswith("k_var_base") or k.startswith("k_fixed_base")):
+            if not (k.startswith("k_var_base") or k.startswith("k_fixed_base") or k.startswith("k_proj_sum_level")):
+                continue
+            if k.startswith("k_proj_sum_level"):      # the levels of ecgpu_lincomb_ct's tree: all launches of the process, summed
+                d = res.setdefault(k, {})
+                d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
                 continue
             # the LAST launch of each kernel is the one on the class inputs (earlier ones build the point arrays)
             res.setdefault(k, {})[row["Counter_Name"]] = float(row["Counter_Value"])
@@ -114,6 +120,18 @@ def rates():
                 same = got == ref[what][0]
                 print("  %-5s %-4s %-13s kernel %8.3f ms  call %8.3f ms  %10.4g /s  x%.2f of the variable-time kernel  results equal: %s" % (
                     name, what, "uniform" if ct else "variable-time", main, total, n / total * 1e3, main / ref[what][1], same), flush=True)
+        # the constant-time `lincomb` beside the bucket method (variable-time names), whole calls
+        for lg in (12, 16, 20):
+            m = 1 << lg
+            for rep in range(2):
+                eng.lincomb_ct_dev(cid, d_k, d_p, None, m, d_o, d_f)
+            t_ct = eng.last_timing("total")
+            r_ct = bytes(eng.to_host(d_o, 2 * L))
+            for rep in range(2):
+                eng.lincomb_dev(cid, d_k, d_p, None, m, d_o, d_f)
+            t_vt = eng.last_timing("total")
+            print("  %-5s lincomb 2^%-2d terms: uniform schedule %8.3f ms (%.3g terms/s), bucket method %7.3f ms, results equal: %s" % (
+                name, lg, t_ct, m / t_ct * 1e3, t_vt, r_ct == bytes(eng.to_host(d_o, 2 * L))), flush=True)
         for b in (d_k, d_p, d_o, d_f):
             b.free()
     eng.close()
@@ -131,7 +149,7 @@ def main():
         rows = {cls: allc[cls].get(k, {}) for cls in CLASSES}
         names = sorted({c for r in rows.values() for c in r})
         uniform = all(len({rows[cls].get(c) for cls in CLASSES}) == 1 for c in names)
-        is_ct = "_ct<" in k
+        is_ct = "_ct<" in k or k.startswith("k_proj_sum_level")
         verdict = "IDENTICAL" if uniform else "DIFFER"
         ok = uniform == is_ct
         bad += 0 if ok else 1

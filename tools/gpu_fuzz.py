@@ -50,6 +50,7 @@ def int_sum(c, k):
 
 def msm_knobs(c):
     os.environ["ECGPU_MSM_SORT2"] = rng.choice(["0", "1"])
+    os.environ["ECGPU_MSM_SORT_PACKED"] = rng.choice(["1", "1", "0"])      # the packed two-level sort (round 4) / the round-3 kernels
     if rng.random() < 0.3:
         os.environ["ECGPU_MSM_CHUNK"] = str(rng.choice([1, 2, 3, 7, 33, 500, 100000]))
     else:
@@ -113,6 +114,17 @@ while time.time() < t_end:
             w, wf = oracle_lib.msm(c.cid, k.reshape(-1), pts.reshape(-1), inf, vartime=True)
             assert bytes(o) == bytes(w) and f == wf, ("msm oracle", c.name, n, cb, dict(os.environ))
             stats["msm_oracle"] += 1
+            if n <= 600 and rng.random() < 0.5:              # the constant-time `lincomb` on the same terms
+                o2, f2 = e.lincomb_ct(c.cid, k.reshape(-1), pts.reshape(-1), inf)
+                assert bytes(o2) == bytes(w) and f2 == wf, ("lincomb_ct", c.name, n)
+                stats["lincomb_ct"] += 1
+            if rng.random() < 0.4:                           # the same terms as x + SEC1 tag records (identities: tag 0, x = 0)
+                ylow = pts[:, L] if c.le else pts[:, 2 * L - 1]
+                tags = np.where(inf != 0, 0, 2 + (ylow & 1)).astype(np.uint8)
+                xs = np.where(inf[:, None] != 0, 0, pts[:, :L]).astype(np.uint8)
+                o3, f3 = e.lincomb_compressed(c.cid, k.reshape(-1), xs.reshape(-1), tags)
+                assert bytes(o3) == bytes(w) and f3 == wf, ("msm_compressed", c.name, n, cb, dict(os.environ))
+                stats["msm_compressed"] += 1
     elif kind == "lanes":
         # several MSMs in flight (ecgpu_set_msm_lanes on an asynchronous context) == the same MSMs one at a time
         msm_knobs(c)
