@@ -465,15 +465,16 @@ __device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src
     const uint32_t nkeys = 1u << bits_b, kshift = (uint32_t)idx_bits + 1, idx_mask = (1u << idx_bits) - 1;
     if (tid < nkeys) hist[tid] = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < np; base += tile) {                 // pass 1: the partition's histogram
-        uint32_t v[MSM_SORT2_PER_LANE];
+    constexpr int P1 = 2 * MSM_SORT2_PER_LANE;                         // pass 1 keeps no ranks: twice the loads in flight per lane
+    for (uint32_t base = 0; base < np; base += T * P1) {               // pass 1: the partition's histogram
+        uint32_t v[P1];
 #pragma unroll
-        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+        for (int u = 0; u < P1; u++) {
             const uint32_t i = base + (uint32_t)u * T + tid;
             v[u] = src[i < np ? i : np - 1];                           // (no exec-masked load: the dead lanes re-read the last entry)
         }
 #pragma unroll
-        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+        for (int u = 0; u < P1; u++) {
             const uint32_t i = base + (uint32_t)u * T + tid;
             (void)msm_lds_rank<HEAVY>(hist, v[u] >> kshift, i < np);
         }
@@ -1099,7 +1100,11 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
         hipLaunchKernelGGL(k_msm_sort_a, dim3((unsigned)p.ntiles2, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint16_t*)digits,
                            (const unsigned long long*)vmask, ne, p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, cursor, tmp);
         // level B: one workgroup per (partition, window); small partitions (small MSMs) get 256 lanes
-        const unsigned tb = ne / p.npart >= 4096 ? 1024u : 256u;
+        unsigned tb = ne / p.npart >= 4096 ? 1024u : 256u;
+        if (const char* e = getenv("ECGPU_MSM_SORTB_T")) {            // tuning knob: lanes per level-B workgroup
+            const int v = atoi(e);
+            if (v == 256 || v == 512 || v == 1024) tb = (unsigned)v;
+        }
         hipLaunchKernelGGL(k_msm_sort_b, dim3((unsigned)p.npart, (unsigned)p.nwin), dim3(tb), 0, stream, (const uint32_t*)tmp, ne,
                            p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, (const uint32_t*)offsets_a, (const uint32_t*)counts_a, counts,
                            offsets, sorted);
