@@ -9,12 +9,14 @@
 //
 //   prepare     one lane per term: decode + validate scalar and point once, keep the point in packed
 //               internal form, recode k into nwin 16-bit (bucket, sign) digits (msm_digit, ecgpu_recode.h)
-//   sort        counting sort of (sign, term index) by bucket, per window, with the histogram of a whole
-//               window (2^(c-1) counters = 128 KiB at c = 16) held in ONE workgroup's LDS: a workgroup owns a
-//               (tile of terms, window) pair, counts with LDS atomics (hist), a scan over tiles and buckets
-//               turns the counts into offsets (tile_scan, scan), and the same workgroup shape scatters with
-//               LDS cursors (scatter).  No global atomics; every bucket becomes a contiguous run, so
-//               accumulation needs no atomics and no conflict handling
+//   sort        counting sort of (sign, term index) by bucket, per window; every bucket becomes a contiguous run, so
+//               accumulation needs no atomics and no conflict handling.  Below 2^17 entries per window in ONE level, with
+//               the histogram of a whole window (2^(c-1) counters = 128 KiB at c = 16) held in one workgroup's LDS: a
+//               workgroup owns a (tile of terms, window) pair, counts with LDS atomics (hist), a scan over tiles and
+//               buckets turns the counts into offsets (tile_scan, scan), and the same workgroup shape scatters with LDS
+//               cursors (scatter).  From 2^17 entries on in TWO levels (k_msm_sort_a / k_msm_sort_b below: partition by the
+//               top bucket bits with LDS-staged coalesced run writes and one packed 32-bit word per entry, then one
+//               workgroup per partition)
 //   accumulate  one lane per `chunk` consecutive sorted entries of a window (ecgpu_msm_chunk.h): complete mixed
 //               additions, a partial sum written at every bucket boundary   <- the hot loop; perfectly balanced
 //               for ANY scalar distribution
@@ -24,7 +26,8 @@
 //   combine     Horner over the windows (c doublings each)
 //
 // Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
-// digits [nwin][n] u16 + validity bits [nwin][n/64] u64, tile histograms [nwin][ntiles][NB] u32, sorted [nwin][n] u32, counts/offsets [nwin][NB]
+// digits [nwin][n] u16 + validity bits [nwin][n/64] u64, tile histograms [nwin][ntiles][NB] u32 (one-level sort) / the level-A
+// output [nwin][n] u32 + partition counts and offsets (two-level sort), sorted [nwin][n] u32, counts/offsets [nwin][NB]
 // u32, partial sums [nwin][NB + nchunks][3 NS], buckets [nwin][NB][3 NS], segment sums, window sums.
 #pragma once
 
