@@ -165,12 +165,18 @@ inline unsigned grid_for(size_t n) { return (unsigned)((n + BLOCK - 1) / BLOCK);
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// MSMs in flight on the lanes: whatever the context does next on its own stream is ordered after them
+int join_lanes(ecgpu_ctx* ctx) {
+    if (!ctx->lanes_pending) return ECGPU_OK;
+    for (auto& l : ctx->lane)
+        if (l.s && l.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.ev_done, 0));
+    ctx->lanes_pending = false;
+    return ECGPU_OK;
+}
+
 int reset_status(ecgpu_ctx* ctx) {
-    if (ctx->lanes_pending) {                 // MSMs in flight on the lanes: later work of the context is ordered after them
-        for (auto& l : ctx->lane)
-            if (l.s && l.ev_done) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.ev_done, 0));
-        ctx->lanes_pending = false;
-    }
+    int rc = join_lanes(ctx);
+    if (rc != ECGPU_OK) return rc;
     if (ctx->async || ctx->keep_status) return ECGPU_OK;          // flags accumulate until ecgpu_synchronize / the call's end
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream));
     return ECGPU_OK;
@@ -1158,6 +1164,7 @@ int ecgpu_copy_to_device(ecgpu_ctx* ctx, void* d_dst, const void* h_src, size_t 
         ctx->err = "ecgpu_copy_to_device: null pointer";
         return arg_error(ctx, __func__);
     }
+    if (int rc = join_lanes(ctx)) return rc;             // (an MSM on a lane may be writing / reading the buffer)
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ECGPU_OK;
@@ -1170,6 +1177,7 @@ int ecgpu_copy_to_host(ecgpu_ctx* ctx, void* h_dst, const void* d_src, size_t by
         ctx->err = "ecgpu_copy_to_host: null pointer";
         return arg_error(ctx, __func__);
     }
+    if (int rc = join_lanes(ctx)) return rc;             // (an MSM on a lane may be writing / reading the buffer)
     HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ECGPU_OK;

@@ -932,6 +932,28 @@ def test_msm_lanes_several_in_flight(eng):
         eng.synchronize()
     assert e.value.code == ecgpu.ERR_SCALAR_RANGE
     assert bytes(eng.to_host(outs[0][0], 2 * c.L)) == want[0][0]
+    # ordering rule of include/ecgpu.h: any OTHER entry point called after a lane MSM waits for the lanes first — a copy to the
+    # host straight after the queued MSMs (no ecgpu_synchronize in between) sees their results, and a later overwrite of the
+    # inputs by a queued batch call cannot overtake the MSM that still reads them
+    eng.set_msm_lanes(3)
+    big = [2, 4, 7]                                                       # the jobs that run the bucket method, i.e. on a lane
+    for j in big:
+        eng.to_device(np.zeros(16, np.uint8), jobs[j][6][1][0])
+    for j in big:
+        c, n, d_s, d_k, d_p, d_f, outs = jobs[j]
+        eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[1])
+    for j in big:
+        c, n, d_s, d_k, d_p, d_f, outs = jobs[j]
+        assert bytes(eng.to_host(outs[1][0], 2 * c.L)) == want[j][0], ("copy after lane MSM", c.name, n)
+    c, n, d_s, d_k, d_p, d_f, outs = jobs[2]
+    eng.to_device(np.zeros(16, np.uint8), outs[1][0])
+    eng.lincomb_dev(c.cid, d_k, d_p, None, n, *outs[1])
+    eng.mul_by_generator_dev(c.cid, d_k, n, d_p, d_f)                    # overwrites the MSM's points: must wait for the lane
+    eng.synchronize()
+    assert bytes(eng.to_host(outs[1][0], 2 * c.L)) == want[2][0]
+    eng.mul_by_generator_dev(c.cid, d_s, n, d_p, d_f)                    # (the points as they were)
+    eng.synchronize()
+    c, n, d_s, d_k, d_p, d_f, outs = jobs[0]
     with pytest.raises(ecgpu.EcgpuError):
         eng.set_msm_lanes(5)
     eng.set_msm_lanes(1)
