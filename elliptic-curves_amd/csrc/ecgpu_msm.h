@@ -163,8 +163,10 @@ k_msm_tile_scan(uint32_t* __restrict__ tile_hist, size_t ntiles, size_t nb, int 
 }
 
 // ---- scan: offsets[w][b] = sum_{b' < b} counts[w][b'] -------------------------------------------------------
+// big_any != nullptr: big_any[window] = 1 if some count of the window exceeds big_limit, else 0 (the packed sort's level A:
+// is there a partition for k_msm_sort_b_big?)
 static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                          size_t nb) {
+                                                          size_t nb, uint32_t big_limit = 0, uint32_t* __restrict__ big_any = nullptr) {
     __shared__ uint32_t part[1024];
     const uint32_t* cw = counts + (size_t)blockIdx.x * nb;
     uint32_t* ow = offsets + (size_t)blockIdx.x * nb;
@@ -172,7 +174,15 @@ static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __rest
     size_t lo = (size_t)threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
     if (lo > nb) lo = nb;
     uint32_t s = 0;
-    for (size_t j = lo; j < hi; j++) s += cw[j];
+    int over = 0;
+    for (size_t j = lo; j < hi; j++) {
+        s += cw[j];
+        over |= cw[j] > big_limit;
+    }
+    if (big_any != nullptr) {
+        over = __syncthreads_or(over);
+        if (threadIdx.x == 0) big_any[blockIdx.x] = over ? 1u : 0u;
+    }
     part[threadIdx.x] = s;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {                 // Hillis-Steele inclusive scan of the partials
@@ -350,12 +360,20 @@ k_msm_sort2(MsmSort2Src src, size_t n, int bits_b, size_t nindex, uint32_t* __re
 //            histogram (pass 1), turns the counts into the window's `counts` / `offsets` rows itself (the partition's start
 //            comes from level A's scan), and scatters tile by tile through the LDS staging buffer with LDS cursors (pass 2).
 //            No separate counting launch, no scan over 2^15 counters, no cursor copy, no global atomic per (tile, key).
-// A partition is ~65,536 entries (256 KiB) at 2^24 terms.  A degenerate input puts a whole window into ONE partition, i.e.
-// one workgroup streams it (a few ms more for 2^24 equal scalars); its lanes then all want the same LDS counter, so a
-// partition above MSM_SORTB_HEAVY entries ranks with one LDS atomic per distinct key and wave (msm_lds_rank<true>).
-constexpr uint32_t MSM_SORTB_HEAVY = 1u << 18;
+// A partition is ~65,536 entries (256 KiB) at 2^24 terms.  A degenerate input (all scalars equal, all ones, bit vectors) puts a
+// whole window into ONE partition; one workgroup streaming 2^24 entries would take 15 ms.  Partitions above
+// msm_sortb_big_limit() entries (four times the mean) are therefore left out by k_msm_sort_b and sorted the round-3 way by
+// k_msm_sort_b_big: tiles of 8192 positions spread over the whole chip, a counting pass with one global atomicAdd per
+// (tile, bucket), a scan per big partition, a scatter pass with global cursors; the lanes of those tiles all want the same
+// few LDS counters and rank with one LDS atomic per distinct key and wave (msm_lds_rank<true>).  With random scalars the three
+// extra launches find nothing to do and exit (~0.02 ms at 2^24 terms).
 constexpr int MSM_SORTP_MAX_BITS_A = 9;        // level-A keys: <= 512 (k_msm_prepare holds nwin x 2^bits_a counters in LDS)
 constexpr int MSM_SORTP_MAX_BITS_B = 8;        // level-B keys: <= 256
+// partitions larger than this go to k_msm_sort_b_big (ne entries per window in npart partitions)
+inline uint32_t msm_sortb_big_limit(size_t ne, size_t npart) {
+    const size_t lim = 4 * (ne / npart);
+    return (uint32_t)(lim < 32768 ? 32768 : lim);
+}
 
 // rank of this lane's entry among the entries of its key counted so far in cnt[] (LDS); AGG: the lanes of a wave that
 // share a key are counted with one atomic per distinct key (loop over the distinct keys of the wave)
@@ -459,7 +477,6 @@ k_msm_sort_a(const uint16_t* __restrict__ digits, const unsigned long long* __re
 
 // grid (npart, nwin); blockDim 256 or 1024.  in: level A's output; part_offsets / part_counts [nwin][npart]: level A's
 // scan / histogram.  Writes counts / offsets [nwin][npart << bits_b] and sorted[w][.] = index | sign << 31.
-template <bool HEAVY>
 __device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src, uint32_t np, uint32_t lo, int bits_b, int idx_bits,
                                                 uint32_t* __restrict__ counts_row, uint32_t* __restrict__ offsets_row,
                                                 uint32_t* __restrict__ sorted_w, uint32_t* hist, uint32_t* cur, uint32_t* cnt,
@@ -479,7 +496,7 @@ __device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src
 #pragma unroll
         for (int u = 0; u < P1; u++) {
             const uint32_t i = base + (uint32_t)u * T + tid;
-            (void)msm_lds_rank<HEAVY>(hist, v[u] >> kshift, i < np);
+            (void)msm_lds_rank<false>(hist, v[u] >> kshift, i < np);
         }
     }
     __syncthreads();
@@ -501,7 +518,7 @@ __device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src
 #pragma unroll
         for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
             const uint32_t i = base + (uint32_t)u * T + tid;
-            rank[u] = msm_lds_rank<HEAVY>(cnt, v[u] >> kshift, i < np);
+            rank[u] = msm_lds_rank<false>(cnt, v[u] >> kshift, i < np);
         }
         __syncthreads();
         const uint32_t total = msm_block_scan(cnt, loc, nkeys, wtot);
@@ -520,7 +537,7 @@ __device__ __forceinline__ void msm_sort_b_body(const uint32_t* __restrict__ src
     }
 }
 static __global__ void __launch_bounds__(1024, 8)
-k_msm_sort_b(const uint32_t* __restrict__ in, size_t n, int bits_b, int idx_bits, uint32_t npart,
+k_msm_sort_b(const uint32_t* __restrict__ in, size_t n, int bits_b, int idx_bits, uint32_t npart, uint32_t big_limit,
              const uint32_t* __restrict__ part_offsets, const uint32_t* __restrict__ part_counts, uint32_t* __restrict__ counts,
              uint32_t* __restrict__ offsets, uint32_t* __restrict__ sorted) {
     __shared__ uint32_t hist[1 << MSM_SORTP_MAX_BITS_B], cur[1 << MSM_SORTP_MAX_BITS_B], cnt[1 << MSM_SORTP_MAX_BITS_B],
@@ -529,12 +546,106 @@ k_msm_sort_b(const uint32_t* __restrict__ in, size_t n, int bits_b, int idx_bits
     const size_t w = blockIdx.y, p = blockIdx.x;
     const uint32_t lo = part_offsets[w * npart + p], np = part_counts[w * npart + p];
     const size_t nb = (size_t)npart << bits_b, row = w * nb + (p << bits_b);
-    if (np > MSM_SORTB_HEAVY)
-        msm_sort_b_body<true>(in + w * n + lo, np, lo, bits_b, idx_bits, counts + row, offsets + row, sorted + w * n, hist, cur, cnt, loc,
-                              wtot, stage);
-    else
-        msm_sort_b_body<false>(in + w * n + lo, np, lo, bits_b, idx_bits, counts + row, offsets + row, sorted + w * n, hist, cur, cnt,
-                               loc, wtot, stage);
+    if (np > big_limit) {                              // left to k_msm_sort_b_big, whose counting pass adds into zeroed counters
+        if (threadIdx.x < (1u << bits_b)) counts[row + threadIdx.x] = 0;
+        return;
+    }
+    msm_sort_b_body(in + w * n + lo, np, lo, bits_b, idx_bits, counts + row, offsets + row, sorted + w * n, hist, cur, cnt, loc, wtot,
+                    stage);
+}
+
+// The big partitions (see above).  grid (tiles of 8192 POSITIONS of the window's level-A array, nwin), 1024 lanes; a tile handles
+// the big partitions it overlaps one after the other and ignores the others.  COUNT_ONLY: counts[w][bucket] += the tile's entries
+// (zeroed by k_msm_sort_b).  Otherwise `cursor` holds the run starts (k_msm_sort_b_big_offsets) and the entries are written.
+template <bool COUNT_ONLY>
+static __global__ void __launch_bounds__(1024, 8)
+k_msm_sort_b_big(const uint32_t* __restrict__ in, size_t n, int bits_b, int idx_bits, uint32_t npart, uint32_t big_limit,
+                 const uint32_t* __restrict__ part_offsets, const uint32_t* __restrict__ part_counts,
+                 const uint32_t* __restrict__ big_any, uint32_t* __restrict__ gcnt, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t cnt[1 << MSM_SORTP_MAX_BITS_B], loc[1 << MSM_SORTP_MAX_BITS_B], gbase[1 << MSM_SORTP_MAX_BITS_B], wtot[16];
+    __shared__ uint32_t stage[COUNT_ONLY ? 1 : MSM_SORT2_TILE];
+    const size_t w = blockIdx.y;
+    if (!big_any[w]) return;                            // the window has no big partition (k_msm_scan): the normal case
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* off = part_offsets + w * npart;
+    const uint32_t* pc = part_counts + w * npart;
+    const uint32_t tot = off[npart - 1] + pc[npart - 1];
+    for (uint32_t lo = blockIdx.x * (uint32_t)MSM_SORT2_TILE; lo < tot; lo += gridDim.x * (uint32_t)MSM_SORT2_TILE) {
+    const uint32_t hi = lo + MSM_SORT2_TILE < tot ? lo + MSM_SORT2_TILE : tot;
+    // first partition that reaches past `lo` (partitions are consecutive; empty ones have zero length)
+    uint32_t a = 0, b = npart;                          // invariant: every partition < a ends at or before lo
+    while (a < b) {
+        const uint32_t m = (a + b) / 2;
+        if (off[m] + pc[m] <= lo) a = m + 1;
+        else b = m;
+    }
+    const uint32_t nkeys = 1u << bits_b, kshift = (uint32_t)idx_bits + 1, idx_mask = (1u << idx_bits) - 1;
+    const size_t nb = (size_t)npart << bits_b;
+    for (uint32_t r = a; r < npart && off[r] < hi; r++) {
+        const uint32_t np = pc[r];
+        if (np <= big_limit) continue;                                  // (wave-uniform)
+        const uint32_t s0 = off[r] > lo ? off[r] : lo, s1 = off[r] + np < hi ? off[r] + np : hi;
+        if (tid < nkeys) cnt[tid] = 0;
+        __syncthreads();
+        uint32_t v[MSM_SORT2_PER_LANE], rank[MSM_SORT2_PER_LANE];
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = s0 + (uint32_t)u * 1024 + tid;
+            v[u] = in[w * n + (i < s1 ? i : s1 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = s0 + (uint32_t)u * 1024 + tid;
+            rank[u] = msm_lds_rank<true>(cnt, v[u] >> kshift, i < s1);
+        }
+        __syncthreads();
+        const uint32_t mine = tid < nkeys ? cnt[tid] : 0u;
+        const size_t gi = w * nb + ((size_t)r << bits_b) + tid;
+        if (COUNT_ONLY) {
+            if (mine) atomicAdd(&gcnt[gi], mine);
+            __syncthreads();
+            continue;
+        }
+        uint32_t gb = 0;
+        if (mine) gb = atomicAdd(&gcnt[gi], mine);
+        const uint32_t total = msm_block_scan(cnt, loc, nkeys, wtot);
+#pragma unroll
+        for (int u = 0; u < MSM_SORT2_PER_LANE; u++) {
+            const uint32_t i = s0 + (uint32_t)u * 1024 + tid;
+            if (i < s1) stage[loc[v[u] >> kshift] + rank[u]] = v[u];
+        }
+        if (mine) gbase[tid] = gb;
+        __syncthreads();
+        for (uint32_t slot = tid; slot < total; slot += 1024) {
+            const uint32_t p = stage[slot], k = p >> kshift;
+            sorted[w * n + gbase[k] + (slot - loc[k])] = (p & idx_mask) | (((p >> idx_bits) & 1u) << 31);
+        }
+        __syncthreads();
+    }
+    }
+}
+
+// grid (npart, nwin), 256 lanes: offsets and cursors of the big partitions from their counted buckets
+static __global__ void __launch_bounds__(256)
+k_msm_sort_b_big_offsets(int bits_b, uint32_t npart, uint32_t big_limit, const uint32_t* __restrict__ part_offsets,
+                         const uint32_t* __restrict__ part_counts, const uint32_t* __restrict__ big_any,
+                         const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t c[1 << MSM_SORTP_MAX_BITS_B], loc[1 << MSM_SORTP_MAX_BITS_B], wtot[16];
+    const size_t w = blockIdx.y;
+    if (!big_any[w]) return;
+    for (size_t p = blockIdx.x; p < npart; p += gridDim.x) {
+    if (part_counts[w * npart + p] <= big_limit) continue;
+    const uint32_t lo = part_offsets[w * npart + p], nkeys = 1u << bits_b, tid = threadIdx.x;
+    const size_t row = (w * npart + p) << bits_b;
+    if (tid < nkeys) c[tid] = counts[row + tid];
+    __syncthreads();
+    (void)msm_block_scan(c, loc, nkeys, wtot);
+    if (tid < nkeys) {
+        offsets[row + tid] = lo + loc[tid];
+        cursor[row + tid] = lo + loc[tid];
+    }
+    __syncthreads();
+    }
 }
 
 // ---- accumulate: the hot loop --------------------------------------------------------------------------------------
@@ -984,7 +1095,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
             p.off_tmpidx = o;  o = align(o + (size_t)p.nwin * ne * 4);
             if (!p.sort_packed) { p.off_tmpkey = o;  o = align(o + (size_t)p.nwin * ne * 2); }
             p.off_count_a = o;  o = align(o + (size_t)p.nwin * p.npart * 4);
-            p.off_offset_a = o; o = align(o + (size_t)p.nwin * p.npart * 4);
+            p.off_offset_a = o; o = align(o + ((size_t)p.nwin * p.npart + p.nwin) * 4);    // + nwin flags (big_any)
             p.off_cursor = o;   o = align(o + (size_t)p.nwin * p.nb * 4);
         }
     }
@@ -1098,7 +1209,9 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
         uint32_t* counts_a = (uint32_t*)(ws + p.off_count_a);
         uint32_t* offsets_a = (uint32_t*)(ws + p.off_offset_a);
         uint32_t* cursor = (uint32_t*)(ws + p.off_cursor);
-        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart);
+        const uint32_t big = msm_sortb_big_limit(ne, p.npart);
+        uint32_t* big_any = offsets_a + (size_t)p.nwin * p.npart;       // nwin flags behind the partition offsets (plan: + nwin words)
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart, big, big_any);
         (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
         hipLaunchKernelGGL(k_msm_sort_a, dim3((unsigned)p.ntiles2, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint16_t*)digits,
                            (const unsigned long long*)vmask, ne, p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, cursor, tmp);
@@ -1109,8 +1222,22 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
             if (v == 256 || v == 512 || v == 1024) tb = (unsigned)v;
         }
         hipLaunchKernelGGL(k_msm_sort_b, dim3((unsigned)p.npart, (unsigned)p.nwin), dim3(tb), 0, stream, (const uint32_t*)tmp, ne,
-                           p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, (const uint32_t*)offsets_a, (const uint32_t*)counts_a, counts,
-                           offsets, sorted);
+                           p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, big, (const uint32_t*)offsets_a, (const uint32_t*)counts_a,
+                           counts, offsets, sorted);
+        // partitions above `big` entries (degenerate scalar sets): count / offsets / scatter over the whole chip, tiles of 8192
+        // positions dealt out to at most 256 workgroups per window; for random scalars big_any[] is all zero and every
+        // workgroup of the three launches exits on its first load
+        const unsigned gb = (unsigned)(p.ntiles2 < 256 ? p.ntiles2 : 256);
+        uint32_t* cursor_b = (uint32_t*)(ws + p.off_cursor);        // (level A's cursors are spent by now; nwin x nb words)
+        hipLaunchKernelGGL((k_msm_sort_b_big<true>), dim3(gb, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint32_t*)tmp, ne,
+                           p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, big, (const uint32_t*)offsets_a, (const uint32_t*)counts_a,
+                           (const uint32_t*)big_any, counts, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_msm_sort_b_big_offsets, dim3(gb < p.npart ? gb : (unsigned)p.npart, (unsigned)p.nwin), dim3(256), 0, stream,
+                           p.sort_bits_b, (uint32_t)p.npart, big, (const uint32_t*)offsets_a, (const uint32_t*)counts_a,
+                           (const uint32_t*)big_any, (const uint32_t*)counts, offsets, cursor_b);
+        hipLaunchKernelGGL((k_msm_sort_b_big<false>), dim3(gb, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint32_t*)tmp, ne,
+                           p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, big, (const uint32_t*)offsets_a, (const uint32_t*)counts_a,
+                           (const uint32_t*)big_any, cursor_b, sorted);
     } else if (p.sort_bits_b) {
         uint32_t* tmp_idx = (uint32_t*)(ws + p.off_tmpidx);
         uint16_t* tmp_key = (uint16_t*)(ws + p.off_tmpkey);
