@@ -95,9 +95,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise EcgpuError(ERR_NO_DEVICE, "HIP extension %s is missing; run __graft_entry__.build()" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+    path = os.environ.get("ECGPU_TOOL_LIB") or LIB_PATH      # (ECGPU_TOOL_LIB: another build of the same library, for A/B measurement tools)
+    if not os.path.exists(path):
+        raise EcgpuError(ERR_NO_DEVICE, "HIP extension %s is missing; run __graft_entry__.build()" % path)
+    lib = ctypes.CDLL(path)
     lib.ecgpu_last_error.restype = ctypes.c_char_p
     lib.ecgpu_version.restype = ctypes.c_char_p
     lib.ecgpu_field_bytes.restype = ctypes.c_size_t

@@ -58,6 +58,12 @@ struct Xyzz {
 template <class C, int L, int V>
 std::integral_constant<int, V> magv(const Mag<C, L, V>&);
 
+// -DECGPU_FUSED_SUB=0 builds the k256 formulas with norm(sub(mul(..), ..)) in place of F::mul_sub / F::sqr_sub (A/B measurements:
+// profiles/r04/k256_fused_sub_ab.txt)
+#ifndef ECGPU_FUSED_SUB
+#define ECGPU_FUSED_SUB 1
+#endif
+
 template <class C>
 struct Group {
     using F = Field<C>;
@@ -291,14 +297,22 @@ struct Group {
         auto X = mj(p.x), Y = mj(p.y), Z = mj(p.z);
         J o;
         if constexpr (C::A_IS_ZERO) {
+            static_assert(C::REPR == REPR_U29_K256, "the a = 0 doubling uses the k256 field's fused subtractions");
             auto aa = F::sqr(X);
             auto bb = F::sqr(Y);
             auto cc = F::sqr(bb);
-            auto d = F::dbl(F::norm(F::sub(F::sqr(F::add(X, bb)), F::add(aa, cc))));     // 2
             auto e3 = F::template mul_small<3>(aa);
-            auto X3 = F::norm(F::sub(F::sqr(e3), F::dbl(d)));                             // 6 -> 1
-            o.x = jstore(X3);
-            o.y = jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
+            if constexpr (ECGPU_FUSED_SUB) {
+                auto d = F::dbl(F::sqr_sub(F::add(X, bb), F::add(aa, cc)));               // 2   (differences: F::sqr_sub / mul_sub,
+                auto X3 = F::sqr_sub(e3, F::dbl(d));                                      //      one reduction each, no norm)
+                o.x = jstore(X3);
+                o.y = jstore(F::mul_sub(e3, F::sub(d, X3), F::template mul_small<8>(cc)));
+            } else {
+                auto d = F::dbl(F::norm(F::sub(F::sqr(F::add(X, bb)), F::add(aa, cc))));
+                auto X3 = F::norm(F::sub(F::sqr(e3), F::dbl(d)));
+                o.x = jstore(X3);
+                o.y = jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
+            }
             o.z = jstore(F::mul(F::dbl(Y), Z));
         } else {
             auto delta = F::sqr(Z);
@@ -328,6 +342,22 @@ struct Group {
     static ECGPU_HD J jac_madd(const J& p, const A& q, bool negq, E* h_out = nullptr) {
         auto X1 = mj(p.x), Y1 = mj(p.y), Z1 = mj(p.z);
         auto zz1 = F::sqr(Z1);
+        if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) {         // (as xyzz_madd: the three differences out of their products' reductions)
+            auto H = F::mul_sub(m(q.x), zz1, X1);
+            if (h_out) *h_out = H.e;
+            auto t = F::mul(Z1, zz1);
+            J o;
+            o.z = jstore(F::mul(Z1, H));
+            auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));
+            auto r = F::mul_sub(Y2, t, Y1);
+            auto HH = F::sqr(H);
+            auto V = F::mul(X1, HH);
+            auto HHH = F::mul(H, HH);
+            auto X3 = F::sqr_sub(r, F::add(HHH, F::dbl(V)));
+            o.x = jstore(X3);
+            o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(Y1), HHH));
+            return o;
+        }
         auto Hn = F::norm(F::sub(F::mul(m(q.x), zz1), X1));
         if (h_out) *h_out = Hn.e;
         auto H = F::template fit<F::SQLIM>(Hn);
@@ -359,6 +389,22 @@ struct Group {
     static ECGPU_HD XZ xyzz_madd(const XZ& p, const A& q, bool negq) {
         auto X1 = mj(p.x), Y1 = mj(p.y), ZZ1 = mj(p.zz), ZZZ1 = mj(p.zzz);
         auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));
+        if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) {
+            // the three differences that feed a multiplication come out of the reduction of the product they follow (F::mul_sub /
+            // F::sqr_sub): no limb-wise subtraction, no carry pass of their own
+            auto Pd = F::mul_sub(m(q.x), ZZ1, X1);
+            auto R = F::mul_sub(Y2, ZZZ1, Y1);
+            auto PP = F::sqr(Pd);
+            auto PPP = F::mul(Pd, PP);
+            auto Q = F::mul(X1, PP);
+            auto X3 = F::sqr_sub(R, F::add(PPP, F::dbl(Q)));
+            XZ o;
+            o.x = jstore(X3);
+            o.y = jstore(F::mul2(R, F::sub(Q, X3), F::neg(Y1), PPP));
+            o.zz = jstore(F::mul(ZZ1, PP));
+            o.zzz = jstore(F::mul(ZZZ1, PPP));
+            return o;
+        }
         auto Pd = F::template fit<F::SQLIM>(F::sub(F::mul(m(q.x), ZZ1), X1));
         auto R = F::template fit<F::SQLIM>(F::sub(F::mul(Y2, ZZZ1), Y1));
         auto PP = F::sqr(Pd);
@@ -381,7 +427,10 @@ struct Group {
         auto PP = F::sqr(Pd);
         auto PPP = F::mul(Pd, PP);
         auto Q = F::mul(X1, PP);
-        auto X3 = F::norm(F::sub(F::sqr(R), F::add(PPP, F::dbl(Q))));
+        auto X3 = [&] {
+            if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) return F::sqr_sub(R, F::add(PPP, F::dbl(Q)));
+            else return F::norm(F::sub(F::sqr(R), F::add(PPP, F::dbl(Q))));
+        }();
         XZ o;
         o.x = jstore(X3);
         o.y = jstore(F::mul2(R, F::sub(Q, X3), F::neg(Y1), PPP));

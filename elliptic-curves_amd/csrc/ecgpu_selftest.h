@@ -46,6 +46,14 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
     }
     case 9: F::to_canonical(wr, F::mul2(x, y, F::add(x, y), F::neg(y))); break;
     case 10: F::to_canonical(wr, F::inv_fermat(x)); break;
+    case 13:                                   // x y - (2 x + y): k256 through the fused F::mul_sub, the others in two steps
+        if constexpr (C::REPR == REPR_U29_K256) F::to_canonical(wr, F::mul_sub(x, y, F::add(F::dbl(x), y)));
+        else F::to_canonical(wr, F::norm(F::sub(F::mul(x, y), F::add(F::dbl(x), y))));
+        break;
+    case 14:                                   // (x + y)^2 - 5 y: F::sqr_sub with a lazy operand and the largest subtrahend in use
+        if constexpr (C::REPR == REPR_U29_K256) F::to_canonical(wr, F::sqr_sub(F::add(x, y), F::add(y, F::dbl(F::dbl(y)))));
+        else F::to_canonical(wr, F::norm(F::sub(F::sqr(F::norm(F::add(x, y))), F::add(y, F::dbl(F::dbl(y))))));
+        break;
     case 11: {
         bool root;
         auto r = F::sqrt(x, &root);

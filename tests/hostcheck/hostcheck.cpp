@@ -91,6 +91,14 @@ int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
         break;
     }
     case 9: F::to_bytes(out, F::mul2(x, y, F::add(x, y), F::neg(y))); break;   // x*y - (x+y)*y
+    case 13:                                                                   // x y - (2 x + y): the fused F::mul_sub (k256)
+        if constexpr (C::REPR == ecgpu::REPR_U29_K256) F::to_bytes(out, F::mul_sub(x, y, F::add(F::dbl(x), y)));
+        else F::to_bytes(out, F::norm(F::sub(F::mul(x, y), F::add(F::dbl(x), y))));
+        break;
+    case 14:                                                                   // (x + y)^2 - 5 y: the fused F::sqr_sub (k256)
+        if constexpr (C::REPR == ecgpu::REPR_U29_K256) F::to_bytes(out, F::sqr_sub(F::add(x, y), F::add(y, F::dbl(F::dbl(y)))));
+        else F::to_bytes(out, F::norm(F::sub(F::sqr(F::norm(F::add(x, y))), F::add(y, F::dbl(F::dbl(y))))));
+        break;
     default: return -1;
     }
     return 0;

@@ -61,7 +61,9 @@ def test_device_field_ops_vs_bigint_and_oracle(eng, curve):
     p = c.p
     want = {0: [(a + b) % p for a, b in zip(vals, other)], 1: [(a - b) % p for a, b in zip(vals, other)],
             2: [a * b % p for a, b in zip(vals, other)], 8: [(2 * a + b) % p for a, b in zip(vals, other)],
-            9: [(-b * b) % p for a, b in zip(vals, other)]}
+            9: [(-b * b) % p for a, b in zip(vals, other)],
+            13: [(a * b - 2 * a - b) % p for a, b in zip(vals, other)],          # a*b - c in one reduction (k256: F::mul_sub)
+            14: [((a + b) ** 2 - 5 * b) % p for a, b in zip(vals, other)]}       # a^2 - c (k256: F::sqr_sub)
     for op, w in want.items():
         assert ints(c, eng.selftest_field(c.cid, op, A, B)) == w, (curve, op)
     assert ints(c, eng.selftest_field(c.cid, 3, A)) == [a * a % p for a in vals]

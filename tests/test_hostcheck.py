@@ -38,6 +38,8 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
             assert got == oracle.field_op(c.cid, op, A, B)
         assert int.from_bytes(hc.field_op(c.cid, 8, A, B), "big") == (2 * a + b) % c.p      # pack/unpack of a lazy value
         assert int.from_bytes(hc.field_op(c.cid, 9, A, B), "big") == (-b * b) % c.p         # fused a*b + c*d
+        assert int.from_bytes(hc.field_op(c.cid, 13, A, B), "big") == (a * b - 2 * a - b) % c.p        # a*b - c in one reduction (k256: F::mul_sub)
+        assert int.from_bytes(hc.field_op(c.cid, 14, A, B), "big") == ((a + b) ** 2 - 5 * b) % c.p     # a^2 - c (k256: F::sqr_sub)
         assert int.from_bytes(hc.field_op(c.cid, 3, A), "big") == a * a % c.p
         assert int.from_bytes(hc.field_op(c.cid, 5, A), "big") == (-a) % c.p
         assert int.from_bytes(hc.field_op(c.cid, 6, A), "big") == 21 * a % c.p

@@ -105,6 +105,22 @@ def k256_mul(a, b):
     return k256_reduce(k256_columns(a, b))
 
 
+def k256_zconst(m):
+    """Z[m] of the generated constants (sub_constant below: what tools/gen_field_consts.py writes into K256U::Z)."""
+    return sub_constant(K_P, 9, 29, m, K_LB, K_LB)[0]
+
+
+def k256_mul_sub(a, b, c, m):
+    """a * b - c with one reduction (Field::mul_sub): (Z[m] - c) enters the low columns; c has magnitude m."""
+    col = k256_columns(a, b)
+    z = k256_zconst(m)
+    for k in range(9):
+        d = chk32(z[k] - c[k])
+        assert z[k] >= c[k]
+        col[k] = chk64(col[k] + d)
+    return k256_reduce(col)
+
+
 def k256_norm(a):
     """carry-propagate a lazy element (limbs < 2^32) and fold the top: magnitude 1."""
     r = [0] * 9
@@ -448,6 +464,22 @@ def selftest(trials=300, seed=1):
         b = [rng.randrange(mb * K_LB) for _ in range(9)]
         r = k256_mul(a, b)
         assert from_limbs(r, K_B) % K_P == from_limbs(a, K_B) * from_limbs(b, K_B) % K_P
+    # the fused a * b - c (Field::mul_sub / sqr_sub): adversarial products at the limit with the largest subtrahends, then random
+    for m in range(1, 7):
+        assert from_limbs(k256_zconst(m), K_B) % K_P == 0
+    for (ma, mb), m in (((7, 1), 6), ((1, 7), 6), ((3, 2), 4), ((2, 2), 3), ((1, 1), 1)):
+        a = [ma * K_LB - 1] * 9
+        b = [mb * K_LB - 1] * 9
+        for c in ([0] * 9, [m * K_LB - 1] * 9):
+            r = k256_mul_sub(a, b, c, m)
+            assert from_limbs(r, K_B) % K_P == (from_limbs(a, K_B) * from_limbs(b, K_B) - from_limbs(c, K_B)) % K_P
+    for _ in range(trials):
+        (ma, mb), m = rng.choice([((1, 1), 1), ((2, 2), 2), ((1, 4), 2), ((1, 1), 3), ((3, 2), 6)])
+        a = [rng.randrange(ma * K_LB) for _ in range(9)]
+        b = [rng.randrange(mb * K_LB) for _ in range(9)]
+        c = [rng.randrange(m * K_LB) for _ in range(9)]
+        r = k256_mul_sub(a, b, c, m)
+        assert from_limbs(r, K_B) % K_P == (from_limbs(a, K_B) * from_limbs(b, K_B) - from_limbs(c, K_B)) % K_P
         n = k256_norm([rng.randrange(1 << 32) for _ in range(9)])
     # p256: limb-magnitude product limit 23 (single products and the fused pairs of the group law)
     rinv = pow(P_R, -1, P_P)
