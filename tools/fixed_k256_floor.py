@@ -17,7 +17,7 @@ VOP1 / VOP2 is half a slot: profiles/r01/isa_issue_rates.txt), 9 x 29-bit limbs,
 The floor below multiplies these out; the measured side comes from profiles/roofline_consts.json (SQ_INSTS_VALU of the
 kernel under rocprofv3 and the slot weights of its gfx950 ISA) and from the driver-timed kernel_ms.
 
-    python tools/fixed_k256_floor.py [kernel_ms]        (default: 0.516, profiles/r03/kernel_stats_fixed_k256.txt)
+    python tools/fixed_k256_floor.py [kernel_ms]        (default: 0.512, the mean of profiles/r04/k256_fused_sub_ab.txt)
 """
 import json
 import os
@@ -25,7 +25,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rc = json.load(open(os.path.join(ROOT, "profiles", "roofline_consts.json")))["k_fixed_base<K256Params>"]
-kernel_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 0.516
+kernel_ms = float(sys.argv[1]) if len(sys.argv) > 1 else 0.512
 n = rc["units_per_launch"]
 
 MUL_COLS, SQR_COLS = 81.0, 45.0 + 9 * 0.5
@@ -34,9 +34,11 @@ LIN, NORM = 9 * 0.5, 9 * 1.5
 M, S = MUL_COLS + REDUCE, SQR_COLS + REDUCE
 
 # one mixed XYZZ addition (madd-2008-s): U2, S2, PP, PPP, Q, R^2, ZZ3, ZZZ3 each reduced, Y3 = R (Q - X3) - Y1 PPP as two
-# products under one reduction; linear steps: P, R, X3 (3 terms), Q - X3, their norms where a product follows a 3-term sum
-madd = (8 * MUL_COLS + 2 * SQR_COLS) + 9 * REDUCE + 8 * LIN + 3 * NORM
-first = 4 * M + 2 * S + 6 * LIN + 2 * NORM                     # affine + affine
+# products under one reduction; the three differences that feed a product (P, R, X3) leave the reduction of the product before
+# them (F::mul_sub / F::sqr_sub, round 4): 9 multiply-adds by one each instead of a limb-wise subtraction + a carry pass; linear
+# steps left: the three (multiple of p) - c, PPP + 2 Q, Q - X3, -Y1, the sign select of y
+madd = (8 * MUL_COLS + 2 * SQR_COLS) + 9 * REDUCE + 3 * 9 + 8 * LIN
+first = 4 * M + 2 * S + 9 + 6 * LIN + 2 * NORM                 # affine + affine (X3 through F::sqr_sub)
 to_proj = 3 * M
 decode = 8 + 8 * 1.0 + 24 * 0.5 + 10 * 6                       # byte swap, fold k -> n - k (8 words), 10 signed windows (shift / mask / sign)
 unpack = 10 * 2 * 9 * 1.5                                      # 10 gathered entries, 2 coordinates: 8 words -> 9 limbs
