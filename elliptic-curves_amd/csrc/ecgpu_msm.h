@@ -105,10 +105,11 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
 #pragma unroll
         for (int h = 0; h < S::SUB; h++) {
             const size_t j = (size_t)h * npad + i;
-            uint32_t carry = 0;
+            MsmDigitStream<S::KW> ds;               // msm_digit's digits in window order, no dynamically indexed scalar word
+            ds.init(sub[h]);
 #pragma unroll 1
             for (int w = 0; w < nwin; w++) {
-                MsmDigit d = msm_digit<S::KW>(sub[h], w, c, nwin, &carry, (uint32_t)j, flip[h], S::KBITS);
+                MsmDigit d = ds.next(w, c, nwin, (uint32_t)j, flip[h], S::KBITS);
                 const bool valid = active && finite && d.nonzero;
                 if (active) digits[(size_t)w * nsub + j] = (uint16_t)(d.bucket | (d.neg << 15));
                 unsigned long long m = __ballot(valid);
@@ -889,6 +890,82 @@ __device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
     return o;
 }
 
+// ---- a = 0 (k256): one COMPLETE projective doubling spread over the four lanes of a quad -----------------------------------
+// Renes–Costello–Batina's doubling for a = 0 (the formulas of Group::dbl_a0: X3 = 2 XY (Y^2 - 9b Z^2), Y3 = 24b Y^2 Z^2 +
+// (Y^2 - 9b Z^2)(Y^2 + 3b Z^2), Z3 = 8 Y^3 Z) has only TWO dependent levels of products, four products each:
+//      {Y^2, Y Z, Z^2, X Y}   ->   {3b Z^2 * 8 Y^2,  Y Z * 8 Y^2,  (Y^2 - 9b Z^2)(Y^2 + 3b Z^2),  (Y^2 - 9b Z^2) * 2 X Y}
+// against three for the Jacobian doubling above, and the accumulator never leaves the homogeneous form the additions of the
+// Horner chain want (no conversion to Jacobian coordinates and back around every run of doublings, no special case for the
+// identity).  Lane r of every quad computes product r of a level; a quad hands its four results round with DPP quad
+// permutes — plain vector moves, no LDS round trip — and the three multiplications by small constants between the levels are one
+// more per-lane step.  ~550 instructions per doubling on the critical path instead of ~800.
+// Every lane must enter with the same point; Y is carried with limb magnitude 2 (the sum that ends a doubling is not
+// normalised: the products of the next one have the room).
+template <int K, class M>
+__device__ __forceinline__ M msm_quad_bcast(const M& v) {
+    M r;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(v.e.v) / sizeof(v.e.v[0])); i++)
+        r.e.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.e.v[i], K * 0x55, 0xf, 0xf, false);
+    return r;
+}
+template <class C>
+__device__ __forceinline__ void msm_hom_dbl_quad(typename Field<C>::M1& X, Mag<C, 2, 2>& Y, typename Field<C>::M1& Z, int role) {
+    using F = Field<C>;
+    static_assert(C::A_IS_ZERO && C::REPR == REPR_U29_K256, "a = 0 on the 9 x 29 field");
+    constexpr uint32_t b3 = 3 * C::B_SMALL;
+    static_assert(3 * b3 < (1u << 12), "small-constant multiplier");
+    // level 1:  Y^2 | Y Z | Z^2 | X Y
+    const auto p1 = F::mul(F::sel(role == 2, Z, F::sel(role == 3, X, Y)), F::sel(role == 0 || role == 3, Y, Z));   // 2*2 = 4
+    const auto yy = msm_quad_bcast<0>(p1), yz = msm_quad_bcast<1>(p1), zz = msm_quad_bcast<2>(p1), xy = msm_quad_bcast<3>(p1);
+    // small constants:  3b Z^2 | 9b Z^2 | 8 Y^2 | (unused)
+    const auto ps = F::template wrap<1, 1>(F::k_mul_small(F::sel(role < 2, zz, yy).e, role == 0 ? b3 : role == 1 ? 3 * b3 : 8u));
+    const auto bzz3 = msm_quad_bcast<0>(ps), bzz9 = msm_quad_bcast<1>(ps), yy8 = msm_quad_bcast<2>(ps);
+    const auto yy_m9 = F::sub(yy, bzz9);                           // 3
+    const auto yy_p3 = F::add(yy, bzz3);                           // 2
+    const auto xy2 = F::dbl(xy);                                   // 2
+    // level 2:  3b Z^2 * 8 Y^2 | Y Z * 8 Y^2 | (Y^2 - 9b Z^2)(Y^2 + 3b Z^2) | (Y^2 - 9b Z^2) * 2 X Y
+    const auto p2 = F::mul(F::sel(role == 0, bzz3, F::sel(role == 1, yz, yy_m9)),
+                           F::sel(role < 2, yy8, F::sel(role == 2, yy_p3, xy2)));                                   // 3*2 = 6
+    X = msm_quad_bcast<3>(p2);
+    Z = msm_quad_bcast<1>(p2);
+    Y = F::add(msm_quad_bcast<0>(p2), msm_quad_bcast<2>(p2));
+}
+
+// The complete addition of the chain (Group::add_a0's formulas) the same way: its twelve products are two dependent levels of
+// three + three (the second with the subtractions of the first folded into its reduction, F::mul_sub) and one level of three
+// two-product sums (F::mul2) — lanes 0..2 of every quad; ~1000 instructions on the critical path instead of ~2150.
+// All coordinates enter and leave with magnitude 1.
+template <class C>
+__device__ __forceinline__ void msm_hom_add_quad(typename Field<C>::M1& X1, typename Field<C>::M1& Y1, typename Field<C>::M1& Z1,
+                                                 const Proj<C>& q, int role) {
+    using F = Field<C>;
+    using G = Group<C>;
+    static_assert(C::A_IS_ZERO && C::REPR == REPR_U29_K256, "a = 0 on the 9 x 29 field");
+    constexpr uint32_t b3 = 3 * C::B_SMALL;
+    const auto X2 = G::m(q.x), Y2 = G::m(q.y), Z2 = G::m(q.z);
+    // level 1a:  X1 X2 | Y1 Y2 | Z1 Z2
+    const auto pa = F::mul(F::sel(role == 1, Y1, F::sel(role == 2, Z1, X1)), F::sel(role == 1, Y2, F::sel(role == 2, Z2, X2)));
+    const auto xx = msm_quad_bcast<0>(pa), yy = msm_quad_bcast<1>(pa), zz = msm_quad_bcast<2>(pa);
+    // level 1b:  (X1 + Y1)(X2 + Y2) - (xx + yy) | (Y1 + Z1)(Y2 + Z2) - (yy + zz) | (X1 + Z1)(X2 + Z2) - (xx + zz)
+    const auto pb = F::mul_sub(F::add(F::sel(role == 1, Y1, X1), F::sel(role == 0, Y1, Z1)),                        // 2*2 = 4
+                               F::add(F::sel(role == 1, Y2, X2), F::sel(role == 0, Y2, Z2)),
+                               F::add(F::sel(role == 1, yy, xx), F::sel(role == 0, yy, zz)));
+    const auto xy = msm_quad_bcast<0>(pb), yz = msm_quad_bcast<1>(pb), xz = msm_quad_bcast<2>(pb);
+    // small constants:  3b zz | 3b yz | 9b xx
+    const auto ps = F::template wrap<1, 1>(F::k_mul_small(F::sel(role == 0, zz, F::sel(role == 1, yz, xx)).e, role == 2 ? 3 * b3 : b3));
+    const auto bzz3 = msm_quad_bcast<0>(ps), byz3 = msm_quad_bcast<1>(ps), bxx9 = msm_quad_bcast<2>(ps);
+    const auto xx3 = F::add(F::dbl(xx), xx);                       // 3
+    const auto yy_m = F::norm(F::sub(yy, bzz3));                   // 3 -> 1
+    const auto yy_p = F::add(yy, bzz3);                            // 2
+    // level 2:  xy yy_m - 3b yz xz | yy_p yy_m + 9b xx xz | yz yy_p + 3 xx xy
+    const auto p2 = F::mul2(F::sel(role == 0, xy, F::sel(role == 1, yy_p, yz)), F::sel(role == 2, yy_p, yy_m),      // 2*2 + 3*1 = 7
+                            F::sel(role == 0, F::neg(byz3), F::sel(role == 1, bxx9, xx3)), F::sel(role == 2, xy, xz));
+    X1 = msm_quad_bcast<0>(p2);
+    Y1 = msm_quad_bcast<1>(p2);
+    Z1 = msm_quad_bcast<2>(p2);
+}
+
 // out = sum_w 2^(c w) wins[w]   (Horner).  One wave; lanes 0..2 share the doublings (above), every lane carries the same
 // accumulator, lane 0 stores.
 // out_xy != nullptr: the result leaves the kernel as a wire record (affine x || y + identity flag, what k_normalize<C, NORM_WIRE>
@@ -907,27 +984,46 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
     const uint32_t* vw = wins + vzero;
     Fe<C::NL> b = G::curve_b();
     Proj<C> acc = load_proj<C>(vw, nwin - 1);
-    for (int w = nwin - 2; w >= 0; w--) {
-        // c doublings in Jacobian coordinates (2M + 5S resp. 3M + 5S instead of the complete 6M + 2S + .. / 8M + 3S + ..):
-        // (X : Y : Z) -> (X Z : Y Z^2 : Z) and back (X Z : Y : Z^3).  The identity has no Jacobian form here: skipped
-        // (by every lane: the accumulator is the same in all of them).
-        if (!G::is_identity(acc)) {
-            Jac<C> j;
-            {
-                auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
-                j.x = Field<C>::mul(X, Z).e;
-                j.y = Field<C>::mul(Y, Field<C>::sqr(Z)).e;
-                j.z = acc.z;
-            }
-            if constexpr (GenericA<C>::value) {
-                for (int s = 0; s < c; s++) j = G::jac_dbl(j);                  // (any-a curves: the one-lane chain)
-            } else {
+    if constexpr (C::A_IS_ZERO && C::REPR == REPR_U29_K256) {
+        // complete doublings and additions in the accumulator's own (homogeneous) form, the products of a level on the lanes of
+        // a quad (msm_hom_dbl_quad, msm_hom_add_quad); every quad of the wave computes the same thing
+        const int role = lane & 3;
+        auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
 #pragma unroll 1
-                for (int s = 0; s < c; s++) j = msm_jac_dbl_lanes<C>(j, lane);
-            }
-            acc = G::jac_to_proj(j);
+        for (int w = nwin - 2; w >= 0; w--) {
+            const Proj<C> q = load_proj<C>(vw, w);                      // in flight under the doublings
+            auto Yw = Field<C>::template wrap<2, 2>(Y.e);
+#pragma unroll 1
+            for (int s = 0; s < c; s++) msm_hom_dbl_quad<C>(X, Yw, Z, role);
+            Y = Field<C>::norm(Yw);
+            msm_hom_add_quad<C>(X, Y, Z, q, role);
         }
-        acc = G::add(acc, load_proj<C>(vw, w), b);
+        acc.x = X.e;
+        acc.y = Y.e;
+        acc.z = Z.e;
+    } else {
+        for (int w = nwin - 2; w >= 0; w--) {
+            // c doublings in Jacobian coordinates (2M + 5S resp. 3M + 5S instead of the complete 6M + 2S + .. / 8M + 3S + ..):
+            // (X : Y : Z) -> (X Z : Y Z^2 : Z) and back (X Z : Y : Z^3).  The identity has no Jacobian form here: skipped
+            // (by every lane: the accumulator is the same in all of them).
+            if (!G::is_identity(acc)) {
+                Jac<C> j;
+                {
+                    auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
+                    j.x = Field<C>::mul(X, Z).e;
+                    j.y = Field<C>::mul(Y, Field<C>::sqr(Z)).e;
+                    j.z = acc.z;
+                }
+                if constexpr (GenericA<C>::value) {
+                    for (int s = 0; s < c; s++) j = G::jac_dbl(j);                  // (any-a curves: the one-lane chain)
+                } else {
+#pragma unroll 1
+                    for (int s = 0; s < c; s++) j = msm_jac_dbl_lanes<C>(j, lane);
+                }
+                acc = G::jac_to_proj(j);
+            }
+            acc = G::add(acc, load_proj<C>(vw, w), b);
+        }
     }
     if (out_xy == nullptr) {
         if (lane == 0) store_proj<C>(out, 0, acc);
@@ -1173,10 +1269,11 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     uint32_t* offsets = (uint32_t*)(ws + p.off_offset);
     uint32_t* partials = (uint32_t*)(ws + p.off_partials);
     // k_msm_prepare: each workgroup takes `reps` groups of BLOCK terms, so that its LDS histogram is flushed once for all of
-    // them (one global atomic per counter and workgroup); at least ~2048 workgroups stay in flight
+    // them (one global atomic per counter and workgroup); at least ~1024 workgroups — four per CU, one resident at a time —
+    // stay in the launch (measured, round 4: 2048 -> 1024 workgroups −3…5 % of the kernel; the flush order does not matter)
     int reps = 1;
     if (p.sort_bits_b) {
-        while (reps < 32 && (n + (size_t)BLOCK * reps * 2 - 1) / ((size_t)BLOCK * reps * 2) >= 2048) reps *= 2;
+        while (reps < 32 && (n + (size_t)BLOCK * reps * 2 - 1) / ((size_t)BLOCK * reps * 2) >= 1024) reps *= 2;
     }
     unsigned g = (unsigned)((n + (size_t)BLOCK * reps - 1) / ((size_t)BLOCK * reps));
     const size_t lds_bytes = p.nb * 4;

@@ -103,6 +103,64 @@ ECGPU_HD MsmDigit msm_digit(const uint32_t* k, int w, int c, int nwin, uint32_t*
     return r;
 }
 
+// The same digits in window order (w = 0, 1, ..) WITHOUT a dynamically indexed scalar word: the sub-scalar sits in kw[] and moves
+// down one word whenever 32 bits have been consumed, so that every window is one funnel shift of (kw[1] : kw[0]) by an offset
+// below 32.  msm_digit(k, w, ..) extracts bits [w c, w c + c) of a register array at a run-time position — a chain of selects per
+// word and half of k_msm_prepare's vector instructions; here a digit costs one v_alignbit, a mask and the recoding step, and one
+// wave-uniform branch (the offset depends on w and c only) moves the words every 32 / c digits.
+template <int NL>
+struct MsmDigitStream {
+    static_assert(NL >= 2, "at least two words");
+    uint32_t kw[NL + 1];
+    uint32_t off, carry;
+    ECGPU_HD void init(const uint32_t* k) {
+#pragma unroll
+        for (int i = 0; i < NL; i++) kw[i] = k[i];
+        kw[NL] = 0;
+        off = 0;
+        carry = 0;
+    }
+    // the next `bits` (0 .. 16) bits of the scalar, zero past its end
+    ECGPU_HD uint32_t take(int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t v = __builtin_amdgcn_alignbit(kw[1], kw[0], off) & ((1u << bits) - 1);
+#else
+        const uint32_t v = (uint32_t)((((uint64_t)kw[1] << 32) | kw[0]) >> off) & ((1u << bits) - 1);
+#endif
+        off += (uint32_t)bits;
+        if (off >= 32) {
+            off -= 32;
+#pragma unroll
+            for (int i = 0; i < NL; i++) kw[i] = kw[i + 1];
+        }
+        return v;
+    }
+    // digit of window w; calls must come with w = 0, 1, .., nwin - 1 (arguments as for msm_digit)
+    ECGPU_HD MsmDigit next(int w, int c, int nwin, uint32_t term_index, bool flip, int kbits = 32 * NL - 1) {
+        MsmDigit r;
+        r.bucket = 0; r.neg = 0; r.nonzero = false;
+        if (w < nwin - 1) {
+            int d = signed_window_step(take(c), c, &carry);
+            if (d != 0) {
+                r.nonzero = true;
+                r.neg = (d < 0) != flip;
+                r.bucket = (uint32_t)(d < 0 ? -d : d) - 1;
+            }
+        } else {
+            const int rem = kbits % c;
+            const int shift = c - 1 - rem;
+            uint32_t d = take(rem) + carry;
+            carry = 0;
+            if (d != 0) {
+                r.nonzero = true;
+                r.neg = flip;
+                r.bucket = ((d - 1) << shift) | (term_index & ((1u << shift) - 1));
+            }
+        }
+        return r;
+    }
+};
+
 // k' = k + 0x8888...8 over NL limbs (+1 limb for the carry). digit(i) = nibble_i(k') - 8 for
 // i < 8*NL, and nibble (0/1) for i = 8*NL: exactly Radix16Decomposition::new's output.
 template <int NL>

@@ -427,8 +427,12 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
         finite[i] = 1;
         for (int h = 0; h < S::SUB; h++) {
             uint32_t carry = 0;
+            MsmDigitStream<S::KW> ds;                                   // what k_msm_prepare uses: must agree digit for digit
+            ds.init(subs[i][h].data());
             for (int w = 0; w < nwin; w++) {
                 MsmDigit d = digit_of(i, h, w, &carry);
+                MsmDigit e = ds.next(w, c, nwin, (uint32_t)(h * npad + i), flips[i][h], S::KBITS);
+                if (e.nonzero != d.nonzero || e.bucket != d.bucket || e.neg != d.neg) return -7;
                 if (d.nonzero) ranks[(size_t)w * ne + h * npad + i] = counts[(size_t)w * nb + d.bucket]++;
             }
         }
