@@ -181,9 +181,14 @@ struct Field {
         r.v[2] += (uint32_t)(t1 >> 29);
         return r;
     }
-    // exact canonical value in [0, p) as 8 little-endian 32-bit words
+    // exact canonical value in [0, p) as 8 little-endian 32-bit words.  NORMED: the limbs are already below LB (a magnitude-1
+    // element, e.g. a fresh product) — the two carry passes that bring a lazy element there are skipped (the two folds below
+    // start from limbs < 2^32 either way; model with adversarial inputs: tools/field_model.py k256_to_words_m1)
+    template <bool NORMED = false>
     static ECGPU_HD void k_to_words(uint32_t* w, const E& a) {
-        E r = k_norm(k_norm(a));                      // limbs < 2^29 + tiny, value < 2^261 + tiny
+        E r;
+        if constexpr (NORMED) r = a;
+        else r = k_norm(k_norm(a));                   // limbs < 2^29 + tiny, value < 2^261 + tiny
         // fold everything at or above 2^256 with 2^256 = 2^32 + 977 = 8 * 2^29 + 977, twice, exactly
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
@@ -752,7 +757,8 @@ struct Field {
     template <int LA, int VA>
     static ECGPU_HD void to_canonical(uint32_t* w, const Mag<C, LA, VA>& a) {
         if constexpr (REPR == REPR_U29_K256) {
-            k_to_words(w, a.e);
+            check_mag<LA, VA>(a.e);
+            k_to_words<(LA <= 1)>(w, a.e);
         } else {
             static_assert(LA <= MAXPROD, "normalise before to_canonical");
             E onep;                                       // plain 1: a * 1 * R^-1 leaves the Montgomery domain
@@ -766,7 +772,8 @@ struct Field {
     template <int LA, int VA>
     static ECGPU_HD void pack(uint32_t* w, const Mag<C, LA, VA>& a) {
         if constexpr (REPR == REPR_U29_K256) {
-            k_to_words(w, a.e);
+            check_mag<LA, VA>(a.e);
+            k_to_words<(LA <= 1)>(w, a.e);
         } else {
             static_assert(LA <= MAXPROD, "normalise before pack");
             E r = p_cond_sub(p_mont_mul(a.e, p_const(PC::ONE)));   // a * R * R^-1 = a, now < 2p with strict limbs

@@ -90,8 +90,17 @@ k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ p
                 } else {
                     store_packed_affine<C>(pts + ii * (2 * N), a.x, a.y);
                 }
-                if constexpr (S::SUB == 2)
-                    store_packed_affine<C>(pts + (npad + ii) * (2 * N), F::mul(G::m(a.x), F::unpack(C::BETA)).e, a.y);
+                if constexpr (S::SUB == 2) {                  // lambda P = (beta x, y): y's packed words are the ones just read
+                    uint32_t bx[N];
+                    F::pack(bx, F::mul(G::m(a.x), F::unpack(C::BETA)));
+                    store_words_vec<N>(pts + (npad + ii) * (2 * N), bx);
+                    if constexpr (F::REPR == REPR_U29_K256) {
+                        store_words_vec<N>(pts + (npad + ii) * (2 * N) + N, cy);
+                    } else {
+                        F::pack(bx, G::m(a.y));
+                        store_words_vec<N>(pts + (npad + ii) * (2 * N) + N, bx);
+                    }
+                }
             }
         } else {
 #pragma unroll

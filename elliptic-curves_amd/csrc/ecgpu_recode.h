@@ -338,24 +338,131 @@ struct K256Scalar {
         add(r, res, one);
     }
 
-    // b2 = n - MINUS_B2 (126 bits): c2 = t * (-b2) = n - t * b2
-    ECGPU_CONST uint32_t B2[4] = {0x9284EB15u, 0xE86C90E4u, 0xA7D46BCDu, 0x3086D221u};
+    // ---- the GLV split on 29-bit limbs -----------------------------------------------------------------------------------------
+    // k -> (r1, r2) with r1 + r2 lambda = k (mod n)    mul/glv.rs:149-156
+    // The reference computes c1 = round(k g1 / 2^384) (-b1), c2 = round(k g2 / 2^384) (-b2), r2 = c1 + c2, r1 = k - r2 lambda,
+    // all modulo n.  As INTEGERS, with the lattice vectors (a1, b1), (a2, b2) (a_i + b_i lambda = 0 mod n; a1 = b2):
+    //      r2 = t1 |b1| - t2 b2,      r1 = k - t1 a1 - t2 a2,      |r1|, |r2| < 2^128
+    // — the same residues, so both only need to be computed modulo 2^145 (five 29-bit limbs), sign = bit 144.  Everything
+    // runs on 29-bit limbs with 64-bit column accumulators that cannot overflow (the field's own technique, ecgpu_field.h):
+    // pure v_mad_u64_u32 chains without carries between the products.  The first version (32-bit words, operand scanning with a
+    // carry per product, a 256 x 256-bit product + reduction mod n for r2 lambda) compiled to 1,840 instructions, 900 of them
+    // register moves, and was a third of k_msm_prepare in GLV mode; this one is ~500.
+    ECGPU_CONST uint32_t L29 = (1u << 29) - 1;
+    ECGPU_CONST uint32_t G1_L29[9] = {0x05DBB031u, 0x049904D2u, 0x1A329FFAu, 0x151428E3u, 0x0EB153DAu, 0x08724942u, 0x0F37A1B2u, 0x0434FA8Du, 0x003086D2u};
+    ECGPU_CONST uint32_t G2_L29[9] = {0x0AC47F71u, 0x0B8DA574u, 0x1D41B185u, 0x0411593Bu, 0x1E4C4221u, 0x1FD4855Fu, 0x00A1BD51u, 0x1AC021D1u, 0x00E4437Eu};
+    ECGPU_CONST uint32_t MINUS_B1_L29[5] = {0x0ABFE4C3u, 0x1AA3FD48u, 0x03A20A1Bu, 0x06FDAC02u, 0x00000E44u};   // |b1|
+    ECGPU_CONST uint32_t B2_L29[5] = {0x1284EB15u, 0x03648724u, 0x151AF37Au, 0x0DA4434Fu, 0x00000308u};         // b2 = a1
+    ECGPU_CONST uint32_t A2_L29[5] = {0x1D44CFD8u, 0x1E08846Cu, 0x18BCFD95u, 0x14A1EF51u, 0x0000114Cu};         // a2 (129 bits)
 
-    // k -> (r1, r2), r1 + r2*lambda = k mod n         mul/glv.rs:149-156
-    // The same values as the reference's four modular multiplications, with the two by -b1 and -b2 done as 128 x 128-bit
-    // products: t1 = round(k g1 / 2^384) < 2^126 and t2 = round(k g2 / 2^384) < 2^128, so t1 * (-b1) < 2^254 < n needs no
-    // reduction and t2 * (-b2) = n - t2 * b2 with t2 * b2 < 2^254 (tests: test_k256_glv_equals_reference on the CPU,
-    // test_k256_glv_decompose_vs_oracle on the GPU).
+    // t = round(k g / 2^384) as five 29-bit limbs (t <= 2^128); kl: k on nine 29-bit limbs, gl: g likewise
+    static ECGPU_HD void mul_shift_384_l29(uint32_t* t, const uint32_t* kl, const uint32_t* gl) {
+        uint64_t c[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++) c[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+#pragma unroll
+            for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)kl[i] * gl[j];         // < 9 * 2^58 per column
+        }
+        // exact base-2^29 digits 13 .. 17 of the product (bit 384 = bit 7 of digit 13), the ones below only through their carry
+        uint64_t v = c[0];
+#pragma unroll
+        for (int i = 1; i <= 13; i++) v = c[i] + (v >> 29);
+        uint32_t d[6];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            d[i] = (uint32_t)v & L29;
+            v = c[14 + i] + (v >> 29);
+        }
+        d[4] = (uint32_t)v & L29;                 // digit 17 (< 2^19: the product is below 2^512)
+        d[5] = 0;
+        uint32_t carry = (d[0] >> 6) & 1u;        // the rounding bit, bit 383
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            uint32_t x = (((d[j] >> 7) | (d[j + 1] << 22)) & L29) + carry;
+            t[j] = x & L29;
+            carry = x >> 29;
+        }
+    }
+    // five signed 64-bit columns -> magnitude (four 32-bit words) and sign of the value they hold modulo 2^145
+    static ECGPU_HD bool signed_columns_to_words(uint32_t* m, const int64_t* col) {
+        uint32_t l[5];
+        int64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            v += col[i];
+            l[i] = (uint32_t)v & L29;
+            v >>= 29;                              // arithmetic: the borrow travels as -1
+        }
+        const bool negative = (l[4] >> 28) != 0;   // bit 144
+        {                                          // two's complement over 145 bits if negative
+            const uint32_t x = negative ? L29 : 0u;
+            uint32_t carry = negative ? 1u : 0u;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                uint32_t y = (l[i] ^ x) + carry;
+                l[i] = y & L29;
+                carry = y >> 29;
+            }
+        }
+        m[0] = l[0] | (l[1] << 29);
+        m[1] = (l[1] >> 3) | (l[2] << 26);
+        m[2] = (l[2] >> 6) | (l[3] << 23);
+        m[3] = (l[3] >> 9) | (l[4] << 20);          // |value| < 2^128: l[4] < 2^12
+        return negative;
+    }
+    // r1 = (neg1 ? -m1 : m1), r2 = (neg2 ? -m2 : m2), magnitudes below 2^128 as four words each
+    static ECGPU_HD void decompose_signed(uint32_t* m1, bool* neg1, uint32_t* m2, bool* neg2, const uint32_t* k) {
+        uint32_t kl[9];
+#pragma unroll
+        for (int l = 0; l < 9; l++) {
+            const int bit = 29 * l, i = bit / 32, sh = bit % 32;
+            uint64_t x = (uint64_t)k[i] >> sh;
+            if (i + 1 < 8) x |= (uint64_t)k[i + 1] << (32 - sh);
+            kl[l] = (uint32_t)x & L29;
+        }
+        uint32_t t1[5], t2[5];
+        mul_shift_384_l29(t1, kl, G1_L29);
+        mul_shift_384_l29(t2, kl, G2_L29);
+        // columns 0 .. 4 only (everything is taken modulo 2^145); three unsigned accumulations, < 10 * 2^58 per column
+        uint64_t u1[5], up[5], uq[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) u1[i] = up[i] = uq[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+#pragma unroll
+            for (int j = 0; i + j < 5; j++) {
+                u1[i + j] += (uint64_t)t1[i] * B2_L29[j];            // t1 a1 + t2 a2
+                u1[i + j] += (uint64_t)t2[i] * A2_L29[j];
+                up[i + j] += (uint64_t)t1[i] * MINUS_B1_L29[j];      // t1 |b1|
+                uq[i + j] += (uint64_t)t2[i] * B2_L29[j];            // t2 b2
+            }
+        }
+        int64_t c1[5], c2[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            c1[i] = (int64_t)kl[i] - (int64_t)u1[i];
+            c2[i] = (int64_t)up[i] - (int64_t)uq[i];
+        }
+        *neg1 = signed_columns_to_words(m1, c1);
+        *neg2 = signed_columns_to_words(m2, c2);
+    }
+    // the same split as canonical residues modulo n (what the reference returns)
     static ECGPU_HD void decompose(uint32_t* r1, uint32_t* r2, const uint32_t* k) {
-        uint32_t t[8], c1[8], c2[8], prod[8];
-        mul_shift_384(t, k, G1);
-        mp_mul<4>(c1, t, MINUS_B1);
-        mul_shift_384(t, k, G2);
-        mp_mul<4>(prod, t, B2);
-        neg(c2, prod);
-        add(r2, c1, c2);
-        mul(t, r2, MINUS_LAMBDA);
-        add(r1, k, t);
+        uint32_t m1[8], m2[8];
+        bool n1, n2;
+        decompose_signed(m1, &n1, m2, &n2, k);
+#pragma unroll
+        for (int i = 4; i < 8; i++) m1[i] = m2[i] = 0;
+        uint32_t d1[8], d2[8];
+        mp_sub<8>(d1, C::ORDER, m1);
+        mp_sub<8>(d2, C::ORDER, m2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            r1[i] = n1 ? d1[i] : m1[i];
+            r2[i] = n2 ? d2[i] : m2[i];
+        }
     }
 };
 
@@ -385,14 +492,7 @@ struct MsmSplit<K256Params, true> {
     static constexpr int KW = 4;
     static constexpr int KBITS = 128;
     static ECGPU_HD void split(const uint32_t* k, uint32_t (*sub)[KW], bool* neg) {
-        uint32_t r1[8], r2[8];
-        K256Scalar::decompose(r1, r2, k);
-        neg[0] = K256Scalar::is_high(r1);
-        neg[1] = K256Scalar::is_high(r2);
-        if (neg[0]) K256Scalar::neg(r1, r1);
-        if (neg[1]) K256Scalar::neg(r2, r2);
-#pragma unroll
-        for (int i = 0; i < KW; i++) { sub[0][i] = r1[i]; sub[1][i] = r2[i]; }
+        K256Scalar::decompose_signed(sub[0], &neg[0], sub[1], &neg[1], k);
     }
 };
 template <class C>

@@ -121,6 +121,44 @@ def k256_mul_sub(a, b, c, m):
     return k256_reduce(col)
 
 
+def k256_to_words_m1(a):
+    """Field::k_to_words<NORMED = true>: the canonical value of a magnitude-1 element (limbs < K_LB) WITHOUT the two carry
+    passes a lazy element needs first — two folds of everything at or above 2^256, one carry pass, one conditional subtraction."""
+    r = list(a)
+    assert all(x < K_LB for x in r)
+    for _ in range(2):
+        carry = 0
+        for k in range(8):
+            v = chk32(r[k] + carry)
+            r[k] = v & K_MASK
+            carry = v >> K_B
+        v8 = chk32(r[8] + carry)
+        e = v8 >> 24
+        r[8] = v8 & 0xFFFFFF
+        r[0] = chk32(r[0] + e * 977)
+        r[1] = chk32(r[1] + e * 8)
+    carry = 0
+    for k in range(8):
+        v = r[k] + carry
+        r[k] = v & K_MASK
+        carry = v >> K_B
+    r[8] += carry
+    s = list(r)
+    s[0] += 977
+    s[1] += 8
+    carry = 0
+    for k in range(8):
+        v = s[k] + carry
+        s[k] = v & K_MASK
+        carry = v >> K_B
+    s[8] += carry
+    ge = (s[8] >> 24) != 0
+    s[8] &= 0xFFFFFF
+    out = s if ge else r
+    assert all(x <= K_MASK for x in out[:8]) and out[8] < (1 << 24)
+    return from_limbs(out, K_B)
+
+
 def k256_norm(a):
     """carry-propagate a lazy element (limbs < 2^32) and fold the top: magnitude 1."""
     r = [0] * 9
@@ -481,6 +519,28 @@ def selftest(trials=300, seed=1):
         r = k256_mul_sub(a, b, c, m)
         assert from_limbs(r, K_B) % K_P == (from_limbs(a, K_B) * from_limbs(b, K_B) - from_limbs(c, K_B)) % K_P
         n = k256_norm([rng.randrange(1 << 32) for _ in range(9)])
+    # k_to_words without the leading carry passes, on magnitude-1 inputs: the extremes, the neighbourhood of every multiple of p
+    # that fits (canonical and shifted limb splits), random limbs
+    cases = [[K_LB - 1] * 9, [0] * 9, [K_MASK] * 9, [K_LB - 1] * 8 + [0]]
+    for mult in range(34):
+        for d in (-2, -1, 0, 1, 2):
+            v = mult * K_P + d
+            if v < 0:
+                continue
+            a = [(v >> (K_B * i)) & K_MASK for i in range(8)] + [v >> (K_B * 8)]
+            if a[8] < K_LB:
+                cases.append(a)
+            for i in range(8):
+                if a[i + 1] > 0 and a[i] + (1 << K_B) < K_LB:
+                    b = list(a)
+                    b[i + 1] -= 1
+                    b[i] += 1 << K_B
+                    cases.append(b)
+    for _ in range(20 * trials):
+        cases.append([rng.randrange(K_LB) for _ in range(9)])
+        cases.append([rng.choice([0, 1, K_MASK, K_MASK + 1, K_LB - 1, rng.randrange(K_LB)]) for _ in range(9)])
+    for a in cases:
+        assert k256_to_words_m1(a) == from_limbs(a, K_B) % K_P
     # p256: limb-magnitude product limit 23 (single products and the fused pairs of the group law)
     rinv = pow(P_R, -1, P_P)
     for (ma, mb), (mc, md) in (((4, 5), (1, 3)), ((12, 1), (11, 1)), ((4, 1), (3, 3))):

@@ -20,12 +20,14 @@ PY
 }
 prof n21 21
 prof n24 24
+if [ -n "${PMC:-}" ]; then
 echo "== counters, 2^21 terms"
 OUT=/tmp/r04u_pmc
 mkdir -p $OUT
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_msm_k256_1 -o pmc -- python $ROOT/bench.py --only msm_k256 --n 2097152 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc1.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_msm_k256_2 -o pmc -- python $ROOT/bench.py --only msm_k256 --n 2097152 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc2.log 2>&1)
 python tools/pmc_summary.py pmc $OUT msm_k256 | grep -E "bucket_finish|reduce_segments|reduce_windows|window_sums|k_msm_combine|k_msm_prepare"
+fi
 echo "== without the profiler"
 for lg in 21 24; do
   python bench.py --only msm_k256 --n $((1 << lg)) --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
