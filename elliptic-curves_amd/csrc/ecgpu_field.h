@@ -33,6 +33,12 @@
 
 namespace ecgpu {
 
+// -DECGPU_FUSED_SUB=0 builds Field::mul_sub / sqr_sub as norm(sub(mul(..), ..)) — the form the point formulas had before the
+// differences moved into the reductions (A/B measurements: profiles/r04/k256_fused_sub_ab.txt, mont_fused_sub_ab.txt)
+#ifndef ECGPU_FUSED_SUB
+#define ECGPU_FUSED_SUB 1
+#endif
+
 template <class C, int L, int V>
 struct Mag {
     Fe<C::NL> e;
@@ -688,13 +694,15 @@ struct Field {
             return wrap<1, 1>(p_reduce(col));
         }
     }
-    // a * b - c  and  a^2 - c  with ONE reduction and a result of magnitude (1, 1): k256 only (round 4).  The subtrahend enters the
-    // low product columns as (multiple of p) - c, limb by limb — one multiply-add by an opaque 1 each: a 64-bit addition would
-    // first need the 32-bit limb zero-extended into a register pair — and the carry pass of the reduction normalises the
-    // difference for free, where norm(sub(mul(a, b), c)) pays a limb-wise subtraction plus a carry pass of its own (9 issue
-    // slots less per use, three uses per mixed XYZZ addition).  The columns have the room: 9 * MAXPROD * LB^2 < 2^64 - 2^58,
-    // the subtrahend adds < 2^32 per column (model: tools/field_model.py k256_mul_sub).  The Montgomery fields reduce by
-    // R^-1, which would scale c: they keep the two steps.
+    // a * b - c  and  a^2 - c  with ONE reduction and no carry pass of their own (round 4).
+    // k256: the subtrahend enters the LOW product columns as (multiple of p) - c, limb by limb — one multiply-add by an opaque 1
+    // each: a 64-bit addition would first need the 32-bit limb zero-extended into a register pair — and the carry pass of the
+    // reduction normalises the difference for free, where norm(sub(mul(a, b), c)) pays a limb-wise subtraction plus a carry pass
+    // of its own (9 issue slots less per use, three uses per mixed XYZZ addition).  The columns have the room: 9 * MAXPROD * LB^2
+    // < 2^64 - 2^58, the subtrahend adds < 2^32 per column (model: tools/field_model.py k256_mul_sub).  Result magnitude (1, 1).
+    // Montgomery fields: the reduction divides by R, so the subtrahend goes into the HIGH columns (UN + k: the ones the final
+    // carry pass turns into the result) — the same multiply-add per limb, the same carry pass saved.  The result is what
+    // norm(sub(mul(a, b), c)) returns: limb magnitude 1, value magnitude 1 + (VC + 1) (models: p256_mont_mul & co., `hi_add`).
     template <int LC, int VC>
     static ECGPU_HD void k_columns_sub(uint64_t* col, const Mag<C, LC, VC>& c) {
         constexpr int m = LC > VC ? LC : VC;
@@ -704,23 +712,51 @@ struct Field {
 #pragma unroll
         for (int k = 0; k < 9; k++) col[k] += (uint64_t)(KC::Z[m][k] - c.e.v[k]) * one;
     }
+    template <int LC, int VC>
+    static ECGPU_HD void p_columns_sub(uint64_t* col, const Mag<C, LC, VC>& c) {
+        static_assert(LC <= PC::LMAX && VC <= PC::VMAX, "no subtraction constant for this magnitude");
+        check_mag<LC, VC>(c.e);
+        const uint32_t one = opaque_const(1u);
+#pragma unroll
+        for (int k = 0; k < UN; k++) col[UN + k] += (uint64_t)(PC::Z[LC][VC][k] - c.e.v[k]) * one;
+    }
     template <int LA, int VA, int LB, int VB, int LC, int VC>
-    static ECGPU_HD M1 mul_sub(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b, const Mag<C, LC, VC>& c) {
-        static_assert(REPR == REPR_U29_K256, "mul_sub is only provided for k256");
-        static_assert(LA * LB <= MAXPROD, "k256 mul_sub: limb magnitude product too large");
-        uint64_t col[17];
-        k_columns(col, a.e.v, b.e.v, false);
-        k_columns_sub(col, c);
-        return wrap<1, 1>(k_reduce(col));
+    static ECGPU_HD auto mul_sub(const Mag<C, LA, VA>& a, const Mag<C, LB, VB>& b, const Mag<C, LC, VC>& c) {
+        if constexpr (!ECGPU_FUSED_SUB) {
+            return norm(sub(mul(a, b), c));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            static_assert(LA * LB <= MAXPROD, "k256 mul_sub: limb magnitude product too large");
+            uint64_t col[17];
+            k_columns(col, a.e.v, b.e.v, false);
+            k_columns_sub(col, c);
+            return wrap<1, 1>(k_reduce(col));
+        } else {
+            static_assert(LA * LB <= MAXPROD, "mul_sub: limb magnitude product too large");
+            static_assert((long)VA * VB <= (1L << PC::VLIMIT_LOG2), "mul_sub: value magnitude product too large");
+            uint64_t col[2 * UN + 1];
+            p_columns(col, a.e.v, b.e.v, false);
+            p_columns_sub(col, c);
+            return wrap<1, VC + 2>(p_reduce(col));
+        }
     }
     template <int LA, int VA, int LC, int VC>
-    static ECGPU_HD M1 sqr_sub(const Mag<C, LA, VA>& a, const Mag<C, LC, VC>& c) {
-        static_assert(REPR == REPR_U29_K256, "sqr_sub is only provided for k256");
-        static_assert(LA * LA <= MAXPROD, "k256 sqr_sub: limb magnitude too large");
-        uint64_t col[17];
-        k_columns_sqr(col, a.e.v);
-        k_columns_sub(col, c);
-        return wrap<1, 1>(k_reduce(col));
+    static ECGPU_HD auto sqr_sub(const Mag<C, LA, VA>& a, const Mag<C, LC, VC>& c) {
+        if constexpr (!ECGPU_FUSED_SUB) {
+            return norm(sub(sqr(a), c));
+        } else if constexpr (REPR == REPR_U29_K256) {
+            static_assert(LA * LA <= MAXPROD, "k256 sqr_sub: limb magnitude too large");
+            uint64_t col[17];
+            k_columns_sqr(col, a.e.v);
+            k_columns_sub(col, c);
+            return wrap<1, 1>(k_reduce(col));
+        } else {
+            static_assert(LA * LA <= MAXPROD, "sqr_sub: limb magnitude too large");
+            static_assert((long)VA * VA <= (1L << PC::VLIMIT_LOG2), "sqr_sub: value magnitude too large");
+            uint64_t col[2 * UN + 1];
+            p_columns_sqr(col, a.e.v);
+            p_columns_sub(col, c);
+            return wrap<1, VC + 2>(p_reduce(col));
+        }
     }
     // limb magnitude back to 1 (k256: value magnitude too; p256: the value is untouched)
     template <int LA, int VA>

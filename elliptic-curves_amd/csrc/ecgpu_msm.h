@@ -881,7 +881,7 @@ __device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
         const auto d = F::dbl(F::norm(F::sub(g, F::add(aa, cc))));                                  // 2
         const auto X3 = F::norm(F::sub(f, F::dbl(d)));                                              // 6 -> 1
         o.x = G::jstore(X3);
-        o.y = G::jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
+        o.y = G::jstore(F::mul_sub(e3, F::sub(d, X3), F::template mul_small<8>(cc)));
         o.z = G::jstore(z3);
     } else {
         const auto p1 = F::sqr(msm_sel3<C>(lane, Z, Y, F::add(Y, Z)));                              // delta | gamma | (Y + Z)^2
@@ -890,10 +890,10 @@ __device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
         const auto beta = msm_lane_bcast(p2, 0), alpha = msm_lane_bcast(p2, 1), gg = msm_lane_bcast(p2, 2);
         const auto alpha3 = F::add(F::dbl(alpha), alpha);                                           // 3
         const auto beta4 = F::dbl(F::dbl(beta));                                                    // 4
-        const auto X3 = F::norm(F::sub(F::sqr(alpha3), F::dbl(beta4)));                             // 10 -> 1
+        const auto X3 = F::sqr_sub(alpha3, F::dbl(beta4));                             // 10 -> 1
         const auto gg8 = F::dbl(F::dbl(F::dbl(gg)));                                                // 8
         o.x = G::jstore(X3);
-        o.y = G::jstore(F::norm(F::sub(F::mul(alpha3, F::sub(beta4, X3)), gg8)));
+        o.y = G::jstore(F::mul_sub(alpha3, F::sub(beta4, X3), gg8));
         o.z = G::jstore(F::norm(F::sub(yz, F::add(gamma, delta))));
     }
     return o;

@@ -58,11 +58,6 @@ struct Xyzz {
 template <class C, int L, int V>
 std::integral_constant<int, V> magv(const Mag<C, L, V>&);
 
-// -DECGPU_FUSED_SUB=0 builds the k256 formulas with norm(sub(mul(..), ..)) in place of F::mul_sub / F::sqr_sub (A/B measurements:
-// profiles/r04/k256_fused_sub_ab.txt)
-#ifndef ECGPU_FUSED_SUB
-#define ECGPU_FUSED_SUB 1
-#endif
 
 template <class C>
 struct Group {
@@ -127,9 +122,9 @@ struct Group {
         auto xx = F::mul(X1, X2);
         auto yy = F::mul(Y1, Y2);
         auto zz = F::mul(Z1, Z2);
-        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
-        auto yz = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(yy, zz)));
-        auto xz = F::norm(F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(xx, zz)));
+        auto xy = F::mul_sub(F::add(X1, Y1), F::add(X2, Y2), F::add(xx, yy));   // 4 -> 1
+        auto yz = F::mul_sub(F::add(Y1, Z1), F::add(Y2, Z2), F::add(yy, zz));
+        auto xz = F::mul_sub(F::add(X1, Z1), F::add(X2, Z2), F::add(xx, zz));
         auto bzz3 = F::template mul_small<b3>(zz);
         auto yy_m = F::sub(yy, bzz3);                       // 3
         auto yy_p = F::add(yy, bzz3);                       // 2
@@ -148,7 +143,7 @@ struct Group {
         auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));       // 2
         auto xx = F::mul(X1, X2);
         auto yy = F::mul(Y1, Y2);
-        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto xy = F::mul_sub(F::add(X1, Y1), F::add(X2, Y2), F::add(xx, yy));   // 4 -> 1
         auto yz = F::add(F::mul(Y2, Z1), Y1);               // 2
         auto xz = F::add(F::mul(X2, Z1), X1);               // 2
         auto bzz3 = F::template mul_small<b3>(Z1);
@@ -191,15 +186,15 @@ struct Group {
         auto xx = F::mul(X1, X2);
         auto yy = F::mul(Y1, Y2);
         auto zz = F::mul(Z1, Z2);
-        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
-        auto yz = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(yy, zz)));   // 4 -> 1
+        auto xy = F::mul_sub(F::add(X1, Y1), F::add(X2, Y2), F::add(xx, yy));   // 4 -> 1
+        auto yz = F::mul_sub(F::add(Y1, Z1), F::add(Y2, Z2), F::add(yy, zz));   // 4 -> 1
         auto xz = F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(xx, zz));            // 4
         auto bzz = F::norm(F::sub(xz, F::mul(b, zz)));      // 6 -> 1
         auto bzz3 = F::add(F::dbl(bzz), bzz);               // 3
         auto yy_m = F::sub(yy, bzz3);                       // 5
         auto yy_p = F::add(yy, bzz3);                       // 4
         auto zz3 = F::add(F::dbl(zz), zz);                  // 3
-        auto bxz = F::norm(F::sub(F::mul(b, xz), F::add(zz3, xx)));                           // 6 -> 1
+        auto bxz = F::mul_sub(b, xz, F::add(zz3, xx));                           // 6 -> 1
         auto bxz3 = F::add(F::dbl(bxz), bxz);               // 3
         auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), zz3));                        // 7 -> 1
         P o;
@@ -214,7 +209,7 @@ struct Group {
         auto Y2 = F::sel(negq, F::neg(m(r.y)), m(r.y));
         auto xx = F::mul(X1, X2);
         auto yy = F::mul(Y1, Y2);
-        auto xy = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(xx, yy)));   // 4 -> 1
+        auto xy = F::mul_sub(F::add(X1, Y1), F::add(X2, Y2), F::add(xx, yy));   // 4 -> 1
         auto yz = F::add(F::mul(Y2, Z1), Y1);               // 2
         auto xz = F::add(F::mul(X2, Z1), X1);               // 2
         auto bz = F::norm(F::sub(xz, F::mul(b, Z1)));       // 4 -> 1
@@ -222,7 +217,7 @@ struct Group {
         auto yy_m = F::sub(yy, bz3);                        // 5
         auto yy_p = F::add(yy, bz3);                        // 4
         auto z3 = F::add(F::dbl(Z1), Z1);                   // 3
-        auto bxz = F::norm(F::sub(F::mul(b, xz), F::add(z3, xx)));                            // 6 -> 1
+        auto bxz = F::mul_sub(b, xz, F::add(z3, xx));                            // 6 -> 1
         auto bxz3 = F::add(F::dbl(bxz), bxz);               // 3
         auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), z3));                         // 7 -> 1
         P o;
@@ -239,12 +234,12 @@ struct Group {
         auto zz = F::sqr(Z);
         auto xy2 = F::dbl(F::mul(X, Y));                    // 2
         auto xz2 = F::dbl(F::mul(X, Z));                    // 2
-        auto bzz = F::norm(F::sub(F::mul(b, zz), xz2));     // 4 -> 1
+        auto bzz = F::mul_sub(b, zz, xz2);     // 4 -> 1
         auto bzz3 = F::add(F::dbl(bzz), bzz);               // 3
         auto yy_m = F::sub(yy, bzz3);                       // 5
         auto yy_p = F::add(yy, bzz3);                       // 4
         auto zz3 = F::add(F::dbl(zz), zz);                  // 3
-        auto bxz2 = F::norm(F::sub(F::mul(b, xz2), F::add(zz3, xx)));                         // 6 -> 1
+        auto bxz2 = F::mul_sub(b, xz2, F::add(zz3, xx));                         // 6 -> 1
         auto bxz6 = F::add(F::dbl(bxz2), bxz2);             // 3
         auto xx3_m_zz3 = F::norm(F::sub(F::add(F::dbl(xx), xx), zz3));                        // 7 -> 1
         auto yz2 = F::dbl(F::mul(Y, Z));                    // 2
@@ -302,17 +297,10 @@ struct Group {
             auto bb = F::sqr(Y);
             auto cc = F::sqr(bb);
             auto e3 = F::template mul_small<3>(aa);
-            if constexpr (ECGPU_FUSED_SUB) {
-                auto d = F::dbl(F::sqr_sub(F::add(X, bb), F::add(aa, cc)));               // 2   (differences: F::sqr_sub / mul_sub,
-                auto X3 = F::sqr_sub(e3, F::dbl(d));                                      //      one reduction each, no norm)
-                o.x = jstore(X3);
-                o.y = jstore(F::mul_sub(e3, F::sub(d, X3), F::template mul_small<8>(cc)));
-            } else {
-                auto d = F::dbl(F::norm(F::sub(F::sqr(F::add(X, bb)), F::add(aa, cc))));
-                auto X3 = F::norm(F::sub(F::sqr(e3), F::dbl(d)));
-                o.x = jstore(X3);
-                o.y = jstore(F::norm(F::sub(F::mul(e3, F::sub(d, X3)), F::template mul_small<8>(cc))));
-            }
+            auto d = F::dbl(F::sqr_sub(F::add(X, bb), F::add(aa, cc)));                   // 2   (differences: F::sqr_sub / mul_sub,
+            auto X3 = F::sqr_sub(e3, F::dbl(d));                                          //      one reduction each, no norm)
+            o.x = jstore(X3);
+            o.y = jstore(F::mul_sub(e3, F::sub(d, X3), F::template mul_small<8>(cc)));
             o.z = jstore(F::mul(F::dbl(Y), Z));
         } else {
             auto delta = F::sqr(Z);
@@ -329,11 +317,11 @@ struct Group {
                 }
             }();
             auto beta4 = F::dbl(F::dbl(beta));                                            // 4
-            auto X3 = F::norm(F::sub(F::sqr(alpha3), F::dbl(beta4)));                     // 10 -> 1
+            auto X3 = F::sqr_sub(alpha3, F::dbl(beta4));                     // 10 -> 1
             auto gg8 = F::dbl(F::dbl(F::dbl(F::sqr(gamma))));                             // 8
             o.x = jstore(X3);
-            o.y = jstore(F::norm(F::sub(F::mul(alpha3, F::sub(beta4, X3)), gg8)));        // 3 * 6; 10 -> 1
-            o.z = jstore(F::norm(F::sub(F::sqr(F::add(Y, Z)), F::add(gamma, delta))));    // 4 -> 1
+            o.y = jstore(F::mul_sub(alpha3, F::sub(beta4, X3), gg8));        // 3 * 6; 10 -> 1
+            o.z = jstore(F::sqr_sub(F::add(Y, Z), F::add(gamma, delta)));    // 4 -> 1
         }
         return o;
     }
@@ -342,7 +330,7 @@ struct Group {
     static ECGPU_HD J jac_madd(const J& p, const A& q, bool negq, E* h_out = nullptr) {
         auto X1 = mj(p.x), Y1 = mj(p.y), Z1 = mj(p.z);
         auto zz1 = F::sqr(Z1);
-        if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) {         // (as xyzz_madd: the three differences out of their products' reductions)
+        if constexpr (C::REPR == REPR_U29_K256) {         // (as xyzz_madd: the three differences out of their products' reductions)
             auto H = F::mul_sub(m(q.x), zz1, X1);
             if (h_out) *h_out = H.e;
             auto t = F::mul(Z1, zz1);
@@ -358,7 +346,7 @@ struct Group {
             o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(Y1), HHH));
             return o;
         }
-        auto Hn = F::norm(F::sub(F::mul(m(q.x), zz1), X1));
+        auto Hn = F::mul_sub(m(q.x), zz1, X1);
         if (h_out) *h_out = Hn.e;
         auto H = F::template fit<F::SQLIM>(Hn);
         auto t = F::mul(Z1, zz1);
@@ -369,7 +357,7 @@ struct Group {
         auto HH = F::sqr(H);
         auto V = F::mul(X1, HH);
         auto HHH = F::mul(H, HH);
-        auto X3 = F::norm(F::sub(F::sqr(r), F::add(HHH, F::dbl(V))));
+        auto X3 = F::sqr_sub(r, F::add(HHH, F::dbl(V)));
         o.x = jstore(X3);
         o.y = jstore(F::mul2(r, F::sub(V, X3), F::neg(Y1), HHH));
         return o;
@@ -389,7 +377,7 @@ struct Group {
     static ECGPU_HD XZ xyzz_madd(const XZ& p, const A& q, bool negq) {
         auto X1 = mj(p.x), Y1 = mj(p.y), ZZ1 = mj(p.zz), ZZZ1 = mj(p.zzz);
         auto Y2 = F::sel(negq, F::neg(m(q.y)), m(q.y));
-        if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) {
+        if constexpr (C::REPR == REPR_U29_K256) {
             // the three differences that feed a multiplication come out of the reduction of the product they follow (F::mul_sub /
             // F::sqr_sub): no limb-wise subtraction, no carry pass of their own
             auto Pd = F::mul_sub(m(q.x), ZZ1, X1);
@@ -410,7 +398,7 @@ struct Group {
         auto PP = F::sqr(Pd);
         auto PPP = F::mul(Pd, PP);
         auto Q = F::mul(X1, PP);
-        auto X3 = F::norm(F::sub(F::sqr(R), F::add(PPP, F::dbl(Q))));
+        auto X3 = F::sqr_sub(R, F::add(PPP, F::dbl(Q)));
         XZ o;
         o.x = jstore(X3);
         o.y = jstore(F::mul2(R, F::sub(Q, X3), F::neg(Y1), PPP));
@@ -427,10 +415,7 @@ struct Group {
         auto PP = F::sqr(Pd);
         auto PPP = F::mul(Pd, PP);
         auto Q = F::mul(X1, PP);
-        auto X3 = [&] {
-            if constexpr (C::REPR == REPR_U29_K256 && ECGPU_FUSED_SUB) return F::sqr_sub(R, F::add(PPP, F::dbl(Q)));
-            else return F::norm(F::sub(F::sqr(R), F::add(PPP, F::dbl(Q))));
-        }();
+        auto X3 = F::sqr_sub(R, F::add(PPP, F::dbl(Q)));
         XZ o;
         o.x = jstore(X3);
         o.y = jstore(F::mul2(R, F::sub(Q, X3), F::neg(Y1), PPP));
@@ -463,9 +448,9 @@ struct Group {
         auto t0 = F::mul(X1, X2);                                                             // 1
         auto t1 = F::mul(Y1, Y2);                                                             // 2
         auto t2 = F::mul(Z1, Z2);                                                             // 3
-        auto t3 = F::norm(F::sub(F::mul(F::add(X1, Y1), F::add(X2, Y2)), F::add(t0, t1)));   // 4-8
-        auto t4 = F::norm(F::sub(F::mul(F::add(X1, Z1), F::add(X2, Z2)), F::add(t0, t2)));   // 9-13
-        auto t5 = F::norm(F::sub(F::mul(F::add(Y1, Z1), F::add(Y2, Z2)), F::add(t1, t2)));   // 14-18
+        auto t3 = F::mul_sub(F::add(X1, Y1), F::add(X2, Y2), F::add(t0, t1));   // 4-8
+        auto t4 = F::mul_sub(F::add(X1, Z1), F::add(X2, Z2), F::add(t0, t2));   // 9-13
+        auto t5 = F::mul_sub(F::add(Y1, Z1), F::add(Y2, Z2), F::add(t1, t2));   // 14-18
         auto z3 = F::mul2(a, t4, b3, t2);                                                     // 19-21
         auto x3 = F::norm(F::sub(t1, z3));                                                    // 22
         auto z3p = F::norm(F::add(t1, z3));                                                   // 23
@@ -486,7 +471,7 @@ struct Group {
         auto Y2 = F::norm(F::sel(negq, F::neg(m(r.y)), F::add(m(r.y), F::zero())));
         auto t0 = F::mul(X1, X2);                                                             // 1
         auto t1 = F::mul(Y1, Y2);                                                             // 2
-        auto t3 = F::norm(F::sub(F::mul(F::add(X2, Y2), F::add(X1, Y1)), F::add(t0, t1)));   // 3-7
+        auto t3 = F::mul_sub(F::add(X2, Y2), F::add(X1, Y1), F::add(t0, t1));   // 3-7
         auto t4 = F::norm(F::add(F::mul(X2, Z1), X1));                                        // 8, 9
         auto t5 = F::norm(F::add(F::mul(Y2, Z1), Y1));                                        // 10, 11
         auto z3 = F::mul2(a, t4, b3, Z1);                                                     // 12-14

@@ -200,7 +200,7 @@ def p256_reduce_rows(c):
         c[i + 8] = chk64(c[i + 8] + u * 0xFFFFFFFF)
 
 
-def p256_mont_mul(a, b, c_extra=None):
+def p256_mont_mul(a, b, c_extra=None, hi_add=None):
     c = [0] * 21
     for i in range(10):
         for j in range(10):
@@ -210,6 +210,9 @@ def p256_mont_mul(a, b, c_extra=None):
         for i in range(10):
             for j in range(10):
                 c[i + j] = chk64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    if hi_add is not None:                       # mul_sub / sqr_sub: (multiple of p) - c enters the result columns
+        for k in range(10):
+            c[10 + k] = chk64(c[10 + k] + chk32(hi_add[k]))
     p256_reduce_rows(c)
     r = [0] * 10
     carry = 0
@@ -220,7 +223,7 @@ def p256_mont_mul(a, b, c_extra=None):
             carry = v >> P_B
         else:
             r[9] = chk32(v)
-    assert all(x < (1 << 28) for x in r[:9]) and r[9] < 32, [hex(x) for x in r]
+    assert all(x < (1 << 28) for x in r[:9]) and (hi_add is not None or r[9] < 32), [hex(x) for x in r]
     return r
 
 
@@ -250,13 +253,16 @@ Q_LB = (1 << 27) + (1 << 18)
 Q_TOP1 = 128                                     # top limb (bits 378..) of a value < 2p
 
 
-def umont_mul(a, b, nl, bits, plimbs):
+def umont_mul(a, b, nl, bits, plimbs, hi_add=None):
     """generic unsaturated Montgomery multiplication (p = -1 mod 2^bits), every accumulator checked"""
     mask = (1 << bits) - 1
     c = [0] * (2 * nl + 1)
     for i in range(nl):
         for j in range(nl):
             c[i + j] = chk64(c[i + j] + chk32(a[i]) * chk32(b[j]))
+    if hi_add is not None:
+        for k in range(nl):
+            c[nl + k] = chk64(c[nl + k] + chk32(hi_add[k]))
     for i in range(nl):
         u = c[i] & mask
         c[i + 1] = chk64(c[i + 1] + (c[i] >> bits) + u * (plimbs[1] + 1))
@@ -278,7 +284,7 @@ def umont_mul(a, b, nl, bits, plimbs):
 P224_P = 2 ** 224 - 2 ** 96 + 1                  # p224/src/arithmetic/field.rs:54-61
 
 
-def umont_mul_general(a, b, nl, bits, plimbs, c_extra=None):
+def umont_mul_general(a, b, nl, bits, plimbs, c_extra=None, hi_add=None):
     """unsaturated Montgomery multiplication for any odd p: u = c_i * (-p^-1) mod 2^bits, c += u * p, every accumulator
     checked.  For p224, p = 1 mod 2^28, so -p^-1 = -1 and u = -c_i mod 2^28."""
     mask = (1 << bits) - 1
@@ -291,6 +297,9 @@ def umont_mul_general(a, b, nl, bits, plimbs, c_extra=None):
         for i in range(nl):
             for j in range(nl):
                 c[i + j] = chk64(c[i + j] + chk32(c_extra[0][i]) * chk32(c_extra[1][j]))
+    if hi_add is not None:
+        for k in range(nl):
+            c[nl + k] = chk64(c[nl + k] + chk32(hi_add[k]))
     for i in range(nl):
         u = (c[i] * pinv) & mask
         for j in range(nl):
@@ -329,7 +338,7 @@ def chk_s64(x):
     return x
 
 
-def p384_mont_mul(a, b, c_extra=None):
+def p384_mont_mul(a, b, c_extra=None, hi_add=None):
     """p384 with SIGNED column accumulators and the Montgomery rows in sparse form:
     u p = -u + u 2^32 - u 2^96 - u 2^128 + u 2^384; in 27-bit columns relative to row i: the -u clears the low 27
     bits of c[i] (carry = arithmetic c[i] >> 27 into column i+1), + u 2^5 into column i+1, - u 2^15 into column i+3,
@@ -340,6 +349,9 @@ def p384_mont_mul(a, b, c_extra=None):
         for i in range(15):
             for j in range(15):
                 c[i + j] = chk_s64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    if hi_add is not None:
+        for k in range(15):
+            c[15 + k] = chk_s64(c[15 + k] + chk32(hi_add[k]))
     for i in range(15):
         u = c[i] & Q_MASK
         c[i + 1] = chk_s64(c[i + 1] + (c[i] >> Q_B) + u * (1 << 5))
@@ -394,7 +406,7 @@ def sparse_bias(name):
     return bias
 
 
-def sparse_mont_mul(name, a, b, c_extra=None):
+def sparse_mont_mul(name, a, b, c_extra=None, hi_add=None):
     p, nl, bits, p0_one, terms, _ = SPARSE[name]
     mask = (1 << bits) - 1
     c = list(sparse_bias(name))
@@ -402,6 +414,9 @@ def sparse_mont_mul(name, a, b, c_extra=None):
         for i in range(nl):
             for j in range(nl):
                 c[i + j] = chk64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    if hi_add is not None:
+        for k in range(nl):
+            c[nl + k] = chk64(c[nl + k] + chk32(hi_add[k]))
     for i in range(nl):
         if p0_one:
             u = (-c[i]) & mask
@@ -426,7 +441,7 @@ def sparse_mont_mul(name, a, b, c_extra=None):
 BIGN_P = 2 ** 256 - 189                          # bignp256/src/arithmetic/field.rs:60-66
 
 
-def bign_mont_mul(a, b, c_extra=None):
+def bign_mont_mul(a, b, c_extra=None, hi_add=None):
     """bign-curve256v1 on 10 x 28 limbs (R = 2^280) with SIGNED column accumulators and the Montgomery rows in sparse form:
     u p = -189 u + u 2^256 with u = c_i / 189 mod 2^28 — -189 u clears the low 28 bits of column i, + 16 u goes into column
     i + 9 (2^256 = 2^4 2^252).  Two multiply-adds per row instead of ten; product limit 11 (10 x 11 x LB^2 < 2^63)."""
@@ -437,6 +452,9 @@ def bign_mont_mul(a, b, c_extra=None):
         for i in range(10):
             for j in range(10):
                 c[i + j] = chk_s64(c[i + j] + chk32(x[i]) * chk32(y[j]))
+    if hi_add is not None:
+        for k in range(10):
+            c[10 + k] = chk_s64(c[10 + k] + chk32(hi_add[k]))
     for i in range(10):
         u = (c[i] * pinv) & mask
         t = chk_s64(c[i] - 189 * u)
@@ -541,6 +559,39 @@ def selftest(trials=300, seed=1):
         cases.append([rng.choice([0, 1, K_MASK, K_MASK + 1, K_LB - 1, rng.randrange(K_LB)]) for _ in range(9)])
     for a in cases:
         assert k256_to_words_m1(a) == from_limbs(a, K_B) % K_P
+    # Field::mul_sub / sqr_sub on the Montgomery fields: the subtrahend's limbs ((multiple of p) - c, anything below 2^32) enter
+    # the high columns before the rows — products at each set's limit with the largest addends, then random ones; the value must
+    # be a b / R + addend and no accumulator may overflow (the chk64 / chk_s64 inside the routines)
+    def fused(mul, pp, nl, bits, lb, top1, maxprod, maxmag, label):
+        rinv_f = pow(1 << (nl * bits), -1, pp)
+        pairs = [(ma, maxprod // ma) for ma in range(1, maxmag + 1) if 1 <= maxprod // ma <= maxmag]
+        for ma, mb in pairs:
+            a = [ma * lb - 1] * (nl - 1) + [top1 * ma - 1]
+            b = [mb * lb - 1] * (nl - 1) + [top1 * mb - 1]
+            for h in ([(1 << 32) - 1] * (nl - 1) + [1 << 20], [0] * nl):
+                r = mul(a, b, h)
+                want = (from_limbs(a, bits) * from_limbs(b, bits) * rinv_f + from_limbs(h, bits)) % pp
+                assert from_limbs(r, bits) % pp == want, label
+                assert all(x < (1 << bits) for x in r[:nl - 1]), label
+        for _ in range(trials // 4):
+            ma, mb = rng.choice(pairs)
+            a = [rng.randrange(ma * lb) for _ in range(nl - 1)] + [rng.randrange(top1 * ma)]
+            b = [rng.randrange(mb * lb) for _ in range(nl - 1)] + [rng.randrange(top1 * mb)]
+            h = [rng.randrange(1 << 32) for _ in range(nl - 1)] + [rng.randrange(1 << 20)]
+            r = mul(a, b, h)
+            assert from_limbs(r, bits) % pp == (from_limbs(a, bits) * from_limbs(b, bits) * rinv_f + from_limbs(h, bits)) % pp, label
+    fused(lambda a, b, h: p256_mont_mul(a, b, hi_add=h), P_P, 10, 28, P_LB, 32, 23, 15, "p256")
+    fused(lambda a, b, h: p384_mont_mul(a, b, hi_add=h), Q_P, 15, 27, Q_LB, Q_TOP1, 30, 28, "p384")
+    fused(lambda a, b, h: bign_mont_mul(a, b, hi_add=h), BIGN_P, 10, 28, P_LB, 32, 11, 11, "bign256")
+    for name, (lb, top1, maxprod, maxmag) in {"SM2U": (P_LB, 32, 24, 15), "P224U": (Q_LB, 512, 30, 28), "P192U": ((1 << 26) + (1 << 17), 2048, 30, 28)}.items():
+        fused(lambda a, b, h, name=name: sparse_mont_mul(name, a, b, hi_add=h), SPARSE[name][0], SPARSE[name][1], SPARSE[name][2], lb, top1,
+              maxprod, maxmag, name)
+    bp256 = 0xA9FB57DBA1EEA9BC3E660A909D838D726E3BF623D52620282013481D1F6E5377
+    bp384 = 0x8CB91E82A3386D280F5D6F7E50E641DF152F7109ED5456B412B1DA197FB71123ACD3A729901D1A71874700133107EC53
+    fused(lambda a, b, h: umont_mul_general(a, b, 10, 28, to_limbs(bp256, 10, 28), hi_add=h), bp256, 10, 28, P_LB, 32, 22, 15, "bp256")
+    fused(lambda a, b, h: umont_mul_general(a, b, 15, 27, to_limbs(bp384, 15, 27), hi_add=h), bp384, 15, 27, Q_LB, 71, 24, 28, "bp384")
+    p521 = 2 ** 521 - 1
+    fused(lambda a, b, h: umont_mul(a, b, 20, 27, to_limbs(p521, 20, 27), hi_add=h), p521, 20, 27, Q_LB, 512, 30, 28, "p521")
     # p256: limb-magnitude product limit 23 (single products and the fused pairs of the group law)
     rinv = pow(P_R, -1, P_P)
     for (ma, mb), (mc, md) in (((4, 5), (1, 3)), ((12, 1), (11, 1)), ((4, 1), (3, 3))):
