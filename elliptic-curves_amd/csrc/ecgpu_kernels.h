@@ -387,6 +387,7 @@ struct BaseTableHbm {
         load_words_vec<2 * C::N>(p.w, table + ((size_t)window * half + index) * (2 * C::N));
     }
 };
+// (k256: three workgroups per CU = 156 registers; compiled for four — 128 registers — the kernel spills 340 bytes per lane)
 template <class C>
 __global__ void __launch_bounds__(BLOCK, C::A_IS_ZERO ? 3 : 1)
 k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __restrict__ table, int w, int nwin,

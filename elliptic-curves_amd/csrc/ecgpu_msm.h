@@ -690,8 +690,13 @@ struct MsmPartialsHbm {       // [slot][4] raw elements: X, Y, ZZ, ZZZ
 };
 
 // one lane per (window, chunk)
+// (-DECGPU_MSM_ACC_WAVES=4, an A/B knob of the build: 128 registers + 108 bytes of scratch per lane for k256 — measured 10 % slower,
+// 15.8 against 14.4 ms at 2^24 terms, profiles/r04/msm_accumulate_four_waves_ab.txt)
+#ifndef ECGPU_MSM_ACC_WAVES
+#define ECGPU_MSM_ACC_WAVES 3
+#endif
 template <class C>
-__global__ void __launch_bounds__(64, C::N <= 8 ? 3 : C::N <= 12 ? 2 : 1)
+__global__ void __launch_bounds__(64, C::N <= 8 ? ECGPU_MSM_ACC_WAVES : C::N <= 12 ? 2 : 1)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
                  int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials) {
@@ -843,11 +848,10 @@ k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int 
     if (threadIdx.x == 0) store_proj<C>(wins, blockIdx.x, acc);
 }
 
-// ---- one Jacobian doubling spread over three lanes of a wave ---------------------------------------------------------------
+// ---- one Jacobian doubling spread over three lanes of a wave (the a = -3 sets; k256: msm_hom_dbl_quad below) ------------------
 // The Horner chain below is ONE dependency chain of c * (nwin - 1) doublings (120 for 128-bit sub-scalars, 240 for 255-bit
 // ones): a single lane issues one instruction every ~5 cycles, so the chain's time is its instruction count.  A doubling's
 // seven or eight field multiplications are only three or four DEPENDENT levels:
-//   a = 0  (dbl-2009-l)   {X^2, Y^2, 2Y Z}  ->  {(Y^2)^2, (X + Y^2)^2, (3 X^2)^2}  ->  {E (D - X3)}
 //   a = -3 (dbl-2001-b)   {Z^2, Y^2, (Y + Z)^2}  ->  {X gamma, (X - delta)(X + delta), gamma^2}  ->  {alpha3^2}  ->  {alpha3 (4 beta - X3)}
 // Lanes 0, 1, 2 of the wave each compute one product of a level (the same instruction stream on per-lane operands: plain
 // SIMT), the three results are handed to every lane through the LDS crossbar (`__shfl`, 9-15 words each) and the cheap
@@ -872,18 +876,8 @@ __device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
     using F = Field<C>;
     auto X = G::mj(p.x), Y = G::mj(p.y), Z = G::mj(p.z);
     Jac<C> o;
-    if constexpr (C::A_IS_ZERO) {
-        const auto p1 = F::mul(msm_sel3<C>(lane, X, Y, F::dbl(Y)), msm_sel3<C>(lane, X, Y, Z));     // X^2 | Y^2 | 2 Y Z
-        const auto aa = msm_lane_bcast(p1, 0), bb = msm_lane_bcast(p1, 1), z3 = msm_lane_bcast(p1, 2);
-        const auto e3 = F::template mul_small<3>(aa);
-        const auto p2 = F::sqr(msm_sel3<C>(lane, bb, F::add(X, bb), e3));                           // bb^2 | (X + bb)^2 | e3^2
-        const auto cc = msm_lane_bcast(p2, 0), g = msm_lane_bcast(p2, 1), f = msm_lane_bcast(p2, 2);
-        const auto d = F::dbl(F::norm(F::sub(g, F::add(aa, cc))));                                  // 2
-        const auto X3 = F::norm(F::sub(f, F::dbl(d)));                                              // 6 -> 1
-        o.x = G::jstore(X3);
-        o.y = G::jstore(F::mul_sub(e3, F::sub(d, X3), F::template mul_small<8>(cc)));
-        o.z = G::jstore(z3);
-    } else {
+    static_assert(!C::A_IS_ZERO, "k256 takes the complete doublings on quad lanes (msm_hom_dbl_quad)");
+    {
         const auto p1 = F::sqr(msm_sel3<C>(lane, Z, Y, F::add(Y, Z)));                              // delta | gamma | (Y + Z)^2
         const auto delta = msm_lane_bcast(p1, 0), gamma = msm_lane_bcast(p1, 1), yz = msm_lane_bcast(p1, 2);
         const auto p2 = F::mul(msm_sel3<C>(lane, X, F::sub(X, delta), gamma), msm_sel3<C>(lane, gamma, F::add(X, delta), gamma));
