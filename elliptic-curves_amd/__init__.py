@@ -41,7 +41,7 @@ ABI_SYMBOLS = [
     "ecgpu_batch_mul_base_and_mul_add", "ecgpu_batch_normalize", "ecgpu_batch_mul_base_dev",
     "ecgpu_batch_mul_dev", "ecgpu_msm_dev", "ecgpu_batch_mul_base_and_mul_add_dev", "ecgpu_batch_normalize_dev",
     "ecgpu_point_sum", "ecgpu_point_sum_dev", "ecgpu_k256_glv_decompose", "ecgpu_valu_probe",
-    "ecgpu_last_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
+    "ecgpu_last_timing", "ecgpu_set_timing", "ecgpu_version", "ecgpu_ecdsa_verify_batch", "ecgpu_ecdsa_verify_batch_dev",
     "ecgpu_schnorr_verify_batch", "ecgpu_schnorr_verify_batch_dev", "ecgpu_batch_decompress",
     "ecgpu_batch_decompress_dev", "ecgpu_batch_ecdh", "ecgpu_batch_ecdh_dev",
     "ecgpu_schnorr_verify_raw_batch", "ecgpu_schnorr_verify_raw_batch_dev", "ecgpu_host_alloc", "ecgpu_host_free",
@@ -273,6 +273,10 @@ class Engine:
 
     def synchronize(self):
         self._chk(self._lib.ecgpu_synchronize(self._ctx))
+
+    def set_timing(self, on=True):
+        """Per-call HIP events (last_timing) on / off; off: nothing but the kernels goes on the stream (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_set_timing(self._ctx, 1 if on else 0))
 
     def set_msm_lanes(self, lanes=2):
         """Two MSMs in flight on an asynchronous context (alternating internal streams and workspaces); their outputs are

@@ -86,6 +86,7 @@ struct ecgpu_ctx {
     // asynchronous mode (ecgpu_set_async): device-pointer calls return once their work is queued; the status word
     // accumulates on the device until ecgpu_synchronize (or a host-pointer call) collects it into `deferred`
     bool async = false, pending = false;
+    bool timing_on = true;       // ecgpu_set_timing: per-call HIP events (ecgpu_last_timing)
     int deferred = 0;
     // MSM lanes (ecgpu_set_msm_lanes): in asynchronous mode consecutive MSMs alternate between two internal streams, each with
     // a workspace of its own, so that the sort and the reduction tail of one MSM (bandwidth- and latency-bound) run beside the
@@ -257,7 +258,9 @@ struct CtWipe {
     }
 };
 
-void record(ecgpu_ctx* ctx, int i) { (void)hipEventRecord(ctx->ev[i], ctx->stream); }
+void record(ecgpu_ctx* ctx, int i) {
+    if (ctx->timing_on) (void)hipEventRecord(ctx->ev[i], ctx->stream);
+}
 
 void resolve_timing(ecgpu_ctx* ctx) {
     if (ctx->spans.empty()) return;
@@ -275,6 +278,10 @@ void resolve_timing(ecgpu_ctx* ctx) {
 void collect_timing(ecgpu_ctx* ctx, std::initializer_list<std::pair<const char*, std::pair<int, int>>> spans) {
     ctx->spans.clear();
     ctx->lane_last = -1;
+    if (!ctx->timing_on) {                     // no events were recorded for this call: ecgpu_last_timing has nothing to report
+        ctx->timing.clear();
+        return;
+    }
     for (auto& s : spans) ctx->spans.emplace_back(s.first, s.second);
     if (!ctx->async) resolve_timing(ctx);
 }
@@ -1210,6 +1217,16 @@ int ecgpu_set_msm_lanes(ecgpu_ctx* ctx, int lanes) {
     int rc = ctx->async ? drain(ctx) : ECGPU_OK;       // nothing in flight on a lane while the mode changes
     ctx->msm_lanes = lanes;
     return rc;
+}
+
+int ecgpu_set_timing(ecgpu_ctx* ctx, int on) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    ctx->timing_on = on != 0;
+    if (!ctx->timing_on) {
+        ctx->spans.clear();
+        ctx->timing.clear();
+    }
+    return ECGPU_OK;
 }
 
 int ecgpu_set_async(ecgpu_ctx* ctx, int on) {

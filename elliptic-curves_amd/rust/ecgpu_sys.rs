@@ -644,5 +644,6 @@ unsafe extern "C" {
     ) -> c_int;
     pub fn ecgpu_valu_probe(ctx: *mut EcgpuCtx, which: c_int, ops_per_sec: *mut f64) -> c_int;
     pub fn ecgpu_last_timing(ctx: *const EcgpuCtx, name: *const c_char, ms: *mut f64) -> c_int;
+    pub fn ecgpu_set_timing(ctx: *mut EcgpuCtx, on: c_int) -> c_int;
     pub fn ecgpu_version() -> *const c_char;
 }

@@ -1559,3 +1559,36 @@ def test_device_pointer_entry_points():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "gpu_dev_pointer_check.py")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "device-pointer entry points: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_timing_events_can_be_switched_off(eng):
+    """ecgpu_set_timing(0): a call puts nothing but its kernels on the stream and ecgpu_last_timing has nothing to report;
+    the results do not depend on it; switching it on again brings the stage timings back (include/ecgpu.h)."""
+    c = pyec.CURVES["k256"]
+    L, n = c.L, 1500
+    pad = lambda x: (x + 15) // 16 * 16
+    ks = rand_scalars(c.cid, n, 0x71A1)
+    want, want_inf = oracle_lib.batch_mul_base(c.cid, ks)
+    d_k = eng.to_device(ks)
+    d_o, d_f = eng.dev_alloc(pad(n * 2 * L)), eng.dev_alloc(pad(n))
+    try:
+        eng.set_timing(False)
+        eng.mul_by_generator_dev(c.cid, d_k, n, d_o, d_f)
+        assert eng.last_timing("main") is None and eng.last_timing("total") is None
+        assert bytes(eng.to_host(d_o, n * 2 * L)) == bytes(want) and bytes(eng.to_host(d_f, n)) == bytes(want_inf)
+        eng.set_async(True)
+        for _ in range(3):
+            eng.mul_by_generator_dev(c.cid, d_k, n, d_o, d_f)
+        eng.synchronize()
+        assert eng.last_timing("main") is None
+        eng.set_timing(True)
+        eng.mul_by_generator_dev(c.cid, d_k, n, d_o, d_f)
+        eng.synchronize()
+        assert eng.last_timing("main") > 0 and eng.last_timing("normalize") > 0
+        assert bytes(eng.to_host(d_o, n * 2 * L)) == bytes(want)
+    finally:
+        eng.set_async(False)
+        eng.set_timing(True)
+        for b in (d_o, d_f, d_k):
+            b.free()
