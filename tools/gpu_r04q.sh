@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: k256 formulas with the differences taken inside the reductions (F::mul_sub / F::sqr_sub; lib/libecgpu.so) against the
 # same library built with -DECGPU_FUSED_SUB=0 (lib/libecgpu_nofused.so), alternating on one box
+# (the second library: tools/build_alt_lib.sh)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ALT=$PWD/elliptic-curves_amd/lib/libecgpu_nofused.so
 run() {

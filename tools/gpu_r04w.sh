@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: Field::mul_sub / sqr_sub on the Montgomery fields (the subtrahend in the high columns) against the same source built
 # with -DECGPU_FUSED_SUB=0 for the two ladders (lib/libecgpu_nofused.so), alternating on one box
+# (the second library: tools/build_alt_lib.sh)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ALT=$PWD/elliptic-curves_amd/lib/libecgpu_nofused.so
 run() {

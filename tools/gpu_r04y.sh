@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4: k_msm_accumulate<K256Params> compiled for four waves per SIMD (128 registers + 108 bytes of scratch per lane,
 # lib/libecgpu_acc4.so) against the default build (152 registers, three waves per SIMD), alternating on one box
+# (the second library: tools/build_alt_lib.sh)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ALT=$PWD/elliptic-curves_amd/lib/libecgpu_acc4.so
 run() {
