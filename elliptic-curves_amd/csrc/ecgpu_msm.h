@@ -769,130 +769,6 @@ k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restr
     if (threadIdx.x == 0) store_proj<C>(buckets, gid, acc);
 }
 
-// ---- reduce ------------------------------------------------------------------------------------------------------------
-
-// k * P for a small non-negative k (double-and-add, k < 2^31)
-template <class C>
-__device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const Fe<C::NL>& b) {
-    using G = Group<C>;
-    Proj<C> acc = G::identity();
-    if (k == 0) return acc;
-    int top = 31 - __clz(k);
-#pragma unroll 1
-    for (int bit = top; bit >= 0; bit--) {
-        acc = G::dbl(acc, b);
-        if ((k >> bit) & 1) acc = G::add(acc, p, b);
-    }
-    return acc;
-}
-
-// segs[w][s] = sum_{j < seg} weight(s*seg + j) * buckets[w][s*seg + j],  weight(b) = (b >> shift_w) + 1 with
-// shift_w = 0 except for the last window (sub-buckets, see msm_digit).  Running-sum trick: walking the
-// segment downwards, `running` is added to `local` once per unit drop of the weight, and the weight of the
-// lowest bucket multiplies the whole segment sum at the end.
-template <class C>
-__global__ void __launch_bounds__(64)
-k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin, int top_shift,
-                      uint32_t* __restrict__ segs) {
-    using G = Group<C>;
-    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= nseg * nwin) return;
-    size_t w = gid / nseg, s = gid % nseg;
-    Fe<C::NL> b = G::curve_b();
-    Proj<C> running = G::identity(), local = G::identity();
-    size_t base = s * seg;
-    const int sh = (int)w == nwin - 1 ? top_shift : 0;
-#pragma unroll 1
-    for (int j = seg - 1; j >= 0; j--) {
-        Proj<C> bk = load_proj<C>(buckets, w * nb + base + j);
-        running = G::add(running, bk, b);
-        if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
-    }
-    uint32_t wmin = (uint32_t)(base >> sh) + 1;
-    local = G::add(local, wmin == 1 ? running : small_mul<C>(running, wmin, b), b);
-    store_proj<C>(segs, gid, local);
-}
-
-// parts[w][g] = sum of the segment sums segs[w][g * per .. (g + 1) * per): one workgroup per (g, w), a strided pass
-// and an LDS tree.  With the default plan (4 buckets per segment, 256 segments per workgroup) a lane adds one segment:
-// the depth is the 8 levels of the tree, where one workgroup per window used to walk 32 segments per lane first.
-template <class C>
-__global__ void __launch_bounds__(BLOCK)
-k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per, uint32_t* __restrict__ parts) {
-    using G = Group<C>;
-    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
-    Fe<C::NL> b = G::curve_b();
-    Proj<C> acc = G::identity();
-    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < nseg ? lo + per : nseg;
-    for (size_t s = lo + threadIdx.x; s < hi; s += BLOCK)
-        acc = G::add(acc, load_proj<C>(segs, (size_t)blockIdx.y * nseg + s), b);
-    acc = block_sum<C>(acc, lds, b);
-    if (threadIdx.x == 0) store_proj<C>(parts, (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
-}
-
-// wins[w] = sum over ranks r and workgroups g of parts[r][w][g] — the one place where the partial results of several
-// GPUs meet (nranks = 1: this GPU's own).  One workgroup per window.
-template <class C>
-__global__ void __launch_bounds__(BLOCK)
-k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int nparts, uint32_t* __restrict__ wins) {
-    using G = Group<C>;
-    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
-    Fe<C::NL> b = G::curve_b();
-    Proj<C> acc = G::identity();
-    const int items = nranks * nparts;
-    for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
-        const int r = t / nparts, g = t % nparts;
-        acc = G::add(acc, load_proj<C>(parts, ((size_t)r * nwin + blockIdx.x) * nparts + g), b);
-    }
-    acc = block_sum<C>(acc, lds, b);
-    if (threadIdx.x == 0) store_proj<C>(wins, blockIdx.x, acc);
-}
-
-// ---- one Jacobian doubling spread over three lanes of a wave (the a = -3 sets; k256: msm_hom_dbl_quad below) ------------------
-// The Horner chain below is ONE dependency chain of c * (nwin - 1) doublings (120 for 128-bit sub-scalars, 240 for 255-bit
-// ones): a single lane issues one instruction every ~5 cycles, so the chain's time is its instruction count.  A doubling's
-// seven or eight field multiplications are only three or four DEPENDENT levels:
-//   a = -3 (dbl-2001-b)   {Z^2, Y^2, (Y + Z)^2}  ->  {X gamma, (X - delta)(X + delta), gamma^2}  ->  {alpha3^2}  ->  {alpha3 (4 beta - X3)}
-// Lanes 0, 1, 2 of the wave each compute one product of a level (the same instruction stream on per-lane operands: plain
-// SIMT), the three results are handed to every lane through the LDS crossbar (`__shfl`, 9-15 words each) and the cheap
-// linear steps in between are done by all lanes alike, so that every lane holds the whole state again.  Three resp. four
-// multiplication times per doubling instead of seven resp. eight.  Every lane must enter with the same point.
-template <class M>
-__device__ __forceinline__ M msm_lane_bcast(const M& v, int src) {
-    M r;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(v.e.v) / sizeof(v.e.v[0])); i++) r.e.v[i] = (uint32_t)__shfl((int)v.e.v[i], src, 64);
-    return r;
-}
-template <class C, class A, class B, class D>
-__device__ __forceinline__ auto msm_sel3(int lane, const A& a, const B& b, const D& d) {
-    using F = Field<C>;
-    return F::sel(lane == 0, a, F::sel(lane == 1, b, d));
-}
-
-template <class C>
-__device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
-    using G = Group<C>;
-    using F = Field<C>;
-    auto X = G::mj(p.x), Y = G::mj(p.y), Z = G::mj(p.z);
-    Jac<C> o;
-    static_assert(!C::A_IS_ZERO, "k256 takes the complete doublings on quad lanes (msm_hom_dbl_quad)");
-    {
-        const auto p1 = F::sqr(msm_sel3<C>(lane, Z, Y, F::add(Y, Z)));                              // delta | gamma | (Y + Z)^2
-        const auto delta = msm_lane_bcast(p1, 0), gamma = msm_lane_bcast(p1, 1), yz = msm_lane_bcast(p1, 2);
-        const auto p2 = F::mul(msm_sel3<C>(lane, X, F::sub(X, delta), gamma), msm_sel3<C>(lane, gamma, F::add(X, delta), gamma));
-        const auto beta = msm_lane_bcast(p2, 0), alpha = msm_lane_bcast(p2, 1), gg = msm_lane_bcast(p2, 2);
-        const auto alpha3 = F::add(F::dbl(alpha), alpha);                                           // 3
-        const auto beta4 = F::dbl(F::dbl(beta));                                                    // 4
-        const auto X3 = F::sqr_sub(alpha3, F::dbl(beta4));                             // 10 -> 1
-        const auto gg8 = F::dbl(F::dbl(F::dbl(gg)));                                                // 8
-        o.x = G::jstore(X3);
-        o.y = G::jstore(F::mul_sub(alpha3, F::sub(beta4, X3), gg8));
-        o.z = G::jstore(F::norm(F::sub(yz, F::add(gamma, delta))));
-    }
-    return o;
-}
-
 // ---- a = 0 (k256): one COMPLETE projective doubling spread over the four lanes of a quad -----------------------------------
 // Renes–Costello–Batina's doubling for a = 0 (the formulas of Group::dbl_a0: X3 = 2 XY (Y^2 - 9b Z^2), Y3 = 24b Y^2 Z^2 +
 // (Y^2 - 9b Z^2)(Y^2 + 3b Z^2), Z3 = 8 Y^3 Z) has only TWO dependent levels of products, four products each:
@@ -967,6 +843,181 @@ __device__ __forceinline__ void msm_hom_add_quad(typename Field<C>::M1& X1, type
     X1 = msm_quad_bcast<0>(p2);
     Y1 = msm_quad_bcast<1>(p2);
     Z1 = msm_quad_bcast<2>(p2);
+}
+
+// workgroup-wide sum of one projective point per lane, result valid in lane 0 (block_sum, ecgpu_kernels.h) — for k256 with the
+// tree's additions on quad lanes wherever a level has at most a quarter of the lanes busy (every level but the first): a level
+// is then ~1,150 instructions (two LDS reads, msm_hom_add_quad, one write) instead of ~2,220, and these trees are pure
+// latency — one workgroup per (part, window), a wave or less per SIMD.
+template <class C>
+__device__ __forceinline__ Proj<C> msm_block_sum(Proj<C> acc, uint32_t* lds, const Fe<C::NL>& b) {
+    if constexpr (!(C::A_IS_ZERO && C::REPR == REPR_U29_K256)) {
+        return block_sum<C>(acc, lds, b);
+    } else {
+        using G = Group<C>;
+        constexpr int NL = C::NL;
+        const int nt = (int)blockDim.x, t = (int)threadIdx.x;
+        auto put = [&](int node, const Proj<C>& p) {
+            uint32_t* d = lds + node * (3 * NL);
+#pragma unroll
+            for (int l = 0; l < NL; l++) { d[l] = p.x.v[l]; d[NL + l] = p.y.v[l]; d[2 * NL + l] = p.z.v[l]; }
+        };
+        auto get = [&](int node) {
+            const uint32_t* o = lds + node * (3 * NL);
+            Proj<C> q;
+#pragma unroll
+            for (int l = 0; l < NL; l++) { q.x.v[l] = o[l]; q.y.v[l] = o[NL + l]; q.z.v[l] = o[2 * NL + l]; }
+            return q;
+        };
+        put(t, acc);
+        __syncthreads();
+        for (int s = nt / 2; s > 0; s >>= 1) {
+            if (4 * s > nt) {                               // the first level: one lane per node
+                if (t < s) acc = G::add(acc, get(t + s), b);
+                __syncthreads();
+                if (t < s) put(t, acc);
+            } else {                                        // node i on the four lanes of quad i (whole quads are in or out)
+                const int i = t >> 2;
+                const bool in = i < s;
+                if (in) {
+                    const Proj<C> p = get(i), q = get(i + s);
+                    auto X = G::m(p.x), Y = G::m(p.y), Z = G::m(p.z);
+                    msm_hom_add_quad<C>(X, Y, Z, q, t & 3);
+                    acc.x = X.e;
+                    acc.y = Y.e;
+                    acc.z = Z.e;
+                }
+                __syncthreads();
+                if (in && (t & 3) == 0) put(i, acc);
+            }
+            __syncthreads();
+        }
+        return acc;                                         // lane 0: node 0 of the last level
+    }
+}
+
+// ---- reduce ------------------------------------------------------------------------------------------------------------
+
+// k * P for a small non-negative k (double-and-add, k < 2^31)
+template <class C>
+__device__ __forceinline__ Proj<C> small_mul(const Proj<C>& p, uint32_t k, const Fe<C::NL>& b) {
+    using G = Group<C>;
+    Proj<C> acc = G::identity();
+    if (k == 0) return acc;
+    int top = 31 - __clz(k);
+#pragma unroll 1
+    for (int bit = top; bit >= 0; bit--) {
+        acc = G::dbl(acc, b);
+        if ((k >> bit) & 1) acc = G::add(acc, p, b);
+    }
+    return acc;
+}
+
+// segs[w][s] = sum_{j < seg} weight(s*seg + j) * buckets[w][s*seg + j],  weight(b) = (b >> shift_w) + 1 with
+// shift_w = 0 except for the last window (sub-buckets, see msm_digit).  Running-sum trick: walking the
+// segment downwards, `running` is added to `local` once per unit drop of the weight, and the weight of the
+// lowest bucket multiplies the whole segment sum at the end.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, size_t nseg, int nwin, int top_shift,
+                      uint32_t* __restrict__ segs) {
+    using G = Group<C>;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nseg * nwin) return;
+    size_t w = gid / nseg, s = gid % nseg;
+    Fe<C::NL> b = G::curve_b();
+    Proj<C> running = G::identity(), local = G::identity();
+    size_t base = s * seg;
+    const int sh = (int)w == nwin - 1 ? top_shift : 0;
+#pragma unroll 1
+    for (int j = seg - 1; j >= 0; j--) {
+        Proj<C> bk = load_proj<C>(buckets, w * nb + base + j);
+        running = G::add(running, bk, b);
+        if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
+    }
+    uint32_t wmin = (uint32_t)(base >> sh) + 1;
+    local = G::add(local, wmin == 1 ? running : small_mul<C>(running, wmin, b), b);
+    store_proj<C>(segs, gid, local);
+}
+
+// parts[w][g] = sum of the segment sums segs[w][g * per .. (g + 1) * per): one workgroup per (g, w), a strided pass
+// and an LDS tree.  With the default plan (4 buckets per segment, 256 segments per workgroup) a lane adds one segment:
+// the depth is the 8 levels of the tree, where one workgroup per window used to walk 32 segments per lane first.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_msm_reduce_windows(const uint32_t* __restrict__ segs, size_t nseg, size_t per, uint32_t* __restrict__ parts) {
+    using G = Group<C>;
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    Fe<C::NL> b = G::curve_b();
+    Proj<C> acc = G::identity();
+    const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < nseg ? lo + per : nseg;
+    for (size_t s = lo + threadIdx.x; s < hi; s += BLOCK)
+        acc = G::add(acc, load_proj<C>(segs, (size_t)blockIdx.y * nseg + s), b);
+    acc = msm_block_sum<C>(acc, lds, b);
+    if (threadIdx.x == 0) store_proj<C>(parts, (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
+}
+
+// wins[w] = sum over ranks r and workgroups g of parts[r][w][g] — the one place where the partial results of several
+// GPUs meet (nranks = 1: this GPU's own).  One workgroup per window.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_msm_window_sums(const uint32_t* __restrict__ parts, int nranks, int nwin, int nparts, uint32_t* __restrict__ wins) {
+    using G = Group<C>;
+    __shared__ uint32_t lds[BLOCK * 3 * C::NL];
+    Fe<C::NL> b = G::curve_b();
+    Proj<C> acc = G::identity();
+    const int items = nranks * nparts;
+    for (int t = threadIdx.x; t < items; t += (int)blockDim.x) {
+        const int r = t / nparts, g = t % nparts;
+        acc = G::add(acc, load_proj<C>(parts, ((size_t)r * nwin + blockIdx.x) * nparts + g), b);
+    }
+    acc = msm_block_sum<C>(acc, lds, b);
+    if (threadIdx.x == 0) store_proj<C>(wins, blockIdx.x, acc);
+}
+
+// ---- one Jacobian doubling spread over three lanes of a wave (the a = -3 sets; k256: msm_hom_dbl_quad below) ------------------
+// The Horner chain below is ONE dependency chain of c * (nwin - 1) doublings (120 for 128-bit sub-scalars, 240 for 255-bit
+// ones): a single lane issues one instruction every ~5 cycles, so the chain's time is its instruction count.  A doubling's
+// seven or eight field multiplications are only three or four DEPENDENT levels:
+//   a = -3 (dbl-2001-b)   {Z^2, Y^2, (Y + Z)^2}  ->  {X gamma, (X - delta)(X + delta), gamma^2}  ->  {alpha3^2}  ->  {alpha3 (4 beta - X3)}
+// Lanes 0, 1, 2 of the wave each compute one product of a level (the same instruction stream on per-lane operands: plain
+// SIMT), the three results are handed to every lane through the LDS crossbar (`__shfl`, 9-15 words each) and the cheap
+// linear steps in between are done by all lanes alike, so that every lane holds the whole state again.  Three resp. four
+// multiplication times per doubling instead of seven resp. eight.  Every lane must enter with the same point.
+template <class M>
+__device__ __forceinline__ M msm_lane_bcast(const M& v, int src) {
+    M r;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(v.e.v) / sizeof(v.e.v[0])); i++) r.e.v[i] = (uint32_t)__shfl((int)v.e.v[i], src, 64);
+    return r;
+}
+template <class C, class A, class B, class D>
+__device__ __forceinline__ auto msm_sel3(int lane, const A& a, const B& b, const D& d) {
+    using F = Field<C>;
+    return F::sel(lane == 0, a, F::sel(lane == 1, b, d));
+}
+
+template <class C>
+__device__ __forceinline__ Jac<C> msm_jac_dbl_lanes(const Jac<C>& p, int lane) {
+    using G = Group<C>;
+    using F = Field<C>;
+    auto X = G::mj(p.x), Y = G::mj(p.y), Z = G::mj(p.z);
+    Jac<C> o;
+    static_assert(!C::A_IS_ZERO, "k256 takes the complete doublings on quad lanes (msm_hom_dbl_quad)");
+    {
+        const auto p1 = F::sqr(msm_sel3<C>(lane, Z, Y, F::add(Y, Z)));                              // delta | gamma | (Y + Z)^2
+        const auto delta = msm_lane_bcast(p1, 0), gamma = msm_lane_bcast(p1, 1), yz = msm_lane_bcast(p1, 2);
+        const auto p2 = F::mul(msm_sel3<C>(lane, X, F::sub(X, delta), gamma), msm_sel3<C>(lane, gamma, F::add(X, delta), gamma));
+        const auto beta = msm_lane_bcast(p2, 0), alpha = msm_lane_bcast(p2, 1), gg = msm_lane_bcast(p2, 2);
+        const auto alpha3 = F::add(F::dbl(alpha), alpha);                                           // 3
+        const auto beta4 = F::dbl(F::dbl(beta));                                                    // 4
+        const auto X3 = F::sqr_sub(alpha3, F::dbl(beta4));                             // 10 -> 1
+        const auto gg8 = F::dbl(F::dbl(F::dbl(gg)));                                                // 8
+        o.x = G::jstore(X3);
+        o.y = G::jstore(F::mul_sub(alpha3, F::sub(beta4, X3), gg8));
+        o.z = G::jstore(F::norm(F::sub(yz, F::add(gamma, delta))));
+    }
+    return o;
 }
 
 // out = sum_w 2^(c w) wins[w]   (Horner).  One wave; lanes 0..2 share the doublings (above), every lane carries the same
