@@ -8,7 +8,8 @@
 //   sum_i k_i P_i = sum_w 2^(c w) * sum_b weight(b) * ( sum_{i : bucket_w(k_i) = b} +-P_i )
 //
 //   prepare     one lane per term: decode + validate scalar and point once, keep the point in packed
-//               internal form, recode k into nwin 16-bit (bucket, sign) digits (msm_digit, ecgpu_recode.h)
+//               internal form, recode k into nwin 16-bit (bucket, sign) digits (MsmDigitStream = msm_digit's digits in window order,
+//               ecgpu_recode.h; k256 up to 2^21 terms: on the two GLV halves, K256Scalar::decompose_signed)
 //   sort        counting sort of (sign, term index) by bucket, per window; every bucket becomes a contiguous run, so
 //               accumulation needs no atomics and no conflict handling.  Below 2^17 entries per window in ONE level, with
 //               the histogram of a whole window (2^(c-1) counters = 128 KiB at c = 16) held in one workgroup's LDS: a
@@ -17,13 +18,15 @@
 //               cursors (scatter).  From 2^17 entries on in TWO levels (k_msm_sort_a / k_msm_sort_b below: partition by the
 //               top bucket bits with LDS-staged coalesced run writes and one packed 32-bit word per entry, then one
 //               workgroup per partition)
-//   accumulate  one lane per `chunk` consecutive sorted entries of a window (ecgpu_msm_chunk.h): complete mixed
-//               additions, a partial sum written at every bucket boundary   <- the hot loop; perfectly balanced
+//   accumulate  one lane per `chunk` consecutive sorted entries of a window (ecgpu_msm_chunk.h): mixed XYZZ additions with an
+//               exactness test per stretch, a partial sum written at every bucket boundary   <- the hot loop; perfectly balanced
 //               for ANY scalar distribution
 //   finish      one lane per (window, bucket): adds the bucket's 1-2 partial sums; a bucket with more than 32 of them
 //               (degenerate inputs) is handed to a whole workgroup
-//   reduce      running-sum trick on segments of buckets, segment sums, window sums
-//   combine     Horner over the windows (c doublings each)
+//   reduce      running-sum trick on segments of buckets, segment sums, window sums (LDS trees; k256: additions on quad lanes)
+//   combine     Horner over the windows (c doublings each) on ONE wave: k256 complete doublings / additions on quad lanes in
+//               homogeneous coordinates (msm_hom_dbl_quad / msm_hom_add_quad), the a = -3 sets Jacobian doublings on three
+//               lanes; the result leaves as an affine wire record
 //
 // Workspace layout (one allocation, offsets in MsmPlan): packed affine points [n][2N] u32,
 // digits [nwin][n] u16 + validity bits [nwin][n/64] u64, tile histograms [nwin][ntiles][NB] u32 (one-level sort) / the level-A
