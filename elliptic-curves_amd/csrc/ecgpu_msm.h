@@ -720,13 +720,15 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
 constexpr uint32_t MSM_BIG_PARTIALS = 32;
 
 // one lane per (window, bucket); big_list[0] = number of deferred buckets, big_list[1..] their ids.
-// One wave per SIMD at most (a few thousand waves in all): the whole register file, so that nothing spills — at three waves
+// Two waves per SIMD for the 256-bit sets (k256: 256 registers, three of them in scratch — left to itself the compiler takes 258
+// and ONE wave per SIMD: 0.137 -> 0.157 / 0.179 ms at 2^21 / 2^24 terms, profiles/r04/msm_tree_quad_lanes.txt), the whole register file
+// for the wider ones.  Never three: at three waves
 // per SIMD 83 registers went to scratch and every lane paid ~100 scratch round trips (0.13 ms for a kernel whose arithmetic
 // is 10 us; profiles/r03/).
 // (A second build of these tail kernels scheduled for instruction-level parallelism, `-amdgpu-sched-strategy=max-ilp`, was
 // measured and dropped: no difference beyond noise, profiles/r03/msm_tail_variants_88130fd.txt.)
 template <class C>
-__global__ void __launch_bounds__(64, 1)
+__global__ void __launch_bounds__(64, C::N <= 8 ? 2 : 1)
 k_msm_bucket_finish(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
                     const uint32_t* __restrict__ sorted, size_t n, size_t nb, int nwin, size_t chunk, size_t nchunks,
