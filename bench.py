@@ -20,6 +20,14 @@ prose that used to be repeated per record is once under "notes": the line stays 
     msm_k256.e2e_ms  (N = 1)             the 2^24-term MSM from HOST memory through ecgpu_msm (PCIe-inclusive; never `value`)
     group_msm_k256   (N > 1, rank 0)     the 2^24-term MSM through the single-process entry ecgpu_group_msm_dev
 
+Every workload rotates over `--sets` (default 4) independently seeded input sets, one per step: the headline's 2^20 x 10 table
+lines (671 MB per set) are not the same lines step after step, and the signature workloads hold 2^20 DISTINCT (z, r, s, Q)
+tuples per set (2^16 nonces, each under 16 different keys and digests).  The check reads the set of the last step.
+`table` (headline record) is the generator table in use: window bits, bytes of device memory, build time; the bench asks for
+the widest table up front (ECGPU_TABLE_EAGER — a long-lived service; the library's default grows the table with use, include/ecgpu.h).
+`fixed_k256_e2e_ms` is the same 2^20-scalar batch through the host-pointer entry ecgpu_batch_mul_base (32 MiB in, 65 MiB out
+over PCIe from page-locked memory; never `value`).
+
 `--only NAME` times a single workload as the top-level record (profiling runs; also var_k256, msm_p256, ecdsa_p256).
 Batch workloads shard embarrassingly (weak scaling, no data-path collective).  The MSM shards its terms (strong
 scaling) and has one exchange step: an RCCL all-gather of each rank's per-window partial sums, after which the window
@@ -146,6 +154,37 @@ def device_dot_mod(torch, d_k, d_s, mod):
             for b in range(L):
                 total += int(m[a, b]) << (wa + 8 * (L - 1 - b))
     return total % mod
+
+
+def _sign_slice(job):
+    """Worker (spawned process): s_i = k_j^-1 (z_i + r_j d_i) mod n for one slice of tuples, j = i mod m -> (s bytes, recovery ids)."""
+    db, zb, rs, kinvs, odds, xhi, L, order, low_s, lo = job
+    m = len(rs)
+    half = order // 2
+    out_s, out_id = bytearray(), bytearray()
+    frm = int.from_bytes
+    for i in range(len(db) // L):
+        j = (lo + i) % m
+        si = kinvs[j] * (frm(zb[i * L:(i + 1) * L], "big") + rs[j] * frm(db[i * L:(i + 1) * L], "big")) % order
+        odd = odds[j]
+        if low_s and si > half:                              # low-S form (k256 NORMALIZE_S): (r, -s) belongs to -R
+            si, odd = order - si, odd ^ 1
+        out_s += si.to_bytes(L, "big")
+        out_id.append(odd | (2 if xhi[j] else 0))
+    return bytes(out_s), bytes(out_id)
+
+
+_SIGN_POOL = None
+
+
+def sign_pool():
+    """A pool of spawned (not forked: the parent holds a HIP context) worker processes for the host side of the signature inputs."""
+    global _SIGN_POOL
+    if _SIGN_POOL is None:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        _SIGN_POOL = ProcessPoolExecutor(max_workers=max(1, min(16, host_cores())), mp_context=mp.get_context("spawn"))
+    return _SIGN_POOL
 
 
 def host_cores():
@@ -280,6 +319,7 @@ def group_msm_child_main(args):
     b.ecgpu = importlib.import_module("elliptic-curves_amd")
     b.eng = b.ecgpu.Engine(0)
     b.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    b.eng.set_table_policy(b.ecgpu.TABLE_EAGER)
     try:
         return b.group_msm()
     finally:
@@ -320,6 +360,9 @@ class Bench:
             self.exchange_kind, self.exchange_reason, self.group = ex.kind, ex.reason, ex.group
         self.eng = self.ecgpu.Engine(local_rank)
         self.eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        # steady-state throughput is what is measured: the widest generator table from the first call on (a long-lived service;
+        # the library's default would grow the table with use, and the record says what the table costs: `table`)
+        self.eng.set_table_policy(self.ecgpu.TABLE_EAGER)
         self.peak = None
 
     def fence(self):
@@ -335,6 +378,51 @@ class Bench:
         if self.peak is None:
             self.peak = self.eng.valu_probe(0)               # v_mad_u64_u32 lane-operations / s on this GPU
         return self.peak
+
+    def make_inputs(self, name, kind, cid, L, n, seed):
+        """One input set of a workload, on the device: {"scal", "pts", "s2", "r", "s", "recid"} (None where the kind has none)."""
+        torch, eng, ecgpu, device = self.torch, self.eng, self.ecgpu, self.device
+        inp = dict(scal=device_random_scalars(torch, n, L, seed, device), pts=None, s2=None, r=None, s=None, recid=None)
+        if kind in ("var", "msm"):
+            inp["s2"] = device_random_scalars(torch, n, L, seed + 50, device)
+            inp["pts"] = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
+            torch.cuda.synchronize()
+            eng.mul_by_generator_dev(cid, inp["s2"], n, inp["pts"], None)          # P_i = s_i * G (untimed setup)
+        if kind in ("ecdsa", "recover"):
+            # n DISTINCT valid signatures: tuple i is nonce k_(i mod m) (m = 2^16 nonce points R = k G computed here, their
+            # inverses on the host) under a key d_i and a digest z_i of its own — Q_i = d_i G computed here,
+            # s_i = k^-1 (z_i + r d_i) mod n on the host cores (worker processes).  What the verifier multiplies by — z/s, r/s,
+            # Q — differs in every tuple; only r repeats.
+            m = min(n, 1 << 16)
+            d_d = device_random_scalars(torch, n, L, seed + 50, device)
+            d_k = device_random_scalars(torch, m, L, seed + 51, device)
+            d_Q = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
+            d_R = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
+            torch.cuda.synchronize()
+            eng.mul_by_generator_dev(cid, d_d, n, d_Q, None)
+            eng.mul_by_generator_dev(cid, d_k, m, d_R, None)
+            torch.cuda.synchronize()
+            order = ecgpu.GROUP_ORDERS[cid]
+            kh, rx, ry = d_k.cpu().numpy(), d_R[:, :L].contiguous().cpu().numpy(), d_R[:, 2 * L - 1].cpu().numpy()
+            rs, kinvs, odds, xhi = [], [], [], []
+            for j in range(m):
+                kj, xj = int.from_bytes(kh[j].tobytes(), "big") or 1, int.from_bytes(rx[j].tobytes(), "big")
+                rs.append(xj % order); kinvs.append(pow(kj, -1, order)); odds.append(int(ry[j]) & 1); xhi.append(xj >= order)
+            db, zb = d_d.cpu().numpy().tobytes(), inp["scal"].cpu().numpy().tobytes()
+            pool = sign_pool()
+            nw = pool._max_workers
+            per = (n + nw - 1) // nw
+            jobs = [(db[lo * L:(lo + per) * L], zb[lo * L:(lo + per) * L], rs, kinvs, odds, xhi, L, order, kind == "recover", lo)
+                    for lo in range(0, n, per)]
+            res = list(pool.map(_sign_slice, jobs))
+            sb, ib = b"".join(r[0] for r in res), b"".join(r[1] for r in res)
+            rb = b"".join(rs[i % m].to_bytes(L, "big") for i in range(m))
+            reps = (n + m - 1) // m
+            inp["r"] = torch.frombuffer(bytearray(rb), dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
+            inp["s"] = torch.frombuffer(bytearray(sb), dtype=torch.uint8).reshape(n, L).to(device)
+            inp["recid"] = torch.frombuffer(bytearray(ib), dtype=torch.uint8).to(device)
+            inp["pts"] = d_Q
+        return inp
 
     def run(self, name, cpu_leg):
         """Times workload `name`: W warm-up steps, then exactly K steps between fences; returns its record (rank 0) or None."""
@@ -354,48 +442,11 @@ class Bench:
             if args.window and kind == "fixed":
                 eng.set_base_window(cid, args.window)
 
-        # ---- synthetic inputs, resident in HBM before the timed region ----
-        seed = 0xEC000000 + SEEDS[name] + 1000 * rank
-        d_scal = device_random_scalars(torch, n, L, seed, device)
-        d_pts = d_s2 = None
-        if kind in ("var", "msm"):
-            d_s2 = device_random_scalars(torch, n, L, seed + 50, device)
-            d_pts = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
-            torch.cuda.synchronize()
-            eng.mul_by_generator_dev(cid, d_s2, n, d_pts, None)          # P_i = s_i * G (untimed setup)
-        d_r = d_s = d_ok = d_recid = None
-        if kind in ("ecdsa", "recover"):
-            # valid signatures: 2^16 distinct (d, k, z) triples signed on the host from k*G computed here, tiled to n
-            m = min(n, 1 << 16)
-            d_d = device_random_scalars(torch, m, L, seed + 50, device)
-            d_k = device_random_scalars(torch, m, L, seed + 51, device)
-            d_Q = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
-            d_R = torch.empty((m, 2 * L), dtype=torch.uint8, device=device)
-            torch.cuda.synchronize()
-            eng.mul_by_generator_dev(cid, d_d, m, d_Q, None)
-            eng.mul_by_generator_dev(cid, d_k, m, d_R, None)
-            torch.cuda.synchronize()
-            n_order = ecgpu.GROUP_ORDERS[cid]
-            dh, kh, zh, rx = (t.cpu().numpy() for t in (d_d, d_k, d_scal[:m], d_R[:, :L].contiguous()))
-            rb, sb, ib = bytearray(), bytearray(), bytearray()
-            ry = d_R[:, 2 * L - 1].cpu().numpy()
-            for i in range(m):
-                di, ki = int.from_bytes(dh[i].tobytes(), "big"), int.from_bytes(kh[i].tobytes(), "big") or 1
-                zi, xi = int.from_bytes(zh[i].tobytes(), "big"), int.from_bytes(rx[i].tobytes(), "big")
-                ri = xi % n_order
-                si = pow(ki, -1, n_order) * (zi + ri * di) % n_order
-                odd = int(ry[i]) & 1
-                if kind == "recover" and si > n_order // 2:               # low-S form (k256 NORMALIZE_S): (r, -s) belongs to -R
-                    si, odd = n_order - si, odd ^ 1
-                rb += ri.to_bytes(L, "big"); sb += si.to_bytes(L, "big"); ib.append(odd | (2 if xi >= n_order else 0))
-            reps = (n + m - 1) // m
-            d_r = torch.frombuffer(rb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
-            d_s = torch.frombuffer(sb, dtype=torch.uint8).reshape(m, L).to(device).repeat(reps, 1)[:n].contiguous()
-            d_scal = d_scal[:m].repeat(reps, 1)[:n].contiguous()
-            d_pts = d_Q.repeat(reps, 1)[:n].contiguous()
-            d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device)
-            d_recid = torch.frombuffer(ib, dtype=torch.uint8).to(device).repeat(reps)[:n].contiguous()
-            del d_d, d_k, d_R, d_Q
+        # ---- synthetic inputs, resident in HBM before the timed region: `nsets` independently seeded sets, one per step in turn ----
+        nsets = max(1, args.sets)
+        sets = [self.make_inputs(name, kind, cid, L, n, 0xEC000000 + SEEDS[name] + 1000 * rank + 7919 * j) for j in range(nsets)]
+        d_scal = d_pts = d_s2 = d_r = d_s = d_recid = None      # (bound to the set of the last step before the check)
+        d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device) if kind in ("ecdsa", "recover") else None
         n_out = 1 if kind == "msm" else n
         d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
         d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
@@ -418,30 +469,37 @@ class Bench:
 
         def read_events():
             main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
-            for st in ("sort", "accumulate", "reduce", "normalize", "main", "total"):
+            for st in ("sort", "accumulate", "reduce", "normalize", "main", "total", "prepare", "finish", "tree", "combine"):
                 v = eng.last_timing(st)
                 if v is not None:
                     stages.setdefault(st, []).append(v)
 
+        written = {}                                   # id of an output buffer -> the input set of the last step that wrote it
+
         def step():
+            j = nstep[0] % nsets
+            nstep[0] += 1
+            inp = sets[j]
+            k_, p_ = inp["scal"], inp["pts"]
+            buf = nstep[0] % lanes if lanes > 1 else 0
+            written[buf] = j
             if kind == "fixed":
-                eng.mul_by_generator_dev(cid, d_scal, n, d_out, d_inf)
+                eng.mul_by_generator_dev(cid, k_, n, d_out, d_inf)
             elif kind == "var":
-                eng.mul_dev(cid, d_scal, d_pts, None, n, d_out, d_inf, constant_time=bool(wl.get("ct")))
+                eng.mul_dev(cid, k_, p_, None, n, d_out, d_inf, constant_time=bool(wl.get("ct")))
             elif kind == "ecdsa":
-                eng.ecdsa_verify_dev(cid, d_scal, d_r, d_s, d_pts, n, False, d_ok)
+                eng.ecdsa_verify_dev(cid, k_, inp["r"], inp["s"], p_, n, False, d_ok)
             elif kind == "recover":
-                eng.ecdsa_recover_dev(cid, d_scal, d_r, d_s, d_recid, n, True, d_out, d_ok)
+                eng.ecdsa_recover_dev(cid, k_, inp["r"], inp["s"], inp["recid"], n, True, d_out, d_ok)
             elif exchange is None:
-                nstep[0] += 1
                 if lanes > 1:                              # several MSMs in flight: each writes buffers of its own
-                    eng.lincomb_dev(cid, d_scal, d_pts, None, n, *lane_out[nstep[0] % lanes])
+                    eng.lincomb_dev(cid, k_, p_, None, n, *lane_out[buf])
                 else:
-                    eng.lincomb_dev(cid, d_scal, d_pts, None, n, d_out, d_inf)
+                    eng.lincomb_dev(cid, k_, p_, None, n, d_out, d_inf)
             else:
                 # sharded MSM: local pipeline down to the per-window partial sums, ONE exchange step (RCCL all-gather of
                 # the parts over xGMI), window sums over all ranks + the Horner chain on every rank
-                eng.msm_parts_dev(cid, d_scal, d_pts, None, n, plan_terms, exchange.mine)
+                eng.msm_parts_dev(cid, k_, p_, None, n, plan_terms, exchange.mine)
             if not queued:
                 read_events()
             if exchange is not None:
@@ -457,7 +515,6 @@ class Bench:
             for _ in range(lanes):                       # the lanes' streams and workspaces exist before the clock starts
                 step()
             eng.synchronize()
-            nstep[0] = 0
         self.fence()
         # queued batches: the per-call timing events (three packets of their own per batch on the stream) are recorded for the
         # LAST timed step only — that step's kernel durations are what roofline.kernel_ms reads; the steps before it put
@@ -492,6 +549,8 @@ class Bench:
 
         units_per_step = n_total if kind == "msm" else n * world
         value = units_per_step * args.steps / elapsed
+        last = sets[written[0]]                        # the inputs of the step whose output d_out / d_ok hold now
+        d_scal, d_pts, d_s2, d_r, d_s, d_recid = (last[k] for k in ("scal", "pts", "s2", "r", "s", "recid"))
 
         # ---- parity check of the last timed step (every rank takes part in the MSM's collective sum) ----
         ok = None
@@ -605,6 +664,10 @@ class Bench:
             "stage_ms": {k: float(np.mean(v)) for k, v in stages.items()},
             "check_vs_oracle": ok,
         }
+        rec["config"]["input_sets"] = nsets
+        if kind in ("fixed", "ecdsa", "recover"):
+            ti = eng.base_table_info(cid)               # the generator table these steps read (built before the timed region)
+            rec["table"] = {"window_bits": ti["window_bits"], "bytes": ti["bytes"], "build_ms": round(ti["build_ms"], 2), "policy": "eager"}
         if cpu_leg:
             ns = min(n, 1 << 17 if kind in ("fixed", "msm") else 1 << 14)
             s_host = d_scal[:ns].cpu().numpy().reshape(-1)
@@ -655,6 +718,39 @@ class Bench:
             eng.host_free(h_p)
         return {"e2e_ms": best * 1e3, "e2e_value": n / best, "e2e_check": ok,
                 "e2e_bytes_h2d": n * 3 * L}
+
+    def e2e_fixed(self, name="fixed_k256"):
+        """SURVEY.md 8d, config 2 with the boundary's host buffers: the same 2^20-scalar batch through the host-pointer entry
+        ecgpu_batch_mul_base — 32 MiB of scalars up, 64 MiB of points + 1 MiB of flags down, page-locked memory, the library's
+        chunked upload / compute / download pipeline.  One warm-up call, then the best of two; never `value`."""
+        torch, eng, ecgpu = self.torch, self.eng, self.ecgpu
+        wl = WORKLOADS[name]
+        cid = ecgpu.CURVE_IDS[wl["curve"]]
+        L = ecgpu.FIELD_BYTES[cid]
+        n = self.args.n or wl["n"]
+        d_scal = device_random_scalars(torch, n, L, 0xEC000000 + SEEDS[name] + 31, self.device)
+        h_s, h_o, h_i = eng.host_alloc(n * L), eng.host_alloc(n * 2 * L), eng.host_alloc(n)
+        try:
+            torch.from_numpy(h_s).copy_(d_scal.view(-1))
+            torch.cuda.synchronize()
+            best = None
+            for it in range(3):
+                t0 = time.perf_counter()
+                eng.mul_by_generator(cid, h_s, out=h_o, inf=h_i)
+                dt = time.perf_counter() - t0
+                if it and (best is None or dt < best):
+                    best = dt
+            ok = None
+            if not self.args.no_check:
+                import oracle_lib
+                oracle_lib.build()
+                idx = np.arange(0, n, max(1, n // 256))[:256]
+                w, wf = oracle_lib.batch_mul_base(cid, h_s.reshape(n, L)[idx].reshape(-1).copy())
+                ok = bytes(w) == bytes(h_o.reshape(n, 2 * L)[idx].reshape(-1)) and bytes(wf) == bytes(h_i[idx])
+        finally:
+            for h in (h_s, h_o, h_i):
+                eng.host_free(h)
+        return {"e2e_ms": best * 1e3, "e2e_value": n / best, "e2e_check": ok, "e2e_bytes": n * (3 * L + 1)}
 
     def group_msm(self, name="msm_k256"):
         """N > 1 only, rank 0 only (the other ranks wait at the barrier that follows): the SAME 2^24-term problem through the
@@ -741,7 +837,7 @@ def compact(r):
     out = {"metric": r["metric"], "value": g(r["value"], 5), "unit": r["unit"], "ms_per_step": g(r["ms_per_step"], 5),
            "units": r["config"]["units_total"], "scaling": r["scaling"],
            "kernel": rf.get("kernel"), "kernel_ms": g(rf.get("kernel_ms")), "kmin": g(rf.get("kernel_ms_min")), "frac": g(rf.get("frac")),
-           "wfrac": g(rf.get("workload_frac_8d")), "cyc": g(rf.get("frac_cycles_pmc")),
+           "wfrac": g(rf.get("workload_frac_8d")), "cyc": g(rf.get("frac_cycles_pmc")), "clk": g(rf.get("clock_ghz_kernel"), 3),
            "mad_frac": g(rf.get("mad_frac")), "algo_x": g(rf.get("algorithmic_speedup")), "traffic": g(rf.get("traffic")),
            "stage_ms": {k: g(v, 3) for k, v in r.get("stage_ms", {}).items() if k not in ("main", "total")},
            "check": r.get("check_vs_oracle")}
@@ -777,6 +873,7 @@ def main():
                     help="time this workload alone as the top-level record (default: fixed_k256 + the other GPU configs as sub-records)")
     ap.add_argument("--n", type=int, default=0, help="override units per GPU (msm: total terms); implies a single workload")
     ap.add_argument("--window", type=int, default=0, help="fixed-base / Pippenger window bits override")
+    ap.add_argument("--sets", type=int, default=4, help="independently seeded input sets per workload, one per step in turn (default 4)")
     ap.add_argument("--check", action="store_true", help="(default) verify the last step of every workload against the oracle")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--sync-calls", action="store_true", help="fixed / variable base: one synchronous call per step instead of the queued calls")
@@ -811,10 +908,11 @@ def main():
             r = b.run(name, False)
             if r is not None:
                 lanes[name] = r
-    e2e = group = None
+    e2e = e2e_fx = group = None
     if not single and not args.no_extras:
         if b.world == 1:
             e2e = b.e2e_msm()
+            e2e_fx = b.e2e_fixed()
         else:
             if b.rank == 0:
                 # in a child process with a deadline: the library's own RCCL communicator (ncclCommInitAll over all GPUs from
@@ -844,6 +942,9 @@ def main():
                 rec[name + "_frac"] = r["roofline"]["frac"]                       # the dominant kernel's executed work / roof
                 rec[name + "_workload_frac"] = r["roofline"]["workload_frac_8d"]  # SURVEY 8d's numerator over the WHOLE step
                 rec[name + "_check"] = r["check_vs_oracle"]
+        if e2e_fx:
+            rec["fixed_k256_e2e_ms"] = e2e_fx["e2e_ms"]
+            rec["fixed_k256_e2e_check"] = e2e_fx["e2e_check"]
         if "msm_k256" in full and e2e:
             full["msm_k256"].update(e2e)
             rec["msm_k256_e2e_ms"] = e2e["e2e_ms"]
@@ -870,6 +971,8 @@ def main():
         if len(line) > 8000:
             print("bench.py: the record is %d bytes (> 8000)" % len(line), file=sys.stderr)
     b.close()
+    if _SIGN_POOL is not None:
+        _SIGN_POOL.shutdown()
     return rec
 
 

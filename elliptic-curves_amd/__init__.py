@@ -61,7 +61,9 @@ ABI_SYMBOLS = [
     "ecgpu_batch_ecdh_ct", "ecgpu_batch_ecdh_ct_dev",
     "ecgpu_lincomb_ct", "ecgpu_lincomb_ct_dev", "ecgpu_msm_compressed", "ecgpu_msm_compressed_dev",
     "ecgpu_batch_mul_compressed", "ecgpu_batch_mul_compressed_dev", "ecgpu_wipe", "ecgpu_group_exchange_reason",
+    "ecgpu_set_table_policy", "ecgpu_set_table_budget", "ecgpu_base_table_info", "ecgpu_group_set_exchange_timeout",
 ]
+TABLE_ADAPTIVE, TABLE_EAGER = 0, 1
 
 
 GROUP_ORDERS = {   # k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73
@@ -95,7 +97,16 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("ECGPU_TOOL_LIB") or LIB_PATH      # (ECGPU_TOOL_LIB: another build of the same library, for A/B measurement tools)
+    path = LIB_PATH
+    alt = os.environ.get("ECGPU_TOOL_LIB")
+    if alt:
+        # another build of the same library for the A/B recipes of tools/gpu_run.sh — honoured only for files that
+        # tools/build_alt_lib.sh put beside the product (lib/libecgpu_<suffix>.so): the variable selects among this tree's own
+        # builds, it cannot point the loader anywhere else
+        alt = os.path.realpath(alt)
+        if os.path.dirname(alt) != os.path.realpath(os.path.dirname(LIB_PATH)) or not os.path.basename(alt).startswith("libecgpu_"):
+            raise EcgpuError(ERR_ARG, "ECGPU_TOOL_LIB must name a lib/libecgpu_<suffix>.so of this tree")
+        path = alt
     if not os.path.exists(path):
         raise EcgpuError(ERR_NO_DEVICE, "HIP extension %s is missing; run __graft_entry__.build()" % path)
     lib = ctypes.CDLL(path)
@@ -262,7 +273,21 @@ class Engine:
         return out
 
     def set_base_window(self, curve, bits):
+        """Pins the comb width of `curve` (4..26); 0 returns it to the table policy."""
         self._chk(self._lib.ecgpu_set_base_window(self._ctx, curve, bits))
+
+    def set_table_policy(self, policy):
+        """TABLE_ADAPTIVE (default: the generator table grows with the work the device has seen) or TABLE_EAGER (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_set_table_policy(self._ctx, int(policy)))
+
+    def set_table_budget(self, max_table_bytes):
+        self._chk(self._lib.ecgpu_set_table_budget(self._ctx, ctypes.c_size_t(int(max_table_bytes))))
+
+    def base_table_info(self, curve):
+        """-> {"window_bits", "bytes", "build_ms"} of the comb table `curve` uses on this context now (window_bits 0: none yet)."""
+        w, b, ms = ctypes.c_int(0), ctypes.c_size_t(0), ctypes.c_double(0)
+        self._chk(self._lib.ecgpu_base_table_info(self._ctx, curve, ctypes.byref(w), ctypes.byref(b), ctypes.byref(ms)))
+        return {"window_bits": w.value, "bytes": b.value, "build_ms": ms.value}
 
     def set_msm_window(self, bits):
         self._chk(self._lib.ecgpu_set_msm_window(self._ctx, bits))
@@ -656,8 +681,15 @@ class Group:
             self._g = None
             raise EcgpuError(rc, "ecgpu_group_init failed")
         self.size = int(self._lib.ecgpu_group_size(self._g))
-        self.exchange = self._lib.ecgpu_group_exchange(self._g).decode()
-        self.exchange_reason = self._lib.ecgpu_group_exchange_reason(self._g).decode()
+
+    @property
+    def exchange(self):
+        """"rccl" or "peer" — as of now: a collective that failed or missed its deadline moves the group to peer copies."""
+        return self._lib.ecgpu_group_exchange(self._g).decode()
+
+    @property
+    def exchange_reason(self):
+        return self._lib.ecgpu_group_exchange_reason(self._g).decode()
 
     def close(self):
         if getattr(self, "_g", None):
@@ -673,6 +705,10 @@ class Group:
     def _chk(self, rc):
         if rc != OK:
             raise EcgpuError(rc, (self._lib.ecgpu_group_last_error(self._g) or b"").decode())
+
+    def set_exchange_timeout(self, seconds):
+        """The MSM's exchange step gives a collective up after this long and completes over peer copies (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_group_set_exchange_timeout(self._g, ctypes.c_double(float(seconds))))
 
     def set_msm_window(self, bits):
         self._chk(self._lib.ecgpu_group_set_msm_window(self._g, int(bits)))

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <set>
 #include <mutex>
@@ -30,6 +31,7 @@ enum : int { ST_BAD_SCALAR = 1, ST_BAD_POINT = 2 };
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    size_t dirty = 0;         // bytes from the start that calls have asked for since the buffer was last wiped (wipe_scratch zeroes these, not cap)
 };
 
 // A context's view of a basepoint comb table.  The table itself is owned by the per-device registry below and shared by
@@ -44,13 +46,22 @@ struct Table {
 struct SharedTable {
     uint32_t* d = nullptr;
     int nwin = 0, refs = 0;
+    size_t bytes = 0;         // device memory of the table
+    double build_ms = 0;      // host wall time of its construction (allocation, kernels, the wait for them)
 };
 struct TableRegistry {
     std::mutex mu;                                               // held while a table is built: a second context of the device waits
     std::map<std::tuple<int, int, int>, SharedTable> tabs;       // (device, curve id, comb width)
-    std::set<std::tuple<int, int, int>> nofit;                   // widths whose allocation was refused: later contexts go straight to
-                                                                 // the width that worked (forgotten when a table of the device is freed)
+    // widths whose allocation was refused -> calls left before the width is tried again: later contexts go straight to the
+    // width that worked, but a refusal is not for ever (the memory may have been another process's or torch's cache);
+    // forgotten at once when a table of the device is freed or enough memory shows as free
+    std::map<std::tuple<int, int, int>, int> nofit;
+    uint64_t seen[12] = {};                                      // generator multiplications asked of this device so far, per curve
 };
+constexpr int NOFIT_RETRY_CALLS = 64;
+// adaptive policy: generator multiplications (log2) after which a device moves from the 16-bit table to the 22-bit one and from
+// there to the context's widest (table_tier below)
+constexpr int TABLE_TIER1_LOG2 = 26, TABLE_TIER2_LOG2 = 29;
 // test-only fault injection (tests/test_gpu_multidevice.py through the exported ecgpu_testhook_table_max_mb; no environment
 // variable: the production path cannot be steered from outside the process): comb tables above this many MiB are refused
 std::atomic<size_t> g_test_table_max_mb{0};
@@ -74,13 +85,20 @@ struct ecgpu_ctx {
     // sized for 288 GB, not for a cache.  k256: W = 26, 10 windows = 9 additions per scalar, 21.5 GB, built in 65 ms;
     // p256 and sm2: W = 24, 11 windows, 5.9 GB; p384: W = 20, 1.0 GB.  ecgpu_set_base_window trades memory for speed.
     int want_w[12] = {26, 24, 20, 24, 24, 24, 20, 24, 20, 24, 20, 24};
+    // Footprint policy (ecgpu_set_table_policy / ecgpu_set_table_budget / ecgpu_set_base_window): want_w is the WIDEST table a
+    // context will use; unless the width is pinned or the policy is eager, the table grows with the number of generator
+    // multiplications the device has been asked for (table_tier) — the reference builds its 30-60 KB tables lazily and prices
+    // a table half the size at 3 % (k256/src/arithmetic/mul.rs:191-192, primeorder/src/tables/basepoint.rs:29-76)
+    bool w_pinned[12] = {};
+    int table_policy = 0;        // ECGPU_TABLE_ADAPTIVE
+    size_t table_budget = 0;     // bytes one comb table may take; 0 = no limit
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r, ec_e, ec_s, ec_id;   // signature verification scratch
     DevBuf ct_flags;             // one verdict byte per element of a uniform-schedule batch
     DevBuf cx_xy, cx_inf;        // x || y + flag records decoded from compressed input (ecgpu_msm_compressed, ecgpu_batch_mul_compressed)
     bool keep_status = false;    // the status word already holds the verdicts of a first stage of the call: do not clear it
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[9] = {};       // 0..2 call spans, 3..4 the MSM's sort / accumulate marks, 5 spare, 6..8 MsmPlan::detail
     std::map<std::string, double> timing;
     std::vector<std::pair<std::string, std::pair<int, int>>> spans;   // event pairs of the last call not yet turned into `timing`
     // asynchronous mode (ecgpu_set_async): device-pointer calls return once their work is queued; the status word
@@ -115,6 +133,7 @@ namespace {
     } while (0)
 
 int ensure(ecgpu_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes > b.dirty) b.dirty = bytes;
     if (bytes <= b.cap) return ECGPU_OK;
     if (b.p) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -130,6 +149,7 @@ int ensure(ecgpu_ctx* ctx, DevBuf& b, size_t bytes) {
 
 // the same for a buffer that is used on another stream of the context (an MSM lane)
 int ensure_on(ecgpu_ctx* ctx, hipStream_t stream, DevBuf& b, size_t bytes) {
+    if (bytes > b.dirty) b.dirty = bytes;
     if (bytes <= b.cap) return ECGPU_OK;
     if (b.p) {
         HIP_TRY(ctx, hipStreamSynchronize(stream));
@@ -242,8 +262,13 @@ struct SyncScope {
 enum : int { WIPE_SCRATCH = 1, WIPE_EC = 2, WIPE_STAGING = 4 };
 void wipe_scratch(ecgpu_ctx* ctx, int what) {
     auto clear = [&](std::initializer_list<DevBuf*> bufs) {
-        for (DevBuf* b : bufs)
-            if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, ctx->stream);
+        // what has been asked of a buffer since its last wipe, not its capacity: after one 2^20-term batch the scratch holds
+        // ~170 MB, and zeroing all of it behind every later 1,024-scalar `_ct` call (or every chunk of a pipelined one) cost tens
+        // of microseconds per call
+        for (DevBuf* b : bufs) {
+            if (b->p && b->dirty) (void)hipMemsetAsync(b->p, 0, b->dirty < b->cap ? b->dirty : b->cap, ctx->stream);
+            b->dirty = 0;
+        }
     };
     if (what & WIPE_SCRATCH) clear({&ctx->proj, &ctx->prefix});
     if (what & WIPE_EC) clear({&ctx->ec_xy, &ctx->ec_inf});
@@ -269,6 +294,8 @@ void resolve_timing(ecgpu_ctx* ctx) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ctx->ev[s.second.first], ctx->ev[s.second.second]) == hipSuccess)
             ctx->timing[s.first] = ms;
+        else
+            (void)hipGetLastError();         // a mark the call never recorded (an MSM of no terms): no span, and no error left behind
     }
     ctx->spans.clear();
 }
@@ -321,6 +348,7 @@ int build_table(ecgpu_ctx* ctx, int w, SharedTable* out) {
     if ((rc = ensure(ctx, ctx->proj, slab * half * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->prefix, slab * half * NS * 4)) != ECGPU_OK) return rc;
     uint32_t* d = nullptr;
+    const auto t_build0 = std::chrono::steady_clock::now();
     if (const size_t cap_mb = g_test_table_max_mb.load()) {     // fault injection for the fallback path (ecgpu_testhook_table_max_mb)
         if (entries * 2 * N * 4 > cap_mb << 20) {
             ctx->err = "basepoint table: allocation refused by the test hook";
@@ -344,6 +372,8 @@ int build_table(ecgpu_ctx* ctx, int w, SharedTable* out) {
     }
     out->d = d;
     out->nwin = nwin;
+    out->bytes = entries * 2 * N * 4;
+    out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
     return ECGPU_OK;
 }
 
@@ -360,25 +390,67 @@ int drop_build_scratch(ecgpu_ctx* ctx) {
     return ECGPU_OK;
 }
 
-// Makes ctx->table[C::ID] point at the device's shared comb table of the width the context asks for (ecgpu_set_base_window;
-// defaults in ecgpu_ctx::want_w), building it if no context of this process has yet.  When the table does not fit — the
-// k256 default is 21.5 GB — the width is lowered two bits at a time (a quarter of the memory, one or two more additions
-// per scalar; results do not depend on it) down to 16 bits (36 MB) before ECGPU_ERR_OOM is returned.
+// bytes of the comb table of width w for curve C
 template <class C>
-int ensure_table(ecgpu_ctx* ctx) {
+size_t comb_table_bytes(int w) {
+    return ((size_t)1 << (w - 1)) * (size_t)signed_window_count(32 * C::N - 1, w) * 2 * C::N * 4;
+}
+
+// The width the adaptive policy gives a device that has been asked for `seen` generator multiplications of a curve so far (the
+// call being served included), capped by `wmax`.  Every step up is taken where the time the narrower table has cost so far equals
+// the time the next table takes to build (a rent-or-buy rule: never more than twice the time of the best fixed choice, whatever
+// the caller goes on to do) — measured on MI355X for k256, profiles/r05/table_tiers.txt: 16 bits = 34 MB built in 1 ms, 9
+// windows more per scalar than at 26; 22 bits = 1.6 GB in 5 ms; 26 bits = 21.5 GB in 65 ms.
+inline int table_tier(uint64_t seen, int wmax) {
+    int w = seen < ((uint64_t)1 << TABLE_TIER1_LOG2) ? 16 : seen < ((uint64_t)1 << TABLE_TIER2_LOG2) ? 22 : wmax;
+    return w < wmax ? w : wmax;
+}
+
+// Makes ctx->table[C::ID] point at the device's shared comb table for a call with n scalars: the width is the context's pinned
+// width (ecgpu_set_base_window), the widest allowed one (eager policy) or the tier the device's history asks for (adaptive, the
+// default), never above the budget (ecgpu_set_table_budget) — and a wider table another context of the device has already built
+// is taken as it is.  The table is built if no context of this process has yet.  When it does not fit — the k256 maximum is
+// 21.5 GB — the width is lowered two bits at a time (a quarter of the memory, one or two more additions per scalar; results
+// do not depend on it) down to 16 bits (36 MB) before ECGPU_ERR_OOM is returned.
+template <class C>
+int ensure_table(ecgpu_ctx* ctx, size_t n = 0) {
     Table& t = ctx->table[C::ID];
-    const int want = ctx->want_w[C::ID];
+    TableRegistry& reg = table_registry(ctx->device);
+    std::unique_lock<std::mutex> lock(reg.mu);
+    const int wmax = ctx->want_w[C::ID];
+    uint64_t& seen = reg.seen[C::ID];
+    seen = seen + n < seen ? ~(uint64_t)0 : seen + n;
+    int want = wmax;
+    if (!ctx->w_pinned[C::ID]) {
+        if (ctx->table_policy == ECGPU_TABLE_ADAPTIVE) want = table_tier(seen, wmax);
+        if (ctx->table_budget)
+            while (want > 4 && comb_table_bytes<C>(want) > ctx->table_budget) want--;
+        for (int w = wmax; w > want; w--) {                      // somebody has paid for a wider one already
+            auto it = reg.tabs.find(std::make_tuple(ctx->device, (int)C::ID, w));
+            if (it != reg.tabs.end() && it->second.d && (!ctx->table_budget || it->second.bytes <= ctx->table_budget)) {
+                want = w;
+                break;
+            }
+        }
+    }
     if (t.d && t.asked == want) return ECGPU_OK;
     if (t.d) {
+        lock.unlock();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // queued kernels may still read the old table
         release_table(ctx, C::ID);
+        lock.lock();
     }
-    TableRegistry& reg = table_registry(ctx->device);
-    std::lock_guard<std::mutex> lock(reg.mu);
     int rc = ECGPU_ERR_OOM;
     for (int w = want;; w -= 2) {
         const auto key = std::make_tuple(ctx->device, (int)C::ID, w);
-        if (w - 2 >= 16 && reg.nofit.count(key)) continue;       // an earlier context of the device was refused this width
+        auto nf = reg.nofit.find(key);
+        if (nf != reg.nofit.end() && w - 2 >= 16) {              // an earlier context of the device was refused this width
+            size_t free_b = 0, total_b = 0;
+            const bool roomy = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > comb_table_bytes<C>(w) + ((size_t)3 << 30) &&
+                               !g_test_table_max_mb.load();
+            if (!roomy && --nf->second > 0) continue;
+            reg.nofit.erase(nf);                                 // memory is back, or the refusal is NOFIT_RETRY_CALLS calls old: try again
+        }
         SharedTable& st = reg.tabs[key];
         if (!st.d) {
             rc = build_table<C>(ctx, w, &st);
@@ -386,7 +458,7 @@ int ensure_table(ecgpu_ctx* ctx) {
                 reg.tabs.erase(key);
                 (void)hipGetLastError();                         // an out-of-memory error is not sticky
                 int rc2 = drop_build_scratch(ctx);
-                if (rc == ECGPU_ERR_OOM) reg.nofit.insert(key);
+                if (rc == ECGPU_ERR_OOM) reg.nofit[key] = NOFIT_RETRY_CALLS;
                 if (rc == ECGPU_ERR_OOM && rc2 == ECGPU_OK && w - 2 >= 16) continue;
                 if (rc == ECGPU_ERR_OOM) ctx->err = "basepoint comb table does not fit in device memory (even at 16-bit windows)";
                 return rc;
@@ -477,7 +549,7 @@ int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy
     constexpr int N = C::N, NS = Field<C>::NS;
     (void)N;
     int rc;
-    if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+    if ((rc = ensure_table<C>(ctx, n)) != ECGPU_OK) return rc;
     if (n == 0) return ECGPU_OK;
     if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
@@ -634,9 +706,9 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
         record(ctx, 0);
         launch_var_base<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
                            (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, ctx->d_status);
-        (void)hipEventRecord(ctx->ev[3], ctx->stream);
+        record(ctx, 3);
         launch_proj_sum<C>(ctx->stream, (uint32_t*)ctx->proj.p, n, (uint32_t*)ctx->prefix.p);
-        (void)hipEventRecord(ctx->ev[4], ctx->stream);
+        record(ctx, 4);
         record(ctx, 1);
         if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
         record(ctx, 2);
@@ -677,14 +749,24 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
+    const bool detail = ctx->timing_on && ctx->ev[6];
+    if (detail)
+        for (int i = 0; i < 3; i++) plan.detail[i] = ctx->ev[6 + i];
     record(ctx, 0);
     launch_msm<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
-                  ctx->msm_ws.p, (uint32_t*)ctx->proj.p, ctx->d_status, ctx->ev[3], ctx->ev[4], (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);
+                  ctx->msm_ws.p, (uint32_t*)ctx->proj.p, ctx->d_status, ctx->timing_on ? ctx->ev[3] : nullptr, ctx->timing_on ? ctx->ev[4] : nullptr, (uint8_t*)d_out_xy,
+                  (uint8_t*)d_out_inf);
     record(ctx, 1);     // (the conversion to affine happens inside the last kernel of the chain: "normalize" is an empty span)
     record(ctx, 2);
     rc = finish(ctx);
-    collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
-                         {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
+    // "accumulate" is the accumulation kernel alone; "reduce" = everything after it = "finish" (bucket finish + running sums) +
+    // "tree" (over the segment sums) + "combine" (window sums, Horner chain, conversion to affine); "sort" = "prepare" + the sort
+    if (detail)
+        collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}}, {"accumulate", {3, 4}},
+                             {"reduce", {4, 1}}, {"prepare", {0, 6}}, {"finish", {4, 7}}, {"tree", {7, 8}}, {"combine", {8, 1}}});
+    else
+        collect_timing(ctx, {{"main", {0, 1}}, {"normalize", {1, 2}}, {"total", {0, 2}}, {"sort", {0, 3}},
+                             {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
     return rc;
 }
 
@@ -712,7 +794,7 @@ int lincomb_ct_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, cons
     record(ctx, 0);
     launch_var_base_ct<C>(ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n,
                           (uint32_t*)ctx->vtab.p, tstride, (uint32_t*)ctx->proj.p, (uint8_t*)ctx->ct_flags.p, ctx->d_status);
-    (void)hipEventRecord(ctx->ev[3], ctx->stream);
+    record(ctx, 3);
     launch_proj_sum<C>(ctx->stream, (uint32_t*)ctx->proj.p, n, (uint32_t*)ctx->prefix.p);
     record(ctx, 1);
     if ((rc = normalize_out<C>(ctx, 1, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
@@ -778,7 +860,7 @@ int msm_parts_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_msm_parts<C>(plan, ctx->stream, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, ctx->msm_ws.p,
-                        (uint32_t*)d_parts, ctx->d_status, ctx->ev[3], ctx->ev[4]);
+                        (uint32_t*)d_parts, ctx->d_status, ctx->timing_on ? ctx->ev[3] : nullptr, ctx->timing_on ? ctx->ev[4] : nullptr);
     record(ctx, 1);
     rc = finish(ctx);
     collect_timing(ctx, {{"main", {0, 1}}, {"total", {0, 1}}, {"sort", {0, 3}}, {"accumulate", {3, 4}}, {"reduce", {4, 1}}});
@@ -979,7 +1061,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     constexpr int NS = Field<C>::NS;
     const size_t L = 4 * C::N;
     int rc;
-    if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+    if ((rc = ensure_table<C>(ctx, n)) != ECGPU_OK) return rc;
     if (n == 0) return (int)ECGPU_OK;
     size_t tstride = var_base_slots<C>(n);
     if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
@@ -1199,8 +1281,48 @@ int ecgpu_set_stream(ecgpu_ctx* ctx, void* stream) {
 
 int ecgpu_set_base_window(ecgpu_ctx* ctx, int curve, int window_bits) {
     if (!ctx || curve < 0 || curve > 11) return ECGPU_ERR_CURVE;
+    if (window_bits == 0) {                                   // back to the automatic choice below the curve's default maximum
+        ctx->want_w[curve] = ecgpu_ctx().want_w[curve];
+        ctx->w_pinned[curve] = false;
+        return ECGPU_OK;
+    }
     if (window_bits < 4 || window_bits > 26) return arg_error(ctx, __func__);
     ctx->want_w[curve] = window_bits;
+    ctx->w_pinned[curve] = true;
+    return ECGPU_OK;
+}
+
+int ecgpu_set_table_policy(ecgpu_ctx* ctx, int policy) {
+    if (!ctx || (policy != ECGPU_TABLE_ADAPTIVE && policy != ECGPU_TABLE_EAGER)) return arg_error(ctx, __func__);
+    ctx->table_policy = policy;
+    return ECGPU_OK;
+}
+
+int ecgpu_set_table_budget(ecgpu_ctx* ctx, size_t max_table_bytes) {
+    if (!ctx) return arg_error(ctx, __func__);
+    ctx->table_budget = max_table_bytes;
+    return ECGPU_OK;
+}
+
+int ecgpu_base_table_info(ecgpu_ctx* ctx, int curve, int* window_bits, size_t* table_bytes, double* build_ms) {
+    if (!ctx || curve < 0 || curve > 11) return ECGPU_ERR_CURVE;
+    const Table& t = ctx->table[curve];
+    int w = 0;
+    size_t bytes = 0;
+    double ms = 0;
+    if (t.d) {
+        TableRegistry& reg = table_registry(ctx->device);
+        std::lock_guard<std::mutex> lock(reg.mu);
+        auto it = reg.tabs.find(std::make_tuple(ctx->device, curve, t.w));
+        if (it != reg.tabs.end()) {
+            w = t.w;
+            bytes = it->second.bytes;
+            ms = it->second.build_ms;
+        }
+    }
+    if (window_bits) *window_bits = w;
+    if (table_bytes) *table_bytes = bytes;
+    if (build_ms) *build_ms = ms;
     return ECGPU_OK;
 }
 
@@ -1269,7 +1391,14 @@ int ecgpu_wipe(ecgpu_ctx* ctx) {
 }
 
 // test-only (not in include/ecgpu.h): comb tables above `mb` MiB are refused as if the allocation had failed; 0 switches it off
-void ecgpu_testhook_table_max_mb(size_t mb) { g_test_table_max_mb.store(mb); }
+void ecgpu_testhook_table_max_mb(size_t mb) {
+    g_test_table_max_mb.store(mb);
+    for (int dev = 0; dev < 64; dev++) {                          // what the hook made the registry remember goes with it
+        TableRegistry& reg = table_registry(dev);
+        std::lock_guard<std::mutex> lock(reg.mu);
+        reg.nofit.clear();
+    }
+}
 
 int ecgpu_last_timing(const ecgpu_ctx* ctx_in, const char* name, double* ms) {
     if (!ctx_in || !name || !ms) return ECGPU_ERR_ARG;
@@ -1449,7 +1578,7 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
         constexpr int N = C::N, NS = Field<C>::NS;
     (void)N;
         int rc;
-        if ((rc = ensure_table<C>(ctx)) != ECGPU_OK) return rc;
+        if ((rc = ensure_table<C>(ctx, n)) != ECGPU_OK) return rc;
         if (n == 0) return (int)ECGPU_OK;
         size_t tstride = var_base_slots<C>(n);
         if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;

@@ -42,7 +42,9 @@ ECGPU_HD Affine<C> load_entry(const Table& table, int window, uint32_t index) {
 // gather latency better than software prefetching does.  An LDS-DMA prefetch (`global_load_lds_dwordx4` of the next
 // entry under the current addition, no staging registers, 3 waves per SIMD) was measured too: 0.644 ms against
 // 0.643 ms — the kernel is not waiting for its gathers.  Repeated with the XYZZ kernel, where the staging registers fit
-// without costing a wave (168 VGPRs, 3 waves per SIMD): 0.545 ms against 0.52 ms.)
+// without costing a wave (168 VGPRs, 3 waves per SIMD): 0.545 ms against 0.52 ms.  And once more in round 5 in the form that helped the
+// MSM's accumulation loop — the next entry requested unconditionally behind the pinned unpacking of the current one, no copies at
+// the back edge, 168 VGPRs: kernel 0.511 / 0.517 against 0.504 / 0.510 ms, same box, alternating — profiles/r05/fixed_prefetch_ab.txt.)
 // whether the never-exceptional argument for the comb does not cover the curve: n not within 2^-4 of 2^bits
 template <class C>
 constexpr bool COMB_NEEDS_CHECK = C::ORDER[C::N - 1] < 0xF0000000u;

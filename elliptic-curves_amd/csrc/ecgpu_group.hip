@@ -15,6 +15,8 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -31,6 +33,7 @@ typedef void* nccl_comm_t;
 typedef int (*nccl_comm_init_all_fn)(nccl_comm_t*, int, const int*);
 typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t);
 typedef int (*nccl_comm_destroy_fn)(nccl_comm_t);
+typedef int (*nccl_comm_abort_fn)(nccl_comm_t);
 typedef const char* (*nccl_error_string_fn)(int);
 constexpr int NCCL_UINT8 = 1;      // ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1
 
@@ -39,6 +42,7 @@ struct Rccl {
     nccl_comm_init_all_fn comm_init_all = nullptr;
     nccl_all_gather_fn all_gather = nullptr;
     nccl_comm_destroy_fn comm_destroy = nullptr;
+    nccl_comm_abort_fn comm_abort = nullptr;           // optional: how a communicator with a collective that will never end is given up
     nccl_error_string_fn error_string = nullptr;
     bool load() {
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
@@ -49,6 +53,7 @@ struct Rccl {
         comm_init_all = (nccl_comm_init_all_fn)dlsym(lib, "ncclCommInitAll");
         all_gather = (nccl_all_gather_fn)dlsym(lib, "ncclAllGather");
         comm_destroy = (nccl_comm_destroy_fn)dlsym(lib, "ncclCommDestroy");
+        comm_abort = (nccl_comm_abort_fn)dlsym(lib, "ncclCommAbort");
         error_string = (nccl_error_string_fn)dlsym(lib, "ncclGetErrorString");
         return comm_init_all && all_gather && comm_destroy;
     }
@@ -67,6 +72,19 @@ struct Member {
     size_t in0_cap = 0, in1_cap = 0, in2_cap = 0;
 };
 
+// test-only fault injection for the exchange step (exported as ecgpu_testhook_group_exchange, not in include/ecgpu.h; no
+// environment variable): 0 off; 1 the collective's enqueue fails on member 0 only while the other members' collectives are
+// enqueued and never complete (the partial failure); 2 the enqueue fails on every member; 3 the collective is enqueued
+// everywhere and never completes (the failure RCCL has actually shown on this pool: a hang).  With a hook set the RCCL leg is
+// entered whatever the group's exchange is, and stand-ins take the place of ncclAllGather.
+std::atomic<int> g_test_exchange_fault{0};
+
+// the stand-in for a collective that never completes: spins until the host releases it (the group does when it gives the
+// exchange up, so the GPU is never left with a kernel that cannot end)
+__global__ void k_group_stall(volatile int* release) {
+    while (!*release) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace
 
 struct ecgpu_group {
@@ -74,6 +92,9 @@ struct ecgpu_group {
     bool use_rccl = false;
     std::string why;                   // how the exchange was chosen (ecgpu_group_exchange_reason)
     Rccl rccl;
+    double exchange_timeout_s = 10.0;  // ecgpu_group_set_exchange_timeout
+    int* stall_release = nullptr;      // page-locked flag of k_group_stall (test hook)
+    std::vector<hipStream_t> abandoned; // exchange streams given up with work still on them (destroyed with the group if they drained)
     std::string err;
     std::mutex err_mu;                 // fail() may be called from several per-device worker threads at once
 };
@@ -196,6 +217,10 @@ void ecgpu_group_destroy(ecgpu_group* g) {
             if (p) ecgpu_dev_free(mb.ctx, p);
         ecgpu_destroy(mb.ctx);
     }
+    if (g->stall_release) *g->stall_release = 1;
+    for (hipStream_t st : g->abandoned)
+        if (hipStreamQuery(st) == hipSuccess) (void)hipStreamDestroy(st);      // (one that still holds a dead collective is left to the process)
+    if (g->stall_release) (void)hipHostFree(g->stall_release);
     delete g;
 }
 
@@ -208,6 +233,15 @@ const char* ecgpu_group_last_error(const ecgpu_group* g) { return g ? g->err.c_s
 const char* ecgpu_group_exchange(const ecgpu_group* g) { return g && g->use_rccl ? "rccl" : "peer"; }
 
 const char* ecgpu_group_exchange_reason(const ecgpu_group* g) { return g ? g->why.c_str() : "null group"; }
+
+int ecgpu_group_set_exchange_timeout(ecgpu_group* g, double seconds) {
+    if (!g || !(seconds > 0)) return ECGPU_ERR_ARG;
+    g->exchange_timeout_s = seconds;
+    return ECGPU_OK;
+}
+
+// test-only (not in include/ecgpu.h): see g_test_exchange_fault
+void ecgpu_testhook_group_exchange(int mode) { g_test_exchange_fault.store(mode); }
 
 int ecgpu_group_set_msm_window(ecgpu_group* g, int window_bits) {
     if (!g) return ECGPU_ERR_ARG;
@@ -252,33 +286,88 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
                                    n_per_device[r], plan_terms, mb.d_parts);           // returns with the parts written
     });
     if (rc != ECGPU_OK) return rc;
-    // the exchange step.  RCCL first where the group has it; a collective that fails is not the end of the call: the parts
-    // are still in every GPU's d_parts, so the peer copies below move them, and the group stays on peer copies from then on.
-    if (g->use_rccl) {
+    // The exchange step.  RCCL first where the group has it.  A collective that fails — or does not END — is not the end of the
+    // call: every member waits for its exchange stream by polling it against the group's deadline (ecgpu_group_set_exchange_timeout),
+    // and stops waiting at once when another member's enqueue has failed (its own collective then has no partner and would never
+    // complete).  On any failure every communicator is aborted, the exchange streams — which may still hold the dead collective —
+    // are replaced by fresh ones, the parts, which are still in every GPU's d_parts, travel by the peer copies below, and the group
+    // stays on peer copies from then on (ecgpu_group_exchange_reason says why).
+    const int fault = g_test_exchange_fault.load();
+    const auto wait_stream = [&](Member& mb, const std::atomic<bool>* give_up) -> int {       // 0 done, 1 deadline / given up, -1 HIP error
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->exchange_timeout_s);
+        for (;;) {
+            const hipError_t q = hipStreamQuery(mb.stream);
+            if (q == hipSuccess) return 0;
+            if (q != hipErrorNotReady) return -1;
+            if ((give_up && give_up->load()) || std::chrono::steady_clock::now() >= t_end) return 1;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    };
+    if (g->use_rccl || fault) {
         int nrc_seen = 0;
+        bool timed_out = false;
         std::mutex nrc_mu;
+        std::atomic<bool> enqueue_failed{false};
+        if (fault && !g->stall_release) {
+            if (hipHostMalloc(reinterpret_cast<void**>(&g->stall_release), sizeof(int), hipHostMallocMapped) != hipSuccess)
+                return fail(g, ECGPU_ERR_HIP, "test hook: no page-locked flag");
+        }
+        if (g->stall_release) *g->stall_release = 0;
         rc = for_each_member(g, [&](int r) -> int {
             Member& mb = g->m[r];
             if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
-            const int nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
+            int nrc = 0;
+            if (fault == 2 || (fault == 1 && r == 0)) {
+                nrc = 1;                                              // (ncclUnhandledCudaError)
+            } else if (fault) {
+                int* d_flag = nullptr;
+                if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flag), g->stall_release, 0) != hipSuccess) return ECGPU_ERR_HIP;
+                hipLaunchKernelGGL(k_group_stall, dim3(1), dim3(1), 0, mb.stream, d_flag);
+            } else {
+                nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
+            }
             if (nrc != 0) {
+                enqueue_failed.store(true);
                 std::lock_guard<std::mutex> lock(nrc_mu);
                 nrc_seen = nrc;
                 return ECGPU_ERR_HIP;
             }
-            return hipStreamSynchronize(mb.stream) == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
+            const int w = wait_stream(mb, &enqueue_failed);
+            if (w == 1 && !enqueue_failed.load()) {
+                std::lock_guard<std::mutex> lock(nrc_mu);
+                timed_out = true;
+            }
+            return w == 0 ? ECGPU_OK : ECGPU_ERR_HIP;
         });
         if (rc != ECGPU_OK) {
+            g->why = std::string("peer: ncclAllGather ") +
+                     (nrc_seen ? std::string("failed (") + (g->rccl.error_string && !fault ? g->rccl.error_string(nrc_seen) : "enqueue error") + ")"
+                      : timed_out ? "did not complete within " + std::to_string(g->exchange_timeout_s) + " s (communicators aborted)"
+                                  : std::string("failed (HIP error on the exchange stream)"));
             g->use_rccl = false;
-            g->why = std::string("peer: ncclAllGather failed (") +
-                     (nrc_seen && g->rccl.error_string ? g->rccl.error_string(nrc_seen) : "HIP error on the exchange stream") + ")";
             g->err.clear();
+            // give the communicators up (ncclCommAbort ends collectives that wait for a partner), release the test stand-ins,
+            // and move to fresh streams: the old ones are destroyed now if they drained, with the group otherwise
+            if (g->stall_release) *g->stall_release = 1;
+            for (auto& mb : g->m) {
+                (void)hipSetDevice(mb.device);
+                if (mb.comm) {
+                    if (g->rccl.comm_abort) (void)g->rccl.comm_abort(mb.comm);
+                    else if (g->rccl.comm_destroy && hipStreamQuery(mb.stream) == hipSuccess) (void)g->rccl.comm_destroy(mb.comm);
+                    mb.comm = nullptr;
+                }
+                hipStream_t fresh = nullptr;
+                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess)
+                    return fail(g, ECGPU_ERR_HIP, "exchange fallback: no fresh stream on device " + std::to_string(mb.device));
+                g->abandoned.push_back(mb.stream);
+                mb.stream = fresh;
+            }
             (void)hipGetLastError();
         }
     }
     if (!g->use_rccl) {
-        // device-to-device copies are asynchronous with respect to the host: an explicit stream + synchronisation, so that
-        // the combining half (on member 0's own stream) starts after every part has landed
+        // device-to-device copies are asynchronous with respect to the host: an explicit stream + a (polled, bounded) wait, so
+        // that the combining half (on member 0's own stream) starts after every part has landed
         rc = for_each_member(g, [&](int r) -> int {
             Member& mb = g->m[r];
             if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
@@ -286,8 +375,8 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
             hipError_t he = mb.device == g->m[0].device
                                 ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
                                 : hipMemcpyPeerAsync(dst, g->m[0].device, mb.d_parts, mb.device, bytes, mb.stream);
-            if (he == hipSuccess) he = hipStreamSynchronize(mb.stream);
-            return he == hipSuccess ? ECGPU_OK : ECGPU_ERR_HIP;
+            if (he != hipSuccess) return ECGPU_ERR_HIP;
+            return wait_stream(mb, nullptr) == 0 ? ECGPU_OK : ECGPU_ERR_HIP;
         });
     }
     if (rc != ECGPU_OK) return rc == ECGPU_ERR_HIP && g->err.empty() ? fail(g, rc, "exchange of the partial sums failed") : rc;

@@ -17,6 +17,9 @@ struct MsmPlan {
     size_t nseg = 0;   // segments per window
     size_t ntiles = 0, tile = 0;   // counting-sort tiles (terms per tile)
     size_t chunk = 0, nchunks = 0; // accumulation: sorted entries per lane, lanes per window
+    // optional timing marks of one launch (ecgpu_last_timing "prepare" / "finish" / "tree" / "combine"): recorded after k_msm_prepare,
+    // after the bucket finish + running sums, after the tree over the segment sums; null = not recorded
+    hipEvent_t detail[3] = {nullptr, nullptr, nullptr};
     size_t off_points = 0, off_digits = 0, off_vmask = 0, off_tilehist = 0, off_sorted = 0, off_count = 0, off_offset = 0,
            off_partials = 0, off_buckets = 0, off_segs = 0, off_wins = 0, off_biglist = 0;
     // two-level sort (large MSMs): level A partitions a window's entries by the top 8 bits of the bucket, level B sorts

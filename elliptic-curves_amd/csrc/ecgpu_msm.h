@@ -714,6 +714,21 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
     msm_chunk_accumulate<C>(sorted + w * n, ow, total, (uint32_t)nb, (uint32_t)chunk, (uint32_t)q, G::curve_b(), points, sink);
 }
 
+// -DECGPU_MSM_FUSED_TAIL=0: bucket finish and running sums as the two launches of round 4 (A/B: profiles/r05/)
+#ifndef ECGPU_MSM_FUSED_TAIL
+#define ECGPU_MSM_FUSED_TAIL 1
+#endif
+// The fused tail kernel (k_msm_finish_segments) keeps two running points, a bucket sum and a stretch in registers: the sets up to
+// 384 bits fit the 512 registers of one wave per SIMD; the twenty-limb p521 keeps the two launches.  And it only pays where its
+// lanes — one per segment of `seg` buckets — fill the chip twice over: measured on MI355X (profiles/r05/msm_tail_fused_ab.txt),
+// k256 at 2^24 terms (131,072 segments) 0.365 against 0.391 ms for bucket finish + running sums, at 2^21 GLV terms (65,536 segments:
+// one wave per SIMD, every lane a chain of 4 x ~3 stretches + 29 point operations) 0.32 against 0.27 ms — a lane per BUCKET is
+// four times the parallelism for the stretch sums, and that is worth more there than the saved launch and round trip.
+template <class C>
+inline bool msm_fused_tail(const MsmPlan& p) {
+    return ECGPU_MSM_FUSED_TAIL != 0 && C::N <= 12 && p.nseg * (size_t)p.nwin >= ((size_t)1 << 17);
+}
+
 // A bucket normally has one or two partial sums.  A degenerate input (all scalars equal, all ones) gives ONE bucket
 // per window thousands of them; such buckets are handed to a whole workgroup each (k_msm_big_buckets) instead of
 // being walked by a single lane.
@@ -759,19 +774,40 @@ k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restr
                   uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_list) {
     using G = Group<C>;
     __shared__ uint32_t lds[BLOCK * 3 * C::NL];
-    if (blockIdx.x >= big_list[0]) return;
-    const size_t gid = big_list[1 + blockIdx.x];
-    const size_t w = gid / nb, b = gid % nb;
+    // the launch is a fixed MSM_BIG_GRID workgroups that deal the listed buckets out among themselves: for random scalars the
+    // list is empty and 4 x MSM_BIG_GRID waves leave on their first load (round 4 launched one workgroup per POSSIBLE list
+    // entry: 75,968 empty waves at 2^24 terms)
+    const uint32_t nbig = big_list[0];
+    for (uint32_t it = blockIdx.x; it < nbig; it += gridDim.x) {
+        const size_t gid = big_list[1 + it];
+        const size_t w = gid / nb, b = gid % nb;
+        const uint32_t first = offsets[gid], cnt = counts[gid];
+        const uint32_t q0 = first / (uint32_t)chunk, q1 = (first + cnt - 1) / (uint32_t)chunk;
+        MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (4 * Field<C>::NS)};
+        MsmPointsHbm<C> points{pts};
+        const Fe<C::NL> cb = G::curve_b();
+        Proj<C> acc = G::identity();
+        for (uint32_t q = q0 + threadIdx.x; q <= q1; q += BLOCK)
+            acc = G::add(acc, msm_stretch_of<C>((uint32_t)b, q, first, cnt, (uint32_t)chunk, cb, src, sorted + w * n, points), cb);
+        acc = block_sum<C>(acc, lds, cb);
+        if (threadIdx.x == 0) store_proj<C>(buckets, gid, acc);
+        __syncthreads();
+    }
+}
+constexpr unsigned MSM_BIG_GRID = 256;
+
+// the buckets k_msm_big_buckets takes, listed BEFORE the accumulation (counts and offsets are all it needs): one lane per
+// (window, bucket).  For the fused tail below, which has no per-bucket launch of its own to do the listing in.
+static __global__ void __launch_bounds__(256)
+k_msm_find_big(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t nbk, uint32_t chunk,
+               uint32_t* __restrict__ big_list, uint32_t max_big) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nbk) return;
     const uint32_t first = offsets[gid], cnt = counts[gid];
-    const uint32_t q0 = first / (uint32_t)chunk, q1 = (first + cnt - 1) / (uint32_t)chunk;
-    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (4 * Field<C>::NS)};
-    MsmPointsHbm<C> points{pts};
-    const Fe<C::NL> cb = G::curve_b();
-    Proj<C> acc = G::identity();
-    for (uint32_t q = q0 + threadIdx.x; q <= q1; q += BLOCK)
-        acc = G::add(acc, msm_stretch_of<C>((uint32_t)b, q, first, cnt, (uint32_t)chunk, cb, src, sorted + w * n, points), cb);
-    acc = block_sum<C>(acc, lds, cb);
-    if (threadIdx.x == 0) store_proj<C>(buckets, gid, acc);
+    if (cnt != 0 && (first + cnt - 1) / chunk - first / chunk >= MSM_BIG_PARTIALS) {
+        const uint32_t slot = atomicAdd(big_list, 1u);
+        if (slot < max_big) big_list[1 + slot] = (uint32_t)gid;     // (always: max_big is an upper bound)
+    }
 }
 
 // ---- a = 0 (k256): one COMPLETE projective doubling spread over the four lanes of a quad -----------------------------------
@@ -937,6 +973,45 @@ k_msm_reduce_segments(const uint32_t* __restrict__ buckets, size_t nb, int seg, 
 #pragma unroll 1
     for (int j = seg - 1; j >= 0; j--) {
         Proj<C> bk = load_proj<C>(buckets, w * nb + base + j);
+        running = G::add(running, bk, b);
+        if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
+    }
+    uint32_t wmin = (uint32_t)(base >> sh) + 1;
+    local = G::add(local, wmin == 1 ? running : small_mul<C>(running, wmin, b), b);
+    store_proj<C>(segs, gid, local);
+}
+
+// The same with the bucket finish inside (round 5): the lane of a segment sums the stretches of its `seg` buckets itself — no
+// k_msm_bucket_finish launch (two rounds of two waves per SIMD whose lanes wait for the slowest bucket of the wave: 0.16 ms at
+// 2^21 terms for ~3 additions per lane) and no round trip of the bucket sums through HBM.  One wave per SIMD and the whole
+// register file: nseg * nwin lanes are one wave per SIMD at 2^21 terms and two rounds of one at 2^24.  Buckets with
+// MSM_BIG_PARTIALS stretches or more (degenerate scalar sets) were listed by k_msm_find_big and summed by k_msm_big_buckets
+// before this kernel runs: they are read from `buckets`.
+template <class C>
+__global__ void __launch_bounds__(64, 1)
+k_msm_finish_segments(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
+                      const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
+                      const uint32_t* __restrict__ sorted, size_t n, size_t nb, int nwin, size_t chunk, size_t nchunks,
+                      const uint32_t* __restrict__ buckets, int seg, size_t nseg, int top_shift, uint32_t* __restrict__ segs) {
+    using G = Group<C>;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= nseg * nwin) return;
+    size_t w = gid / nseg, s = gid % nseg;
+    const Fe<C::NL> b = G::curve_b();
+    MsmPartialsHbm<C> src{const_cast<uint32_t*>(partials) + w * (nb + nchunks) * (4 * Field<C>::NS)};
+    MsmPointsHbm<C> points{pts};
+    Proj<C> running = G::identity(), local = G::identity();
+    size_t base = s * seg;
+    const int sh = (int)w == nwin - 1 ? top_shift : 0;
+#pragma unroll 1
+    for (int j = seg - 1; j >= 0; j--) {
+        const size_t gb = w * nb + base + j;
+        const uint32_t first = offsets[gb], cnt = counts[gb];
+        Proj<C> bk;
+        if (cnt != 0 && (first + cnt - 1) / (uint32_t)chunk - first / (uint32_t)chunk >= MSM_BIG_PARTIALS)
+            bk = load_proj<C>(buckets, gb);
+        else
+            bk = msm_bucket_finish<C>((uint32_t)(base + j), first, cnt, (uint32_t)chunk, b, src, sorted + w * n, points);
         running = G::add(running, bk, b);
         if (j > 0 && ((base + j) >> sh) != ((base + j - 1) >> sh)) local = G::add(local, running, b);
     }
@@ -1219,7 +1294,8 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
         size_t per_window = (lanes + p.nwin - 1) / p.nwin;
         p.chunk = (ne + per_window - 1) / per_window;
         if (p.chunk < 32) p.chunk = 32;
-        p.chunk = (p.chunk + 3) & ~(size_t)3;               // chunks start on 16-byte boundaries of the index stream
+        // (no rounding to a multiple of four: the index stream starts anywhere inside a 16-byte quad, ecgpu_msm_chunk.h.  Round 4
+        // rounded up — 57 -> 60 entries at 2^21 GLV terms, and the third round of waves was 16 % empty)
         if (const char* e = getenv("ECGPU_MSM_CHUNK")) {
             long v = atol(e);
             if (v >= 1 && v <= (1L << 30)) p.chunk = (size_t)v;
@@ -1239,6 +1315,10 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
             if (bb > 31 - idx_bits) bb = 31 - idx_bits;
             if (bb > MSM_SORTP_MAX_BITS_B) bb = MSM_SORTP_MAX_BITS_B;
             bool packed = bb >= 1 && p.c - 1 - bb <= MSM_SORTP_MAX_BITS_A;
+            // k_msm_prepare keeps the level-A histogram of every window in LDS (nwin * npart words) and is launched without the
+            // large-LDS attribute: with 9 level-A bits (more than 2^24 entries per window) the 33 windows of p521 would need 67.6 KB
+            // — such a plan keeps the unpacked form with its 8 level-A bits
+            packed = packed && (size_t)p.nwin * (p.nb >> bb) * 4 <= (size_t)64 * 1024;
             if (const char* e = getenv("ECGPU_MSM_SORT_PACKED")) packed = packed && atoi(e) != 0;   // 0: the round-3 kernels (A/B runs)
             if (packed) {
                 p.sort_packed = true;
@@ -1277,7 +1357,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
 // the tree over the segment sums.  These kernels hold a few thousand waves at most and each lane walks a chain of dependent
 // point operations: their time is latency, not throughput.
 template <class C>
-void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t* parts, hipEvent_t ev_accumulated) {
+void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t* parts) {
     const size_t ne = p.nsub;
     uint32_t* pts = (uint32_t*)(ws + p.off_points);
     uint32_t* sorted = (uint32_t*)(ws + p.off_sorted);
@@ -1288,19 +1368,31 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
     uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
     uint32_t* segs = (uint32_t*)(ws + p.off_segs);
     const size_t nbk = p.nb * p.nwin;
-    (void)hipMemsetAsync(big_list, 0, 4, stream);
-    hipLaunchKernelGGL((k_msm_bucket_finish<C>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
-                       (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
-    hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3((unsigned)p.max_big), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
-                       (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
-                       p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
-    (void)hipEventRecord(ev_accumulated, stream);
     size_t nsg = p.nseg * p.nwin;
-    hipLaunchKernelGGL((k_msm_reduce_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
-                       (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
+    if (msm_fused_tail<C>(p)) {
+        // (k_msm_find_big ran before the accumulation: launch_msm_parts)
+        hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3(MSM_BIG_GRID), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
+                           (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
+                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
+        hipLaunchKernelGGL((k_msm_finish_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
+                           (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
+                           (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, (const uint32_t*)buckets, p.seg, p.nseg,
+                           msm_top_shift(p.kbits, p.c), segs);
+    } else {
+        (void)hipMemsetAsync(big_list, 0, 4, stream);
+        hipLaunchKernelGGL((k_msm_bucket_finish<C>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
+                           (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
+                           (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
+        hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3(MSM_BIG_GRID), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
+                           (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
+                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
+        hipLaunchKernelGGL((k_msm_reduce_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
+                           (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
+    }
+    if (p.detail[1]) (void)hipEventRecord(p.detail[1], stream);
     hipLaunchKernelGGL((k_msm_reduce_windows<C>), dim3((unsigned)p.nparts, (unsigned)p.nwin), dim3(BLOCK), 0, stream,
                        (const uint32_t*)segs, p.nseg, p.per_part, parts);
+    if (p.detail[2]) (void)hipEventRecord(p.detail[2], stream);
 }
 
 // First half of the pipeline: everything up to the per-window partial sums parts[nwin][nparts] (projective, internal
@@ -1313,8 +1405,8 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     if (n == 0) {
         hipLaunchKernelGGL(k_store_identity<C>, dim3((unsigned)((nparts_total + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, parts,
                            nparts_total);
-        (void)hipEventRecord(ev_sorted, stream);
-        (void)hipEventRecord(ev_accumulated, stream);
+        if (ev_sorted) (void)hipEventRecord(ev_sorted, stream);
+        if (ev_accumulated) (void)hipEventRecord(ev_accumulated, stream);
         return;
     }
     const size_t ne = p.nsub;
@@ -1360,6 +1452,7 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     if (!p.glv)
         hipLaunchKernelGGL((k_msm_prepare<C, false>), dim3(g), dim3(BLOCK), prep_lds, stream, d_scalars, d_xy, d_inf, n, p.npad, p.c,
                            p.nwin, pts, digits, vmask, d_status, counts_a0, p.sort_bits_b, (int)p.npart, reps);
+    if (p.detail[0]) (void)hipEventRecord(p.detail[0], stream);
     if (p.sort_packed) {
         uint32_t* tmp = (uint32_t*)(ws + p.off_tmpidx);
         uint32_t* counts_a = (uint32_t*)(ws + p.off_count_a);
@@ -1425,12 +1518,20 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
                            (const uint16_t*)digits, (const unsigned long long*)vmask, ne, p.tile, p.nb,
                            (const uint32_t*)tile_hist, (const uint32_t*)offsets, sorted);
     }
-    (void)hipEventRecord(ev_sorted, stream);
+    if (msm_fused_tail<C>(p)) {                         // the buckets k_msm_big_buckets will take, listed while nothing waits for it
+        uint32_t* big_list = (uint32_t*)(ws + p.off_biglist);
+        const size_t nbk = p.nb * p.nwin;
+        (void)hipMemsetAsync(big_list, 0, 4, stream);
+        hipLaunchKernelGGL(k_msm_find_big, dim3((unsigned)((nbk + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)counts,
+                           (const uint32_t*)offsets, nbk, (uint32_t)p.chunk, big_list, (uint32_t)p.max_big);
+    }
+    if (ev_sorted) (void)hipEventRecord(ev_sorted, stream);
     size_t nlanes = p.nchunks * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
                        (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials);
-    launch_msm_tail<C>(p, stream, ws, parts, ev_accumulated);
+    if (ev_accumulated) (void)hipEventRecord(ev_accumulated, stream);       // the accumulation kernel alone (round 4 recorded this after the bucket finish)
+    launch_msm_tail<C>(p, stream, ws, parts);
 }
 
 // Second half: the window sums over `nranks` sets of partial sums (laid out [rank][nwin][nparts]) and the Horner chain

@@ -28,36 +28,58 @@ namespace ecgpu {
 
 // The sorted (sign, index) entries of a lane's chunk, fetched four at a time: one 16-byte load per four additions
 // instead of a 4-byte one per addition (a quarter of the requests, and a lane's 128-byte line is asked for 8 times
-// instead of 32).  `run` must be 16-byte aligned and readable up to the next multiple of four past the last entry taken.
+// instead of 32) — and one quad AHEAD: the quad after the current one is requested when the current one is entered, so
+// the load has four additions to complete in (round 4 requested a quad with the last entry of its predecessor and needed
+// its first entry — the address of the next point — in the same step: every fourth step the wave sat out a load).
+// `run` must be 16-byte aligned and readable up to the second multiple of four past the last entry taken (the device
+// workspace continues behind the runs; entries past the chunk are requested, never used).
 struct MsmIndexStream {
     const uint32_t* run;
-    uint32_t b0, b1, b2, b3;
-    ECGPU_HD void fetch(uint32_t pos4) {
+    uint32_t b0, b1, b2, b3;                         // the current quad, rotating
+    uint32_t n0, n1, n2, n3;                         // the quad after it
+    ECGPU_HD void fetch_next(uint32_t pos4) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint4 v = *reinterpret_cast<const uint4*>(run + pos4);
-        b0 = v.x; b1 = v.y; b2 = v.z; b3 = v.w;
+        n0 = v.x; n1 = v.y; n2 = v.z; n3 = v.w;
 #else
-        b0 = run[pos4]; b1 = run[pos4 + 1]; b2 = run[pos4 + 2]; b3 = run[pos4 + 3];
+        n0 = run[pos4]; n1 = run[pos4 + 1]; n2 = run[pos4 + 2]; n3 = run[pos4 + 3];
 #endif
     }
     ECGPU_HD void rotate() { b0 = b1; b1 = b2; b2 = b3; }
     // positions first, first + 1, ... are then handed out by take()
     ECGPU_HD void start(const uint32_t* r, uint32_t first) {
         run = r;
-        fetch(first & ~3u);
+        fetch_next(first & ~3u);
+        b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+        fetch_next((first & ~3u) + 4);
         for (uint32_t s = first & 3u; s != 0; s--) rotate();
     }
-    // the entry at `pos` (calls must come in position order); `more`: an entry at pos + 1 will be asked for
-    ECGPU_HD uint32_t take(uint32_t pos, bool more) {
+    // the entry at `pos` (calls must come in position order)
+    ECGPU_HD uint32_t take(uint32_t pos) {
         const uint32_t e = b0;
         if (((pos + 1) & 3u) == 0) {
-            if (more) fetch(pos + 1);
+            b0 = n0; b1 = n1; b2 = n2; b3 = n3;
+            fetch_next(pos + 5);
         } else {
             rotate();
         }
         return e;
     }
 };
+
+// The limbs of `a` are computed, and every memory operation that follows in the source is issued, on their own side of this
+// point.  The accumulation loop needs it: the one wait of a step is the one for the point prefetched a whole addition ago, and it
+// has to come BEFORE the step's own stores and loads are issued — gfx9 counts loads and stores in one counter (vmcnt) that the
+// compiler can only wait to zero once both kinds are in flight, so a wait placed after them sits out their whole latency.
+template <class C>
+ECGPU_HD void msm_pin_before_memory_ops(Affine<C>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < C::NL; i++) asm volatile("" : "+v"(a.x.v[i]), "+v"(a.y.v[i]) : : "memory");
+#else
+    (void)a;
+#endif
+}
 
 // Points: void load(PackedPoint<2N>&, uint32_t term) const.   Sink: void put(size_t slot, const Xyzz<C>&).
 // `ow` = bucket start offsets of this window (nb entries), `total` = length of the window's run.
@@ -80,13 +102,16 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
     }
     uint32_t b = lo;
     uint32_t bend = b + 1 < nb ? ow[b + 1] : total;
+    uint32_t bnext = b + 2 < nb ? ow[b + 2] : total;  // the end of the bucket after this one: asked for one bucket ahead (below)
     Xyzz<C> acc;
     acc.x = acc.y = acc.zz = acc.zzz = F::one().e;
     bool fresh = true;                               // no term of the current stretch taken yet
+    bool pending = false;                            // the stretch that ended with the previous entry is still to be written
+    uint32_t pslot = 0;
     PackedPoint<2 * N> pw;
     MsmIndexStream idx;
     idx.start(run, start);
-    uint32_t e = idx.take(start, start + 1 < end);
+    uint32_t e = idx.take(start);
     points.load(pw, e & 0x7FFFFFFFu);
 #pragma unroll 1
     for (uint32_t pos = start; pos < end;) {
@@ -95,8 +120,22 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
         cur.y = F::unpack(pw.w + N).e;
         const bool neg = (e >> 31) != 0;
         pos++;
-        if (pos < end) {                             // fetch the next point under the current addition
-            e = idx.take(pos, pos + 1 < end);
+        msm_pin_before_memory_ops(cur);
+        // Every memory operation of a step is issued HERE, at its head, and is a whole addition old when the next head waits
+        // for the prefetched point: the partial sum of a stretch that ended with the previous entry (a lane that leaves a bucket
+        // makes its whole wave walk this path, so it must not wait on anything: round 4 stored at the end of the step and then
+        // read ow[b + 1] for the new bucket, i.e. drained the stores AND a dependent load with the wave stalled — at 128
+        // entries per bucket, the 2^21-term share of an 8-GPU run, four steps of five have a leaving lane in the wave), the
+        // bucket end after next, the next point.
+        if (pending) {
+            sink.put((size_t)pslot, acc);            // as it is: the exactness test and the conversion happen in the finish
+            bnext = b + 2 < nb ? ow[b + 2] : total;
+            pending = false;
+        }
+        {   // the next point under the current addition; unconditionally (after the last entry: the same point again, unused) so
+            // that the registers of the point just unpacked can take it without a copy at the loop's back edge
+            const uint32_t en = idx.take(pos);
+            e = pos < end ? en : e;
             points.load(pw, e & 0x7FFFFFFFu);
         }
         if (fresh) {
@@ -106,16 +145,22 @@ ECGPU_HD void msm_chunk_accumulate(const uint32_t* __restrict__ run, const uint3
             acc = G::xyzz_madd(acc, cur, neg);
         }
         if (pos == bend || pos == end) {             // leaving the bucket, or the chunk ends inside it
-            sink.put((size_t)b + q, acc);            // as it is: the exactness test and the conversion happen in the finish
+            pslot = b + q;
+            pending = true;
             fresh = true;
             if (pos == bend && pos < end) {
-                do {
-                    b++;
-                    bend = b + 1 < nb ? ow[b + 1] : total;
-                } while (bend == pos);               // skip empty buckets; pos < end <= total terminates this
+                b++;
+                bend = bnext;                        // known since the head of the step that entered the bucket left now
+                if (bend == pos) {                   // empty buckets (rare): walk on with loads that are waited for
+                    do {
+                        b++;
+                        bend = b + 1 < nb ? ow[b + 1] : total;
+                    } while (bend == pos);           // pos < end <= total terminates this
+                }
             }
         }
     }
+    if (pending) sink.put((size_t)pslot, acc);
 }
 
 // The sum of one stretch from its stored XYZZ partial: converted if the exactness test passes, otherwise recomputed

@@ -56,7 +56,20 @@ unsafe impl Send for Engine {}
 pub static ENGINE: LazyLock<Option<Mutex<Engine>>> = LazyLock::new(|| {
     let mut ctx = core::ptr::null_mut();
     // no gfx950 device -> None: every adapter below then reports "not handled" and the CPU code runs
-    (unsafe { ecgpu_init(&mut ctx, 0) } == ECGPU_OK).then(|| Mutex::new(Engine(ctx)))
+    if unsafe { ecgpu_init(&mut ctx, 0) } != ECGPU_OK {
+        return None;
+    }
+    // The generator tables follow the library's default footprint policy (ECGPU_TABLE_ADAPTIVE: 34 MB until the device has
+    // multiplied 2^26 scalars by G, 21.5 GB only from 2^29 on — the reference's own table is 30-60 KB and lazily built,
+    // primeorder/src/tables/basepoint.rs:29-76).  A service that wants the steady-state rate from its first batch sets
+    // ECGPU_TABLE_POLICY=eager; ECGPU_TABLE_BUDGET_MB caps a table whatever the policy.
+    if std::env::var("ECGPU_TABLE_POLICY").map_or(false, |v| v == "eager") {
+        unsafe { ecgpu_set_table_policy(ctx, ECGPU_TABLE_EAGER) };
+    }
+    if let Some(mb) = std::env::var("ECGPU_TABLE_BUDGET_MB").ok().and_then(|v| v.parse::<usize>().ok()) {
+        unsafe { ecgpu_set_table_budget(ctx, mb << 20) };
+    }
+    Some(Mutex::new(Engine(ctx)))
 });
 
 /// All GPUs of the node: used for MSMs of `NODE_MIN_TERMS` terms and more.
@@ -73,7 +86,15 @@ pub static NODE: LazyLock<Option<Mutex<Node>>> = LazyLock::new(|| {
     }
     let devices: Vec<c_int> = (0..ndev as c_int).collect();
     let mut g = core::ptr::null_mut();
-    (unsafe { ecgpu_group_init(&mut g, devices.as_ptr(), devices.len() as c_int) } == ECGPU_OK).then(|| Mutex::new(Node(g)))
+    if unsafe { ecgpu_group_init(&mut g, devices.as_ptr(), devices.len() as c_int) } != ECGPU_OK {
+        return None;
+    }
+    // `lincomb` must return: the exchange of the partial sums is given up after this long (a collective that hangs is the failure
+    // RCCL has shown) and the call completes over peer copies — include/ecgpu.h ecgpu_group_set_exchange_timeout, default 10 s
+    if let Some(sec) = std::env::var("ECGPU_EXCHANGE_TIMEOUT_S").ok().and_then(|v| v.parse::<f64>().ok()) {
+        unsafe { ecgpu_group_set_exchange_timeout(g, sec) };
+    }
+    Some(Mutex::new(Node(g)))
 });
 
 /// Below this many terms a sum stays on the CPU (a launch costs ~1 ms end to end).

@@ -36,6 +36,8 @@ pub const ECGPU_ERR_NO_DEVICE: c_int = -4;
 pub const ECGPU_ERR_HIP: c_int = -5;
 pub const ECGPU_ERR_OOM: c_int = -6;
 pub const ECGPU_ERR_ARG: c_int = -7;
+pub const ECGPU_TABLE_ADAPTIVE: c_int = 0;
+pub const ECGPU_TABLE_EAGER: c_int = 1;
 
 #[link(name = "ecgpu")]
 unsafe extern "C" {
@@ -51,6 +53,15 @@ unsafe extern "C" {
     pub fn ecgpu_dev_free(ctx: *mut EcgpuCtx, d_ptr: *mut c_void);
     pub fn ecgpu_copy_to_device(ctx: *mut EcgpuCtx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn ecgpu_copy_to_host(ctx: *mut EcgpuCtx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn ecgpu_set_table_policy(ctx: *mut EcgpuCtx, policy: c_int) -> c_int;
+    pub fn ecgpu_set_table_budget(ctx: *mut EcgpuCtx, max_table_bytes: usize) -> c_int;
+    pub fn ecgpu_base_table_info(
+        ctx: *mut EcgpuCtx,
+        curve: c_int,
+        window_bits: *mut c_int,
+        table_bytes: *mut usize,
+        build_ms: *mut f64,
+    ) -> c_int;
     pub fn ecgpu_set_base_window(ctx: *mut EcgpuCtx, curve: c_int, window_bits: c_int) -> c_int;
     pub fn ecgpu_set_msm_window(ctx: *mut EcgpuCtx, window_bits: c_int) -> c_int;
     pub fn ecgpu_set_async(ctx: *mut EcgpuCtx, on: c_int) -> c_int;
@@ -214,6 +225,7 @@ unsafe extern "C" {
     pub fn ecgpu_group_exchange(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_exchange_reason(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_set_msm_window(group: *mut EcgpuGroup, window_bits: c_int) -> c_int;
+    pub fn ecgpu_group_set_exchange_timeout(group: *mut EcgpuGroup, seconds: f64) -> c_int;
     pub fn ecgpu_group_msm(
         group: *mut EcgpuGroup,
         curve: c_int,

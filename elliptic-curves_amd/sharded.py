@@ -233,11 +233,18 @@ def init_exchange(torch, dist, local_device, prefer="nccl", probe=True):
         dist.all_gather_into_tensor(every, t, group=group)
         torch.cuda.synchronize()
         good = bool((every.view(-1, 1024)[:, 0].cpu() == torch.arange(1, dist.get_world_size() + 1, dtype=torch.uint8)).all())
+        if not good:
+            reason = "nccl group in the main process returned wrong bytes from its first all-gather"
     except Exception as e:                                           # raised errors only: a hang here is what the canary is for
         good, group, reason = False, None, "nccl group in the main process failed: %s" % str(e).splitlines()[0][:300]
     vote = torch.tensor([1 if good else 0], dtype=torch.int32)
     dist.all_reduce(vote, op=dist.ReduceOp.MIN)
     if int(vote.item()) != 1:
+        if group is not None:                                        # not to be used: do not leave it alive beside the gloo fallback
+            try:
+                dist.destroy_process_group(group)
+            except Exception:
+                pass
         return Exchange("gloo-fallback", reason if not good else "another rank's nccl group failed", None)
     return Exchange("rccl", reason, group)
 

@@ -125,11 +125,35 @@ void ecgpu_dev_free(ecgpu_ctx *ctx, void *d_ptr);
 int ecgpu_copy_to_device(ecgpu_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int ecgpu_copy_to_host(ecgpu_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
-/* Fixed-base window width for later ecgpu_batch_mul_base* calls on `curve` (4..26; defaults: k256 26 —
- * 9 additions per scalar over a 21.5 GB table —, p256 24 — 10 additions, 5.9 GB —, p384 20 — 1.0 GB; the table takes
- * ceil(bits/w) * 2^(w-1) * 2L bytes — 21.5 GB at 26 — plus at most 2 GB of scratch while it is built).
- * The table is rebuilt on next use. A tuning knob, like the reference's WINDOW_SIZE constants
- * (k256/src/arithmetic/tables.rs:12, p384/src/arithmetic/tables.rs:8). */
+/* ---- the generator (comb) tables and their footprint ----------------------------------------------------------------------
+ * `mul_by_generator` reads a precomputed table of multiples of G that lives in device memory, shared by all contexts of a device:
+ * ceil((bits - 1) / w) windows of 2^(w-1) affine entries (2L bytes each), w = the window width.  Wider tables mean fewer additions
+ * per scalar and more memory and build time — k256: 16 bits = 34 MB built in ~1 ms, 15 additions per scalar, 0.83 ms per 2^20
+ * scalars; 22 bits = 1.6 GB in ~6 ms, 11 additions, 0.73 ms; 26 bits = 21.5 GB in ~55 ms, 9 additions, 0.61 ms (measured: profiles/r05/table_tiers.txt, crossover batch sizes in
+ * INTEGRATION.md).  The reference makes the same trade with its WINDOW_SIZE constants and builds lazily
+ * (k256/src/arithmetic/mul.rs:191-192 prices a table half the size at 3 %; primeorder/src/tables/basepoint.rs:29-76).
+ *
+ * Default (ECGPU_TABLE_ADAPTIVE): the width follows the number of generator multiplications the DEVICE has been asked for so far,
+ * the call being served included: 16 bits below 2^26, 22 bits below 2^29, then the curve's widest (k256 26, p256 / sm2 / the
+ * other 256- and 224- / 192-bit sets 24, p384 / p521 / bp384 20) — each step where the time lost to the narrower table so far equals
+ * the build time of the next one, so a caller never pays more than twice the best fixed choice and a 1,024-scalar call never
+ * allocates gigabytes.  A step up costs the calling thread the build once; the narrower table is freed when its last user lets go.
+ * ECGPU_TABLE_EAGER: the widest table at the first call (a long-lived service: pay 65 ms once at start-up).
+ * A table that does not fit is replaced by one two bits narrower, down to 16 bits, before ECGPU_ERR_OOM is returned. */
+enum { ECGPU_TABLE_ADAPTIVE = 0, ECGPU_TABLE_EAGER = 1 };
+int ecgpu_set_table_policy(ecgpu_ctx *ctx, int policy);
+
+/* No comb table built for this context from now on takes more than max_table_bytes of device memory (0 = no limit, the default): the
+ * width is lowered until the table fits the budget.  Tables already in use are kept until the next call on their curve. */
+int ecgpu_set_table_budget(ecgpu_ctx *ctx, size_t max_table_bytes);
+
+/* The comb table `curve` uses on this context right now: its window width (0 = none built yet), its bytes of device memory and
+ * the wall time its construction took (whichever context of the device paid it).  Any of the three pointers may be NULL. */
+int ecgpu_base_table_info(ecgpu_ctx *ctx, int curve, int *window_bits, size_t *table_bytes, double *build_ms);
+
+/* Pins the width for later generator multiplications on `curve` to exactly window_bits (4..26), whatever the policy and the
+ * budget; 0 returns the curve to the policy.  The table is rebuilt on next use.  A tuning knob, like the reference's WINDOW_SIZE
+ * constants (k256/src/arithmetic/tables.rs:12, p384/src/arithmetic/tables.rs:8). */
 int ecgpu_set_base_window(ecgpu_ctx *ctx, int curve, int window_bits);
 
 /* Pippenger window width c for later ecgpu_msm* calls (4..16), 0 = choose from n (default). */
@@ -285,6 +309,12 @@ const char *ecgpu_group_exchange(const ecgpu_group *group);         /* "rccl" or
  * group whose RCCL exchange fails at run time falls back to peer copies for that call and all later ones */
 const char *ecgpu_group_exchange_reason(const ecgpu_group *group);
 int ecgpu_group_set_msm_window(ecgpu_group *group, int window_bits);
+/* The exchange step of ecgpu_group_msm* never waits longer than this (default 10 s; seconds > 0): every member polls its exchange
+ * stream against the deadline instead of blocking on it.  A collective that fails on any member, or has not completed by then
+ * (the way RCCL has failed on this hardware is a hang, not an error code), is given up — communicators aborted (ncclCommAbort),
+ * fresh exchange streams — and the call completes over peer copies, as do all later calls; ecgpu_group_exchange_reason reports it.
+ * ECGPU_ERR_HIP only if the peer copies miss the deadline too. */
+int ecgpu_group_set_exchange_timeout(ecgpu_group *group, double seconds);
 /* `lincomb` over all GPUs of the group, host buffers (every GPU uploads its own shard over its own PCIe link). */
 int ecgpu_group_msm(ecgpu_group *group, int curve, const uint8_t *scalars, const uint8_t *points_xy,
                     const uint8_t *points_inf, size_t n, uint8_t *out_xy, uint8_t *out_inf);

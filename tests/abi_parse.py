@@ -8,7 +8,10 @@ C_TO_RUST = {
     "void": None,
     "int": "c_int",
     "size_t": "usize",
+    "double": "f64",
     "double *": "*mut f64",
+    "int *": "*mut c_int",
+    "size_t *": "*mut usize",
     "uint8_t *": "*mut u8",
     "const uint8_t *": "*const u8",
     "void *": "*mut c_void",

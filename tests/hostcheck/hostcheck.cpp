@@ -392,7 +392,7 @@ int msm(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, const u
     int seg = nb < 32 ? (int)nb : 32;
     size_t nseg = nb / seg;
     std::vector<Affine<C>> pts(ne);
-    std::vector<uint32_t> ranks((size_t)nwin * ne), sorted((size_t)nwin * ne + 4), counts((size_t)nwin * nb, 0),
+    std::vector<uint32_t> ranks((size_t)nwin * ne), sorted((size_t)nwin * ne + 16), counts((size_t)nwin * nb, 0),
         offsets((size_t)nwin * nb);
     std::vector<uint8_t> finite(n, 0);
     std::vector<std::array<std::array<uint32_t, S::KW>, S::SUB>> subs(n);

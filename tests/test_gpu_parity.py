@@ -1,6 +1,8 @@
 """-m gpu parity tests: the HIP path, called through the C ABI (ctypes -> libecgpu.so), compared
 bit-for-bit with (1) the reference's golden vectors in tests/golden/, (2) the oracle on the same
 seeded inputs, and (3) at BASELINE sizes, size-independent group identities."""
+import os
+
 import numpy as np
 import pytest
 
@@ -125,7 +127,7 @@ def test_fixed_base_vs_oracle(eng, curve, window):
     want, winf = oracle_lib.batch_mul_base(c.cid, scal)
     assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
     assert inf[0] == 1 and not out[: 2 * c.L].any()          # k = 0 -> identity encoding
-    eng.set_base_window(c.cid, {"k256": 26, "p256": 24, "p384": 20, "sm2": 24, "p224": 24, "p192": 24, "p521": 20, "bp256": 24, "bp384": 20, "bp256t1": 24, "bp384t1": 20}[curve])        # back to the defaults
+    eng.set_base_window(c.cid, 0)        # un-pinned: back to the table policy
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
@@ -1592,3 +1594,53 @@ def test_timing_events_can_be_switched_off(eng):
         eng.set_timing(True)
         for b in (d_o, d_f, d_k):
             b.free()
+
+
+@pytest.mark.parametrize("fault,devices", [(1, [0, 0, 0]), (2, [0, 0]), (3, [0, 0]), (3, [0])])
+def test_group_exchange_never_hangs_the_caller(eng, fault, devices):
+    """The exchange step of ecgpu_group_msm has a deadline (ecgpu_group_set_exchange_timeout).  Fault injection through the exported
+    test hook ecgpu_testhook_group_exchange (not in include/ecgpu.h): 1 = the collective's enqueue fails on member 0 while the other
+    members' collectives are in flight and can never complete (the partial failure), 2 = it fails everywhere, 3 = it is enqueued
+    everywhere and never completes — the way RCCL has actually failed on this pool.  Every time the call must RETURN, with the bytes
+    of the single-context MSM, having fallen back to peer copies on fresh streams, say so in exchange_reason, and stay healthy for the
+    next call."""
+    import ctypes
+    import time
+    ecgpu = ecgpu_module()
+    hook = ecgpu.load_library().ecgpu_testhook_group_exchange
+    hook.restype, hook.argtypes = None, [ctypes.c_int]
+    c = pyec.CURVES["k256"]
+    n = (1 << 15) + 77
+    k = rand_scalars(c.cid, n, 0xEC0031F7 + fault)
+    pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xEC0032F7 + fault))
+    want, wf = eng.lincomb(c.cid, k, pts)
+    grp = ecgpu.Group(devices)
+    try:
+        grp.set_exchange_timeout(1.5)
+        hook(fault)
+        t0 = time.perf_counter()
+        got, gf = grp.lincomb(c.cid, k, pts)
+        dt = time.perf_counter() - t0
+        hook(0)
+        assert bytes(got) == bytes(want) and gf == wf
+        assert grp.exchange == "peer" and "ncclAllGather" in grp.exchange_reason, grp.exchange_reason
+        if fault == 3:
+            assert "did not complete" in grp.exchange_reason and 1.0 < dt < 20.0, (dt, grp.exchange_reason)
+        else:
+            assert "failed" in grp.exchange_reason and dt < 10.0, (dt, grp.exchange_reason)      # (no wait for the deadline)
+        got, gf = grp.lincomb(c.cid, k, pts)                      # the group goes on over peer copies
+        assert bytes(got) == bytes(want) and gf == wf
+    finally:
+        hook(0)
+        grp.close()
+
+
+def test_generator_table_policy_budget_and_pinning():
+    """include/ecgpu.h "the generator (comb) tables and their footprint", checked in a process of its own (the tables and the count
+    of multiplications seen are per device and process: other tests' contexts would be part of the picture):
+    tests/gpu_table_policy_check.py."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_table_policy_check.py")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A second build of libecgpu.so for A/B measurements (tools/gpu_r04{q,w,y}.sh load it through ECGPU_TOOL_LIB): the named
+# A second build of libecgpu.so for A/B measurements (the `ab:` recipe of tools/gpu_run.sh loads it through ECGPU_TOOL_LIB): the named
 # translation units are recompiled with extra flags into elliptic-curves_amd/build_alt/, everything else is linked from the main
 # build.      bash tools/build_alt_lib.sh <suffix> "<extra hipcc flags>" <group>_<Curve> [...]
 #   bash tools/build_alt_lib.sh nofused "-DECGPU_FUSED_SUB=0" var_P256Params var_P384Params        -> lib/libecgpu_nofused.so

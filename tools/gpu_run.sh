@@ -11,7 +11,15 @@
 #   benchall              the default bench line (all four GPU configs as sub-records) with --check
 #   prof:<workload>       rocprofv3 --kernel-trace --stats of bench.py --workload W  -> prof_<W>/ + kernel_stats summary
 #   pmc:<workload>        three rocprofv3 --pmc passes (VALU counters, FETCH_SIZE, WRITE_SIZE) of bench.py --workload W
+#   env:<VAR=VAL>[,<VAR=VAL>...]:<workload>[:<log2 n>]   the same alternation with environment knobs (ECGPU_MSM_CHUNK=88 ...) instead
+#                         of a second library
+#   libtest:<suffix>:<expr>   pytest -m gpu -k <expr> (+ for spaces) on lib/libecgpu_<suffix>.so (a build variant under test)
+#   san:<asan|tsan>       the host-heavy GPU tests (pipelined host-pointer calls, MSM lanes, asynchronous mode, the group entry points and
+#                         its exchange deadline, the table registry) on lib/libecgpu_<kind>.so (make -C elliptic-curves_amd asan tsan):
+#                         sanitizer runtime preloaded, reports in san_<kind>.log
 #   sweep:<script>        bash tools/<script>.sh
+#   ab:<suffix>:<workload>[:<log2 n>]   same-box A/B of lib/libecgpu_<suffix>.so (tools/build_alt_lib.sh) against the default
+#                         build, alternating default / alt / default / alt: ms per step, check, dominant kernel, stage times
 #   py:<file>             python <file>  (a one-off measurement script under tools/)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -60,6 +68,42 @@ for recipe in "$@"; do
       done
       python tools/pmc_summary.py pmc "$OUT" "$w" | tee "$OUT/pmc_summary_$w.txt"
       find "$OUT" -name "*.db" -delete; find "$OUT" -name "*counter_collection.csv" -size +2M -delete ;;
+    ab)
+      IFS=: read -r suffix w lg <<< "$arg"
+      nflag=""; [ -n "${lg:-}" ] && nflag="--n $((1 << lg))"
+      for v in default "$suffix" default "$suffix"; do
+        if [ "$v" = default ]; then unset ECGPU_TOOL_LIB; else export ECGPU_TOOL_LIB=$ROOT/elliptic-curves_amd/lib/libecgpu_$suffix.so; fi
+        timeout 600 python bench.py --only "$w" $nflag --steps "${AB_STEPS:-10}" --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+r = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('== $w ${lg:-} $v', round(r['ms_per_step'], 4), r.get('check_vs_oracle'), 'kernel_ms', round(r['roofline']['kernel_ms'], 4), {k: round(x, 3) for k, x in (r.get('stage_ms') or {}).items()})"
+      done 2>&1 | tee -a "$OUT/ab_${suffix}.txt"
+      unset ECGPU_TOOL_LIB ;;
+    env)
+      IFS=: read -r kv w lg <<< "$arg"
+      nflag=""; [ -n "${lg:-}" ] && nflag="--n $((1 << lg))"
+      for v in default knob default knob; do
+        pre=""; [ "$v" = knob ] && pre="env ${kv//,/ }"
+        timeout 600 $pre python bench.py --only "$w" $nflag --steps "${AB_STEPS:-10}" --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+r = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('== $w ${lg:-} $v $kv', round(r['ms_per_step'], 4), r.get('check_vs_oracle'), 'kernel_ms', round(r['roofline']['kernel_ms'], 4), {k: round(x, 3) for k, x in (r.get('stage_ms') or {}).items()})"
+      done 2>&1 | tee -a "$OUT/env_knobs.txt" ;;
+    libtest)
+      IFS=: read -r suffix expr <<< "$arg"
+      ECGPU_TOOL_LIB=$ROOT/elliptic-curves_amd/lib/libecgpu_$suffix.so timeout 1700 python -m pytest tests -m gpu -q -x -k "${expr//+/ }" \
+        -p no:cacheprovider > "$OUT/libtest_$suffix.txt" 2>&1; tail -6 "$OUT/libtest_$suffix.txt" ;;
+    san)
+      RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.$arg-x86_64.so
+      # asan: the distribution's runtimes (ROCm's libclang_rt.asan aborts inside its hsa_amd_memory_pool_allocate interceptor here)
+      [ "$arg" = asan ] && RT="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+      SEL="pipelined or lanes or asynchronous or group_multi or group_exchange or host_pointer_msm_in_chunks or uniform_schedule_device_resident or comb_table_falls_back"
+      LD_PRELOAD=$RT ECGPU_TOOL_LIB=$ROOT/elliptic-curves_amd/lib/libecgpu_$arg.so \
+        ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:halt_on_error=0:log_path=$OUT/san_asan_report UBSAN_OPTIONS=print_stacktrace=1 \
+        TSAN_OPTIONS="halt_on_error=0 second_deadlock_stack=1 suppressions=$ROOT/tools/tsan_hip_runtime.supp log_path=$OUT/san_tsan_report" \
+        timeout 1500 python -m pytest tests -m gpu -q -k "$SEL" -p no:cacheprovider > "$OUT/san_$arg.log" 2>&1
+      tail -8 "$OUT/san_$arg.log"; ls "$OUT" | grep -c "san_${arg}_report" || true
+      python tools/san_summary.py "$OUT" "$arg" | tee "$OUT/san_${arg}_summary.txt" ;;
     sweep) timeout 1500 bash "tools/$arg.sh" 2>&1 | tee "$OUT/sweep_$arg.txt" | tail -40 ;;
     py) timeout 1500 python "$arg" 2>&1 | tee "$OUT/py_$(basename "$arg" .py).txt" | tail -60 ;;
     *) echo "unknown recipe $recipe" ;;

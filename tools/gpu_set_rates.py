@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rates of one parameter set (2^20 units per call, device-resident inputs): fixed base, variable base, MSM.
     python tools/gpu_set_rates.py <name> [<name> ...]       names: k256 p256 p384 sm2 p224 p192 p521 bp256 bp384 bp256t1 bp384t1 bign256
-ECGPU_TOOL_LIB=<path of another build of libecgpu.so> measures that build instead (before / after comparisons on one box)."""
+ECGPU_TOOL_LIB=<lib/libecgpu_<suffix>.so of tools/build_alt_lib.sh> measures that build instead (before / after comparisons on one box)."""
 import importlib
 import os
 import sys
@@ -13,8 +13,6 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ec = importlib.import_module("elliptic-curves_amd")
 from gpu_common import rand_scalars  # noqa: E402
 
-if os.environ.get("ECGPU_TOOL_LIB"):
-    ec.LIB_PATH = os.path.abspath(os.environ["ECGPU_TOOL_LIB"])
     print("library: %s" % ec.LIB_PATH)
 
 e = ec.Engine(0)
