@@ -1064,7 +1064,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     if ((rc = ensure_table<C>(ctx, n)) != ECGPU_OK) return rc;
     if (n == 0) return (int)ECGPU_OK;
     size_t tstride = var_base_slots<C>(n);
-    if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
+    if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_u1, n * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_u2, n * L)) != ECGPU_OK) return rc;
@@ -1076,7 +1076,6 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     const Table& t = ctx->table[C::ID];
     uint32_t* pa = (uint32_t*)ctx->proj.p;
-    uint32_t* pb = pa + n * 3 * NS;
     uint8_t *u1 = (uint8_t*)ctx->ec_u1.p, *u2 = (uint8_t*)ctx->ec_u2.p, *q = (uint8_t*)ctx->ec_q.p;
     uint8_t* valid = (uint8_t*)ctx->ec_valid.p;
     record(ctx, 0);
@@ -1099,8 +1098,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
                                 (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
     record(ctx, 3);
     launch_fixed_base<C>(ctx->stream, u1, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
-    launch_var_base<C>(ctx->stream, u2, q, nullptr, n, (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
-    launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+    launch_var_base<C>(ctx->stream, u2, q, nullptr, n, (uint32_t*)ctx->vtab.p, tstride, nullptr, ctx->d_status, pa);   // pa[i] += u2[i] Q[i]
     record(ctx, 1);
     if ((rc = normalize_out<C>(ctx, n, mode == VERIFY_RECOVER ? d_out_xy : ctx->ec_xy.p, ctx->ec_inf.p)) != ECGPU_OK) return rc;
     if (mode == VERIFY_RECOVER)
@@ -1581,17 +1579,15 @@ int ecgpu_batch_mul_base_and_mul_add_dev(ecgpu_ctx* ctx, int curve, const void* 
         if ((rc = ensure_table<C>(ctx, n)) != ECGPU_OK) return rc;
         if (n == 0) return (int)ECGPU_OK;
         size_t tstride = var_base_slots<C>(n);
-        if ((rc = ensure(ctx, ctx->proj, 2 * n * 3 * NS * 4)) != ECGPU_OK) return rc;
+        if ((rc = ensure(ctx, ctx->proj, n * 3 * NS * 4)) != ECGPU_OK) return rc;
         if ((rc = ensure(ctx, ctx->vtab, tstride * var_base_tab_words<C>() * 4)) != ECGPU_OK) return rc;
         if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
         const Table& t = ctx->table[C::ID];
         uint32_t* pa = (uint32_t*)ctx->proj.p;
-        uint32_t* pb = pa + n * 3 * NS;
-        record(ctx, 0);
+            record(ctx, 0);
         launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_a, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
         launch_var_base<C>(ctx->stream, (const uint8_t*)d_b, (const uint8_t*)d_points_xy, (const uint8_t*)d_points_inf, n,
-                           (uint32_t*)ctx->vtab.p, tstride, pb, ctx->d_status);
-        launch_proj_add_pairs<C>(ctx->stream, pa, (const uint32_t*)pb, n);
+                           (uint32_t*)ctx->vtab.p, tstride, nullptr, ctx->d_status, pa);                                   // pa[i] += b[i] P[i]
         record(ctx, 1);
         if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) return rc;
         record(ctx, 2);

@@ -72,9 +72,6 @@ template <> void launch_proj_sum<CurveT>(hipStream_t s, uint32_t* a, size_t n, u
     }
     if (src != a) (void)hipMemcpyAsync(a, src, 3 * Field<CurveT>::NS * 4, hipMemcpyDeviceToDevice, s);
 }
-template <> void launch_proj_add_pairs<CurveT>(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n) {
-    hipLaunchKernelGGL(k_proj_add_pairs<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, pa, pb, n);
-}
 template <> void launch_ecdsa_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                               const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2,
                                               uint8_t* q_out, uint8_t* valid) {

@@ -471,14 +471,4 @@ __global__ void __launch_bounds__(BLOCK) k_proj_sum_level(const uint32_t* __rest
     if (threadIdx.x == 0) store_proj<C>(out, blockIdx.x, acc);
 }
 
-// pa[i] = pa[i] + pb[i]
-template <class C>
-__global__ void __launch_bounds__(BLOCK) k_proj_add_pairs(uint32_t* pa, const uint32_t* pb, size_t n) {
-    using G = Group<C>;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Fe<C::NL> b = G::curve_b();
-    store_proj<C>(pa, i, G::add(load_proj<C>(pa, i), load_proj<C>(pb, i), b));
-}
-
 }  // namespace ecgpu

@@ -53,7 +53,6 @@ template <class C> void launch_fixed_base(hipStream_t s, const uint8_t* scalars,
 template <class C> void launch_load_proj(hipStream_t s, const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status);
 template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
                                          int* status);
-template <class C> void launch_proj_add_pairs(hipStream_t s, uint32_t* pa, const uint32_t* pb, size_t n);
 // a[0] = sum of the n projective points a[0..n) (a is clobbered; tmp holds ceil(n / 256) points)
 template <class C> void launch_proj_sum(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp);
 template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
@@ -89,7 +88,8 @@ template <class C> void launch_selftest_point(hipStream_t s, int op, const uint8
 template <class C> size_t var_base_slots(size_t n);     // table slots (threads) the launch will use
 template <class C> size_t var_base_tab_words();         // 32-bit words of table scratch per slot
 template <class C> void launch_var_base(hipStream_t s, const uint8_t* scalars, const uint8_t* xy, const uint8_t* inf,
-                                        size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status);
+                                        size_t n, uint32_t* tab, size_t slots, uint32_t* proj_out, int* status,
+                                        uint32_t* add_io = nullptr);      // add_io[i] += k[i] P[i] in place instead of proj_out[i] = k[i] P[i]
 
 // ---- group "ct": uniform-schedule variants (ecgpu_ct.h); flags: n bytes of scratch (one verdict byte per element) ----
 template <class C> int ct_base_luts();                  // generator LUTs: one per 6-bit window (CT_BASE_W), 32 affine entries each: lut i = {e * 2^(6 i) * G, e = 1..32}

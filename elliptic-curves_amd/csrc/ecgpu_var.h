@@ -36,7 +36,7 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
            const uint8_t* __restrict__ points_inf, size_t n, uint32_t* __restrict__ tab, size_t tstride,
-           uint32_t* __restrict__ proj_out, int* status) {
+           uint32_t* __restrict__ proj_out, int* status, uint32_t* __restrict__ add_io) {
     using G = Group<C>;
     constexpr int N = C::N, NL = C::NL;
     const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // < tstride
@@ -47,6 +47,14 @@ k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poin
         load_scalar<C>(k, scalars, i, status);
         Affine<C> a;
         bool finite = load_affine<C>(&a, points_xy, points_inf, i, b, status);
+        // add_io: the verification shape a G + b P (`mul_by_generator_and_mul_add_vartime`, primeorder/src/mul_backend.rs:29-40,
+        // k256/src/arithmetic/mul.rs:303-310 — one loop in the reference): a G is in add_io[i] already (k_fixed_base), the product is
+        // added to it in place — no launch of its own for the addition, no second projective array through HBM
+        if (add_io) {
+            const Proj<C> ag = load_proj<C>(add_io, i);
+            store_proj<C>(add_io, i, finite ? G::add(ag, var_base_mul<C>(a, k, b, io), b) : ag);
+            continue;
+        }
         if (!finite) {
             store_proj<C>(proj_out, i, G::identity());
             continue;

@@ -536,7 +536,7 @@ int msm_plain(int c, size_t chunk, const uint8_t* scalars, const uint8_t* pxy, c
 }
 
 // ---- the verification / decompression kernels' per-element logic (ecgpu_verify.h) around the CPU mirrors of the
-// fixed-base and variable-base kernels: k_ecdsa_prepare -> k_fixed_base + k_var_base + k_proj_add_pairs -> k_normalize ->
+// fixed-base and variable-base kernels: k_ecdsa_prepare -> k_fixed_base + k_var_base (which adds its product to the fixed-base one) -> k_normalize ->
 // k_ecdsa_finish, element by element
 template <class C>
 bool sum_affine_x(const BaseTable<C>& table, const uint32_t* a, const uint32_t* b, const uint32_t* cx, const uint32_t* cy,

@@ -35,13 +35,15 @@ KERNELS = {
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
     "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
 }
+# per-group compile flags of elliptic-curves_amd/Makefile (FLAGS_var / FLAGS_msm: the k256 reduction as assembly blocks)
+GROUP_FLAGS = {"var": ["-DECGPU_K256_ASM_REDUCE=1"], "msm": ["-DECGPU_K256_ASM_REDUCE=1"]}
 HALF_SLOT_EXCEPT = ("_co_",)          # carry-producing / -consuming VOP2 ops were measured at the full cost
 
 def isa_histogram(group, curve, substr):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-DECGPU_CURVE=" + curve, "-S",
-                               "--cuda-device-only", "-o", out, os.path.join(CSRC, "ecgpu_inst_%s.hip" % group)],
+                               "--cuda-device-only", "-o", out, os.path.join(CSRC, "ecgpu_inst_%s.hip" % group)] + GROUP_FLAGS.get(group, []),
                               stderr=subprocess.DEVNULL)
         txt = open(out).read()
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)s_endpgm", txt, re.S | re.M):
@@ -51,7 +53,8 @@ def isa_histogram(group, curve, substr):
         c = collections.Counter(ops)
         total = sum(c.values())
         # (inline-asm instructions print without an encoding suffix: the v_cmp / v_cndmask of ecgpu_ctmul.h are 32-bit encodings)
-        half = sum(v for k, v in c.items() if (k.endswith("_e32") or k in ("v_cndmask_b32", "v_cmp_ne_u32"))
+        # (... and the masks / moves / 32-bit adds of the k256 reduction blocks, ecgpu_k256_reduce_asm.h)
+        half = sum(v for k, v in c.items() if (k.endswith("_e32") or k in ("v_cndmask_b32", "v_cmp_ne_u32", "v_and_b32", "v_mov_b32", "v_add_u32"))
                    and not any(x in k for x in HALF_SLOT_EXCEPT))
         mad = sum(v for k, v in c.items() if k.startswith("v_mad_u64_u32"))
         return {"static_valu": total, "slots_per_inst": (total - half / 2) / total, "mad_share": mad / total,
