@@ -44,6 +44,24 @@ __device__ __forceinline__ void load_words_vec(uint32_t* dst, const uint32_t* sr
         for (int i = 0; i < NW; i++) dst[i] = src[i];
     }
 }
+// The same as exactly NW / 4 aligned 16-byte loads, for data that is used at once (the table-entry gather of k_fixed_base): every
+// loaded quad passes through an empty asm statement as four live registers, so the compiler cannot re-cut the record.  Left to
+// itself it turned the 64-byte entry into seven overlapping loads at 8-byte offsets once the k256 reduction's register window
+// (ecgpu_k256_reduce_asm.h) changed the allocation around it.  (The wait for the data sits at the asm statement: not for loads
+// that are meant to stay in flight, like the accumulation loop's prefetch.)
+template <int NW>
+__device__ __forceinline__ void load_words_vec_exact(uint32_t* dst, const uint32_t* src) {
+    static_assert(NW % 4 == 0, "whole 16-byte pieces");
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4 v[NW / 4];
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) v[i] = s[i];
+#pragma unroll
+    for (int i = 0; i < NW / 4; i++) {
+        asm volatile("" : "+v"(v[i].x), "+v"(v[i].y), "+v"(v[i].z), "+v"(v[i].w));
+        dst[4 * i] = v[i].x; dst[4 * i + 1] = v[i].y; dst[4 * i + 2] = v[i].z; dst[4 * i + 3] = v[i].w;
+    }
+}
 template <int NW>
 __device__ __forceinline__ void store_words_vec(uint32_t* dst, const uint32_t* src) {
     if constexpr (NW % 4 == 0) {
@@ -384,7 +402,8 @@ struct BaseTableHbm {
     const uint32_t* table;    // [nwin][2^(w-1)][2] packed elements
     size_t half;
     __device__ void load(PackedPoint<2 * C::N>& p, int window, uint32_t index) const {
-        load_words_vec<2 * C::N>(p.w, table + ((size_t)window * half + index) * (2 * C::N));
+        if constexpr ((2 * C::N) % 4 == 0) load_words_vec_exact<2 * C::N>(p.w, table + ((size_t)window * half + index) * (2 * C::N));
+        else load_words_vec<2 * C::N>(p.w, table + ((size_t)window * half + index) * (2 * C::N));
     }
 };
 // (k256: three workgroups per CU = 156 registers; compiled for four — 128 registers — the kernel spills 340 bytes per lane)

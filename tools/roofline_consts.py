@@ -36,7 +36,7 @@ KERNELS = {
     "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
 }
 # per-group compile flags of elliptic-curves_amd/Makefile (FLAGS_var / FLAGS_msm: the k256 reduction as assembly blocks)
-GROUP_FLAGS = {"var": ["-DECGPU_K256_ASM_REDUCE=1"], "msm": ["-DECGPU_K256_ASM_REDUCE=1"]}
+GROUP_FLAGS = {"base": ["-DECGPU_K256_ASM_REDUCE=1"], "var": ["-DECGPU_K256_ASM_REDUCE=1"], "msm": ["-DECGPU_K256_ASM_REDUCE=1"]}
 HALF_SLOT_EXCEPT = ("_co_",)          # carry-producing / -consuming VOP2 ops were measured at the full cost
 
 def isa_histogram(group, curve, substr):
