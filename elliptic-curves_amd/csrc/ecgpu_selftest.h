@@ -11,7 +11,9 @@
 namespace ecgpu {
 
 // field: 0 a + b, 1 a - b, 2 a * b, 3 a^2, 4 1/a (division steps; 0 -> 0), 5 -a, 7 2a, 8 pack/unpack of the lazy value
-// 2a + b, 9 the fused a*b - (a + b)*b, 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain of lazily reduced
+// 2a + b, 9 the fused a*b - (a + b)*b, 15 (k256) 7 a * b + 6 a * b with BOTH operands lazy at the largest limb magnitudes a product
+// takes (7 x 1 and 3 x 2 + 1 x 1), reduced by the assembly blocks AND by the compiler's k_reduce from the same columns: the nine
+// limbs must agree, else the record is all ones; 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain of lazily reduced
 // operations at the magnitudes the point formulas use, 20 a through the wire -> words -> wire conversion only, 21 a through
 // the internal domain and back.  Inputs must be canonical (< p), else ST_BAD_POINT.
 template <class C>
@@ -53,6 +55,36 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
     case 14:                                   // (x + y)^2 - 5 y: F::sqr_sub with a lazy operand and the largest subtrahend in use
         if constexpr (C::REPR == REPR_U29_K256) F::to_canonical(wr, F::sqr_sub(F::add(x, y), F::add(y, F::dbl(F::dbl(y)))));
         else F::to_canonical(wr, F::norm(F::sub(F::sqr(F::norm(F::add(x, y))), F::add(y, F::dbl(F::dbl(y))))));
+        break;
+    case 15:
+        if constexpr (C::REPR == REPR_U29_K256) {
+            const auto x2 = F::dbl(x);                                  // limb magnitudes 2, 3, 7
+            const auto x3 = F::add(x2, x);
+            const auto x7 = F::add(F::add(x3, x3), x);
+            const auto y2 = F::dbl(y);
+            uint64_t c1[17], c2[17];
+            bool same = true;
+            // 7 x * y: one product at the limit of a column (magnitude product 7)
+            F::k_columns(c1, x7.e.v, y.e.v, false);
+#pragma unroll
+            for (int t = 0; t < 17; t++) c2[t] = c1[t];
+            const auto r1 = F::k_reduce(c1), r2 = F::k_reduce_cpp(c2);
+            // 3 x * 2 y + x * y = 7 x y as two products under one reduction (mul2's shape: 6 + 1)
+            F::k_columns(c1, x3.e.v, y2.e.v, false);
+            F::k_columns(c1, x.e.v, y.e.v, true);
+#pragma unroll
+            for (int t = 0; t < 17; t++) c2[t] = c1[t];
+            const auto r3 = F::k_reduce(c1), r4 = F::k_reduce_cpp(c2);
+#pragma unroll
+            for (int t = 0; t < 9; t++) same = same && r1.v[t] == r2.v[t] && r3.v[t] == r4.v[t];
+            F::to_canonical(wr, F::add(F::template wrap<1, 1>(r1), F::template wrap<1, 1>(r3)));                 // 14 x y
+            if (!same) {
+#pragma unroll
+                for (int t = 0; t < N; t++) wr[t] = 0xFFFFFFFFu;
+            }
+        } else {
+            F::to_canonical(wr, F::mul(x, y));
+        }
         break;
     case 11: {
         bool root;

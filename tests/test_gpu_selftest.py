@@ -66,6 +66,13 @@ def test_device_field_ops_vs_bigint_and_oracle(eng, curve):
             14: [((a + b) ** 2 - 5 * b) % p for a, b in zip(vals, other)]}       # a^2 - c (k256: F::sqr_sub)
     for op, w in want.items():
         assert ints(c, eng.selftest_field(c.cid, op, A, B)) == w, (curve, op)
+    if curve == "k256":
+        # the reduction in assembly (csrc/ecgpu_k256_reduce_asm.h) against the compiler's rendering of the same function, from the same
+        # product columns, on lazy operands at the largest limb magnitudes (7 x 1, and 3 x 2 + 1 x 1 under one reduction): the device
+        # compares the nine limbs (a mismatch comes back as all-ones bytes), the value is checked here
+        adv = edge_values(c) + [p - 1 - k for k in range(40)] + [(1 << 256) - 1 - (1 << 33) - (k << 40) for k in range(8)] + vals[:2000]
+        advo = [adv[(i * 7 + 3) % len(adv)] for i in range(len(adv))]
+        assert ints(c, eng.selftest_field(c.cid, 15, fe(c, adv), fe(c, advo))) == [14 * a * b % p for a, b in zip(adv, advo)]
     assert ints(c, eng.selftest_field(c.cid, 3, A)) == [a * a % p for a in vals]
     assert ints(c, eng.selftest_field(c.cid, 5, A)) == [(-a) % p for a in vals]
     assert ints(c, eng.selftest_field(c.cid, 7, A)) == [2 * a % p for a in vals]

@@ -75,14 +75,14 @@ print()
 print("what is left, in the kernel's own terms:")
 print("  (a) the executed code is %.1f %% above the by-construction floor: register moves (%d static v_mov_b32) and the operand" % (
     100 * (meas_slots / floor_slots - 1), top["v_mov_b32_e32"]))
-print("      marshalling of 64-bit accumulator pairs; a hand-scheduled field layer at the floor would save at most that")
+print("      marshalling of 64-bit accumulator pairs outside the reductions (round 5 wrote the REDUCTION by hand, csrc/ecgpu_k256_reduce_asm.h:")
+print("      round 4 stood at +10.5 % with 370 moves; what is left sits in the affine + affine addition, the conversions and the recoding)")
 print("  (b) the kernel issues in %.0f %% of its cycles; the gather-free ladders reach 90 %%.  The difference is the 10 random 64-byte" % (
     100 * rc["insts_valu"] * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * SIMDS)))
-print("      gathers per scalar from a 21.5 GB table (measured: 2^20 copies of ONE scalar run 12 %% faster at every table size,")
+print("      gathers per scalar from a 21.5 GB table (measured: 2^20 copies of ONE scalar run 12 % faster at every table size,")
 print("      DESIGN.md section 8); narrower tables need more additions and lose more (W = 16: +45 %)")
 best = kernel_ms * floor_slots / meas_slots
 print("  kernel with (a) closed completely: %.3f ms; with (a) and the gathers free: %.3f ms" % (
     best, best * (rc["insts_valu"] * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * SIMDS)) / util_best))
-print("  step = kernel + k_normalize (0.124 ms: one inversion per lane, latency-bound; the workgroup-shared inversion of round 4")
-print("  measured 0.121-0.133, profiles/r04/normalize_wg_dead_end.txt): %.3f ms with (a) closed — the 0.61 ms target sits at the" % (best + 0.124))
-print("  by-construction floor of this design, i.e. it needs the whole field layer in hand-written assembly AND nothing else lost")
+print("  step = kernel + k_normalize (0.121 ms: one inversion per lane, latency-bound; the workgroup-shared inversion of round 4")
+print("  measured 0.121-0.133, profiles/r04/normalize_wg_dead_end.txt): %.3f ms with (a) closed; measured step 0.613-0.626 ms" % (best + 0.121))

@@ -40,15 +40,16 @@ print()
 print("by construction, issue slots per addition:  mixed XYZZ addition %.0f + point unpacking %.0f + loop %.0f = %.0f" % (madd, unpack, loop, floor_slots))
 print("measured: %.0f VALU instructions x %.4f slots = %.0f slots per addition  (%.1f %% above the floor)" % (
     meas_insts, rc["slots_per_inst"], meas_slots, 100 * (meas_slots / floor_slots - 1)))
-print("  static ISA of the loop body (hipcc -S): 1,673 instructions, 1,071 of them v_mad_u64_u32 (8 x 81 + 2 x 45 products, 9 reductions of 36, 27 for the")
-print("  folded differences), 96 v_mov_b32; the exit path of a lane that leaves a bucket is four stores")
+print("  static ISA of the mixed addition (tools/k256_madd_isa_diff.py, profiles/r05/k256_madd_isa_diff.txt): 1,504 instructions, 1,071 of them")
+print("  v_mad_u64_u32 (8 x 81 + 2 x 45 products, 9 reductions of 34, 27 for the folded differences), 27 v_mov_b32 (round 4: 1,629 / 91): the")
+print("  reduction is a hand-scheduled assembly block (csrc/ecgpu_k256_reduce_asm.h); a step's stores and loads are all issued at its head")
 print()
 print("time at 100 %% issue (1024 SIMDs, one slot per 4 cycles, 2.4 GHz):  floor %.2f ms, executed code %.2f ms" % (t_floor, t_meas))
 print("measured kernel %.2f ms  ->  issue utilisation %.2f at 2.4 GHz (frac), %.2f of the cycles the chip had (frac_cycles_pmc)" % (kernel_ms, t_meas / kernel_ms, cyc))
 print()
-print("what was tried on the gap (DESIGN.md section 8): four waves per SIMD instead of three (128 registers + scratch: +10 %), scheduler")
-print("strategies of the compiler (max-ilp, iterative-minreg, no machine scheduler: 1,666 ... 1,674 instructions in the loop body), opaque")
-print("fold constants (+36 instructions); what moved it this round: the differences folded into the reductions (2,048 -> 1,994 static")
-print("instructions, -0.24 ms on the MSM).  HBM traffic: %.1f GB fetched per launch against %.1f GB algorithmic (64 B point + 4 B index per" % (
+print("round 4 executed 1,468 slots per addition (+6.1 % over this floor) in 14.3 ms; what closed the gap in round 5: the reduction in assembly")
+print("(-5.4 % static slots of the addition) and the loop's bookkeeping (no register copies at the back edge, index quads and bucket ends")
+print("fetched ahead).  What is left is the clock (~2.0 GHz under this load against the 2.4 the roof is drawn at) and 15 % of the cycles in")
+print("which no wave of a SIMD can issue.  HBM traffic: %.1f GB fetched per launch against %.1f GB algorithmic (64 B point + 4 B index per" % (
     rc["fetch_bytes"] / 1e9, adds * 68 / 1e9))
 print("addition) = %.2f TB/s of 8: the kernel is bound by its vector instructions, not by its gathers" % (rc["fetch_bytes"] / 1e9 / kernel_ms))
