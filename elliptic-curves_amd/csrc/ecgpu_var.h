@@ -32,7 +32,9 @@ struct VarTabHbm {
     }
 };
 
-template <class C>
+// ADD: the verification shape (add_io below) as an instantiation of its own — the plain kernel's register allocation is not to
+// know about it (with the branch inside one kernel p384's spilled registers went from 146 to 275 and the ladder slowed by 1.5 %)
+template <class C, bool ADD = false>
 __global__ void __launch_bounds__(BLOCK, 2)
 k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
            const uint8_t* __restrict__ points_inf, size_t n, uint32_t* __restrict__ tab, size_t tstride,
@@ -50,9 +52,11 @@ k_var_base(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ poin
         // add_io: the verification shape a G + b P (`mul_by_generator_and_mul_add_vartime`, primeorder/src/mul_backend.rs:29-40,
         // k256/src/arithmetic/mul.rs:303-310 — one loop in the reference): a G is in add_io[i] already (k_fixed_base), the product is
         // added to it in place — no launch of its own for the addition, no second projective array through HBM
-        if (add_io) {
-            const Proj<C> ag = load_proj<C>(add_io, i);
-            store_proj<C>(add_io, i, finite ? G::add(ag, var_base_mul<C>(a, k, b, io), b) : ag);
+        if constexpr (ADD) {
+            if (finite) {                       // (the product first: a G is loaded when the ladder's registers are free again)
+                const Proj<C> kp = var_base_mul<C>(a, k, b, io);
+                store_proj<C>(add_io, i, G::add(load_proj<C>(add_io, i), kp, b));
+            }
             continue;
         }
         if (!finite) {

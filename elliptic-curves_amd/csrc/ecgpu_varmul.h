@@ -25,6 +25,12 @@
 #include "ecgpu_point.h"
 #include "ecgpu_recode.h"
 
+// -DECGPU_VAR_PREFETCH=0: the k256 GLV ladder as round 4 had it (table entries fetched in front of their additions) — A/B:
+// profiles/r05/var_ladder_table_prefetch_ab.txt
+#ifndef ECGPU_VAR_PREFETCH
+#define ECGPU_VAR_PREFETCH 1
+#endif
+
 namespace ecgpu {
 
 // Table chain shared by both ladders: entry e (0..7) = (e + 1) P.  2P is a doubling, (e + 1) P = e P + P a mixed addition
@@ -76,6 +82,9 @@ ECGPU_HD Proj<C> var_base_mul_plain(const Affine<C>& a, const uint32_t* k, const
     digits.init(k);
     Jac<C> acc = G::jac_from_affine(a);   // placeholder until the first non-zero digit
     bool started = false;
+    // (Requesting a digit's table entry before the four doublings that precede its addition was measured for these ladders in round 5
+    // and changes nothing — p256 15.75 against 15.71 ms, p384 43.95 against 43.85, same box, alternating: with two waves per SIMD the
+    // 2 NL strided loads are not what a wave waits for.  The GLV ladder below, with two entries per step, gains 1.9 % and keeps it.)
     int d = 0;
 #pragma unroll 1
     for (int di = 8 * N; di >= 0; di--) {
@@ -161,6 +170,48 @@ ECGPU_HD Proj<K256Params> var_base_mul_glv(const Affine<K256Params>& a, const ui
     Jac<C> acc = G::jac_from_affine(a);         // placeholder until the first non-zero digit
     bool started = false;
     int e1 = 0, e2 = 0;
+#if ECGPU_VAR_PREFETCH
+    // Both halves' table entries are requested BEFORE the four doublings that precede their additions (round 5): unconditionally — a
+    // zero digit asks for entry 0 and does not use it —, so that the 4 NL strided loads of two per-lane entries have four doublings to
+    // arrive in: 8.42 -> 8.26 ms per 2^20 multiplications, although 56 more registers go to scratch around the table build
+    Affine<C> q1, q2;
+    auto fetch = [&](Affine<C>& q, int e) {
+        const int idx = e == 0 ? 0 : (e < 0 ? -e : e) - 1;
+        q.x = tab.get_el(idx, 0);
+        q.y = tab.get_el(idx, 1);
+    };
+    e1 = d1.digit(33);
+    e2 = d2.digit(33);
+    fetch(q1, e1);
+    fetch(q2, e2);
+#pragma unroll 1
+    for (int di = 33;; di--) {
+        if (started) {
+#pragma unroll 1
+            for (int s = 0; s < 4; s++) acc = G::jac_dbl(acc);
+        }
+        if (di == 0) break;
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {  // one copy of the addition code for both halves
+            const int e = half ? e2 : e1;
+            if (e == 0) continue;
+            Affine<C> q = half ? q2 : q1;
+            if (half) q.x = F::mul(G::mj(q.x), beta).e;
+            const bool neg = (e < 0) != (half ? s2 : s1);
+            if (started) {
+                acc = G::jac_madd(acc, q, neg);
+            } else {
+                if (neg) q.y = G::neg_coord(q.y);
+                acc = G::jac_from_affine(q);
+                started = true;
+            }
+        }
+        e1 = d1.digit(di - 1);
+        e2 = d2.digit(di - 1);
+        fetch(q1, e1);
+        fetch(q2, e2);
+    }
+#else
 #pragma unroll 1
     for (int di = 33; di >= 0; di--) {
         if (started) {
@@ -189,6 +240,7 @@ ECGPU_HD Proj<K256Params> var_base_mul_glv(const Affine<K256Params>& a, const ui
             }
         }
     }
+#endif
     // back to the original curve: Z * Zg; the table entries are (x' : y' : Zg) there
     const auto zg = G::mj(tab.get_el(7, 2));
     Proj<C> r = G::identity();

@@ -553,3 +553,41 @@ def test_baseline_config0_cpu_plumbing_record():
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["config"]["workload"] == "cpu_k256_1024" and rec["config"]["units"] == 1024 and rec["n_gpus"] == 0
     assert rec["check_vs_model"] is True and rec["value"] > 1000
+
+
+@pytest.mark.parametrize("curve,low_s", [("p256", False), ("k256", True)])
+def test_bench_signature_inputs_are_valid_signatures(oracle, curve, low_s):
+    """bench.py's signature workloads hold n DISTINCT tuples per input set: tuple i reuses nonce k_(i mod m) under a key d_i and a
+    digest z_i of its own, s_i = k^-1 (z_i + r d_i) computed by `_sign_slice` in worker processes.  Here the same helper on a small
+    batch, with the points from the oracle: every tuple must verify (p256) resp. recover to its own key (k256, low-S form with the
+    recovery id the helper derives) — the reference's `verify_prehashed` / `recover_from_prehash` semantics."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    c = pyec.CURVES[curve]
+    L, order = c.L, c.n
+    rng = np.random.default_rng(0xEC0051F7 + c.cid)
+    n, m = 48, 5
+    d = oracle.scalar_reduce(c.cid, rng.integers(0, 256, n * L, dtype=np.uint8))
+    z = oracle.scalar_reduce(c.cid, rng.integers(0, 256, n * L, dtype=np.uint8))
+    k = oracle.scalar_reduce(c.cid, rng.integers(0, 256, m * L, dtype=np.uint8))
+    Q, _ = oracle.batch_mul_base(c.cid, d)
+    R, _ = oracle.batch_mul_base(c.cid, k)
+    rs, kinvs, odds, xhi = [], [], [], []
+    for j in range(m):
+        kj = int.from_bytes(bytes(k[j * L:(j + 1) * L]), "big")
+        xj = int.from_bytes(bytes(R[j * 2 * L:j * 2 * L + L]), "big")
+        rs.append(xj % order); kinvs.append(pow(kj, -1, order)); odds.append(int(R[(j + 1) * 2 * L - 1]) & 1); xhi.append(xj >= order)
+    sb, ib = bench._sign_slice((bytes(d), bytes(z), rs, kinvs, odds, xhi, L, order, low_s, 0))
+    r = np.frombuffer(b"".join(rs[i % m].to_bytes(L, "big") for i in range(n)), np.uint8)
+    s = np.frombuffer(sb, np.uint8)
+    if low_s:
+        keys, ok = oracle.ecdsa_recover(c.cid, z, r, s, np.frombuffer(ib, np.uint8), True)
+        assert bool(np.asarray(ok).all()) and bytes(keys) == bytes(Q)
+    else:
+        assert bool(np.asarray(oracle.ecdsa_verify(c.cid, z, r, s, Q)).all())
+    # a second slice with an offset lands on the right nonces
+    sb2, _ = bench._sign_slice((bytes(d[7 * L:]), bytes(z[7 * L:]), rs, kinvs, odds, xhi, L, order, low_s, 7))
+    assert sb2 == sb[7 * L:]

@@ -14,4 +14,4 @@ def test_p224_p521_wire_codecs_move_whole_words():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "wire_codec_isa_check.py"), "--curve", "P224Params", "--curve",
                         "P521Params", "--groups", "var"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "k_var_base<ecgpu::P521Params>" in r.stdout and "halfword loads" in r.stdout          # the check saw the codec
+    assert "k_var_base<ecgpu::P521Params, false>" in r.stdout and "halfword loads" in r.stdout          # the check saw the codec

@@ -14,7 +14,9 @@ import sys
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("ecgpu::", "")
+    # (k_var_base<C, false> / <C, true>: the plain ladder and the one that adds its product to a G — one name for both, as bench.py
+    # and roofline_consts.py key them; a workload's profile holds the variant that workload runs)
+    return name.split("(")[0].replace("void ", "").replace("ecgpu::", "").replace(", false>", ">").replace(", true>", ">")
 
 
 def stats(d):

@@ -29,9 +29,9 @@ CSRC = os.path.join(ROOT, "elliptic-curves_amd", "csrc")
 KERNELS = {
     "k_fixed_base<K256Params>": ("base", "K256Params", "k_fixed_base", 1 << 20, "fixed_k256"),
     "k_normalize<K256Params, 0>": ("base", "K256Params", "k_normalizeINS_10K256ParamsELi0E", 1 << 20, "fixed_k256"),
-    "k_var_base<P256Params>": ("var", "P256Params", "k_var_base", 1 << 20, "var_p256"),
-    "k_var_base<P384Params>": ("var", "P384Params", "k_var_base", 1 << 20, "var_p384"),
-    "k_var_base<K256Params>": ("var", "K256Params", "k_var_base", 1 << 20, "recover_k256"),   # b R of a G + b R: 2^20 launches per call
+    "k_var_base<P256Params>": ("var", "P256Params", "k_var_baseINS_10P256ParamsELb0E", 1 << 20, "var_p256"),     # <C, false>: the plain ladder
+    "k_var_base<P384Params>": ("var", "P384Params", "k_var_baseINS_10P384ParamsELb0E", 1 << 20, "var_p384"),
+    "k_var_base<K256Params>": ("var", "K256Params", "k_var_baseINS_10K256ParamsELb1E", 1 << 20, "recover_k256"),   # <C, true>: adds its product to a G;   # b R of a G + b R: 2^20 launches per call
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
     "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
 }
