@@ -183,7 +183,8 @@ def sign_pool():
     if _SIGN_POOL is None:
         import multiprocessing as mp
         from concurrent.futures import ProcessPoolExecutor
-        _SIGN_POOL = ProcessPoolExecutor(max_workers=max(1, min(16, host_cores())), mp_context=mp.get_context("spawn"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))     # N ranks share the box's cores: each rank takes its share
+        _SIGN_POOL = ProcessPoolExecutor(max_workers=max(1, min(16, host_cores() // max(1, world))), mp_context=mp.get_context("spawn"))
     return _SIGN_POOL
 
 
@@ -444,6 +445,8 @@ class Bench:
 
         # ---- synthetic inputs, resident in HBM before the timed region: `nsets` independently seeded sets, one per step in turn ----
         nsets = max(1, args.sets)
+        if kind in ("ecdsa", "recover") and world > 1:
+            nsets = min(nsets, 2)                      # (the host side of 2^20 signatures per set and rank: keep an N-rank run's setup short)
         sets = [self.make_inputs(name, kind, cid, L, n, 0xEC000000 + SEEDS[name] + 1000 * rank + 7919 * j) for j in range(nsets)]
         d_scal = d_pts = d_s2 = d_r = d_s = d_recid = None      # (bound to the set of the last step before the check)
         d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device) if kind in ("ecdsa", "recover") else None

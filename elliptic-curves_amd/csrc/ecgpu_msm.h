@@ -56,7 +56,7 @@ namespace ecgpu {
 // taken here as well, in dynamic LDS (nwin * npart counters, LDS atomics, one global atomicAdd per non-empty counter and
 // workgroup): the sort then needs no pass of its own over the digits to count them.
 template <class C, bool GLV>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, C::N <= 12 ? 4 : 1)   // four waves per SIMD: k256 GLV took 129 registers around the reduction window (ecgpu_k256_reduce_asm.h)
 k_msm_prepare(const uint8_t* __restrict__ scalars, const uint8_t* __restrict__ points_xy,
               const uint8_t* __restrict__ points_inf, size_t n, size_t npad, int c, int nwin, uint32_t* __restrict__ pts,
               uint16_t* __restrict__ digits, unsigned long long* __restrict__ vmask, int* status,
@@ -718,15 +718,19 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
 #ifndef ECGPU_MSM_FUSED_TAIL
 #define ECGPU_MSM_FUSED_TAIL 1
 #endif
-// The fused tail kernel (k_msm_finish_segments) keeps two running points, a bucket sum and a stretch in registers: the sets up to
-// 384 bits fit the 512 registers of one wave per SIMD; the twenty-limb p521 keeps the two launches.  And it only pays where its
-// lanes — one per segment of `seg` buckets — fill the chip twice over: measured on MI355X (profiles/r05/msm_tail_fused_ab.txt),
-// k256 at 2^24 terms (131,072 segments) 0.365 against 0.391 ms for bucket finish + running sums, at 2^21 GLV terms (65,536 segments:
-// one wave per SIMD, every lane a chain of 4 x ~3 stretches + 29 point operations) 0.32 against 0.27 ms — a lane per BUCKET is
-// four times the parallelism for the stretch sums, and that is worth more there than the saved launch and round trip.
+// The fused tail kernel (k_msm_finish_segments: the bucket finish inside the running sums — no launch and no round trip of the
+// bucket sums) is built and correct but NOT the default: measured on MI355X (profiles/r05/msm_tail_fused_ab.txt), k256, before
+// the reduction went to assembly: 0.365 against 0.391 ms at 2^24 terms, 0.32 against 0.27 at 2^21 GLV terms (65,536 segment lanes
+// = one wave per SIMD, every lane a chain of 4 x ~3 stretches + 29 point operations; a lane per BUCKET is four times the
+// parallelism for the stretch sums).  With the assembly reduction k_msm_bucket_finish needs 168 registers instead of 256 + scratch
+// and runs three waves per SIMD: the two launches then win at both sizes (0.49 against 0.64 ms at 2^24, 0.37 against 0.40 at 2^21
+// on a box with slow tail kernels).  ECGPU_MSM_FUSED_TAIL=1 selects the fused form (sets up to 384 bits: the twenty-limb p521 does
+// not fit its registers).
 template <class C>
 inline bool msm_fused_tail(const MsmPlan& p) {
-    return ECGPU_MSM_FUSED_TAIL != 0 && C::N <= 12 && p.nseg * (size_t)p.nwin >= ((size_t)1 << 17);
+    (void)p;
+    if (const char* e = getenv("ECGPU_MSM_FUSED_TAIL")) return e[0] == '1' && ECGPU_MSM_FUSED_TAIL != 0 && C::N <= 12;
+    return false;
 }
 
 // A bucket normally has one or two partial sums.  A degenerate input (all scalars equal, all ones) gives ONE bucket

@@ -92,8 +92,9 @@ int ecgpu_device_count(void);
 /* Creates a context on HIP device `device` (as numbered by the HIP runtime in this process).
  * Basepoint tables are built lazily on first use per curve and kept on the device: ONE table per (device, curve, width)
  * for the whole process, shared by every context on that device and freed with the last of them — the analogue of the
- * reference's process-wide `LazyLock<BasepointTable>` (k256/src/arithmetic/tables.rs:18).  If a table does not fit (k256's
- * default is 21.5 GB) its comb width is lowered two bits at a time (a quarter of the memory, one or two more additions per
+ * reference's process-wide `LazyLock<BasepointTable>` (k256/src/arithmetic/tables.rs:18).  Which width a call gets is the table
+ * policy's decision (below: "the generator (comb) tables and their footprint").  If a table does not fit (k256's widest
+ * is 21.5 GB) its comb width is lowered two bits at a time (a quarter of the memory, one or two more additions per
  * scalar, identical results) down to 16 bits before ECGPU_ERR_OOM is returned. */
 int ecgpu_init(ecgpu_ctx **ctx, int device);
 void ecgpu_destroy(ecgpu_ctx *ctx);
@@ -138,7 +139,7 @@ int ecgpu_copy_to_host(ecgpu_ctx *ctx, void *h_dst, const void *d_src, size_t by
  * other 256- and 224- / 192-bit sets 24, p384 / p521 / bp384 20) — each step where the time lost to the narrower table so far equals
  * the build time of the next one, so a caller never pays more than twice the best fixed choice and a 1,024-scalar call never
  * allocates gigabytes.  A step up costs the calling thread the build once; the narrower table is freed when its last user lets go.
- * ECGPU_TABLE_EAGER: the widest table at the first call (a long-lived service: pay 65 ms once at start-up).
+ * ECGPU_TABLE_EAGER: the widest table at the first call (a long-lived service: pay ~55 ms once at start-up).
  * A table that does not fit is replaced by one two bits narrower, down to 16 bits, before ECGPU_ERR_OOM is returned. */
 enum { ECGPU_TABLE_ADAPTIVE = 0, ECGPU_TABLE_EAGER = 1 };
 int ecgpu_set_table_policy(ecgpu_ctx *ctx, int policy);

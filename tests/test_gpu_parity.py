@@ -1644,3 +1644,29 @@ def test_generator_table_policy_budget_and_pinning():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_table_policy_check.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("curve", ["k256", "p256", "p384"])
+def test_msm_fused_tail_form(eng, curve, monkeypatch):
+    """ECGPU_MSM_FUSED_TAIL=1: the bucket finish inside the running sums (k_msm_finish_segments, with the degenerate buckets listed
+    by k_msm_find_big before the accumulation and summed by k_msm_big_buckets) — not the default form, kept
+    correct: random scalars, and a scalar set that puts thousands of terms into single buckets, against the default form and the
+    exact dot product."""
+    c = pyec.CURVES[curve]
+    n = (1 << 18) + 333                                   # (above every curve's small-MSM threshold: the bucket method)
+    s = rand_scalars(c.cid, n, 0xEC0061F7 + c.cid)
+    pts, _ = eng.mul_by_generator(c.cid, s)
+    for case in ("random", "few distinct scalars"):
+        k = rand_scalars(c.cid, n, 0xEC0062F7 + c.cid)
+        if case != "random":
+            k = np.tile(k[: 3 * c.L], n // 3 + 1)[: n * c.L].copy()          # three scalars: every window has three huge buckets
+        want, wf = eng.lincomb(c.cid, k, pts)
+        monkeypatch.setenv("ECGPU_MSM_FUSED_TAIL", "1")
+        got, gf = eng.lincomb(c.cid, k, pts)
+        monkeypatch.delenv("ECGPU_MSM_FUSED_TAIL")
+        assert bytes(got) == bytes(want) and gf == wf, (curve, case)
+        ki = [int.from_bytes(bytes(k[i * c.L:(i + 1) * c.L]), "big") for i in range(n)]
+        si = [int.from_bytes(bytes(s[i * c.L:(i + 1) * c.L]), "big") for i in range(n)]
+        dot = sum(a * b for a, b in zip(ki, si)) % c.n
+        o, oi = oracle_lib.batch_mul_base(c.cid, np.frombuffer(dot.to_bytes(c.L, "big"), np.uint8))
+        assert bytes(got) == bytes(o) and gf == int(oi[0]), (curve, case)

@@ -85,4 +85,4 @@ best = kernel_ms * floor_slots / meas_slots
 print("  kernel with (a) closed completely: %.3f ms; with (a) and the gathers free: %.3f ms" % (
     best, best * (rc["insts_valu"] * rc["slots_per_inst"] * 4 / (rc["gui_cycles"] / 8 * SIMDS)) / util_best))
 print("  step = kernel + k_normalize (0.121 ms: one inversion per lane, latency-bound; the workgroup-shared inversion of round 4")
-print("  measured 0.121-0.133, profiles/r04/normalize_wg_dead_end.txt): %.3f ms with (a) closed; measured step 0.613-0.626 ms" % (best + 0.121))
+print("  measured 0.121-0.133, profiles/r04/normalize_wg_dead_end.txt): %.3f ms with (a) closed; measured step 0.608-0.626 ms" % (best + 0.121))
