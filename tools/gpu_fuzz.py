@@ -277,7 +277,7 @@ while time.time() < t_end:
         assert bytes(o) == bytes(w) and bytes(f) == bytes(wf), ("fixed", c.name, n, wdt, ct)
         stats["fixed_ct"] += 1 if ct else 0
         if wdt:
-            e.set_base_window(c.cid, DEFAULT_W[c.name])
+            e.set_base_window(c.cid, 0)                       # un-pinned: back to the table policy
         stats["fixed"] += 1
     else:
         n = rng.randrange(1, 1500)
