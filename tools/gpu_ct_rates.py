@@ -3,6 +3,7 @@
 tools/ct_isa_check.py — executed-instruction counters of the kernels for inputs that differ as much as inputs can.
 
     python tools/gpu_ct_rates.py               rates (2^20 device-resident elements, HIP-event kernel times), then the counters
+    python tools/gpu_ct_rates.py --rates       the rates only
     python tools/gpu_ct_rates.py --child CLASS (internal) one launch set under rocprofv3 --pmc for input class CLASS
 
 Counter check: each of {zero scalars, all-ones-pattern scalars (n - 1), random scalars} x {points = G, random points} is run
@@ -141,6 +142,8 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "--child":
         return child(sys.argv[2])
     rates()
+    if "--rates" in sys.argv:
+        return 0
     print("\nexecuted-instruction counters per launch (%d elements), one process per input class:" % N_PMC)
     allc = {cls: counters(cls) for cls in CLASSES}
     kernels = sorted({k for c in allc.values() for k in c})

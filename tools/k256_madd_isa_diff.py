@@ -46,7 +46,7 @@ def hist(lines):
 
 
 def main():
-    cpp, asm = madd_body([]), madd_body(["-DECGPU_K256_ASM_REDUCE=1"])
+    cpp, asm = madd_body(["-DECGPU_K256_ASM_REDUCE=0"]), madd_body(["-DECGPU_K256_ASM_REDUCE=1"])
     hc, sc = hist(cpp)
     ha, sa = hist(asm)
     zero_ext = lambda ls: sum(1 for l in ls if re.match(r"v_mov_b32(_e32)? v\d+, (0|v\d+)$", l))

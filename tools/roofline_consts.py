@@ -35,8 +35,8 @@ KERNELS = {
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
     "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
 }
-# per-group compile flags of elliptic-curves_amd/Makefile (FLAGS_var / FLAGS_msm: the k256 reduction as assembly blocks)
-GROUP_FLAGS = {"base": ["-DECGPU_K256_ASM_REDUCE=1"], "var": ["-DECGPU_K256_ASM_REDUCE=1"], "msm": ["-DECGPU_K256_ASM_REDUCE=1"]}
+# per-group compile flags of elliptic-curves_amd/Makefile (FLAGS_<group>: none at present)
+GROUP_FLAGS = {}
 HALF_SLOT_EXCEPT = ("_co_",)          # carry-producing / -consuming VOP2 ops were measured at the full cost
 
 def isa_histogram(group, curve, substr):
