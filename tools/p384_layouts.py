@@ -64,7 +64,65 @@ def cost(nl, bits, split=False):
                 vroom=vroom, vfix=vfix)
 
 
+def karatsuba_and_windows():
+    """Round 4's review, item 8: "model the multiplication, not only the limb width" — one level of Karatsuba on the 15 limbs (8 + 7)
+    and signed 5-bit windows for the variable-time ladder, in the same slot units as cost() above; build whichever comes out >= 5 %
+    ahead.  Neither does."""
+    r = cost(15, 27)
+    nl, mul, sqr = 15, r["mul"], r["sqr"]
+    print("\n--- one level of Karatsuba, 15 = 8 + 7 limbs (a = a0 + a1 2^216) ---")
+    # subtractive form on the signed columns: a b = z0 + z2 2^432 + (z0 + z2 - (a0 - a1)(b0 - b1)) 2^216
+    prods = 8 * 8 + 7 * 7 + 8 * 8
+    limb_subs = 2 * 8 * 0.5                  # a0 - a1, b0 - b1: 32-bit subtractions
+    # z0 (15 columns) and z2 (13) are needed twice, at their own position and shifted by 8 limbs: the middle product is accumulated
+    # onto the overlapping result columns by its own multiply-adds (free), the shifted copies are 64-bit additions
+    col_adds = 15 + 13
+    extra = limb_subs + col_adds
+    saved = nl * nl - prods
+    kmul = mul - saved + extra
+    print("products %d against %d (-%d multiply-adds); + %d 64-bit column additions + %d limb subtractions (%.0f slots)" % (prods, nl * nl, saved, col_adds, 16, extra))
+    print("multiplication %.1f -> %.1f slots (%.1f %%)" % (mul, kmul, 100 * (kmul / mul - 1)))
+    sq_prods = 36 + 28 + 36                  # three half-size squarings
+    ksqr = sqr - (nl * (nl + 1) / 2 - sq_prods) + limb_subs / 2 + col_adds
+    print("squaring       %.1f -> %.1f slots (%.1f %%): %d products against %d do not pay for the same %d column additions -> squarings stay schoolbook" % (
+        sqr, ksqr, 100 * (ksqr / sqr - 1), sq_prods, nl * (nl + 1) // 2, col_adds))
+    nmul = 4 * 3 + 8                         # multiplications per digit (4 doublings of 3M + 5S, one mixed addition of 8M + 3S)
+    gain = nmul * (mul - kmul)
+    print("per digit: %d multiplications x %.1f slots = %.0f of %.0f slots = %.1f %%" % (nmul, mul - kmul, gain, r["digit"], 100 * gain / r["digit"]))
+    # headroom: the middle product multiplies DIFFERENCES (limb magnitude ma + mb each side), 8 products per column
+    lim_k = (1 << (63 - 2 * 27)) // (8 * 4 + 15)
+    dbl_muls = [DBL[2], DBL[3], DBL[5]]                                   # beta, alpha, alpha3 * (4 beta - X3): the multiplications of the doubling
+    madd_muls = [m for i, m in enumerate(MADD) if i not in (0, 5, 8)]     # all but zz1, HH, r^2
+    over = 4 * sum(1 for a, b in dbl_muls if a * b > lim_k) + sum(1 for a, b in madd_muls if a * b > lim_k)
+    print("headroom: a signed column takes 15 products of magnitudes ma mb <= %d today; the middle product's operands are differences of two\n"
+          "  halves (magnitude x 2 each -> x 4 per product) on columns that also carry z0 + z2: ma mb <= %d -> %d multiplications per digit\n"
+          "  (alpha3 (3) x (4 beta - X3) (6) of every doubling) need an operand normalised first (%.1f slots each): %.0f of the %.0f slots gained"
+          % (r["limit"], lim_k, over, 2.5 * nl, over * 2.5 * nl, gain))
+    net = gain - over * 2.5 * nl
+    print("=> Karatsuba: %.1f %% of the ladder before, %.1f %% after the normalisations (and z0, z2 held apart: 28 more live 64-bit columns in a\n"
+          "   kernel that already spills 146 registers at two waves per SIMD): not built" % (100 * gain / r["digit"], 100 * net / r["digit"]))
+
+    print("\n--- signed 5-bit windows for the variable-time ladder ---")
+    jadd = 11 * mul + 5 * sqr                # Jacobian + Jacobian (add-2007-bl) for the table
+    inv = 6.0e4 - 7 * jadd - 7 * 5 * mul     # what is left of the measured ~6e4 slots of table construction: the inversion by division steps
+    def ladder(wbits, ndig, entries):
+        table = (entries - 1) * jadd + inv + (entries - 1) * 5 * mul
+        return ndig * (wbits * r["dbl"] + r["madd"]) + table, table
+    t4, tab4 = ladder(4, 97, 8)
+    t5, tab5 = ladder(5, 77, 16)
+    print("4-bit: 97 digits x (4 doublings + 1 mixed addition) = %.4g slots + table of  8 affine entries %.3g = %.4g" % (t4 - tab4, tab4, t4))
+    print("5-bit: 77 digits x (5 doublings + 1 mixed addition) = %.4g slots + table of 16 affine entries %.3g = %.4g  (%.1f %%)" % (t5 - tab5, tab5, t5, 100 * (t5 / t4 - 1)))
+    print("  20 mixed additions fewer (%.3g slots), 1 doubling more (385 against 388 - 3: none), 8 table entries more (%.3g slots);" % (20 * r["madd"], tab5 - tab4))
+    print("  the table lives in HBM scratch per lane (VarTabHbm, ecgpu_var.h: 8 x 2 x 64 B = 1 KB per lane, 131,072 resident lanes = 134 MB);\n"
+          "  16 entries double it and the build's stores, the gather per digit stays one 128-byte entry")
+    print("=> 5-bit windows: %.1f %% fewer slots, before the scratch gathers: var_p384 43.4-44.5 ms -> ~%.1f at best, target 41: not built" % (100 * (1 - t5 / t4), 43.9 * t5 / t4))
+    print("   (a width-5 NAF would need ~64 additions, but its positions depend on the scalar: in a wave of 64 scalars some lane adds at\n"
+          "    nearly every position, so every lane walks every addition — the fixed windows are the SIMT-friendly form)")
+
+
 def main():
+    if "--karatsuba-windows" in sys.argv:
+        return karatsuba_and_windows()
     rows = [cost(15, 27), cost(14, 28), cost(13, 30, split=True), cost(13, 30)]
     base = rows[0]["digit"]
     print("%-22s %6s %7s %8s %8s %9s %9s %8s %10s %8s  %s" % ("layout", "limit", "R/4p", "mul", "sqr", "doubling", "addition", "v.fixes", "per digit", "vs 15x27",
