@@ -174,6 +174,80 @@ ECGPU_HD Proj<C> ct_dbl4(const Proj<C>& acc, const Fe<C::NL>& b) {
     }
 }
 
+// The four doublings AND the table scan for the digit that follows them, interleaved (round 5): the reads of entries 2s + 1, 2s + 2
+// are issued in front of doubling s and selected behind it, so that they fly under ~850 multiply-adds instead of being waited
+// for in a loop of their own between the doublings and the addition (the stand-alone scan's waits were what the second wave per
+// SIMD had to cover: 84 % of the kernel's cycles issued an instruction against 89 % for the variable-time ladder).  The same
+// entries, masks and selections in the same order for every input: nothing for tools/ct_isa_check.py to object to.  Costs the
+// registers of two entries in flight across a doubling (2 x 3 NL) and of the selection (3 NL H): used where that fits (NL <= 10).
+#ifndef ECGPU_CT_SCAN_UNDER_DBL
+#define ECGPU_CT_SCAN_UNDER_DBL 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ECGPU_CT_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ECGPU_CT_SCHED_FENCE() ((void)0)
+#endif
+template <class C>
+constexpr bool ct_scan_under_dbl() { return ECGPU_CT_SCAN_UNDER_DBL && C::NL <= 10; }
+
+template <class C, class TabIO, int H>
+ECGPU_HD Proj<C> ct_dbl4_scan(const Proj<C>& acc, const Fe<C::NL>& b, const TabIO& tab, const uint32_t* xabs, Proj<C>* t) {
+    using G = Group<C>;
+    using F = Field<C>;
+#pragma unroll
+    for (int h = 0; h < H; h++) t[h] = G::identity();
+    auto fetch = [&](int s, Proj<C>* e) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            e[u].x = tab.get_el(2 * s + u, 0);
+            e[u].y = tab.get_el(2 * s + u, 1);
+            e[u].z = tab.get_el(2 * s + u, 2);
+        }
+    };
+    auto select = [&](int s, const Proj<C>* e) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int h = 0; h < H; h++) {
+                ct_pick_words<C::NL>(t[h].x.v, e[u].x.v, xabs[h], (uint32_t)(2 * s + u + 1));
+                ct_pick_words<C::NL>(t[h].y.v, e[u].y.v, xabs[h], (uint32_t)(2 * s + u + 1));
+                ct_pick_words<C::NL>(t[h].z.v, e[u].z.v, xabs[h], (uint32_t)(2 * s + u + 1));
+            }
+    };
+    if constexpr (C::A_IS_ZERO) {
+        Proj<C> r = acc;
+#pragma unroll 1
+        for (int s = 0; s < 4; s++) {
+            Proj<C> e[2];
+            fetch(s, e);
+            ECGPU_CT_SCHED_FENCE();
+            r = G::dbl(r, b);
+            ECGPU_CT_SCHED_FENCE();
+            select(s, e);
+        }
+        return r;
+    } else {
+        const auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
+        const uint32_t inf = ct_mask(F::is_zero(Z));
+        const Fe<C::NL> one = F::one().e;
+        typename G::J j;
+        j.x = ct_sel_fe<C>(inf, one, F::mul(X, Z).e);
+        j.y = ct_sel_fe<C>(inf, one, F::mul(Y, F::sqr(Z)).e);
+        j.z = acc.z;
+#pragma unroll 1
+        for (int s = 0; s < 4; s++) {
+            Proj<C> e[2];
+            fetch(s, e);
+            ECGPU_CT_SCHED_FENCE();
+            j = G::jac_dbl(j);
+            ECGPU_CT_SCHED_FENCE();
+            select(s, e);
+        }
+        return G::jac_to_proj(j);
+    }
+}
+
 // p: the point in homogeneous coordinates ((0 : 1 : 0) for the identity), k: N words < n.
 template <class C, class TabIO>
 ECGPU_HD Proj<C> var_base_mul_ct_plain(const Proj<C>& p, const uint32_t* k, const Fe<C::NL>& b, TabIO& tab) {
@@ -185,11 +259,16 @@ ECGPU_HD Proj<C> var_base_mul_ct_plain(const Proj<C>& p, const uint32_t* k, cons
     Proj<C> acc = G::identity();
 #pragma unroll 1
     for (int di = 8 * N; di >= 0; di--) {
-        if (di != 8 * N) acc = ct_dbl4<C>(acc, b);
         bool neg;
         const uint32_t xabs = ct_abs_digit(digits.digit(di), &neg);
         Proj<C> t;
-        ct_table_scan<C, TabIO, 1>(tab, &xabs, &t);
+        if constexpr (ct_scan_under_dbl<C>()) {
+            if (di != 8 * N) acc = ct_dbl4_scan<C, TabIO, 1>(acc, b, tab, &xabs, &t);
+            else ct_table_scan<C, TabIO, 1>(tab, &xabs, &t);
+        } else {
+            if (di != 8 * N) acc = ct_dbl4<C>(acc, b);
+            ct_table_scan<C, TabIO, 1>(tab, &xabs, &t);
+        }
         acc = G::add(acc, t, b, neg);
     }
     return acc;
@@ -223,13 +302,18 @@ ECGPU_HD Proj<K256Params> var_base_mul_ct_glv(const Proj<K256Params>& p, const u
     Proj<C> acc = G::identity();
 #pragma unroll 1
     for (int di = 32; di >= 0; di--) {
-        if (di != 32) acc = ct_dbl4<C>(acc, b);
         bool neg[2];
         uint32_t xabs[2];
         xabs[0] = ct_abs_digit(d1.digit(di), &neg[0]);
         xabs[1] = ct_abs_digit(d2.digit(di), &neg[1]);
         Proj<C> t[2];
-        ct_table_scan<C, TabIO, 2>(tab, xabs, t);
+        if constexpr (ct_scan_under_dbl<C>()) {
+            if (di != 32) acc = ct_dbl4_scan<C, TabIO, 2>(acc, b, tab, xabs, t);
+            else ct_table_scan<C, TabIO, 2>(tab, xabs, t);
+        } else {
+            if (di != 32) acc = ct_dbl4<C>(acc, b);
+            ct_table_scan<C, TabIO, 2>(tab, xabs, t);
+        }
         t[1].x = F::mul(G::m(t[1].x), beta).e;
         acc = G::add(acc, t[0], b, neg[0] != s1);
         acc = G::add(acc, t[1], b, neg[1] != s2);
