@@ -42,6 +42,12 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
 #include "ecgpu_msm_chunk.h"
+#include "ecgpu_rows.h"
+
+// -DECGPU_MSM_COMBINE_ROWS=0: the doublings of the k256 Horner chain on quad lanes as in round 4 (A/B: profiles/r05/msm_combine_rows_ab.txt)
+#ifndef ECGPU_MSM_COMBINE_ROWS
+#define ECGPU_MSM_COMBINE_ROWS 1
+#endif
 
 namespace ecgpu {
 
@@ -1127,6 +1133,27 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
         // a quad (msm_hom_dbl_quad, msm_hom_add_quad); every quad of the wave computes the same thing
         const int role = lane & 3;
         auto X = G::m(acc.x), Y = G::m(acc.y), Z = G::m(acc.z);
+#if ECGPU_MSM_COMBINE_ROWS
+        // round 5: the c doublings between two windows on the ROWS of the wave (ecgpu_rows.h: one limb per lane, the four products of
+        // a level on the four rows; ~190 instructions per doubling instead of 569), the addition of a window's sum on quad lanes as before
+        __shared__ uint32_t rows_lds[48];
+        RowsDblK256 rd;
+        rd.init();
+#pragma unroll 1
+        for (int w = nwin - 2; w >= 0; w--) {
+            const Proj<C> q = load_proj<C>(vw, w);                      // in flight under the doublings
+            uint32_t A, B, Q = 0;
+            rd.enter(rows_lds, X.e, Y.e, Z.e, A, B);
+#pragma unroll 1
+            for (int s = 0; s < c; s++) Q = rd.step(A, B);
+            Fe<C::NL> x2, y2, z2;
+            rd.leave(Q, x2, y2, z2);
+            X = Field<C>::template wrap<1, 1>(x2);
+            Y = Field<C>::norm(Field<C>::template wrap<2, 2>(y2));
+            Z = Field<C>::template wrap<1, 1>(z2);
+            msm_hom_add_quad<C>(X, Y, Z, q, role);
+        }
+#else
 #pragma unroll 1
         for (int w = nwin - 2; w >= 0; w--) {
             const Proj<C> q = load_proj<C>(vw, w);                      // in flight under the doublings
@@ -1136,6 +1163,7 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
             Y = Field<C>::norm(Yw);
             msm_hom_add_quad<C>(X, Y, Z, q, role);
         }
+#endif
         acc.x = X.e;
         acc.y = Y.e;
         acc.z = Z.e;

@@ -7,6 +7,7 @@
 #pragma once
 
 #include "ecgpu_kernels.h"
+#include "ecgpu_rows.h"
 
 namespace ecgpu {
 
@@ -15,7 +16,9 @@ namespace ecgpu {
 // takes (7 x 1 and 3 x 2 + 1 x 1), reduced by the assembly blocks AND by the compiler's k_reduce from the same columns: the nine
 // limbs must agree, else the record is all ones; 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain of lazily reduced
 // operations at the magnitudes the point formulas use, 20 a through the wire -> words -> wire conversion only, 21 a through
-// the internal domain and back.  Inputs must be canonical (< p), else ST_BAD_POINT.
+// the internal domain and back; 16 (k256; n a multiple of 64) the ROW-PARALLEL multiplication of ecgpu_rows.h: the operands of the
+// wave's first four lanes on its four rows, 7 a * b + 3 a * 2 b = 13 a b of lane (i mod 4) of the wave in every lane i.
+// Inputs must be canonical (< p), else ST_BAD_POINT.
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                                                           uint8_t* __restrict__ out, int* status) {
@@ -86,6 +89,36 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
             F::to_canonical(wr, F::mul(x, y));
         }
         break;
+    case 16:
+        if constexpr (C::REPR == REPR_U29_K256) {
+            RowsK256 k;
+            k.init();
+            const auto x3 = F::add(F::dbl(x), x);
+            const auto x7 = F::add(F::add(x3, x3), x);                  // limb magnitudes 3, 7
+            const auto y2 = F::dbl(y);
+            uint32_t a7 = 0, a3 = 0, b1 = 0, b2 = 0;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {                               // row r takes the operands of the wave's lane r
+                const uint32_t u7 = (uint32_t)__shfl((int)x7.e.v[t], (int)k.row, 64), u3 = (uint32_t)__shfl((int)x3.e.v[t], (int)k.row, 64);
+                const uint32_t v1 = (uint32_t)__shfl((int)y.e.v[t], (int)k.row, 64), v2 = (uint32_t)__shfl((int)y2.e.v[t], (int)k.row, 64);
+                a7 = k.pos == (uint32_t)t ? u7 : a7;
+                a3 = k.pos == (uint32_t)t ? u3 : a3;
+                b1 = k.pos == (uint32_t)t ? v1 : b1;
+                b2 = k.pos == (uint32_t)t ? v2 : b2;
+            }
+            const uint32_t p1 = k.mul(a7, b1), p2 = k.mul(a3, b2);
+            Fe<9> r1, r2;
+            const uint32_t src = ((threadIdx.x & 3u) * 16u) * 4u;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                r1.v[t] = lane_pull(src + 4u * t, p1);
+                r2.v[t] = lane_pull(src + 4u * t, p2);
+            }
+            F::to_canonical(wr, F::add(F::template wrap<1, 1>(r1), F::template wrap<1, 1>(r2)));
+        } else {
+            F::to_canonical(wr, F::mul(x, y));
+        }
+        break;
     case 11: {
         bool root;
         auto r = F::sqrt(x, &root);
@@ -120,7 +153,9 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
 // point: 0 P + Q (complete), 1 P + Q (complete, mixed), 2 2P, 3 -P, 4 P - Q, 5 P - Q (mixed), and the incomplete
 // formulas of the ladders / the comb / the bucket sums on inputs inside their domain (P, Q finite, P != +-Q; the caller
 // sees the identity otherwise): 6 2P by the Jacobian doubling, 7 P + Q by the Jacobian mixed addition, 8 P + Q by the
-// XYZZ mixed addition, 9 P + Q by the XYZZ affine + affine addition.  Output: affine + identity flag (one inversion per lane).
+// XYZZ mixed addition, 9 P + Q by the XYZZ affine + affine addition; 10 (k256; n a multiple of 64) 32 P of the WAVE'S FIRST point in
+// every lane, by five row-parallel complete doublings (ecgpu_rows.h RowsDblK256: what k_msm_combine's Horner chain runs on).
+// Output: affine + identity flag (one inversion per lane).
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_selftest_point(int op, const uint8_t* __restrict__ pxy, const uint8_t* __restrict__ pinf,
                                                           const uint8_t* __restrict__ qxy, const uint8_t* __restrict__ qinf, size_t n,
@@ -147,6 +182,30 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_point(int op, const uint8_t*
     case 7: if (pf && qf) r = G::jac_to_proj(G::jac_madd(G::jac_dbl(G::jac_from_affine(pa)), qa, false)); break;   // 2P + Q
     case 8: if (pf && qf) r = G::xyzz_to_proj(G::xyzz_madd(G::xyzz_from_affine(pa, false), qa, false)); break;
     case 9: if (pf && qf) r = G::xyzz_to_proj(G::xyzz_mmadd(pa, qa, false)); break;
+    case 10:
+        if constexpr (C::REPR == REPR_U29_K256) {
+            __shared__ uint32_t rows_lds[BLOCK / 64][48];
+            Fe<9> X, Y, Z;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                X.v[t] = (uint32_t)__shfl((int)p.x.v[t], 0, 64);
+                Y.v[t] = (uint32_t)__shfl((int)p.y.v[t], 0, 64);
+                Z.v[t] = (uint32_t)__shfl((int)p.z.v[t], 0, 64);
+            }
+            RowsDblK256 rd;
+            rd.init();
+            uint32_t A, B, Q = 0;
+            rd.enter(rows_lds[threadIdx.x / 64], X, Y, Z, A, B);
+#pragma unroll 1
+            for (int s = 0; s < 5; s++) Q = rd.step(A, B);
+            rd.leave(Q, X, Y, Z);
+            r.x = X;
+            r.y = F::norm(F::template wrap<2, 2>(Y)).e;
+            r.z = Z;
+        } else {
+            atomicOr(status, ST_BAD_SCALAR);
+        }
+        break;
     default: atomicOr(status, ST_BAD_SCALAR);
     }
     if (G::is_identity(r)) {

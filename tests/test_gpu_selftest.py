@@ -141,3 +141,42 @@ def test_device_point_ops_vs_model_and_oracle(eng, curve):
     assert dec(*eng.selftest_point(c.cid, 7, fp, None, fq)) == [pyec.add(c, pyec.add(c, a, a), b) for a, b in zip(Pf, Qf)]
     for op in (8, 9):
         assert dec(*eng.selftest_point(c.cid, op, fp, None, fq)) == [pyec.add(c, a, b) for a, b in zip(Pf, Qf)], (curve, op)
+
+
+def test_device_row_parallel_k256_field_and_doubling(eng):
+    """csrc/ecgpu_rows.h — the k256 field spread over rows of 16 lanes (one limb per lane, four products per wave; model:
+    tools/rows_field_model.py), which k_msm_combine's Horner chain runs its doublings on.  Field op 16: lane i gets 7 a b + 3 a 2 b
+    = 13 a b of lane (i mod 4) of its wave — products at limb magnitudes 7 x 1 and 3 x 2, edge values in the first four lanes of
+    some wave.  Point op 10: every lane gets 32 P of its wave's first point, by five row-parallel complete doublings (the identity
+    and points of every kind in first place)."""
+    c = pyec.CURVES["k256"]
+    p = c.p
+    rng = random.Random(0x50775)
+    edge = edge_values(c) + [p - 1 - k for k in range(19)] + [(1 << 256) - 1 - (1 << 33) - (k << 40) for k in range(8)]
+    nw = 96                                                    # waves
+    vals, other = [], []
+    for w in range(nw):
+        for l in range(64):
+            if l < 4 and w < 40:
+                a, b = edge[(4 * w + l) % len(edge)], edge[(7 * w + 3 * l + 1) % len(edge)]
+            else:
+                a, b = rng.randrange(p), rng.randrange(p)
+            vals.append(a)
+            other.append(b)
+    got = ints(c, eng.selftest_field(c.cid, 16, fe(c, vals), fe(c, other)))
+    want = [13 * vals[i - i % 64 + i % 4] * other[i - i % 64 + i % 4] % p for i in range(len(vals))]
+    assert got == want
+    G = pyec.G(c)
+    firsts = [pyec.INF, G, pyec.neg(c, G), pyec.mul(c, 2, G), pyec.mul(c, (c.n - 1) // 2, G), pyec.mul(c, (c.n + 1) // 2, G)] + \
+             [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(10)]
+    P = []
+    for f in firsts:
+        P += [f] + [pyec.mul(c, rng.randrange(1, c.n), G) for _ in range(3)] + [G] * 60     # the other lanes' points must not matter
+    pxy = np.frombuffer(b"".join(pyec.enc_point(c, x)[0] for x in P), np.uint8)
+    pinf = np.array([pyec.enc_point(c, x)[1] for x in P], np.uint8)
+    out, inf = eng.selftest_point(c.cid, 10, pxy, pinf)
+    got = [pyec.dec_point(c, bytes(out[2 * c.L * i: 2 * c.L * (i + 1)]), int(inf[i])) for i in range(len(P))]
+    want = []
+    for f in firsts:
+        want += [pyec.mul(c, 32, f) if f is not pyec.INF else pyec.INF] * 64
+    assert got == want

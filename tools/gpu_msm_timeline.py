@@ -30,5 +30,16 @@ idx = starts[min(len(starts) - 1, 3)]
 end = starts[starts.index(idx) + 1] if starts.index(idx) + 1 < len(starts) else len(rows)
 t0 = rows[idx][0]
 print("n = 2^%d: one step, times in ms from the start of k_msm_prepare" % lg)
+prev_end, busy, gaps = None, 0, 0
 for s, e, name, q, grid in rows[idx:end]:
-    print("  %9.3f .. %9.3f  (%7.3f)  queue %-3s grid %-9s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, q, grid, name[:60]))
+    gap = 0 if prev_end is None else s - prev_end
+    print("  %9.3f .. %9.3f  (%7.3f)  gap before %6.1f us  queue %-3s grid %-9s %s" % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, gap / 1e3, q, grid, name[:60]))
+    if name.startswith("k_msm_combine"):
+        busy += e - s
+        gaps += max(gap, 0)
+        print("  step: %.3f ms from the first kernel's start to the last one's end = %.3f ms in kernels + %.3f ms between them (%d launches)" % (
+            (e - t0) / 1e6, busy / 1e6, gaps / 1e6, rows[idx:end].index((s, e, name, q, grid)) + 1))
+        break
+    busy += e - s
+    gaps += max(gap, 0)
+    prev_end = max(e, prev_end or 0)
