@@ -97,6 +97,22 @@ struct ModInv {
         return zeta;
     }
 
+    // acc + a b on signed 32-bit factors.  On the device as v_mad_i64_i32 by hand: the limbs are known to be non-negative, the
+    // compiler therefore rewrites sext(limb) as zext(limb), no longer recognises the signed multiply-add and expands every product
+    // into an unsigned multiply-add, a second one for the sign of the other factor and two moves (the round-5 ISA of k_normalize:
+    // 118 + 34 multiplies and 119 moves per batch for 90 products).  SA: `a` is wave-uniform (a limb of the constant modulus).
+    template <bool SA = false>
+    static ECGPU_HD int64_t smad(int32_t a, int32_t b, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        int64_t r;
+        if constexpr (SA) asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "s"(a), "v"(b), "v"(acc) : "vcc");
+        else asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc) : "vcc");
+        return r;
+#else
+        return acc + (int64_t)a * b;
+#endif
+    }
+
     // (d, e) <- t (d, e) / 2^30 mod p, with d, e kept in (-2p, p)
     static ECGPU_HD void update_de(S30& d, S30& e, const Trans& t, const S30& p, uint32_t pinv30) {
         const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
@@ -104,22 +120,22 @@ struct ModInv {
         int32_t md = (u & sd) + (v & se);
         int32_t me = (q & sd) + (r & se);
         int32_t di = d.v[0], ei = e.v[0];
-        int64_t cd = (int64_t)u * di + (int64_t)v * ei;
-        int64_t ce = (int64_t)q * di + (int64_t)r * ei;
+        int64_t cd = smad(u, di, smad(v, ei, 0));
+        int64_t ce = smad(q, di, smad(r, ei, 0));
         md -= (int32_t)((pinv30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
         me -= (int32_t)((pinv30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-        cd += (int64_t)p.v[0] * md;
-        ce += (int64_t)p.v[0] * me;
+        cd = smad<true>(p.v[0], md, cd);
+        ce = smad<true>(p.v[0], me, ce);
         cd >>= 30;                                         // the low 30 bits are zero by construction
         ce >>= 30;
 #pragma unroll
         for (int i = 1; i < NL; i++) {
             di = d.v[i];
             ei = e.v[i];
-            cd += (int64_t)u * di + (int64_t)v * ei;
-            ce += (int64_t)q * di + (int64_t)r * ei;
-            cd += (int64_t)p.v[i] * md;
-            ce += (int64_t)p.v[i] * me;
+            cd = smad(u, di, smad(v, ei, cd));
+            ce = smad(q, di, smad(r, ei, ce));
+            cd = smad<true>(p.v[i], md, cd);
+            ce = smad<true>(p.v[i], me, ce);
             d.v[i - 1] = (int32_t)cd & M30;
             cd >>= 30;
             e.v[i - 1] = (int32_t)ce & M30;
@@ -132,16 +148,16 @@ struct ModInv {
     static ECGPU_HD void update_fg(S30& f, S30& g, const Trans& t) {
         const int32_t u = t.u, v = t.v, q = t.q, r = t.r;
         int32_t fi = f.v[0], gi = g.v[0];
-        int64_t cf = (int64_t)u * fi + (int64_t)v * gi;
-        int64_t cg = (int64_t)q * fi + (int64_t)r * gi;
+        int64_t cf = smad(u, fi, smad(v, gi, 0));
+        int64_t cg = smad(q, fi, smad(r, gi, 0));
         cf >>= 30;
         cg >>= 30;
 #pragma unroll
         for (int i = 1; i < NL; i++) {
             fi = f.v[i];
             gi = g.v[i];
-            cf += (int64_t)u * fi + (int64_t)v * gi;
-            cg += (int64_t)q * fi + (int64_t)r * gi;
+            cf = smad(u, fi, smad(v, gi, cf));
+            cg = smad(q, fi, smad(r, gi, cg));
             f.v[i - 1] = (int32_t)cf & M30;
             cf >>= 30;
             g.v[i - 1] = (int32_t)cg & M30;
@@ -196,6 +212,93 @@ struct ModInv {
             zeta = divsteps_30(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], &t);
             update_de(d, e, t, p, pinv30);
             update_fg(f, g, t);
+        }
+        normalize(d, f.v[NL - 1], p);
+        to_words(out, d);
+    }
+
+    // ---- the variable-time form: for ONE public value inverted by a wave (the affine conversion at the end of k_msm_combine) ----
+    // Measured (profiles/r05/inversion_ab.txt): the conversion of an MSM's result 0.154 -> 0.144 ms (combine stage, 2^21 terms); in
+    // k_normalize, where the 64 lanes of a wave invert 64 different values and every batch takes as long as its slowest lane, the
+    // same 0.114 ms as the branch-free form — k_normalize keeps the branch-free one for every caller.
+    // The same batches of 30 division steps with the same transition matrices, but the steps of a batch are taken several at a
+    // time (Bernstein-Yang's original delta, eta = -delta; libsecp256k1's doc/safegcd_implementation.md, "variable time"): all the
+    // trailing zeros of g at once, and then the multiple of f that clears the low min(eta + 1, remaining, 6) bits of g in one
+    // addition (w = -g / f mod 2^6 = f g (f^2 - 2), Newton from f^2 = 1 mod 8).  A lane takes 8-10 iterations per batch instead of
+    // 30 steps; a wave takes as many as its slowest lane, and stops when g = 0 in all of them (g = 0 is a fixed point: further
+    // batches change nothing that is read).  724 steps bound the original delta for 256-bit inputs: at most MAXB batches.
+    ECGPU_CONST int MAXB_VAR = NW == 6 ? 19 : NW == 7 ? 22 : NW == 8 ? 25 : NW == 12 ? 37 : 52;     // (49 bits + 57) / 17 steps, / 30
+
+    static ECGPU_HD uint32_t mad_lo(uint32_t a, uint32_t b, uint32_t c) {      // a b + c mod 2^32 (full-rate on the device)
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t r;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"((uint64_t)c) : "vcc");
+        return (uint32_t)r;
+#else
+        return a * b + c;
+#endif
+    }
+    static ECGPU_HD int32_t divsteps_30_var(int32_t eta, uint32_t f0, uint32_t g0, Trans* t) {
+        uint32_t u = 1, v = 0, q = 0, r = 1;
+        uint32_t f = f0, g = g0;
+        int i = 30;
+        for (;;) {
+            const int zeros = __builtin_ctz(g | (0xFFFFFFFFu << i));         // (a sentinel bit: never more than i)
+            g >>= zeros;
+            u <<= zeros;
+            v <<= zeros;
+            eta -= zeros;
+            i -= zeros;
+            if (i == 0) break;
+            if (eta < 0) {                                                   // delta > 0 and g odd: (f, g) <- (g, -f)
+                uint32_t tmp;
+                eta = -eta;
+                tmp = f; f = g; g = 0u - tmp;
+                tmp = u; u = q; q = 0u - tmp;
+                tmp = v; v = r; r = 0u - tmp;
+            }
+            const int limit = (eta + 1) > i ? i : (eta + 1);
+            const uint32_t m = (0xFFFFFFFFu >> (32 - limit)) & 63u;
+            const uint32_t fl = f & 63u, gl = g & 63u;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t w = __umul24(__umul24(fl, gl), __umul24(fl, fl) - 2u) & m;    // -g / f mod 2^min(limit, 6) (24-bit multiplies: full rate)
+#else
+            const uint32_t w = (fl * gl * (fl * fl - 2u)) & m;
+#endif
+            g = mad_lo(f, w, g);
+            q = mad_lo(u, w, q);
+            r = mad_lo(v, w, r);
+        }
+        t->u = (int32_t)u;
+        t->v = (int32_t)v;
+        t->q = (int32_t)q;
+        t->r = (int32_t)r;
+        return eta;
+    }
+    static ECGPU_HD void invert_var(uint32_t* out, const uint32_t* x, const uint32_t* pw) {
+        const S30 p = from_words(pw);
+        const uint32_t pinv30 = inv30(pw[0]);
+        S30 f = p, g = from_words(x), d, e;
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            d.v[i] = 0;
+            e.v[i] = i == 0 ? 1 : 0;
+        }
+        int32_t eta = -1;
+#pragma unroll 1
+        for (int it = 0; it < MAXB_VAR; it++) {
+            Trans t;
+            eta = divsteps_30_var(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], &t);
+            update_de(d, e, t, p, pinv30);
+            update_fg(f, g, t);
+            int32_t any = 0;
+#pragma unroll
+            for (int i = 0; i < NL; i++) any |= g.v[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__builtin_amdgcn_ballot_w64(any != 0) == 0) break;           // wave-uniform: every lane is done
+#else
+            if (any == 0) break;
+#endif
         }
         normalize(d, f.v[NL - 1], p);
         to_words(out, d);

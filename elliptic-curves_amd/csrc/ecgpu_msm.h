@@ -1203,7 +1203,7 @@ __global__ void __launch_bounds__(64) k_msm_combine(const uint32_t* __restrict__
 #pragma unroll
     for (int i = 0; i < N; i++) wx[i] = wy[i] = 0;
     if (!ident) {
-        const typename F::M1 zinv = F::inv(G::m(acc.z));
+        const typename F::M1 zinv = F::template inv<true>(G::m(acc.z));     // (an MSM's scalars are public: the variable-time steps)
         F::to_canonical(wx, F::mul(G::m(acc.x), zinv));
         F::to_canonical(wy, F::mul(G::m(acc.y), zinv));
     }

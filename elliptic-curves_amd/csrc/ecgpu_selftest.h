@@ -18,7 +18,7 @@ namespace ecgpu {
 // operations at the magnitudes the point formulas use, 20 a through the wire -> words -> wire conversion only, 21 a through
 // the internal domain and back; 16 (k256; n a multiple of 64) the ROW-PARALLEL multiplication of ecgpu_rows.h: the operands of the
 // wave's first four lanes on its four rows, 7 a * b + 3 a * 2 b = 13 a b of lane (i mod 4) of the wave in every lane i.
-// Inputs must be canonical (< p), else ST_BAD_POINT.
+// 17 1/a by the variable-time division steps (0 -> 0).  Inputs must be canonical (< p), else ST_BAD_POINT.
 template <class C>
 __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n,
                                                           uint8_t* __restrict__ out, int* status) {
@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_field(int op, const uint8_t*
     case 2: F::to_canonical(wr, F::mul(x, y)); break;
     case 3: F::to_canonical(wr, F::sqr(x)); break;
     case 4: F::to_canonical(wr, F::inv(x)); break;
+    case 17: F::to_canonical(wr, F::template inv<true>(x)); break;          // the variable-time division steps (ModInv::invert_var)
     case 5: F::to_canonical(wr, F::neg(x)); break;
     case 7: F::to_canonical(wr, F::dbl(x)); break;
     case 8: {

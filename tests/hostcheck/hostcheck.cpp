@@ -75,6 +75,7 @@ int field_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     case 3: F::to_bytes(out, F::sqr(x)); break;
     case 4: F::to_bytes(out, F::inv(x)); break;
     case 10: F::to_bytes(out, F::inv_fermat(x)); break;    // independent check of the safegcd inversion
+    case 17: F::to_bytes(out, F::template inv<true>(x)); break;    // the variable-time division steps (ModInv::invert_var)
     case 11: {                                            // square root: the root, or zero if there is none
         bool root;
         auto r = F::sqrt(x, &root);

@@ -78,6 +78,7 @@ def test_device_field_ops_vs_bigint_and_oracle(eng, curve):
     assert ints(c, eng.selftest_field(c.cid, 7, A)) == [2 * a % p for a in vals]
     inv = [pow(a, -1, p) if a else 0 for a in vals]
     assert ints(c, eng.selftest_field(c.cid, 4, A)) == inv                     # safegcd division steps
+    assert ints(c, eng.selftest_field(c.cid, 17, A)) == inv                    # ... in their variable-time form (ModInv::invert_var)
     assert ints(c, eng.selftest_field(c.cid, 10, A[: 64 * c.L])) == inv[:64]   # Fermat chain
     # the oracle on a sample (it restates the reference's own field code)
     for i in range(0, len(vals), 97):

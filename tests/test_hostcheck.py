@@ -49,6 +49,8 @@ def test_field_ops_vs_oracle_and_bigint(oracle, curve):
     for a in _edge_values(c) + shapes + [rng.randrange(c.p) for _ in range(300)]:
         inv = int.from_bytes(hc.field_op(c.cid, 4, a.to_bytes(c.L, "big")), "big")
         assert inv == (pow(a, -1, c.p) if a else 0), hex(a)
+        inv = int.from_bytes(hc.field_op(c.cid, 17, a.to_bytes(c.L, "big")), "big")     # the variable-time division steps
+        assert inv == (pow(a, -1, c.p) if a else 0), hex(a)
     for a in _edge_values(c)[:8] + [rng.randrange(c.p) for _ in range(12)]:
         inv = int.from_bytes(hc.field_op(c.cid, 10, a.to_bytes(c.L, "big")), "big")
         assert inv == (pow(a, -1, c.p) if a else 0)

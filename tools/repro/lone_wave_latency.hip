@@ -36,6 +36,20 @@ __global__ void __launch_bounds__(64) k_chain(uint64_t* out, int iters, uint32_t
             REP64(asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a));)
         } else if constexpr (V == 6) {     // 64 dependent 64-bit shift + add pairs (the carry step of a reduction)
             REP64(asm volatile("v_lshrrev_b64 %0, 29, %0\n\tv_lshl_add_u64 %0, %0, 0, %1" : "+v"(c0) : "v"(c1));)
+        } else if constexpr (V == 8) {     // 64 dependent scalar additions (the scalar ALU: wave-uniform values)
+            uint32_t sx = __builtin_amdgcn_readfirstlane(x), sa = __builtin_amdgcn_readfirstlane(a);
+            REP64(asm volatile("s_add_u32 %0, %0, %1" : "+s"(sx) : "s"(sa) : "scc");)
+            x = sx;
+        } else if constexpr (V == 9) {     // 64 scalar operations on four values in turn
+            uint32_t s0 = __builtin_amdgcn_readfirstlane(x), s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, sa = __builtin_amdgcn_readfirstlane(a);
+            REP8(asm volatile("s_add_u32 %0, %0, %4\n\ts_xor_b32 %1, %1, %4\n\ts_add_u32 %2, %2, %4\n\ts_and_b32 %3, %3, %4\n\t"
+                              "s_add_u32 %0, %0, %4\n\ts_xor_b32 %1, %1, %4\n\ts_add_u32 %2, %2, %4\n\ts_and_b32 %3, %3, %4"
+                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "s"(sa) : "scc");)
+            x = s0 + s1 + s2 + s3;
+        } else if constexpr (V == 10) {    // 64 32-bit vector additions on four values in turn
+            REP8(asm volatile("v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4\n\t"
+                              "v_add_u32 %0, %0, %4\n\tv_add_u32 %1, %1, %4\n\tv_add_u32 %2, %2, %4\n\tv_add_u32 %3, %3, %4"
+                              : "+v"(x), "+v"(y0), "+v"(y1), "+v"(y2) : "v"(a));)
         } else if constexpr (V == 7) {     // eight crossbar trips in flight, then one wait
             REP8(asm volatile("ds_bpermute_b32 %0, %8, %0\n\tds_bpermute_b32 %1, %8, %1\n\tds_bpermute_b32 %2, %8, %2\n\tds_bpermute_b32 %3, %8, %3\n\t"
                               "ds_bpermute_b32 %4, %8, %4\n\tds_bpermute_b32 %5, %8, %5\n\tds_bpermute_b32 %6, %8, %6\n\tds_bpermute_b32 %7, %8, %7\n\t"
@@ -81,7 +95,10 @@ int main() {
     run<1>("v_mad_u64_u32, four accumulators in turn", 256);
     run<2>("v_mad_u64_u32, eight accumulators in turn", 512);
     run<5>("v_add_u32, dependent", 64);
+    run<10>("v_add_u32, four values in turn", 64);
     run<6>("v_lshrrev_b64 + v_lshl_add_u64, dependent pairs (per pair)", 64);
+    run<8>("s_add_u32, dependent (scalar ALU)", 64);
+    run<9>("s_add / s_xor / s_and, four values in turn (scalar ALU)", 64);
     run<3>("ds_bpermute_b32 + wait, dependent", 64);
     run<7>("ds_bpermute_b32, eight in flight per wait (per instruction)", 64);
     run<4>("v_mov_b32_dpp row_shr:1 (+ s_nop 1), dependent", 64);
