@@ -554,11 +554,15 @@ int ecgpu_batch_decompress_dev(ecgpu_ctx *ctx, int curve, const void *d_xs, cons
  * ecgpu_selftest_field: out[i] = op(a[i], b[i]) on canonical field elements (L bytes each; b may be NULL for unary ops).
  *   op 0 a + b, 1 a - b, 2 a * b, 3 a^2, 4 1/a by division steps (0 for 0), 5 -a, 7 2a, 8 pack / unpack round trip of the
  *   lazily reduced 2a + b, 9 the fused a*b - (a + b)*b, 10 1/a by Fermat, 11 sqrt(a) or 0, 12 a 25-step chain at the
- *   magnitudes the point formulas use.  The reference's counterparts: `FieldElement::{add, sub, mul, square, invert,
+ *   magnitudes the point formulas use, 13 / 14 the fused a*b - c and a^2 - c, 15 (k256) the reduction in assembly against the
+ *   compiler's from the same columns (14 a b, or all ones on a mismatch), 16 (k256; n a multiple of 64) the row-parallel
+ *   multiplication of the MSM's Horner chain: 13 a b of lane (i mod 4) of the wave in every lane i, 17 1/a by the variable-time
+ *   division steps.  The reference's counterparts: `FieldElement::{add, sub, mul, square, invert,
  *   negate, double, sqrt}` (k256/src/arithmetic/field.rs, p256/src/arithmetic/field.rs, primefield/src/monty.rs).
  * ecgpu_selftest_point: out[i] = op(P[i], Q[i]); op 0 P + Q (complete), 1 the same mixed, 2 2P, 3 -P, 4 P - Q, 5 the same
  *   mixed, and the incomplete formulas inside their domain (P, Q finite, P != +-Q): 6 2P (Jacobian), 7 2P + Q (Jacobian
- *   doubling + mixed addition), 8 P + Q (XYZZ mixed), 9 P + Q (XYZZ affine + affine).
+ *   doubling + mixed addition), 8 P + Q (XYZZ mixed), 9 P + Q (XYZZ affine + affine), 10 (k256; n a multiple of 64) 32 P of
+ *   the wave's FIRST point in every lane, by five row-parallel complete doublings.
  * ECGPU_ERR_POINT: an input >= p / off the curve; ECGPU_ERR_SCALAR_RANGE: unknown op. */
 int ecgpu_selftest_field(ecgpu_ctx *ctx, int curve, int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out);
 int ecgpu_selftest_point(ecgpu_ctx *ctx, int curve, int op, const uint8_t *p_xy, const uint8_t *p_inf, const uint8_t *q_xy,
