@@ -184,8 +184,10 @@ k_msm_tile_scan(uint32_t* __restrict__ tile_hist, size_t ntiles, size_t nb, int 
 // ---- scan: offsets[w][b] = sum_{b' < b} counts[w][b'] -------------------------------------------------------
 // big_any != nullptr: big_any[window] = 1 if some count of the window exceeds big_limit, else 0 (the packed sort's level A:
 // is there a partition for k_msm_sort_b_big?)
+// copy: a second array that receives the same offsets (the scatter's cursors: no copy launch between the scan and the scatter)
 static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                          size_t nb, uint32_t big_limit = 0, uint32_t* __restrict__ big_any = nullptr) {
+                                                          size_t nb, uint32_t big_limit = 0, uint32_t* __restrict__ big_any = nullptr,
+                                                          uint32_t* __restrict__ copy = nullptr) {
     __shared__ uint32_t part[1024];
     const uint32_t* cw = counts + (size_t)blockIdx.x * nb;
     uint32_t* ow = offsets + (size_t)blockIdx.x * nb;
@@ -211,8 +213,10 @@ static __global__ void __launch_bounds__(1024) k_msm_scan(const uint32_t* __rest
         __syncthreads();
     }
     uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    uint32_t* cp = copy != nullptr ? copy + (size_t)blockIdx.x * nb : nullptr;
     for (size_t j = lo; j < hi; j++) {
         ow[j] = run;
+        if (cp != nullptr) cp[j] = run;
         run += cw[j];
     }
 }
@@ -708,9 +712,10 @@ template <class C>
 __global__ void __launch_bounds__(64, C::N <= 8 ? ECGPU_MSM_ACC_WAVES : C::N <= 12 ? 2 : 1)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
                  const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, size_t n, size_t nb,
-                 int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials) {
+                 int nwin, size_t chunk, size_t nchunks, uint32_t* __restrict__ partials, uint32_t* __restrict__ zero_word) {
     using G = Group<C>;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0 && zero_word != nullptr) *zero_word = 0;       // the counter of k_msm_bucket_finish's list (no memset launch in the chain)
     if (gid >= nchunks * nwin) return;
     size_t w = gid / nchunks, q = gid % nchunks;
     const uint32_t* ow = offsets + w * nb;
@@ -1411,7 +1416,7 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
                            (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, (const uint32_t*)buckets, p.seg, p.nseg,
                            msm_top_shift(p.kbits, p.c), segs);
     } else {
-        (void)hipMemsetAsync(big_list, 0, 4, stream);
+        // (big_list[0] = 0 was written by the first lane of k_msm_accumulate)
         hipLaunchKernelGGL((k_msm_bucket_finish<C>), dim3((unsigned)((nbk + 63) / 64)), dim3(64), 0, stream,
                            (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
                            (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
@@ -1492,8 +1497,8 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
         uint32_t* cursor = (uint32_t*)(ws + p.off_cursor);
         const uint32_t big = msm_sortb_big_limit(ne, p.npart);
         uint32_t* big_any = offsets_a + (size_t)p.nwin * p.npart;       // nwin flags behind the partition offsets (plan: + nwin words)
-        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart, big, big_any);
-        (void)hipMemcpyAsync(cursor, offsets_a, (size_t)p.nwin * p.npart * 4, hipMemcpyDeviceToDevice, stream);
+        hipLaunchKernelGGL(k_msm_scan, dim3(p.nwin), dim3(1024), 0, stream, (const uint32_t*)counts_a, offsets_a, p.npart, big, big_any,
+                           cursor);                                     // (offsets and the scatter's cursors in one launch)
         hipLaunchKernelGGL(k_msm_sort_a, dim3((unsigned)p.ntiles2, (unsigned)p.nwin), dim3(1024), 0, stream, (const uint16_t*)digits,
                            (const unsigned long long*)vmask, ne, p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, cursor, tmp);
         // level B: one workgroup per (partition, window); small partitions (small MSMs) get 256 lanes
@@ -1561,7 +1566,8 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
     size_t nlanes = p.nchunks * p.nwin;
     hipLaunchKernelGGL(k_msm_accumulate<C>, dim3((unsigned)((nlanes + 63) / 64)), dim3(64), 0, stream,
                        (const uint32_t*)pts, (const uint32_t*)sorted, (const uint32_t*)counts,
-                       (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials);
+                       (const uint32_t*)offsets, ne, p.nb, p.nwin, p.chunk, p.nchunks, partials,
+                       msm_fused_tail<C>(p) ? (uint32_t*)nullptr : (uint32_t*)(ws + p.off_biglist));
     if (ev_accumulated) (void)hipEventRecord(ev_accumulated, stream);       // the accumulation kernel alone (round 4 recorded this after the bucket finish)
     launch_msm_tail<C>(p, stream, ws, parts);
 }
