@@ -14,9 +14,17 @@ prose that used to be repeated per record is once under "notes": the line stays 
     var_p256    (configs[2])             p256 variable-base (ECDH shape), 2^20 pairs/GPU   -> scalar-muls/s
     msm_k256    (configs[3])             k256 MSM, 2^24 terms in total, sharded over GPUs  -> terms/s
     var_p384    (configs[4])             p384 variable-base, 2^20 pairs per GPU            -> scalar-muls/s
-    msm_k256_2p21  (N = 1 only)          one GPU's share of configs[3] on 8 GPUs; its per-term rate over the 2^24 rate is the
-                                         single-GPU projection of the 8-GPU efficiency (`projected_8gpu_efficiency`)
+    msm_k256_2p21  (N = 1 only)          one GPU's share of configs[3] on 8 GPUs, timed right after configs[3] (same thermal state); its
+                                         per-term rate over the 2^24 rate is the single-GPU projection of the 8-GPU efficiency
+                                         (`projected_8gpu_efficiency`)
     ecdsa_p256, recover_k256             the signature callers of the path
+    fixed_k256_ct, lincomb_ct_k256,      the names north_star uses in their CONSTANT-TIME meaning (`mul_by_generator`, `lincomb`, `P * k`): the
+    var_p256_ct                          uniform-schedule kernels.  The headline and msm_k256 are the reference's *_vartime forms.
+    msm_k256[_2p21]_lanes (N = 1)        the same MSMs with 3 / 2 in flight (ecgpu_set_msm_lanes); msm_k256_2p21_sharded_lanes: the share as a
+                                         SHARDED step (parts / exchange / finish) with consecutive local halves on two rotating lanes;
+                                         N > 1: msm_k256_sharded_lanes (the 2^24-term MSM itself in that form) and `per_rank` under msm_k256
+                                         (every rank's local half, exchange alone, combining half: a scaling run that explains itself)
+    fixed_k256_tier_ms (N = 1)           the headline batch on the narrower generator tables of the library's DEFAULT (adaptive) policy
     msm_k256.e2e_ms  (N = 1)             the 2^24-term MSM from HOST memory through ecgpu_msm (PCIe-inclusive; never `value`)
     group_msm_k256   (N > 1, rank 0)     the 2^24-term MSM through the single-process entry ecgpu_group_msm_dev
 
@@ -71,8 +79,19 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # reference field-multiplication count x canonical IMAD32 per field multiplication
 # (F256 = 2*8^2 + 8 = 136, F384 = 2*12^2 + 12 = 300), and algorithmic HBM bytes per unit.
 WORKLOADS = {
-    "fixed_k256": dict(curve="k256", kind="fixed", n=1 << 20, metric="k256 fixed-base scalar-muls/sec", unit="scalar-muls/s",
-                       imad_per_unit=812 * 136, bytes_per_unit=96, kernel="k_fixed_base<K256Params>", scaling="weak"),
+    # the headline is the VARIABLE-TIME generator multiplication (`mul_by_generator_vartime`, k256/src/arithmetic/mul.rs:205-232: a signed
+    # comb whose table reads and additions follow the scalar); the constant-time `mul_by_generator` (:180-197) is fixed_k256_ct below
+    "fixed_k256": dict(curve="k256", kind="fixed", n=1 << 20, metric="k256 fixed-base scalar-muls/sec (variable-time: mul_by_generator_vartime)",
+                       unit="scalar-muls/s", imad_per_unit=812 * 136, bytes_per_unit=96, kernel="k_fixed_base<K256Params>", scaling="weak",
+                       form="variable-time comb (ecgpu_batch_mul_base_dev = mul_by_generator_vartime)"),
+    # `mul_by_generator` proper: the reference's constant-time schedule (k256 mul.rs:180-197 / primeorder basepoint.rs:82-99) —
+    # every entry of every LUT read and one kept under a mask, complete formulas, no scalar-dependent branch or address
+    "fixed_k256_ct": dict(curve="k256", kind="fixed", ct=True, n=1 << 20, metric="k256 fixed-base scalar-muls/sec (uniform schedule: mul_by_generator)",
+                          unit="scalar-muls/s", imad_per_unit=812 * 136, bytes_per_unit=96, kernel="k_fixed_base_ct<K256Params>", scaling="weak"),
+    # `LinearCombination::lincomb` in its constant-time meaning (k256 mul.rs:84-98, primeorder projective.rs:484-496): one
+    # uniform-schedule multiplication per term + a tree of complete additions (ecgpu_lincomb_ct_dev); 2^20 terms
+    "lincomb_ct_k256": dict(curve="k256", kind="lincomb_ct", n=1 << 20, metric="k256 lincomb terms/sec (uniform schedule: lincomb)",
+                            unit="terms/s", imad_per_unit=960 * 136, bytes_per_unit=96, kernel="k_var_base_ct<K256Params>", scaling="weak"),
     "var_p256": dict(curve="p256", kind="var", n=1 << 20, metric="p256 variable-base scalar-muls/sec", unit="scalar-muls/s",
                      imad_per_unit=4336 * 136, bytes_per_unit=160, kernel="k_var_base<P256Params>", scaling="weak"),
     "var_k256": dict(curve="k256", kind="var", n=1 << 20, metric="k256 variable-base scalar-muls/sec", unit="scalar-muls/s",
@@ -107,10 +126,16 @@ WORKLOADS["msm_k256_2p21"] = dict(WORKLOADS["msm_k256"], n=1 << 21, metric="k256
 # (profiles/r03/msm_lanes.txt: two lanes are best at 2^21 terms, three at 2^24)
 WORKLOADS["msm_k256_lanes"] = dict(WORKLOADS["msm_k256"], lanes=3, metric="k256 MSM terms/sec, three MSMs in flight")
 WORKLOADS["msm_k256_2p21_lanes"] = dict(WORKLOADS["msm_k256_2p21"], lanes=2, metric="k256 MSM terms/sec (2^21-term share), two MSMs in flight")
-SEEDS = {"msm_k256_lanes": 4, "msm_k256_2p21_lanes": 10, "var_p256_ct": 11, "msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
+# one GPU's share as a SHARDED step (ecgpu_msm_parts_dev / ecgpu_msm_finish_dev) with the local halves of consecutive MSMs on two rotating
+# lanes: the exchange + combining half of step i under the accumulation of step i + 1 (N = 1: one rank, the "exchange" is the identity)
+WORKLOADS["msm_k256_2p21_sharded_lanes"] = dict(WORKLOADS["msm_k256_2p21"], lanes=2, sharded=True,
+                                                 metric="k256 MSM terms/sec (2^21-term share), sharded step on two lanes")
+# N > 1: the whole 2^24-term MSM, sharded, consecutive MSMs on two lanes per GPU
+WORKLOADS["msm_k256_sharded_lanes"] = dict(WORKLOADS["msm_k256"], lanes=2, sharded=True, metric="k256 MSM terms/sec, sharded steps on two lanes per GPU")
+SEEDS = {"fixed_k256_ct": 12, "lincomb_ct_k256": 13, "msm_k256_2p21_sharded_lanes": 10, "msm_k256_sharded_lanes": 4, "msm_k256_lanes": 4, "msm_k256_2p21_lanes": 10, "var_p256_ct": 11, "msm_k256_2p21": 10, "fixed_k256": 2, "var_p256": 3, "msm_k256": 4, "var_p384": 5, "var_k256": 6, "ecdsa_p256": 7, "msm_p256": 8, "recover_k256": 9}
 # BASELINE configs[2], [3], [4] beside the top-level configs[1], then the two signature workloads of SURVEY.md 8(f) (callers of the
 # path: p256 verification, k256 public-key recovery) so that they are driver-timed too
-DEFAULT_SUBS = ["var_p256", "msm_k256", "var_p384", "msm_k256_2p21", "ecdsa_p256", "recover_k256", "var_p256_ct"]
+DEFAULT_SUBS = ["var_p256", "msm_k256", "msm_k256_2p21", "var_p384", "ecdsa_p256", "recover_k256", "var_p256_ct", "fixed_k256_ct", "lincomb_ct_k256"]
 NOMINAL_PEAK = 256 * 4 * 16 * 2.4e9   # IMAD32/s at the 2.4 GHz peak engine clock (the probe, all CUs multiplying, runs at ~2.1)
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3 TB/s achievable)
 ROOFLINE_CONSTS = os.path.join(ROOT, "profiles", "roofline_consts.json")
@@ -223,8 +248,8 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
                                     sample_points[lo * 2 * L: hi * 2 * L])
         elif kind == "recover":
             oracle_lib.ecdsa_recover(cid, s, extra[0][lo * L: hi * L], extra[1][lo * L: hi * L], extra[2][lo:hi], True)
-        else:
-            oracle_lib.msm(cid, s, sample_points[lo * 2 * L: hi * 2 * L], vartime=True)
+        else:       # the MSM's CPU counterpart: `lincomb_vartime`; for the uniform-schedule workload the constant-time `lincomb`
+            oracle_lib.msm(cid, s, sample_points[lo * 2 * L: hi * 2 * L], vartime=kind != "lincomb_ct")
 
     avail = sample_scalars.size // L
     pilot = min(avail, 256 if kind != "fixed" else 2048)
@@ -249,6 +274,7 @@ def cpu_baseline(wl, cid, L, sample_scalars, sample_points, extra=None, target_w
     total = per_thread * cores
     algo = {"fixed": "mul_by_generator (33/49-LUT basepoint table)", "var": "ProjectivePoint * Scalar (LUT + radix-16)",
             "msm": "lincomb_vartime (GLV + wNAF-5 Straus), one %d-term lincomb per thread" % per_thread,
+            "lincomb_ct": "lincomb (constant-time GLV + radix-16 Straus), one %d-term lincomb per thread" % per_thread,
             "ecdsa": "verify_prehashed: s^-1, u1 G + u2 Q (mul_by_generator_and_mul_add_vartime), x mod n == r",
             "recover": "recover_from_prehash: decompress R, r^-1, lincomb(G, u1, R, u2), verify_prehash"}[kind]
     return {"value": total / dt, "unit": wl["unit"], "cores": cores, "kind": "port",
@@ -384,7 +410,7 @@ class Bench:
         """One input set of a workload, on the device: {"scal", "pts", "s2", "r", "s", "recid"} (None where the kind has none)."""
         torch, eng, ecgpu, device = self.torch, self.eng, self.ecgpu, self.device
         inp = dict(scal=device_random_scalars(torch, n, L, seed, device), pts=None, s2=None, r=None, s=None, recid=None)
-        if kind in ("var", "msm"):
+        if kind in ("var", "msm", "lincomb_ct"):
             inp["s2"] = device_random_scalars(torch, n, L, seed + 50, device)
             inp["pts"] = torch.empty((n, 2 * L), dtype=torch.uint8, device=device)
             torch.cuda.synchronize()
@@ -450,25 +476,35 @@ class Bench:
         sets = [self.make_inputs(name, kind, cid, L, n, 0xEC000000 + SEEDS[name] + 1000 * rank + 7919 * j) for j in range(nsets)]
         d_scal = d_pts = d_s2 = d_r = d_s = d_recid = None      # (bound to the set of the last step before the check)
         d_ok = torch.zeros((n + 16,), dtype=torch.uint8, device=device) if kind in ("ecdsa", "recover") else None
-        n_out = 1 if kind == "msm" else n
+        n_out = 1 if kind in ("msm", "lincomb_ct") else n
         d_out = torch.empty((n_out, 2 * L), dtype=torch.uint8, device=device)
         d_inf = torch.empty((max(n_out, 16),), dtype=torch.uint8, device=device)
-        exchange = None
-        if kind == "msm" and world > 1:
+        # The MSM as a SHARDED step — local half (ecgpu_msm_parts_dev), ONE exchange (RCCL all-gather of the per-window partial sums
+        # over xGMI), combining half on every rank (ecgpu_msm_finish_dev): always with N > 1 ranks, and at N = 1 for the workloads
+        # that time one rank's share in that form (`sharded`: the exchange of one rank is the identity).
+        sharded = kind == "msm" and (world > 1 or bool(wl.get("sharded")))
+        lanes = int(wl.get("lanes", 1)) if kind == "msm" else 1
+        lane_out = [(d_out, d_inf)] + [(torch.empty_like(d_out), torch.empty_like(d_inf)) for _ in range(lanes - 1)]
+        exchanges, plan_terms = [], 0
+        if sharded:
             plan_terms = (n_total + world - 1) // world              # the largest shard: every rank plans the same windows
-            exchange = ecgpu.RecordExchange(torch, dist, eng.msm_parts_bytes(cid, plan_terms), device, group=self.group)
+            nbytes = eng.msm_parts_bytes(cid, plan_terms)
+            for _ in range(lanes):                                   # a parts record (and its gathered form) per lane
+                if world > 1:
+                    exchanges.append(ecgpu.RecordExchange(torch, dist, nbytes, device, group=self.group))
+                else:
+                    exchanges.append(ecgpu.LocalRecord(torch, nbytes, device))
         torch.cuda.synchronize()     # inputs were written on torch's stream; make sure they are there whatever stream the engine uses
 
         main_ms, stages = [], {}
-        # fixed / variable base: the batches are queued back to back (ecgpu_set_async) and the queue is drained inside the
-        # timed region; the per-call HIP events are then read for the last timed step.  The other kinds keep the
-        # synchronous calls and read every step's events.
-        queued = kind in ("fixed", "var") and not args.sync_calls
-        lanes = int(wl.get("lanes", 1)) if kind == "msm" and exchange is None else 1
+        # fixed / variable base, and the sharded MSM of an N-rank job: the calls are queued back to back (ecgpu_set_async) and the queue
+        # is drained inside the timed region — no rank's host stands between two steps —; the per-call HIP events are then read for
+        # the last timed step.  The other kinds keep the synchronous calls and read every step's events.
+        queued = (kind in ("fixed", "var") or (sharded and world > 1)) and not args.sync_calls
         if lanes > 1:
             queued = True
-            lane_out = [(d_out, d_inf)] + [(torch.empty_like(d_out), torch.empty_like(d_inf)) for _ in range(lanes - 1)]
         nstep = [0]
+        pend = []                                      # sharded steps on lanes whose combining half is still to be queued: (lane, input set)
 
         def read_events():
             main_ms.append(eng.last_timing("accumulate" if kind == "msm" else "main") or 0.0)
@@ -477,46 +513,69 @@ class Bench:
                 if v is not None:
                     stages.setdefault(st, []).append(v)
 
-        written = {}                                   # id of an output buffer -> the input set of the last step that wrote it
+        written = {}                                   # index of an output buffer -> the input set of the last step that wrote it
 
-        def step():
+        def combine_pending():
+            """exchange + combining half of the oldest local half in flight, on the engine's stream (= torch's current stream: the
+            collective is ordered behind ecgpu_msm_parts_join_dev and before ecgpu_msm_finish_dev on the device, no host wait)"""
+            b, j = pend.pop(0)
+            ex = exchanges[b]
+            eng.msm_parts_join_dev(ex.mine)
+            eng.msm_finish_dev(cid, ex.gather(consumer_on_current_stream=True), world, plan_terms, *lane_out[b])
+            written[b] = j
+
+        def step(read=False):
             j = nstep[0] % nsets
             nstep[0] += 1
             inp = sets[j]
             k_, p_ = inp["scal"], inp["pts"]
             buf = nstep[0] % lanes if lanes > 1 else 0
-            written[buf] = j
+            if not (sharded and lanes > 1):
+                written[buf] = j
             if kind == "fixed":
-                eng.mul_by_generator_dev(cid, k_, n, d_out, d_inf)
+                eng.mul_by_generator_dev(cid, k_, n, d_out, d_inf, constant_time=bool(wl.get("ct")))
             elif kind == "var":
                 eng.mul_dev(cid, k_, p_, None, n, d_out, d_inf, constant_time=bool(wl.get("ct")))
+            elif kind == "lincomb_ct":
+                eng.lincomb_ct_dev(cid, k_, p_, None, n, d_out, d_inf)
             elif kind == "ecdsa":
                 eng.ecdsa_verify_dev(cid, k_, inp["r"], inp["s"], p_, n, False, d_ok)
             elif kind == "recover":
                 eng.ecdsa_recover_dev(cid, k_, inp["r"], inp["s"], inp["recid"], n, True, d_out, d_ok)
-            elif exchange is None:
-                if lanes > 1:                              # several MSMs in flight: each writes buffers of its own
-                    eng.lincomb_dev(cid, k_, p_, None, n, *lane_out[buf])
-                else:
-                    eng.lincomb_dev(cid, k_, p_, None, n, d_out, d_inf)
+            elif not sharded:
+                eng.lincomb_dev(cid, k_, p_, None, n, *lane_out[buf])     # (several MSMs in flight: each writes buffers of its own)
+            elif lanes > 1:
+                # local half of step i on lane i % lanes; THEN the exchange + combining half of step i - 1 on the engine's stream,
+                # beside it (include/ecgpu.h, ecgpu_msm_parts_join_dev)
+                eng.msm_parts_dev(cid, k_, p_, None, n, plan_terms, exchanges[buf].mine)
+                pend.append((buf, j))
+                if len(pend) > 1:
+                    combine_pending()
+                return
             else:
-                # sharded MSM: local pipeline down to the per-window partial sums, ONE exchange step (RCCL all-gather of
-                # the parts over xGMI), window sums over all ranks + the Horner chain on every rank
-                eng.msm_parts_dev(cid, k_, p_, None, n, plan_terms, exchange.mine)
-            if not queued:
+                ex = exchanges[0]
+                eng.msm_parts_dev(cid, k_, p_, None, n, plan_terms, ex.mine)
+                if read:
+                    read_events()                      # (the local half's events: the combining half below replaces them)
+                eng.msm_finish_dev(cid, ex.gather(consumer_on_current_stream=True), world, plan_terms, d_out, d_inf)
+                return
+            if read:
                 read_events()
-            if exchange is not None:
-                eng.msm_finish_dev(cid, exchange.gather(), world, plan_terms, d_out, d_inf)
+
+        def flush():
+            while pend:
+                combine_pending()
 
         for _ in range(args.warmup):
             step()
-        main_ms.clear(); stages.clear()
+        flush()
         if queued:
             eng.set_async(True)
         if lanes > 1:
             eng.set_msm_lanes(lanes)
             for _ in range(lanes):                       # the lanes' streams and workspaces exist before the clock starts
                 step()
+            flush()
             eng.synchronize()
         self.fence()
         # queued batches: the per-call timing events (three packets of their own per batch on the stream) are recorded for the
@@ -529,26 +588,31 @@ class Bench:
         for i in range(args.steps):
             if events_last_only and i == args.steps - 1:
                 eng.set_timing(True)
-            step()
+            step(read=not queued)
+        flush()
         if queued:
             eng.synchronize()            # waits for the queue and raises if any queued batch failed its input checks
         self.fence()
         elapsed = time.perf_counter() - t0
         if queued:
-            read_events()
+            if not sharded:
+                read_events()
+            elif lanes > 1:                              # the last lane's accumulation kernel (ecgpu_last_timing reads the lane's events)
+                main_ms.append(eng.last_timing("accumulate") or 0.0)
             if lanes > 1:
                 eng.set_msm_lanes(1)
             eng.set_async(False)
             if lanes == 1:
                 # the queued steps leave ONE sample of the kernel's duration (the HIP events of the last step); five more steps,
                 # outside the timed region and synchronous, give kernel_ms a minimum and a mean to stand on
+                eng.set_timing(True)
                 for _ in range(5):
-                    step()
-                    read_events()
+                    step(read=True)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64)           # (the control plane is gloo: a host tensor)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        per_rank = self.per_rank_stages(cid, sets[0], n, plan_terms, exchanges[0], d_out, d_inf) if sharded and world > 1 else None
 
         units_per_step = n_total if kind == "msm" else n * world
         value = units_per_step * args.steps / elapsed
@@ -558,22 +622,31 @@ class Bench:
         # ---- parity check of the last timed step (every rank takes part in the MSM's collective sum) ----
         ok = None
         if not args.no_check:
-            if kind == "msm":
+            if kind in ("msm", "lincomb_ct"):
                 part = device_dot_mod(torch, d_scal, d_s2, ecgpu.GROUP_ORDERS[cid])
-                if world > 1:
+                if world > 1 and kind == "msm":
                     parts = [None] * world
                     dist.all_gather_object(parts, part)
                     part = sum(parts) % ecgpu.GROUP_ORDERS[cid]
             if rank == 0:
                 import oracle_lib
                 oracle_lib.build()
-                if kind == "msm":
+                if kind in ("msm", "lincomb_ct"):
                     # P_i = s_i G  =>  sum_i k_i P_i == (sum_i k_i s_i mod n) G, whatever the term count
                     w, wf = oracle_lib.batch_mul_base(cid, np.frombuffer(part.to_bytes(L, "big"), np.uint8))
                     ok = bytes(w) == bytes(d_out[0].cpu().numpy()) and int(wf[0]) == int(d_inf[0].item())
                     if n_total <= (1 << 12) and world == 1:
                         w2, wf2 = oracle_lib.msm(cid, d_scal.cpu().numpy().reshape(-1), d_pts.cpu().numpy().reshape(-1), vartime=True)
                         ok = ok and bytes(w2) == bytes(w) and wf2 == int(wf[0])
+                    if kind == "lincomb_ct":
+                        # and the first 256 terms against the oracle's constant-time `lincomb` driver (k256 mul.rs:84-98), byte for byte
+                        m = min(n, 256)
+                        d_o2 = torch.empty((1, 2 * L), dtype=torch.uint8, device=device)
+                        d_i2 = torch.zeros((16,), dtype=torch.uint8, device=device)
+                        torch.cuda.synchronize()
+                        eng.lincomb_ct_dev(cid, d_scal[:m].contiguous(), d_pts[:m].contiguous(), None, m, d_o2, d_i2)
+                        w2, wf2 = oracle_lib.msm(cid, d_scal[:m].cpu().numpy().reshape(-1), d_pts[:m].cpu().numpy().reshape(-1), vartime=False)
+                        ok = ok and bytes(w2) == bytes(d_o2[0].cpu().numpy()) and int(wf2) == int(d_i2[0].item())
                 elif kind == "ecdsa":
                     m = min(n, 256)
                     w = oracle_lib.ecdsa_verify(cid, d_scal[:m].cpu().numpy().reshape(-1), d_r[:m].cpu().numpy().reshape(-1),
@@ -640,8 +713,8 @@ class Bench:
                        "window_bits": args.window or "default", "parallelism": "shard%d" % world,
                        **({"exchange": self.exchange_kind, "exchange_reason": self.exchange_reason} if world > 1 else {}),
                        **({"dry_run": "ranks share one GPU, %s exchange" % self.backend} if os.environ.get("ECGPU_BENCH_SHARE_GPU") else {})},
-            "calls": "%d MSMs in flight (ecgpu_set_async + ecgpu_set_msm_lanes), drained inside the timed region; kernel_ms = the last "
-                     "accumulation kernel with the other lanes' kernels beside it" % lanes if lanes > 1
+            "calls": "%d %s in flight (ecgpu_set_async + ecgpu_set_msm_lanes), drained inside the timed region; kernel_ms = the last "
+                     "accumulation kernel with the other lanes' kernels beside it" % (lanes, "sharded steps" if sharded else "MSMs") if lanes > 1
                      else "queued (ecgpu_set_async), drained inside the timed region; kernel_ms = mean (kernel_ms_min: minimum) over the HIP "
                           "events of the last timed step and of five synchronous steps after the timed region" if queued
                      else "synchronous, kernel_ms averaged over the HIP events of every timed step",
@@ -668,11 +741,15 @@ class Bench:
             "check_vs_oracle": ok,
         }
         rec["config"]["input_sets"] = nsets
+        if wl.get("form"):
+            rec["config"]["form"] = wl["form"]
+        if per_rank:
+            rec["per_rank"] = per_rank
         if kind in ("fixed", "ecdsa", "recover"):
             ti = eng.base_table_info(cid)               # the generator table these steps read (built before the timed region)
             rec["table"] = {"window_bits": ti["window_bits"], "bytes": ti["bytes"], "build_ms": round(ti["build_ms"], 2), "policy": "eager"}
         if cpu_leg:
-            ns = min(n, 1 << 17 if kind in ("fixed", "msm") else 1 << 14)
+            ns = min(n, 1 << 17 if kind in ("fixed", "msm", "lincomb_ct") else 1 << 14)
             s_host = d_scal[:ns].cpu().numpy().reshape(-1)
             p_host = d_pts[:ns].cpu().numpy().reshape(-1) if d_pts is not None else None
             extra = (d_r[:ns].cpu().numpy().reshape(-1), d_s[:ns].cpu().numpy().reshape(-1)) if kind in ("ecdsa", "recover") else None
@@ -680,6 +757,37 @@ class Bench:
                 extra = extra + (d_recid[:ns].cpu().numpy(),)
             rec["cpu_baseline"] = cpu_baseline(wl, cid, L, s_host, p_host, extra)
         return rec
+
+    def per_rank_stages(self, cid, inp, n, plan_terms, ex, d_out, d_inf):
+        """N > 1, after the timed region: what every rank's share of the sharded MSM is made of, so that a scaling run explains itself
+        — three synchronous, separately timed steps per rank: the local half (host clock around the call + its stage events), the
+        exchange alone (ranks aligned by a barrier first, so that the figure is the collective and not the wait for the slowest rank),
+        the combining half.  Minimum of the three; every rank's record travels to rank 0 over the gloo control plane."""
+        torch, dist, eng, world = self.torch, self.dist, self.eng, self.world
+        best = {}
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.msm_parts_dev(cid, inp["scal"], inp["pts"], None, n, plan_terms, ex.mine)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            st = {k: eng.last_timing(k) for k in ("sort", "accumulate", "reduce")}
+            dist.barrier()                                   # (gloo: the control plane)
+            t2 = time.perf_counter()
+            allrec = ex.gather(consumer_on_current_stream=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            eng.msm_finish_dev(cid, allrec, world, plan_terms, d_out, d_inf)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            cur = {"parts_ms": (t1 - t0) * 1e3, "exchange_us": (t3 - t2) * 1e6, "finish_ms": (t4 - t3) * 1e3,
+                   **{k + "_ms": v for k, v in st.items() if v is not None}}
+            for k, v in cur.items():
+                best[k] = min(best.get(k, v), v)
+        mine = {"rank": self.rank, "terms": n, **{k: float("%.4g" % v) for k, v in best.items()}}
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        return every
 
     def e2e_msm(self, name="msm_k256"):
         """SURVEY.md 8d, config 4 "end-to-end incl. PCIe": the same 2^24-term problem handed over in (page-locked) HOST memory
@@ -816,38 +924,35 @@ class Bench:
 
 
 NOTES = {
-    "roofline": "bound valu-int (SURVEY 8d: neither HBM nor MFMA bounds the path). peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz "
-                "v_mad_u64_u32 slots/s (MI355X_MICROARCH.md; full-rate issue measured by ecgpu_valu_probe = peak_probe). achieved = "
-                "SQ_INSTS_VALU per launch (rocprofv3 PMC pass under profiles/, roofline_consts.json) x issue slots per instruction "
-                "(ISA histogram) x 64 / kernel_ms (HIP events on the launch stream, this run). frac = achieved/peak; wfrac = reference algorithm's multiply-adds per unit (SURVEY 8d) x units / STEP time / peak (the whole workload, not its dominant kernel); kmin = minimum kernel_ms; cyc = issue "
-                "cycles / GRBM_GUI_ACTIVE of the PMC pass (no clock in it); algo_x = reference algorithm's IMAD32 (SURVEY 8d) over "
-                "the same time and peak (>1: fewer operations than the reference's algorithm); traffic = FETCH_SIZE + WRITE_SIZE "
-                "bytes per launch",
-    "cpu": "oracle/ C restatement of the reference's own CPU algorithm (kind port; no rustc in the image), all granted host "
-           "cores busy ~1.2 s on slices of the same seeded workload after a single-thread pilot; one = single-thread rate",
-    "check": "last timed step vs the oracle: batch workloads 256 sampled outputs byte for byte AND the sum of ALL outputs == "
-             "(sum k_i [s_i]) G; MSMs == (sum k_i s_i mod n) G exactly; signatures: every verdict / every recovered key",
-    "calls": "fixed / variable base: batches queued (ecgpu_set_async) and drained inside the timed region, per-call timing events on the last timed step only (ecgpu_set_timing); others synchronous; "
-             "*_lanes_ms: the same MSMs with two (2^21) / three (2^24) in flight (ecgpu_set_msm_lanes: rotating streams + workspaces), per MSM",
+    "roofline": "bound valu-int (SURVEY 8d). peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz v_mad_u64_u32 slots/s; achieved = SQ_INSTS_VALU per launch "
+                "(rocprofv3 PMC, profiles/roofline_consts.json) x issue slots per instruction (ISA histogram) x 64 / kernel_ms (HIP events, this run); "
+                "frac = achieved/peak; fvp = achieved / this GPU's probed issue rate (a slow box lowers frac, not fvp); wfrac = 8d multiply-adds x "
+                "units / STEP time / peak; cyc = issue cycles / GRBM_GUI_ACTIVE (PMC); clk = PMC cycles / kernel_ms; algo_x = 8d IMAD32 / kernel time "
+                "/ peak; traffic = FETCH_SIZE + WRITE_SIZE bytes per launch; units: the metric's, per second",
+    "cpu": "oracle/ C restatement of the reference's CPU algorithm (kind port; no rustc here), all granted cores ~1.2 s; one = 1 thread",
+    "check": "last timed step vs the oracle: batches 256 sampled outputs byte for byte AND sum of ALL outputs == (sum k_i [s_i]) G; MSMs == "
+             "(sum k_i s_i mod n) G (lincomb_ct also 256 terms vs the oracle's constant-time lincomb); signatures: every verdict / key",
+    "calls": "batches (and sharded MSM steps at N > 1) queued (ecgpu_set_async), drained inside the timed region; others synchronous; *_lanes: 2 "
+             "(2^21) / 3 (2^24) MSMs in flight; *_sharded_lanes: parts / exchange / finish of consecutive MSMs on 2 rotating lanes",
 }
 
 
 def compact(r):
-    """A sub-record for the one-line output: numbers only (the prose lives once in NOTES), < 600 bytes each — the driver keeps
+    """A sub-record for the one-line output: numbers only (the prose lives once in NOTES), ~400 bytes each — the driver keeps
     the last 8 KB of the line."""
     rf = r.get("roofline", {})
     g = lambda v, d=4: None if v is None else float(("%%.%dg" % d) % v)
-    out = {"metric": r["metric"], "value": g(r["value"], 5), "unit": r["unit"], "ms_per_step": g(r["ms_per_step"], 5),
-           "units": r["config"]["units_total"], "scaling": r["scaling"],
+    out = {"metric": r["metric"], "value": g(r["value"], 5), "ms_per_step": g(r["ms_per_step"], 5),
            "kernel": rf.get("kernel"), "kernel_ms": g(rf.get("kernel_ms")), "kmin": g(rf.get("kernel_ms_min")), "frac": g(rf.get("frac")),
-           "wfrac": g(rf.get("workload_frac_8d")), "cyc": g(rf.get("frac_cycles_pmc")), "clk": g(rf.get("clock_ghz_kernel"), 3),
-           "mad_frac": g(rf.get("mad_frac")), "algo_x": g(rf.get("algorithmic_speedup")), "traffic": g(rf.get("traffic")),
+           "fvp": g(rf.get("frac_vs_probe")), "wfrac": g(rf.get("workload_frac_8d")), "cyc": g(rf.get("frac_cycles_pmc")),
+           "clk": g(rf.get("clock_ghz_kernel"), 3), "mad_frac": g(rf.get("mad_frac")), "algo_x": g(rf.get("algorithmic_speedup")),
+           "traffic": g(rf.get("traffic")),
            "stage_ms": {k: g(v, 3) for k, v in r.get("stage_ms", {}).items() if k not in ("main", "total")},
            "check": r.get("check_vs_oracle")}
     cb = r.get("cpu_baseline")
     if cb:
         out["cpu"] = {"value": g(cb["value"]), "cores": cb["cores"], "one": g(cb["single_thread_value"]), "kind": cb["kind"]}
-    for k in ("e2e_ms", "e2e_value", "e2e_check", "share_of_2p24_rate", "projected_8gpu_efficiency"):
+    for k in ("e2e_ms", "e2e_value", "e2e_check", "share_of_2p24_rate", "projected_8gpu_efficiency", "per_rank"):
         if k in r:
             out[k] = g(r[k]) if isinstance(r[k], float) else r[k]
     return out
@@ -902,15 +1007,28 @@ def main():
     subs = [] if single else [x for x in DEFAULT_SUBS if b.world == 1 or x != "msm_k256_2p21"]
     full = {}
     for name in subs:
-        r = b.run(name, cpu_leg)
+        # (the CPU leg beside BASELINE's own configs and the signature callers; the uniform-schedule twins share their oracle functions)
+        r = b.run(name, cpu_leg and name not in ("var_p256_ct", "fixed_k256_ct"))
         if r is not None:
             full[name] = r
     lanes = {}
-    if not single and b.world == 1 and not args.no_extras:       # the two MSM sizes again with two MSMs in flight (top-level keys only)
-        for name in ("msm_k256_lanes", "msm_k256_2p21_lanes"):
+    if not single and not args.no_extras:       # the MSM sizes again with several MSMs in flight (top-level keys only)
+        for name in (("msm_k256_lanes", "msm_k256_2p21_lanes", "msm_k256_2p21_sharded_lanes") if b.world == 1 else ("msm_k256_sharded_lanes",)):
             r = b.run(name, False)
             if r is not None:
                 lanes[name] = r
+    tiers = None
+    if not single and b.world == 1 and not args.no_extras and rec is not None:
+        # The library's DEFAULT table policy grows the generator table with use (16 -> 22 -> 26 bits after 2^26 / 2^29 multiplications on
+        # the device); the headline asks for the widest up front.  What the same batch costs on the two narrower tiers:
+        tiers = {"26": float("%.4g" % rec["ms_per_step"]), "check": True}
+        for w in (16, 22):
+            args.window = w
+            r = b.run("fixed_k256", False)
+            tiers[str(w)] = float("%.4g" % r["ms_per_step"])
+            tiers["check"] = tiers["check"] and bool(r["check_vs_oracle"] or args.no_check)
+        args.window = 0
+        b.eng.set_base_window(b.ecgpu.CURVE_IDS["k256"], 0)
     e2e = e2e_fx = group = None
     if not single and not args.no_extras:
         if b.world == 1:
@@ -940,11 +1058,12 @@ def main():
             if name in full:
                 r = full[name]
                 rec[name + "_value"] = r["value"]
-                rec[name + "_unit"] = r["unit"]
                 rec[name + "_ms_per_step"] = r["ms_per_step"]
                 rec[name + "_frac"] = r["roofline"]["frac"]                       # the dominant kernel's executed work / roof
                 rec[name + "_workload_frac"] = r["roofline"]["workload_frac_8d"]  # SURVEY 8d's numerator over the WHOLE step
                 rec[name + "_check"] = r["check_vs_oracle"]
+        if tiers:
+            rec["fixed_k256_tier_ms"] = tiers       # ms per 2^20 scalars by table width (bits): the default (adaptive) policy's three tiers
         if e2e_fx:
             rec["fixed_k256_e2e_ms"] = e2e_fx["e2e_ms"]
             rec["fixed_k256_e2e_check"] = e2e_fx["e2e_check"]
@@ -959,8 +1078,10 @@ def main():
         for name, r in lanes.items():                            # throughput with several MSMs in flight per GPU (ecgpu_set_msm_lanes)
             rec[name + "_ms"] = r["ms_per_step"]
             rec[name + "_check"] = r["check_vs_oracle"]
-        if len(lanes) == 2:                                      # per-term rate of a 2^21-term share over the 2^24 rate, both with MSMs in flight
-            rec["msm_k256_2p21_lanes_share"] = lanes["msm_k256_lanes"]["ms_per_step"] / (8.0 * lanes["msm_k256_2p21_lanes"]["ms_per_step"])
+        if "msm_k256_lanes" in lanes:                            # per-term rate of a 2^21-term share over the 2^24 rate, both with MSMs in flight
+            for nm in ("msm_k256_2p21_lanes", "msm_k256_2p21_sharded_lanes"):
+                if nm in lanes:
+                    rec[nm + "_share"] = lanes["msm_k256_lanes"]["ms_per_step"] / (8.0 * lanes[nm]["ms_per_step"])
         rec["configs"] = {k: compact(v) for k, v in full.items()}
         if group:
             rec["configs"]["group_msm_k256"] = group
@@ -969,6 +1090,10 @@ def main():
             rec["configs"]["cpu_k256_1024"] = {k: c0[k] for k in ("metric", "value", "unit", "ms_per_step", "check_vs_model")}
         rec["cargo"] = cargo_probe()
         rec["notes"] = NOTES
+        for k, v in list(rec.items()):                           # (sub-workload keys at six significant digits: the line stays below 8 KB)
+            if isinstance(v, float) and k not in ("value", "ms_per_step"):
+                rec[k] = float("%.6g" % v)
+        rec["roofline"] = {k: (float("%.6g" % v) if isinstance(v, float) else v) for k, v in rec["roofline"].items()}
         line = json.dumps(rec, separators=(",", ":"))
         print(line, flush=True)
         if len(line) > 8000:

@@ -61,9 +61,10 @@ ABI_SYMBOLS = [
     "ecgpu_batch_ecdh_ct", "ecgpu_batch_ecdh_ct_dev",
     "ecgpu_lincomb_ct", "ecgpu_lincomb_ct_dev", "ecgpu_msm_compressed", "ecgpu_msm_compressed_dev",
     "ecgpu_batch_mul_compressed", "ecgpu_batch_mul_compressed_dev", "ecgpu_wipe", "ecgpu_group_exchange_reason",
-    "ecgpu_set_table_policy", "ecgpu_set_table_budget", "ecgpu_base_table_info", "ecgpu_group_set_exchange_timeout",
+    "ecgpu_set_table_policy", "ecgpu_set_table_budget", "ecgpu_base_table_info", "ecgpu_group_set_exchange_timeout", "ecgpu_group_set_exchange", "ecgpu_msm_parts_join_dev",
 ]
 TABLE_ADAPTIVE, TABLE_EAGER = 0, 1
+EXCHANGE_PEER, EXCHANGE_RCCL = 1, 2
 
 
 GROUP_ORDERS = {   # k256/src/lib.rs:71, p256/src/lib.rs:60, p384/src/lib.rs:73
@@ -89,20 +90,21 @@ class EcgpuError(RuntimeError):
 
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """Loads libecgpu.so (built in-tree by `make -C elliptic-curves_amd` / __graft_entry__.build())."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(variant=None):
+    """Loads libecgpu.so (built in-tree by `make -C elliptic-curves_amd` / __graft_entry__.build()).
+
+    `variant` names another build of this tree that lives beside it, lib/libecgpu_<variant>.so — "knobs" is the tool build in
+    which the ECGPU_* tuning knobs are read from the environment (csrc/ecgpu_knobs.h; the product never reads it); the A/B
+    recipes of tools/gpu_run.sh name theirs through ECGPU_TOOL_LIB, which replaces the DEFAULT library of the process.
+    Either way only files lib/libecgpu_<suffix>.so of this tree can be selected: the loader cannot be pointed anywhere else."""
+    if variant in _libs:
+        return _libs[variant]
     path = LIB_PATH
-    alt = os.environ.get("ECGPU_TOOL_LIB")
+    alt = os.path.join(os.path.dirname(LIB_PATH), "libecgpu_%s.so" % variant) if variant else os.environ.get("ECGPU_TOOL_LIB")
     if alt:
-        # another build of the same library for the A/B recipes of tools/gpu_run.sh — honoured only for files that
-        # tools/build_alt_lib.sh put beside the product (lib/libecgpu_<suffix>.so): the variable selects among this tree's own
-        # builds, it cannot point the loader anywhere else
         alt = os.path.realpath(alt)
         if os.path.dirname(alt) != os.path.realpath(os.path.dirname(LIB_PATH)) or not os.path.basename(alt).startswith("libecgpu_"):
             raise EcgpuError(ERR_ARG, "ECGPU_TOOL_LIB must name a lib/libecgpu_<suffix>.so of this tree")
@@ -133,7 +135,7 @@ def load_library():
     lib.ecgpu_group_destroy.argtypes = [ctypes.c_void_p]
     lib.ecgpu_msm_parts_bytes.restype = ctypes.c_size_t
     lib.ecgpu_msm_parts_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
-    _lib = lib
+    _libs[variant] = lib
     return lib
 
 
@@ -202,8 +204,8 @@ class Engine:
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
     (bench.py does) or synchronised."""
 
-    def __init__(self, device=0):
-        self._lib = load_library()
+    def __init__(self, device=0, variant=None):
+        self._lib = load_library(variant)       # variant="knobs": the tool build that reads the ECGPU_* tuning knobs (load_library)
         self._pinned = {}
         self._ctx = ctypes.c_void_p()
         rc = self._lib.ecgpu_init(ctypes.byref(self._ctx), int(device))
@@ -635,6 +637,10 @@ class Engine:
         self._chk(self._lib.ecgpu_msm_parts_dev(self._ctx, curve, _dp(d_scalars), _dp(d_points_xy), _dp(d_points_inf),
                                                 ctypes.c_size_t(n), ctypes.c_size_t(plan_terms), _dp(d_parts)))
 
+    def msm_parts_join_dev(self, d_parts):
+        """The context's stream waits (on the device) for the local half that wrote `d_parts` on a lane (include/ecgpu.h)."""
+        self._chk(self._lib.ecgpu_msm_parts_join_dev(self._ctx, _dp(d_parts)))
+
     def msm_finish_dev(self, curve, d_parts_all, nranks, plan_terms, d_out_xy, d_out_inf):
         self._chk(self._lib.ecgpu_msm_finish_dev(self._ctx, curve, _dp(d_parts_all), int(nranks), ctypes.c_size_t(plan_terms),
                                                  _dp(d_out_xy), _dp(d_out_inf)))
@@ -672,8 +678,9 @@ class Group:
     """All GPUs of a node from one process (ecgpu_group_*): batch calls slice the index range, lincomb shards its terms
     and exchanges per-window partial sums once."""
 
-    def __init__(self, devices):
-        self._lib = load_library()
+    def __init__(self, devices, variant=None, exchange=None):
+        """exchange: None (RCCL when it can be had, else peer copies), "peer", or "rccl" (EcgpuError instead of the fallback)."""
+        self._lib = load_library(variant)
         self._g = ctypes.c_void_p()
         devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
         rc = self._lib.ecgpu_group_init(ctypes.byref(self._g), devs, len(devices))
@@ -681,6 +688,16 @@ class Group:
             self._g = None
             raise EcgpuError(rc, "ecgpu_group_init failed")
         self.size = int(self._lib.ecgpu_group_size(self._g))
+        if exchange is not None:
+            try:
+                self.set_exchange(exchange)
+            except EcgpuError:
+                self.close()
+                raise
+
+    def set_exchange(self, mode):
+        """ecgpu_group_set_exchange: "peer" = peer copies from now on; "rccl" = raise unless the group exchanges over RCCL."""
+        self._chk(self._lib.ecgpu_group_set_exchange(self._g, {"peer": EXCHANGE_PEER, "rccl": EXCHANGE_RCCL}[mode]))
 
     @property
     def exchange(self):
@@ -798,4 +815,4 @@ def version():
     return load_library().ecgpu_version().decode()
 
 
-from .sharded import Exchange, RecordExchange, TensorExchange, init_exchange, lincomb_sharded, run_nccl_probe, shard_range  # noqa: E402,F401
+from .sharded import Exchange, LocalRecord, RecordExchange, TensorExchange, init_exchange, lincomb_sharded, run_nccl_probe, shard_range  # noqa: E402,F401

@@ -19,9 +19,14 @@
 
 #include "../../include/ecgpu.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_knobs.h"
 #include "ecgpu_recode.h"
 
 using namespace ecgpu;
+
+#ifndef ECGPU_FIXED_SOA_DEFAULT
+#define ECGPU_FIXED_SOA_DEFAULT true
+#endif
 
 namespace {
 
@@ -113,6 +118,7 @@ struct ecgpu_ctx {
         hipStream_t s = nullptr;
         DevBuf ws, proj, prefix;
         hipEvent_t ev_in = nullptr, ev_a = nullptr, ev_b = nullptr, ev_done = nullptr;
+        const void* parts_out = nullptr;   // the parts record an ecgpu_msm_parts_dev on this lane wrote last (ecgpu_msm_parts_join_dev)
     };
     bool lanes_pending = false;  // an MSM was queued on a lane since the last other call: that call first waits for the lanes (ev_done)
     int msm_lanes = 1;
@@ -420,37 +426,70 @@ int ensure_table(ecgpu_ctx* ctx, size_t n = 0) {
     const int wmax = ctx->want_w[C::ID];
     uint64_t& seen = reg.seen[C::ID];
     seen = seen + n < seen ? ~(uint64_t)0 : seen + n;
-    int want = wmax;
-    if (!ctx->w_pinned[C::ID]) {
+    // the width this call should get, from the registry as it is NOW (called again whenever the lock was dropped)
+    const auto choose = [&]() -> int {
+        int want = wmax;
+        if (ctx->w_pinned[C::ID]) return want;
         if (ctx->table_policy == ECGPU_TABLE_ADAPTIVE) want = table_tier(seen, wmax);
         if (ctx->table_budget)
             while (want > 4 && comb_table_bytes<C>(want) > ctx->table_budget) want--;
         for (int w = wmax; w > want; w--) {                      // somebody has paid for a wider one already
             auto it = reg.tabs.find(std::make_tuple(ctx->device, (int)C::ID, w));
-            if (it != reg.tabs.end() && it->second.d && (!ctx->table_budget || it->second.bytes <= ctx->table_budget)) {
-                want = w;
-                break;
+            if (it != reg.tabs.end() && it->second.d && (!ctx->table_budget || it->second.bytes <= ctx->table_budget)) return w;
+        }
+        return want;
+    };
+    // a refusal of `w` on this device is on record: has it expired (memory back, or NOFIT_RETRY_CALLS calls old)?  Erases it if so.
+    const auto refusal_over = [&](int w) -> bool {
+        auto nf = reg.nofit.find(std::make_tuple(ctx->device, (int)C::ID, w));
+        if (nf == reg.nofit.end()) return true;
+        size_t free_b = 0, total_b = 0;
+        const bool roomy = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > comb_table_bytes<C>(w) + ((size_t)3 << 30) &&
+                           !g_test_table_max_mb.load();
+        if (!roomy && --nf->second > 0) return false;
+        reg.nofit.erase(nf);
+        return true;
+    };
+    int want = choose();
+    if (t.d && t.asked == want) {
+        if (t.w >= want) return ECGPU_OK;
+        // The context sits on a NARROWER table than it asked for (the wide one did not fit when it was built).  That refusal is not
+        // for ever (include/ecgpu.h): when it has expired the wide table is tried again — before the narrow one is let go, so that
+        // a second refusal costs one failed allocation and nothing else.
+        if (!refusal_over(want)) return ECGPU_OK;
+        const auto key = std::make_tuple(ctx->device, (int)C::ID, want);
+        SharedTable& st = reg.tabs[key];
+        if (!st.d) {
+            const int rc = build_table<C>(ctx, want, &st);
+            if (rc != ECGPU_OK) {
+                reg.tabs.erase(key);
+                (void)hipGetLastError();
+                (void)drop_build_scratch(ctx);
+                if (rc != ECGPU_ERR_OOM) return rc;
+                reg.nofit[key] = NOFIT_RETRY_CALLS;              // still no room: stay on the narrow table for another stretch of calls
+                return ECGPU_OK;
             }
         }
+        st.refs++;                                               // ours from here on: it cannot go away while the lock is dropped
+        const Table fresh{st.d, want, st.nwin, want};
+        lock.unlock();
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));         // queued kernels may still read the narrow table
+        release_table(ctx, C::ID);
+        t = fresh;
+        return drop_build_scratch(ctx);
     }
-    if (t.d && t.asked == want) return ECGPU_OK;
     if (t.d) {
         lock.unlock();
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));      // queued kernels may still read the old table
         release_table(ctx, C::ID);
         lock.lock();
+        want = choose();      // the registry may have changed meanwhile: a wider table this call meant to share can be gone with its last owner
     }
     int rc = ECGPU_ERR_OOM;
     for (int w = want;; w -= 2) {
         const auto key = std::make_tuple(ctx->device, (int)C::ID, w);
-        auto nf = reg.nofit.find(key);
-        if (nf != reg.nofit.end() && w - 2 >= 16) {              // an earlier context of the device was refused this width
-            size_t free_b = 0, total_b = 0;
-            const bool roomy = hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > comb_table_bytes<C>(w) + ((size_t)3 << 30) &&
-                               !g_test_table_max_mb.load();
-            if (!roomy && --nf->second > 0) continue;
-            reg.nofit.erase(nf);                                 // memory is back, or the refusal is NOFIT_RETRY_CALLS calls old: try again
-        }
+        if (w - 2 >= 16 && !refusal_over(w)) continue;           // an earlier context of the device was refused this width
+        reg.nofit.erase(key);
         SharedTable& st = reg.tabs[key];
         if (!st.d) {
             rc = build_table<C>(ctx, w, &st);
@@ -534,12 +573,19 @@ int ensure_ct_lut(ecgpu_ctx* ctx) {
 
 // launches the normalisation of n projective points in ctx->proj to wire-format output
 template <class C>
-int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf) {
+int normalize_out(ecgpu_ctx* ctx, size_t n, void* d_out_xy, void* d_out_inf, bool soa = false) {
     int rc;
     if ((rc = ensure(ctx, ctx->prefix, n * Field<C>::NS * 4)) != ECGPU_OK) return rc;
     launch_normalize<C>(ctx->stream, false, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, n, (uint8_t*)d_out_xy,
-                        (uint8_t*)d_out_inf, nullptr);
+                        (uint8_t*)d_out_inf, nullptr, soa);
     return ECGPU_OK;
+}
+
+// The hand-over between k_fixed_base and k_normalize quad-major (store_proj_soa, ecgpu_kernels.h: a wave's load or store is 1,024
+// contiguous bytes instead of 64 pieces 144 bytes apart)?  A/B: ECGPU_FIXED_SOA = 0 / 1 in the tool build (profiles/r06/).
+inline bool fixed_soa() {
+    if (const char* e = knob("ECGPU_FIXED_SOA")) return e[0] != '0';
+    return ECGPU_FIXED_SOA_DEFAULT;
 }
 
 // ---- device-pointer implementations --------------------------------------------------------------------
@@ -555,14 +601,15 @@ int mul_base_dev(ecgpu_ctx* ctx, const void* d_scalars, size_t n, void* d_out_xy
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     const Table& t = ctx->table[C::ID];
     record(ctx, 0);
+    const bool soa = !compressed && fixed_soa();
     launch_fixed_base<C>(ctx->stream, (const uint8_t*)d_scalars, n, (const uint32_t*)t.d, t.w, t.nwin, (uint32_t*)ctx->proj.p,
-                         ctx->d_status);
+                         ctx->d_status, soa);
     record(ctx, 1);
     if (compressed) {
         if ((rc = ensure(ctx, ctx->prefix, n * NS * 4)) != ECGPU_OK) return rc;
         launch_normalize_compressed<C>(ctx->stream, (const uint32_t*)ctx->proj.p, (uint32_t*)ctx->prefix.p, n, (uint8_t*)d_out_xy,
                                        (uint8_t*)d_out_inf);
-    } else if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf)) != ECGPU_OK) {
+    } else if ((rc = normalize_out<C>(ctx, n, d_out_xy, d_out_inf, soa)) != ECGPU_OK) {
         return rc;
     }
     record(ctx, 2);
@@ -673,6 +720,26 @@ int point_sum_dev(ecgpu_ctx* ctx, const void* d_xy, const void* d_inf, size_t n,
     return rc;
 }
 
+// The lane the next MSM (or local half of a sharded MSM) of an asynchronous context with ecgpu_set_msm_lanes > 1 goes to: lanes take
+// turns; a lane's stream, events and workspace exist from its first use on.
+int next_lane(ecgpu_ctx* ctx, size_t workspace_bytes, ecgpu_ctx::MsmLane** out) {
+    ctx->lane_last = (int)(ctx->msm_seq % (unsigned)ctx->msm_lanes);
+    ecgpu_ctx::MsmLane& l = ctx->lane[ctx->msm_seq++ % (unsigned)ctx->msm_lanes];
+    ctx->spans.clear();
+    ctx->timing.clear();
+    if (!l.s) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_in, hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreate(&l.ev_a));
+        HIP_TRY(ctx, hipEventCreate(&l.ev_b));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
+    }
+    int rc = ensure_on(ctx, l.s, l.ws, workspace_bytes);
+    if (rc != ECGPU_OK) return rc;
+    *out = &l;
+    return ECGPU_OK;
+}
+
 // largest term count for which the per-term multiplication + tree sum replaces the bucket method (0: never);
 // ECGPU_MSM_SMALL_LOG2 overrides the measured default (tuning knob, -1 disables)
 template <class C>
@@ -680,7 +747,7 @@ size_t msm_small_max() {
     // measured (round 1, tools/gpu_msm_sweep.py is today's form of the sweep): k256 0.75-0.91 ms against 1.21-1.36 ms up to 2^16 terms (1.51 against 1.39 at 2^17),
     // p256 1.23-1.44 against 1.39-1.59 ms, p384 3.3-3.4 against 3.7-4.1 ms up to 2^10 and level beyond
     int lg = C::N > 8 ? 10 : 16;
-    if (const char* e = getenv("ECGPU_MSM_SMALL_LOG2")) lg = atoi(e);
+    if (const char* e = knob("ECGPU_MSM_SMALL_LOG2")) lg = atoi(e);
     return lg <= 0 ? 0 : (size_t)1 << (lg > 24 ? 24 : lg);
 }
 
@@ -721,18 +788,10 @@ int msm_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const void*
     if (ctx->async && ctx->msm_lanes > 1) {
         // one of the lanes: everything of this MSM on the lane's stream and in the lane's buffers, ordered after what the
         // context's stream holds now (the inputs); its output is ordered by ecgpu_synchronize only
-        ctx->lane_last = (int)(ctx->msm_seq % (unsigned)ctx->msm_lanes);
-        ecgpu_ctx::MsmLane& l = ctx->lane[ctx->msm_seq++ % (unsigned)ctx->msm_lanes];
-        ctx->spans.clear();
-        ctx->timing.clear();
-        if (!l.s) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_in, hipEventDisableTiming));
-            HIP_TRY(ctx, hipEventCreate(&l.ev_a));
-            HIP_TRY(ctx, hipEventCreate(&l.ev_b));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
-        }
-        if ((rc = ensure_on(ctx, l.s, l.ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
+        ecgpu_ctx::MsmLane* lp = nullptr;
+        if ((rc = next_lane(ctx, plan.workspace_bytes, &lp)) != ECGPU_OK) return rc;
+        ecgpu_ctx::MsmLane& l = *lp;
+        l.parts_out = nullptr;
         if ((rc = ensure_on(ctx, l.s, l.proj, 3 * NS * 4)) != ECGPU_OK) return rc;
         if ((rc = ensure_on(ctx, l.s, l.prefix, NS * 4)) != ECGPU_OK) return rc;
         HIP_TRY(ctx, hipEventRecord(l.ev_in, ctx->stream));
@@ -856,6 +915,25 @@ int msm_parts_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const
     }
     const int c = ctx->msm_c ? ctx->msm_c : msm_choose_window<C>(plan_terms);
     MsmPlan plan = msm_plan<C>(n, c, msm_use_glv<C>(plan_terms));
+    if (ctx->async && ctx->msm_lanes > 1) {
+        // Local halves of CONSECUTIVE sharded MSMs on rotating lanes (throughput form): this one runs on its lane's
+        // stream and workspace, ordered after what the context's stream holds now (the inputs), beside the exchange and the
+        // combining half of the previous one, which the caller keeps on the context's stream:
+        //     parts(i) -> lane i % L      ecgpu_msm_parts_join_dev(d_parts(i - 1)); all-gather(i - 1); ecgpu_msm_finish_dev(i - 1)
+        // d_parts belongs to the lane until ecgpu_msm_parts_join_dev(d_parts) (the context's stream then waits for it) or
+        // ecgpu_synchronize.
+        ecgpu_ctx::MsmLane* lp = nullptr;
+        if ((rc = next_lane(ctx, plan.workspace_bytes, &lp)) != ECGPU_OK) return rc;
+        ecgpu_ctx::MsmLane& l = *lp;
+        HIP_TRY(ctx, hipEventRecord(l.ev_in, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(l.s, l.ev_in, 0));
+        launch_msm_parts<C>(plan, l.s, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, l.ws.p, (uint32_t*)d_parts,
+                            ctx->d_status, l.ev_a, l.ev_b);
+        HIP_TRY(ctx, hipEventRecord(l.ev_done, l.s));
+        l.parts_out = d_parts;
+        ctx->lanes_pending = true;
+        return finish(ctx);
+    }
     if ((rc = ensure(ctx, ctx->msm_ws, plan.workspace_bytes)) != ECGPU_OK) return rc;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
@@ -875,6 +953,13 @@ int msm_finish_dev(ecgpu_ctx* ctx, const void* d_parts_all, int nranks, size_t p
     MsmPlan plan = msm_plan<C>(0, c, msm_use_glv<C>(plan_terms));   // only c, nwin and nparts matter here
     if ((rc = ensure(ctx, ctx->proj, 3 * NS * 4)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->bases, (size_t)plan.nwin * 3 * NS * 4)) != ECGPU_OK) return rc;
+    // With local halves in flight on lanes this call does NOT wait for them (that is the point of the lanes): it reads d_parts_all,
+    // which the caller's exchange produced on this stream after ecgpu_msm_parts_join_dev, and scratch of its own.
+    if (ctx->async && ctx->msm_lanes > 1) {          // (nor does it touch the timing marks: ecgpu_last_timing keeps reading the last lane's)
+        launch_msm_finish<C>(plan, ctx->stream, (const uint32_t*)d_parts_all, nranks, (uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p,
+                             (uint8_t*)d_out_xy, (uint8_t*)d_out_inf);
+        return finish(ctx);
+    }
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     record(ctx, 0);
     launch_msm_finish<C>(plan, ctx->stream, (const uint32_t*)d_parts_all, nranks, (uint32_t*)ctx->bases.p, (uint32_t*)ctx->proj.p,
@@ -918,7 +1003,7 @@ constexpr size_t MSM_PIPE_CHUNK = (size_t)1 << 22;   // terms per partial MSM of
 // ECGPU_MSM_PIPE_LOG2 moves that (tuning knob; the tests use it to drive the chunked path with small inputs); the
 // chunked path needs chunk starts that keep p224's 28-byte records 4-byte aligned, which every power of two does
 inline size_t msm_pipe_chunk() {
-    if (const char* e = getenv("ECGPU_MSM_PIPE_LOG2")) {
+    if (const char* e = knob("ECGPU_MSM_PIPE_LOG2")) {
         int v = atoi(e);
         if (v >= 8 && v <= 26) return (size_t)1 << v;
     }
@@ -1534,6 +1619,17 @@ int ecgpu_msm_parts_dev(ecgpu_ctx* ctx, int curve, const void* d_scalars, const 
     return dispatch(curve, [&](auto c) {
         return msm_parts_dev<decltype(c)>(ctx, d_scalars, d_points_xy, d_points_inf, n, plan_terms, d_parts);
     });
+}
+
+int ecgpu_msm_parts_join_dev(ecgpu_ctx* ctx, const void* d_parts) {
+    if (!check_ctx(ctx)) return ECGPU_ERR_ARG;
+    if (!d_parts) return arg_error(ctx, __func__);
+    for (auto& l : ctx->lane)
+        if (l.s && l.ev_done && l.parts_out == d_parts) {
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.ev_done, 0));
+            l.parts_out = nullptr;
+        }
+    return ECGPU_OK;          // (written on the context's own stream, or already joined: nothing to wait for)
 }
 
 int ecgpu_msm_finish_dev(ecgpu_ctx* ctx, int curve, const void* d_parts_all, int nranks, size_t plan_terms, void* d_out_xy,

@@ -1,5 +1,6 @@
-// ecgpu_group.hip — the multi-GPU entry points of include/ecgpu.h: one context per device, one worker thread per device
-// for the duration of a call, built on the single-GPU C ABI (ecgpu_api.hip) and the HIP runtime only.
+// ecgpu_group.hip — the multi-GPU entry points of include/ecgpu.h: one context per device, one worker thread per device for
+// the life of the group (parked on a condition variable between calls: no thread is created or joined per call), built on the
+// single-GPU C ABI (ecgpu_api.hip) and the HIP runtime only.
 //
 //   batch workloads   index range cut into one contiguous slice per GPU; no exchange
 //   MSM               terms cut into one contiguous shard per GPU; every GPU runs ecgpu_msm_parts_dev on its shard, ONE
@@ -7,9 +8,9 @@
 //                     ecgpu_msm_finish_dev runs the window sums + the Horner chain once
 //
 // Exchange: RCCL's ncclAllGather over xGMI when librccl can be loaded (dlopen, no link-time dependency: a process that
-// already carries torch's RCCL keeps exactly one copy) and the group's devices are distinct; otherwise — and with
-// ECGPU_GROUP_EXCHANGE=peer — a peer copy of every GPU's parts into GPU 0's buffer (hipMemcpyPeer; direct over xGMI once
-// peer access is enabled).  RCCL's reductions cannot add curve points, so "all-reduce of partial bucket sums" is an
+// already carries torch's RCCL keeps exactly one copy) and the group's devices are distinct; otherwise — and after
+// ecgpu_group_set_exchange(ECGPU_EXCHANGE_PEER) — a peer copy of every GPU's parts into GPU 0's buffer (hipMemcpyPeer; direct
+// over xGMI once peer access is enabled).  RCCL's reductions cannot add curve points, so "all-reduce of partial bucket sums" is an
 // all-gather + the device-side combine in either mode.
 #include <hip/hip_runtime.h>
 
@@ -17,8 +18,10 @@
 
 #include <atomic>
 #include <chrono>
-#include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -62,7 +65,10 @@ struct Rccl {
 struct Member {
     int device = 0;
     ecgpu_ctx* ctx = nullptr;
-    hipStream_t stream = nullptr;      // exchange stream: the RCCL collective or the peer copy, then synchronised
+    hipStream_t work = nullptr;        // the context's stream for the life of the group (ecgpu_set_stream): local half, combining half
+    hipStream_t stream = nullptr;      // exchange stream: waits for ev_parts on the device, then the RCCL collective or the peer copy
+    hipEvent_t ev_parts = nullptr;     // recorded on `work` behind the local half
+    bool leak_parts = false;           // a collective that could not be ended may still read d_parts: that allocation is never freed
     nccl_comm_t comm = nullptr;
     void* d_parts = nullptr;           // this GPU's parts record
     size_t parts_cap = 0;
@@ -87,8 +93,20 @@ __global__ void k_group_stall(volatile int* release) {
 
 }  // namespace
 
+// the worker thread of member r >= 1: parked on `cv`, runs the job it is handed with its member index, reports `rc`
+struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    const std::function<int(int)>* job = nullptr;
+    bool done = false, quit = false;
+    int rc = 0;
+};
+
 struct ecgpu_group {
     std::vector<Member> m;
+    std::vector<std::unique_ptr<Worker>> workers;      // workers[r - 1] serves member r (member 0 runs on the calling thread)
+    uint8_t* h_out = nullptr;          // page-locked staging of the MSM's result record (one asynchronous copy behind the last kernel)
     bool use_rccl = false;
     std::string why;                   // how the exchange was chosen (ecgpu_group_exchange_reason)
     Rccl rccl;
@@ -123,23 +141,55 @@ void shard(size_t n, int r, int world, size_t* lo, size_t* hi) {      // contigu
     *hi = *lo + base + ((size_t)r < rem ? 1 : 0);
 }
 
-// runs f(r) on one thread per member; returns the first non-zero result
+void worker_main(ecgpu_group* g, int r) {
+    Worker& w = *g->workers[r - 1];
+    (void)hipSetDevice(g->m[r].device);
+    std::unique_lock<std::mutex> lk(w.mu);
+    for (;;) {
+        w.cv.wait(lk, [&] { return w.job != nullptr || w.quit; });
+        if (w.quit) return;
+        const std::function<int(int)>* job = w.job;
+        lk.unlock();
+        int rc;
+        try {
+            rc = (*job)(r);
+        } catch (...) {
+            rc = ECGPU_ERR_HIP;
+        }
+        lk.lock();
+        w.rc = rc;
+        w.job = nullptr;
+        w.done = true;
+        w.cv.notify_all();
+    }
+}
+
+// runs f(r) for every member — member 0 on the calling thread, the others on their parked worker threads — and returns when all
+// of them have; the first non-zero result is the call's
 template <class F>
 int for_each_member(ecgpu_group* g, F&& f) {
     const int nd = (int)g->m.size();
     std::vector<int> rc(nd, ECGPU_OK);
-    std::vector<std::thread> th;
-    try {
-        for (int r = 1; r < nd; r++) th.emplace_back([&, r] { rc[r] = f(r); });
-    } catch (...) {
-        for (auto& t : th) t.join();
-        return fail(g, ECGPU_ERR_HIP, "could not start the per-device threads");
+    const std::function<int(int)> job = [&f](int r) -> int { return f(r); };
+    for (int r = 1; r < nd; r++) {
+        Worker& w = *g->workers[r - 1];
+        std::lock_guard<std::mutex> lk(w.mu);
+        w.done = false;
+        w.job = &job;
+        w.cv.notify_all();
     }
     rc[0] = f(0);
-    for (auto& t : th) t.join();
-    for (int r = 0; r < nd; r++)           // (the workers have been joined: no concurrent writer of g->err any more)
-        if (rc[r] != ECGPU_OK)
-            return fail(g, rc[r], std::string("device ") + std::to_string(g->m[r].device) + ": " + ecgpu_last_error(g->m[r].ctx));
+    for (int r = 1; r < nd; r++) {
+        Worker& w = *g->workers[r - 1];
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.done; });
+        rc[r] = w.rc;
+    }
+    for (int r = 0; r < nd; r++)           // (every worker is parked again: no concurrent writer of g->err any more)
+        if (rc[r] != ECGPU_OK) {
+            const char* ce = ecgpu_last_error(g->m[r].ctx);
+            return fail(g, rc[r], std::string("device ") + std::to_string(g->m[r].device) + ": " + (ce ? ce : ""));
+        }
     return ECGPU_OK;
 }
 
@@ -160,12 +210,30 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
         for (int q = 0; q < r; q++) distinct = distinct && devices[q] != devices[r];
         int rc = ecgpu_init(&g->m[r].ctx, devices[r]);
         if (rc == ECGPU_OK && (hipSetDevice(devices[r]) != hipSuccess ||
-                               hipStreamCreateWithFlags(&g->m[r].stream, hipStreamNonBlocking) != hipSuccess))
+                               hipStreamCreateWithFlags(&g->m[r].stream, hipStreamNonBlocking) != hipSuccess ||
+                               hipStreamCreateWithFlags(&g->m[r].work, hipStreamNonBlocking) != hipSuccess ||
+                               hipEventCreateWithFlags(&g->m[r].ev_parts, hipEventDisableTiming) != hipSuccess))
             rc = ECGPU_ERR_HIP;
+        // the member's context works on a stream the group knows, so that the exchange can be ordered behind the local half on the
+        // device (an event) instead of by a host wait
+        if (rc == ECGPU_OK) rc = ecgpu_set_stream(g->m[r].ctx, g->m[r].work);
         if (rc != ECGPU_OK) {
             ecgpu_group_destroy(g);
             return rc;
         }
+    }
+    try {
+        for (int r = 1; r < ndev; r++) {
+            g->workers.emplace_back(new Worker());
+            g->workers.back()->th = std::thread(worker_main, g, r);
+        }
+    } catch (...) {
+        ecgpu_group_destroy(g);
+        return ECGPU_ERR_HIP;
+    }
+    if (hipSetDevice(devices[0]) != hipSuccess || hipHostMalloc(reinterpret_cast<void**>(&g->h_out), 512, hipHostMallocDefault) != hipSuccess) {
+        ecgpu_group_destroy(g);
+        return ECGPU_ERR_HIP;
     }
     // direct peer copies into GPU 0 (xGMI) where the topology allows it; hipMemcpyPeer stages through the host otherwise
     for (int r = 1; r < ndev; r++) {
@@ -175,12 +243,8 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
             (void)hipDeviceEnablePeerAccess(devices[0], 0);          // "already enabled" is fine
     }
     (void)hipGetLastError();
-    const char* mode = getenv("ECGPU_GROUP_EXCHANGE");
-    const bool want_rccl = !(mode && std::strcmp(mode, "peer") == 0);
-    const bool must_rccl = mode && std::strcmp(mode, "rccl") == 0;
-    if (!want_rccl) {
-        g->why = "peer: ECGPU_GROUP_EXCHANGE=peer";
-    } else if (!distinct) {
+    // (no environment variable decides this: ecgpu_group_set_exchange is how a caller asks for one exchange or the other)
+    if (!distinct) {
         g->why = "peer: duplicate devices in the group (RCCL wants one communicator rank per device)";
     } else if (!g->rccl.load()) {
         const char* de = dlerror();
@@ -198,25 +262,36 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
             (void)hipGetLastError();
         }
     }
-    if (must_rccl && !g->use_rccl) {                                // asked for RCCL explicitly and it is not to be had
-        ecgpu_group_destroy(g);
-        return ECGPU_ERR_HIP;
-    }
     *out = g;
     return ECGPU_OK;
 }
 
 void ecgpu_group_destroy(ecgpu_group* g) {
     if (!g) return;
+    for (auto& w : g->workers) {
+        if (!w->th.joinable()) continue;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        w->th.join();
+    }
+    if (g->stall_release) *g->stall_release = 1;                   // (test stand-ins still spinning would keep their streams busy for ever)
     for (auto& mb : g->m) {
         if (!mb.ctx) continue;
         (void)hipSetDevice(mb.device);
         if (mb.comm && g->rccl.comm_destroy) (void)g->rccl.comm_destroy(mb.comm);
         if (mb.stream) (void)hipStreamDestroy(mb.stream);
-        for (void* p : {mb.d_parts, mb.d_all, mb.d_in0, mb.d_in1, mb.d_in2})
+        if (mb.d_parts && !mb.leak_parts) ecgpu_dev_free(mb.ctx, mb.d_parts);
+        for (void* p : {mb.d_all, mb.d_in0, mb.d_in1, mb.d_in2})
             if (p) ecgpu_dev_free(mb.ctx, p);
+        (void)ecgpu_set_stream(mb.ctx, nullptr);               // back on its own stream before `work` goes
         ecgpu_destroy(mb.ctx);
+        if (mb.work) (void)hipStreamDestroy(mb.work);
+        if (mb.ev_parts) (void)hipEventDestroy(mb.ev_parts);
     }
+    if (g->h_out) (void)hipHostFree(g->h_out);
     if (g->stall_release) *g->stall_release = 1;
     for (hipStream_t st : g->abandoned)
         if (hipStreamQuery(st) == hipSuccess) (void)hipStreamDestroy(st);      // (one that still holds a dead collective is left to the process)
@@ -233,6 +308,24 @@ const char* ecgpu_group_last_error(const ecgpu_group* g) { return g ? g->err.c_s
 const char* ecgpu_group_exchange(const ecgpu_group* g) { return g && g->use_rccl ? "rccl" : "peer"; }
 
 const char* ecgpu_group_exchange_reason(const ecgpu_group* g) { return g ? g->why.c_str() : "null group"; }
+
+int ecgpu_group_set_exchange(ecgpu_group* g, int mode) {
+    if (!g) return ECGPU_ERR_ARG;
+    g->err.clear();
+    if (mode == ECGPU_EXCHANGE_RCCL)          // "RCCL or nothing": an error, not a fallback, when the group is on peer copies
+        return g->use_rccl ? ECGPU_OK : fail(g, ECGPU_ERR_HIP, "the group has no RCCL exchange (" + g->why + ")");
+    if (mode != ECGPU_EXCHANGE_PEER) return fail(g, ECGPU_ERR_ARG, "ecgpu_group_set_exchange: mode must be ECGPU_EXCHANGE_PEER or ECGPU_EXCHANGE_RCCL");
+    if (!g->use_rccl) return ECGPU_OK;
+    for (auto& mb : g->m) {                   // no collective is in flight between calls: the communicators can simply go
+        (void)hipSetDevice(mb.device);
+        if (mb.comm && g->rccl.comm_destroy) (void)g->rccl.comm_destroy(mb.comm);
+        mb.comm = nullptr;
+    }
+    (void)hipGetLastError();
+    g->use_rccl = false;
+    g->why = "peer: ecgpu_group_set_exchange(ECGPU_EXCHANGE_PEER)";
+    return ECGPU_OK;
+}
 
 int ecgpu_group_set_exchange_timeout(ecgpu_group* g, double seconds) {
     if (!g || !(seconds > 0)) return ECGPU_ERR_ARG;
@@ -276,119 +369,196 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
                                           "use ecgpu_group_set_msm_window");
     int rc;
     for (int r = 0; r < nd; r++) {
+        if (g->m[r].leak_parts && bytes > g->m[r].parts_cap) {       // (growing frees the old allocation: this one stays, see below)
+            g->m[r].d_parts = nullptr;
+            g->m[r].parts_cap = 0;
+            g->m[r].leak_parts = false;
+        }
         if ((rc = grow(g, g->m[r], &g->m[r].d_parts, &g->m[r].parts_cap, bytes)) != ECGPU_OK) return rc;
         if ((r == 0 || g->use_rccl) && (rc = grow(g, g->m[r], &g->m[r].d_all, &g->m[r].all_cap, bytes * nd)) != ECGPU_OK) return rc;
     }
-    // local halves, one thread per GPU
-    rc = for_each_member(g, [&](int r) -> int {
-        Member& mb = g->m[r];
-        return ecgpu_msm_parts_dev(mb.ctx, curve, d_scalars[r], d_points_xy[r], d_points_inf ? d_points_inf[r] : nullptr,
-                                   n_per_device[r], plan_terms, mb.d_parts);           // returns with the parts written
-    });
-    if (rc != ECGPU_OK) return rc;
-    // The exchange step.  RCCL first where the group has it.  A collective that fails — or does not END — is not the end of the
-    // call: every member waits for its exchange stream by polling it against the group's deadline (ecgpu_group_set_exchange_timeout),
-    // and stops waiting at once when another member's enqueue has failed (its own collective then has no partner and would never
-    // complete).  On any failure every communicator is aborted, the exchange streams — which may still hold the dead collective —
-    // are replaced by fresh ones, the parts, which are still in every GPU's d_parts, travel by the peer copies below, and the group
-    // stays on peer copies from then on (ecgpu_group_exchange_reason says why).
+    // The result record of the combining half: x || y, then the flag at the next 16-byte boundary (scratch on member 0).
+    Member& m0 = g->m[0];
+    const size_t flag_off = (2 * L + 15) / 16 * 16, rec_bytes = flag_off + 16;
+    if ((rc = grow(g, m0, &m0.d_in2, &m0.in2_cap, 2 * L + 64)) != ECGPU_OK) return rc;
+    void* d_o = m0.d_in2;
+    void* d_f = (uint8_t*)m0.d_in2 + flag_off;
+
+    // One pass over the members, each on its own thread, and the host waits ONCE per member:
+    //   local half (ecgpu_msm_parts_dev, queued on the member's work stream; the context is asynchronous for the length of the call)
+    //   -> ev_parts -> the exchange stream waits for it ON THE DEVICE -> the collective / the peer copy is queued behind it
+    //   -> the host waits for the local half (hipEventSynchronize: compute, it ends), then for the exchange stream against the group's
+    //      deadline — spinning on hipStreamQuery for the first 200 us (a 41 KiB exchange takes tens of microseconds), then in 50 us naps.
+    // The exchange has a stream of its own so that one that never ENDS — how RCCL has failed on this pool — leaves the contexts' work
+    // streams clean: every member stops waiting at the deadline, or at once when another member's enqueue has failed (its own
+    // collective then has no partner), the communicators are aborted, the exchange streams replaced by fresh ones, the parts — still
+    // in every GPU's d_parts — travel by peer copies, and the group stays on peer copies (ecgpu_group_exchange_reason says why).
     const int fault = g_test_exchange_fault.load();
-    const auto wait_stream = [&](Member& mb, const std::atomic<bool>* give_up) -> int {       // 0 done, 1 deadline / given up, -1 HIP error
-        const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double>(g->exchange_timeout_s);
+    struct Shared {
+        std::atomic<bool> enqueue_failed{false};
+        std::mutex mu;
+        int nrc_seen = 0;
+        bool timed_out = false;
+    } sh;
+    const auto wait_exchange = [&](Member& mb, const std::atomic<bool>* give_up) -> int {     // 0 done, 1 deadline / given up, -1 HIP error
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto t_end = t0 + std::chrono::duration<double>(g->exchange_timeout_s);
+        const auto t_spin = t0 + std::chrono::microseconds(200);
         for (;;) {
             const hipError_t q = hipStreamQuery(mb.stream);
             if (q == hipSuccess) return 0;
             if (q != hipErrorNotReady) return -1;
-            if ((give_up && give_up->load()) || std::chrono::steady_clock::now() >= t_end) return 1;
-            std::this_thread::sleep_for(std::chrono::microseconds(50));
+            const auto now = std::chrono::steady_clock::now();
+            if ((give_up && give_up->load()) || now >= t_end) return 1;
+            if (now >= t_spin) std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
     };
-    if (g->use_rccl || fault) {
-        int nrc_seen = 0;
-        bool timed_out = false;
-        std::mutex nrc_mu;
-        std::atomic<bool> enqueue_failed{false};
-        if (fault && !g->stall_release) {
-            if (hipHostMalloc(reinterpret_cast<void**>(&g->stall_release), sizeof(int), hipHostMallocMapped) != hipSuccess)
-                return fail(g, ECGPU_ERR_HIP, "test hook: no page-locked flag");
-        }
-        if (g->stall_release) *g->stall_release = 0;
-        rc = for_each_member(g, [&](int r) -> int {
+    // with_parts: the local half is part of the pass (the first pass); use_coll: the exchange is the collective (or its stand-ins)
+    const auto pass = [&](bool with_parts, bool use_coll) -> int {
+        return for_each_member(g, [&](int r) -> int {
             Member& mb = g->m[r];
-            if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
-            int nrc = 0;
-            if (fault == 2 || (fault == 1 && r == 0)) {
-                nrc = 1;                                              // (ncclUnhandledCudaError)
-            } else if (fault) {
-                int* d_flag = nullptr;
-                if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flag), g->stall_release, 0) != hipSuccess) return ECGPU_ERR_HIP;
-                hipLaunchKernelGGL(k_group_stall, dim3(1), dim3(1), 0, mb.stream, d_flag);
+            const auto bail = [&](int code) { sh.enqueue_failed.store(true); return code; };   // the others must not wait for this member
+            if (hipSetDevice(mb.device) != hipSuccess) return bail(ECGPU_ERR_HIP);
+            int e;
+            // the context is asynchronous from here to the end of its local half, whatever path leaves this function
+            struct AsyncScope {
+                ecgpu_ctx* ctx = nullptr;
+                ~AsyncScope() { if (ctx) (void)ecgpu_set_async(ctx, 0); }
+            } scope;
+            if (with_parts) {
+                if ((e = ecgpu_set_async(mb.ctx, 1)) != ECGPU_OK) return bail(e);
+                scope.ctx = mb.ctx;
+                e = ecgpu_msm_parts_dev(mb.ctx, curve, d_scalars[r], d_points_xy[r], d_points_inf ? d_points_inf[r] : nullptr, n_per_device[r],
+                                        plan_terms, mb.d_parts);
+                if (e == ECGPU_OK && hipEventRecord(mb.ev_parts, mb.work) != hipSuccess) e = ECGPU_ERR_HIP;
+                if (e != ECGPU_OK) return bail(e);
+            }
+            if (hipStreamWaitEvent(mb.stream, mb.ev_parts, 0) != hipSuccess) return bail(ECGPU_ERR_HIP);
+            bool coll_failed = false;
+            if (use_coll) {
+                int nrc = 0;
+                if (fault == 2 || (fault == 1 && r == 0)) {
+                    nrc = 1;                                              // (ncclUnhandledCudaError)
+                } else if (fault) {
+                    int* d_flag = nullptr;
+                    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&d_flag), g->stall_release, 0) != hipSuccess) return bail(ECGPU_ERR_HIP);
+                    hipLaunchKernelGGL(k_group_stall, dim3(1), dim3(1), 0, mb.stream, d_flag);
+                } else {
+                    nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
+                }
+                if (nrc != 0) {                                          // the others stop waiting at once; this member still ends its local
+                    std::lock_guard<std::mutex> lock(sh.mu);             // half properly below (its input errors are the call's result)
+                    sh.nrc_seen = nrc;
+                    sh.enqueue_failed.store(true);
+                    coll_failed = true;
+                }
             } else {
-                nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
+                uint8_t* dst = (uint8_t*)m0.d_all + (size_t)r * bytes;
+                const hipError_t he = mb.device == m0.device
+                                          ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
+                                          : hipMemcpyPeerAsync(dst, m0.device, mb.d_parts, mb.device, bytes, mb.stream);
+                if (he != hipSuccess) return bail(ECGPU_ERR_HIP);
             }
-            if (nrc != 0) {
-                enqueue_failed.store(true);
-                std::lock_guard<std::mutex> lock(nrc_mu);
-                nrc_seen = nrc;
-                return ECGPU_ERR_HIP;
+            if (with_parts) {
+                // the local half: compute, it ends; its input errors (a scalar >= n, a point off the curve) are reported here
+                e = hipEventSynchronize(mb.ev_parts) == hipSuccess ? ecgpu_synchronize(mb.ctx) : ECGPU_ERR_HIP;
+                scope.ctx = nullptr;
+                const int e2 = ecgpu_set_async(mb.ctx, 0);
+                if (e == ECGPU_OK) e = e2;
+                if (e != ECGPU_OK) return bail(e);
             }
-            const int w = wait_stream(mb, &enqueue_failed);
-            if (w == 1 && !enqueue_failed.load()) {
-                std::lock_guard<std::mutex> lock(nrc_mu);
-                timed_out = true;
+            if (coll_failed) return ECGPU_ERR_HIP;
+            const int w = wait_exchange(mb, use_coll ? &sh.enqueue_failed : nullptr);
+            if (w == 1 && !sh.enqueue_failed.load()) {
+                std::lock_guard<std::mutex> lock(sh.mu);
+                sh.timed_out = true;
             }
             return w == 0 ? ECGPU_OK : ECGPU_ERR_HIP;
         });
-        if (rc != ECGPU_OK) {
-            g->why = std::string("peer: ncclAllGather ") +
-                     (nrc_seen ? std::string("failed (") + (g->rccl.error_string && !fault ? g->rccl.error_string(nrc_seen) : "enqueue error") + ")"
-                      : timed_out ? "did not complete within " + std::to_string(g->exchange_timeout_s) + " s (communicators aborted)"
-                                  : std::string("failed (HIP error on the exchange stream)"));
-            g->use_rccl = false;
-            g->err.clear();
-            // give the communicators up (ncclCommAbort ends collectives that wait for a partner), release the test stand-ins,
-            // and move to fresh streams: the old ones are destroyed now if they drained, with the group otherwise
-            if (g->stall_release) *g->stall_release = 1;
-            for (auto& mb : g->m) {
-                (void)hipSetDevice(mb.device);
-                if (mb.comm) {
-                    if (g->rccl.comm_abort) (void)g->rccl.comm_abort(mb.comm);
-                    else if (g->rccl.comm_destroy && hipStreamQuery(mb.stream) == hipSuccess) (void)g->rccl.comm_destroy(mb.comm);
-                    mb.comm = nullptr;
+    };
+    const bool coll = g->use_rccl || fault;
+    if (fault && !g->stall_release) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&g->stall_release), sizeof(int), hipHostMallocMapped) != hipSuccess)
+            return fail(g, ECGPU_ERR_HIP, "test hook: no page-locked flag");
+    }
+    if (g->stall_release) *g->stall_release = 0;
+    rc = pass(true, coll);
+    // An input error or a HIP failure of a local half is the call's result; only a failed EXCHANGE is retried over peer copies — when
+    // every local half has ended (a member whose enqueue failed left before waiting for its own: compute, it ends).
+    bool parts_done = true;
+    if (rc != ECGPU_OK)
+        for (auto& mb : g->m)
+            parts_done = hipSetDevice(mb.device) == hipSuccess && hipEventSynchronize(mb.ev_parts) == hipSuccess && parts_done;
+    if (rc != ECGPU_OK && g->stall_release) *g->stall_release = 1;     // (the stand-ins of the test hook never outlive a failed pass)
+    if (rc != ECGPU_OK && coll && parts_done && (sh.nrc_seen || sh.timed_out) && rc == ECGPU_ERR_HIP) {
+        const std::string why = std::string("peer: ncclAllGather ") +
+                                (sh.nrc_seen ? std::string("failed (") + (g->rccl.error_string && !fault ? g->rccl.error_string(sh.nrc_seen) : "enqueue error") + ")"
+                                 : sh.timed_out ? "did not complete within " + std::to_string(g->exchange_timeout_s) + " s (communicators aborted)"
+                                                : std::string("failed (HIP error on the exchange stream)"));
+        // fresh exchange streams for everybody BEFORE anything is given up: a failure here leaves the group as it was
+        std::vector<hipStream_t> fresh(nd, nullptr);
+        for (int r = 0; r < nd; r++)
+            if (hipSetDevice(g->m[r].device) != hipSuccess || hipStreamCreateWithFlags(&fresh[r], hipStreamNonBlocking) != hipSuccess) {
+                for (int q = 0; q < r; q++) {
+                    (void)hipSetDevice(g->m[q].device);
+                    (void)hipStreamDestroy(fresh[q]);
                 }
-                hipStream_t fresh = nullptr;
-                if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess)
-                    return fail(g, ECGPU_ERR_HIP, "exchange fallback: no fresh stream on device " + std::to_string(mb.device));
-                g->abandoned.push_back(mb.stream);
-                mb.stream = fresh;
+                if (g->stall_release) *g->stall_release = 1;
+                return fail(g, ECGPU_ERR_HIP, "exchange fallback: no fresh stream on device " + std::to_string(g->m[r].device));
             }
-            (void)hipGetLastError();
+        g->why = why;
+        g->use_rccl = false;
+        {
+            std::lock_guard<std::mutex> lock(g->err_mu);
+            g->err.clear();
         }
-    }
-    if (!g->use_rccl) {
-        // device-to-device copies are asynchronous with respect to the host: an explicit stream + a (polled, bounded) wait, so
-        // that the combining half (on member 0's own stream) starts after every part has landed
-        rc = for_each_member(g, [&](int r) -> int {
+        // give the communicators up (ncclCommAbort ends collectives that wait for a partner), release the test stand-ins, and move
+        // to the fresh streams: the old ones are destroyed with the group if they drained
+        if (g->stall_release) *g->stall_release = 1;
+        for (int r = 0; r < nd; r++) {
             Member& mb = g->m[r];
-            if (hipSetDevice(mb.device) != hipSuccess) return ECGPU_ERR_HIP;
-            uint8_t* dst = (uint8_t*)g->m[0].d_all + (size_t)r * bytes;
-            hipError_t he = mb.device == g->m[0].device
-                                ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
-                                : hipMemcpyPeerAsync(dst, g->m[0].device, mb.d_parts, mb.device, bytes, mb.stream);
-            if (he != hipSuccess) return ECGPU_ERR_HIP;
-            return wait_stream(mb, nullptr) == 0 ? ECGPU_OK : ECGPU_ERR_HIP;
-        });
+            (void)hipSetDevice(mb.device);
+            if (mb.comm) {
+                if (g->rccl.comm_abort) {
+                    (void)g->rccl.comm_abort(mb.comm);
+                } else if (g->rccl.comm_destroy && hipStreamQuery(mb.stream) == hipSuccess) {
+                    (void)g->rccl.comm_destroy(mb.comm);
+                } else {
+                    // No way to end the collective: it may still read d_parts and write d_all whenever its partners show up.  The
+                    // communicator is left to the process; d_all is given up (never freed; the retry below gets a fresh destination
+                    // on member 0) and d_parts — which the retry reads, as the collective does — is never freed either.
+                    mb.d_all = nullptr;
+                    mb.all_cap = 0;
+                    mb.leak_parts = true;
+                    if (r == 0 && (rc = grow(g, mb, &mb.d_all, &mb.all_cap, bytes * nd)) != ECGPU_OK) return rc;
+                }
+                mb.comm = nullptr;
+            }
+            g->abandoned.push_back(mb.stream);
+            mb.stream = fresh[r];
+        }
+        (void)hipGetLastError();
+        sh.enqueue_failed.store(false);
+        sh.nrc_seen = 0;
+        sh.timed_out = false;
+        rc = pass(false, false);
     }
-    if (rc != ECGPU_OK) return rc == ECGPU_ERR_HIP && g->err.empty() ? fail(g, rc, "exchange of the partial sums failed") : rc;
-    // the combining half, once
-    Member& m0 = g->m[0];
-    void *d_o = nullptr, *d_f = nullptr;
-    if ((rc = grow(g, m0, &m0.d_in2, &m0.in2_cap, 2 * L + 64)) != ECGPU_OK) return rc;
-    d_o = m0.d_in2;
-    d_f = (uint8_t*)m0.d_in2 + (2 * L + 15) / 16 * 16;
-    if ((rc = ecgpu_msm_finish_dev(m0.ctx, curve, m0.d_all, nd, plan_terms, d_o, d_f)) != ECGPU_OK) return fail(g, rc, ecgpu_last_error(m0.ctx));
-    if ((rc = ecgpu_copy_to_host(m0.ctx, out_xy, d_o, 2 * L)) != ECGPU_OK) return fail(g, rc, ecgpu_last_error(m0.ctx));
-    if (out_inf && (rc = ecgpu_copy_to_host(m0.ctx, out_inf, d_f, 1)) != ECGPU_OK) return fail(g, rc, ecgpu_last_error(m0.ctx));
+    if (rc != ECGPU_OK) {
+        std::lock_guard<std::mutex> lock(g->err_mu);
+        if (rc == ECGPU_ERR_HIP && g->err.empty()) g->err = "exchange of the partial sums failed";
+        return rc;
+    }
+    // the combining half, once: queued on member 0's work stream with the copy of its record behind it — one more wait
+    if (hipSetDevice(m0.device) != hipSuccess) return fail(g, ECGPU_ERR_HIP, "hipSetDevice");
+    if ((rc = ecgpu_set_async(m0.ctx, 1)) != ECGPU_OK) return fail(g, rc, ecgpu_last_error(m0.ctx));
+    rc = ecgpu_msm_finish_dev(m0.ctx, curve, m0.d_all, nd, plan_terms, d_o, d_f);
+    if (rc == ECGPU_OK && hipMemcpyAsync(g->h_out, d_o, rec_bytes, hipMemcpyDeviceToHost, m0.work) != hipSuccess) rc = ECGPU_ERR_HIP;
+    const int rs = ecgpu_synchronize(m0.ctx);
+    const int ra = ecgpu_set_async(m0.ctx, 0);
+    if (rc == ECGPU_OK) rc = rs != ECGPU_OK ? rs : ra;
+    if (rc != ECGPU_OK) return fail(g, rc, ecgpu_last_error(m0.ctx));
+    std::memcpy(out_xy, g->h_out, 2 * L);
+    if (out_inf) *out_inf = g->h_out[flag_off];
     return ECGPU_OK;
 }
 

@@ -4,6 +4,7 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_ecdsa.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_knobs.h"
 #include "ecgpu_selftest.h"
 
 namespace ecgpu {
@@ -25,16 +26,19 @@ template <> void launch_table_entries<CurveT>(hipStream_t s, const uint32_t* bas
 // instructions whatever K is, so the kernel is fastest when there is about one wave per SIMD (1024 of them):
 // K = ceil(n / 65536), capped at 64 for large batches.
 template <> void launch_normalize<CurveT>(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
-                                          uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs) {
+                                          uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs, bool soa) {
     if (n == 0) return;
     size_t k = (n + 65535) / 65536;
     if (k > 64) k = 64;
-    if (const char* e = getenv("ECGPU_NORM_K")) {          // tuning knob: points per lane
+    if (const char* e = knob("ECGPU_NORM_K")) {          // tuning knob: points per lane
         long v = atol(e);
         if (v >= 1 && v <= 1024) k = (size_t)v;
     }
     size_t nthreads = (n + k - 1) / k;
-    if (out_internal)
+    if (soa && !out_internal)
+        hipLaunchKernelGGL((k_normalize<CurveT, NORM_WIRE, true>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
+                           out_xy, out_inf, out_limbs);
+    else if (out_internal)
         hipLaunchKernelGGL((k_normalize<CurveT, NORM_PACKED>), dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, proj, prefix, n, nthreads,
                            out_xy, out_inf, out_limbs);
     else
@@ -51,8 +55,11 @@ template <> void launch_normalize_compressed<CurveT>(hipStream_t s, const uint32
                        out_x, out_tag, (uint32_t*)nullptr);
 }
 template <> void launch_fixed_base<CurveT>(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
-                                           int nwin, uint32_t* proj_out, int* status) {
-    hipLaunchKernelGGL(k_fixed_base<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, scalars, n, table, w, nwin, proj_out, status);
+                                           int nwin, uint32_t* proj_out, int* status, bool soa) {
+    if (soa)
+        hipLaunchKernelGGL((k_fixed_base<CurveT, true>), dim3(grid_for(n)), dim3(BLOCK), 0, s, scalars, n, table, w, nwin, proj_out, status);
+    else
+        hipLaunchKernelGGL((k_fixed_base<CurveT, false>), dim3(grid_for(n)), dim3(BLOCK), 0, s, scalars, n, table, w, nwin, proj_out, status);
 }
 template <> void launch_load_proj<CurveT>(hipStream_t s, const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status) {
     hipLaunchKernelGGL(k_load_proj<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, xyz, n, proj_out, status);

@@ -195,6 +195,57 @@ __device__ __forceinline__ Proj<C> load_proj(const uint32_t* base, size_t idx) {
     p.z = load_raw<C>(s + 2 * NS);
     return p;
 }
+// The same records QUAD-MAJOR ("limb-major" hand-over between k_fixed_base and k_normalize): 16-byte piece q of record idx at
+// base + (q * n + idx) * 4 words, so that the 64 lanes of a wave, which own 64 consecutive records, read or write 1,024 contiguous
+// bytes per load / store instruction — the record-major form above puts the lanes 3 NS words apart (144 bytes for k256: one
+// instruction touches ~72 cache lines).  NQ pieces per record: 3 NS / 4 for a projective point, NS / 4 for one raw element.
+template <int NQ>
+__device__ __forceinline__ void store_quads_soa(uint32_t* base, size_t n, size_t idx, int q0, const uint32_t* w) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        *reinterpret_cast<uint4*>(base + ((size_t)(q0 + q) * n + idx) * 4) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+template <int NQ>
+__device__ __forceinline__ void load_quads_soa(uint32_t* w, const uint32_t* base, size_t n, size_t idx, int q0) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(base + ((size_t)(q0 + q) * n + idx) * 4);
+        w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w;
+    }
+}
+// element `comp` (0 = X, 1 = Y, 2 = Z) of record idx
+template <class C>
+__device__ __forceinline__ void store_raw_soa(uint32_t* base, size_t n, size_t idx, int comp, const Fe<C::NL>& e) {
+    constexpr int NS = Field<C>::NS;
+    uint32_t w[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) w[i] = i < C::NL ? e.v[i] : 0u;
+    store_quads_soa<NS / 4>(base, n, idx, comp * (NS / 4), w);
+}
+template <class C>
+__device__ __forceinline__ Fe<C::NL> load_raw_soa(const uint32_t* base, size_t n, size_t idx, int comp) {
+    constexpr int NS = Field<C>::NS;
+    uint32_t w[NS];
+    load_quads_soa<NS / 4>(w, base, n, idx, comp * (NS / 4));
+    Fe<C::NL> e;
+#pragma unroll
+    for (int i = 0; i < C::NL; i++) e.v[i] = w[i];
+    return e;
+}
+template <class C>
+__device__ __forceinline__ void store_proj_soa(uint32_t* base, size_t n, size_t idx, const Proj<C>& p) {
+    store_raw_soa<C>(base, n, idx, 0, p.x);
+    store_raw_soa<C>(base, n, idx, 1, p.y);
+    store_raw_soa<C>(base, n, idx, 2, p.z);
+}
+template <class C>
+__device__ __forceinline__ Proj<C> load_proj_soa(const uint32_t* base, size_t n, size_t idx) {
+    Proj<C> p;
+    p.x = load_raw_soa<C>(base, n, idx, 0);
+    p.y = load_raw_soa<C>(base, n, idx, 1);
+    p.z = load_raw_soa<C>(base, n, idx, 2);
+    return p;
+}
 // packed affine point (2 x N words) <-> registers
 template <class C>
 __device__ __forceinline__ Affine<C> load_packed_affine(const uint32_t* src) {
@@ -315,7 +366,8 @@ __global__ void __launch_bounds__(BLOCK) k_table_entries(const uint32_t* bases, 
 //                       (y even / odd), 0x00 for the identity (to out_inf) — `ToSec1Point::to_sec1_point(true)`,
 //                       primeorder/src/affine.rs:387-401
 enum : int { NORM_WIRE = 0, NORM_PACKED = 1, NORM_COMPRESSED = 2 };
-template <class C, int MODE>
+// SOA: `proj` and `prefix` are quad-major (store_proj_soa; what k_fixed_base<C, true> leaves) instead of record-major.
+template <class C, int MODE, bool SOA = false>
 __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint32_t* prefix, size_t n, size_t nthreads,
                                                      uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_packed) {
     using F = Field<C>;
@@ -327,11 +379,23 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
     // Both passes are software-pipelined by hand: the loads of the lane's NEXT point are issued before the multiplications of
     // the current one.  With one wave per SIMD (the launch is sized that way: one inversion per lane) nothing else hides a
     // load's ~2 us, and the loop-carried product keeps the compiler from hoisting the loads itself.
+    const auto load_z = [&](size_t j) -> Fe<C::NL> {
+        if constexpr (SOA) return load_raw_soa<C>(proj, n, j, 2);
+        else return load_raw<C>(proj + j * (3 * NS) + 2 * NS);
+    };
+    const auto load_point = [&](size_t j) -> Proj<C> {
+        if constexpr (SOA) return load_proj_soa<C>(proj, n, j);
+        else return load_proj<C>(proj, j);
+    };
+    const auto load_prefix = [&](uint32_t* w, size_t j) {
+        if constexpr (SOA) load_quads_soa<NS / 4>(w, prefix, n, j, 0);
+        else load_words_vec<NS>(w, prefix + j * NS);
+    };
     typename F::M1 acc = F::one();
-    Fe<C::NL> z_next = load_raw<C>(proj + (t < n ? t : 0) * (3 * NS) + 2 * NS);
+    Fe<C::NL> z_next = load_z(t < n ? t : 0);
     for (size_t j = t; j < n; j += nthreads) {
         const Fe<C::NL> z = z_next;
-        if (j + nthreads < n) z_next = load_raw<C>(proj + (j + nthreads) * (3 * NS) + 2 * NS);
+        if (j + nthreads < n) z_next = load_z(j + nthreads);
         const bool ident = F::is_zero(G::m(z));
         {   // running product before this point, and whether the point is the identity, in the spare word
             static_assert(NS > C::NL, "raw form has no spare word");
@@ -339,24 +403,25 @@ __global__ void __launch_bounds__(BLOCK) k_normalize(const uint32_t* proj, uint3
 #pragma unroll
             for (int i = 0; i < NS; i++) w[i] = i < C::NL ? acc.e.v[i] : 0u;
             w[NS - 1] = ident ? 1u : 0u;
-            store_words_vec<NS>(prefix + j * NS, w);
+            if constexpr (SOA) store_quads_soa<NS / 4>(prefix, n, j, 0, w);
+            else store_words_vec<NS>(prefix + j * NS, w);
         }
         if (!ident) acc = F::mul(acc, G::m(z));
     }
     typename F::M1 inv = F::inv(acc);
     if (n <= t) return;
     size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
-    Proj<C> p_next = load_proj<C>(proj, last);
+    Proj<C> p_next = load_point(last);
     uint32_t pw_next[NS];
-    load_words_vec<NS>(pw_next, prefix + last * NS);
+    load_prefix(pw_next, last);
     for (size_t j = last;; j -= nthreads) {
         const Proj<C> p = p_next;
         uint32_t pw[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) pw[i] = pw_next[i];
         if (j >= nthreads) {
-            p_next = load_proj<C>(proj, j - nthreads);
-            load_words_vec<NS>(pw_next, prefix + (j - nthreads) * NS);
+            p_next = load_point(j - nthreads);
+            load_prefix(pw_next, j - nthreads);
         }
         if (pw[NS - 1]) {
             if constexpr (MODE == NORM_WIRE) {
@@ -407,7 +472,7 @@ struct BaseTableHbm {
     }
 };
 // (k256: three workgroups per CU = 156 registers; compiled for four — 128 registers — the kernel spills 340 bytes per lane)
-template <class C>
+template <class C, bool SOA = false>
 __global__ void __launch_bounds__(BLOCK, C::A_IS_ZERO ? 3 : 1)
 k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __restrict__ table, int w, int nwin,
              uint32_t* __restrict__ proj_out, int* status) {
@@ -418,7 +483,9 @@ k_fixed_base(const uint8_t* __restrict__ scalars, size_t n, const uint32_t* __re
     uint32_t k[N];
     load_scalar<C>(k, scalars, i, status);
     BaseTableHbm<C> tab{table, (size_t)1 << (w - 1)};
-    store_proj<C>(proj_out, i, fixed_base_mul<C>(k, tab, w, nwin, G::curve_b()));
+    const Proj<C> r = fixed_base_mul<C>(k, tab, w, nwin, G::curve_b());
+    if constexpr (SOA) store_proj_soa<C>(proj_out, n, i, r);      // quad-major: what k_normalize<C, NORM_WIRE, true> reads
+    else store_proj<C>(proj_out, i, r);
 }
 
 // ---- helpers for batch_normalize / point_sum ----------------------------------------------------------

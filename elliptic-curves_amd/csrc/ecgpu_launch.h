@@ -44,12 +44,15 @@ struct MsmPlan {
 // ---- group "base": table construction, fixed-base kernel, normalisation, small helpers ----
 template <class C> void launch_window_bases(hipStream_t s, uint32_t* bases, int w, int nwin);
 template <class C> void launch_table_entries(hipStream_t s, const uint32_t* bases, uint32_t* entries, int w, int nwin);
+// soa: proj / prefix quad-major (launch_fixed_base's soa form); wire output only
 template <class C> void launch_normalize(hipStream_t s, bool out_internal, const uint32_t* proj, uint32_t* prefix, size_t n,
-                                         uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs);
+                                         uint8_t* out_xy, uint8_t* out_inf, uint32_t* out_limbs, bool soa = false);
 template <class C> void launch_normalize_compressed(hipStream_t s, const uint32_t* proj, uint32_t* prefix, size_t n, uint8_t* out_x,
                                                     uint8_t* out_tag);
+// soa: proj_out quad-major (store_proj_soa, ecgpu_kernels.h) for launch_normalize(..., soa = true); n must then be the record count
+// the normalisation is launched with
 template <class C> void launch_fixed_base(hipStream_t s, const uint8_t* scalars, size_t n, const uint32_t* table, int w,
-                                          int nwin, uint32_t* proj_out, int* status);
+                                          int nwin, uint32_t* proj_out, int* status, bool soa = false);
 template <class C> void launch_load_proj(hipStream_t s, const uint8_t* xyz, size_t n, uint32_t* proj_out, int* status);
 template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const uint8_t* inf, size_t n, uint32_t* proj_out,
                                          int* status);

@@ -2,8 +2,21 @@
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
 #include "ecgpu_ecdsa.h"
+#include "ecgpu_knobs.h"
+
+#include <cstdlib>
 
 namespace ecgpu {
+
+// ecgpu_knobs.h: the environment is read by the tool build only
+const char* knob(const char* name) {
+#if defined(ECGPU_TUNING_KNOBS) && ECGPU_TUNING_KNOBS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // k256 GLV split, exposed for parity checks against glv::decompose_scalar
 __global__ void k_k256_glv(const uint8_t* scalars, size_t n, uint8_t* r1_out, uint8_t* r2_out, int* status) {

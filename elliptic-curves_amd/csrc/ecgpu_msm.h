@@ -41,6 +41,7 @@
 
 #include "ecgpu_kernels.h"
 #include "ecgpu_launch.h"
+#include "ecgpu_knobs.h"
 #include "ecgpu_msm_chunk.h"
 #include "ecgpu_rows.h"
 
@@ -708,6 +709,9 @@ struct MsmPartialsHbm {       // [slot][4] raw elements: X, Y, ZZ, ZZZ
 #ifndef ECGPU_MSM_ACC_WAVES
 #define ECGPU_MSM_ACC_WAVES 3
 #endif
+static_assert(ECGPU_MSM_ACC_WAVES >= 1 && ECGPU_MSM_ACC_WAVES <= 4,
+              "the k256 reduction's assembly blocks own v[94:127] (ecgpu_k256_reduce_asm.h): a kernel that includes them needs 128 VGPRs, "
+              "i.e. at most four waves per SIMD");
 template <class C>
 __global__ void __launch_bounds__(64, C::N <= 8 ? ECGPU_MSM_ACC_WAVES : C::N <= 12 ? 2 : 1)
 k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ sorted,
@@ -740,7 +744,7 @@ k_msm_accumulate(const uint32_t* __restrict__ pts, const uint32_t* __restrict__ 
 template <class C>
 inline bool msm_fused_tail(const MsmPlan& p) {
     (void)p;
-    if (const char* e = getenv("ECGPU_MSM_FUSED_TAIL")) return e[0] == '1' && ECGPU_MSM_FUSED_TAIL != 0 && C::N <= 12;
+    if (const char* e = knob("ECGPU_MSM_FUSED_TAIL")) return e[0] == '1' && ECGPU_MSM_FUSED_TAIL != 0 && C::N <= 12;
     return false;
 }
 
@@ -786,13 +790,14 @@ __global__ void __launch_bounds__(BLOCK)
 k_msm_big_buckets(const uint32_t* __restrict__ partials, const uint32_t* __restrict__ counts,
                   const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ pts,
                   const uint32_t* __restrict__ sorted, size_t n, size_t nb, size_t chunk, size_t nchunks,
-                  uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_list) {
+                  uint32_t* __restrict__ buckets, const uint32_t* __restrict__ big_list, uint32_t max_big) {
     using G = Group<C>;
     __shared__ uint32_t lds[BLOCK * 3 * C::NL];
     // the launch is a fixed MSM_BIG_GRID workgroups that deal the listed buckets out among themselves: for random scalars the
     // list is empty and 4 x MSM_BIG_GRID waves leave on their first load (round 4 launched one workgroup per POSSIBLE list
     // entry: 75,968 empty waves at 2^24 terms)
-    const uint32_t nbig = big_list[0];
+    // (the writers count every candidate but store only the first max_big: the list is never read past what was written)
+    const uint32_t nbig = big_list[0] < max_big ? big_list[0] : max_big;
     for (uint32_t it = blockIdx.x; it < nbig; it += gridDim.x) {
         const size_t gid = big_list[1 + it];
         const size_t w = gid / nb, b = gid % nb;
@@ -1231,6 +1236,7 @@ __global__ void __launch_bounds__(BLOCK) k_store_identity(uint32_t* out, size_t 
 // plain, fastest c at 2^12 / 2^14 / 2^16 / 2^17 ... 2^19 / 2^20 / 2^21 ... = 9 / 11 / 12 / 13 / 14 / 16; GLV (2 n entries of
 // 128 bits: c = 15 gives 9 full windows, c = 16 eight and a carry-only ninth): 13 up to 2^18 terms, 15 from 2^19.
 // Below 2^17 the curve is flat: the parts that do not depend on n dominate whatever c is.
+constexpr size_t MSM_GLV_MAX_TERMS = (size_t)13 << 17;      // 1.625 x 2^20 (msm_use_glv)
 inline int msm_window_bits(size_t n, bool glv) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
@@ -1238,27 +1244,32 @@ inline int msm_window_bits(size_t n, bool glv) {
     if (glv) c = lg <= 15 ? lg - 2 : (lg <= 18 ? 13 : 15);
     else if (lg <= 16) c = lg - 3;
     else if (lg <= 19) c = 13;
-    else if (lg == 20) c = 14;
+    else if (lg == 20) c = n < MSM_GLV_MAX_TERMS ? 14 : 16;     // (k256 takes the plain scalar from there on: 16, as for 2^21)
     else c = 16;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;
 }
 
-// GLV halves or the plain folded scalar?  k256 only, up to 2^21 terms by default (see MsmSplit; measured, r02c sweep:
-// GLV / plain = 0.88 / 1.22 ms at 2^14 terms, 1.10 / 1.46 at 2^17, 1.56 / 1.93 at 2^19, 3.58 / 3.74 at 2^21, 6.46 / 6.16 at
-// 2^22, 22.8 / 20.1 at 2^24); ECGPU_MSM_GLV = 0 / 1 forces it off / on, ECGPU_MSM_GLV_MAX_LOG2 moves the threshold (tuning
-// knobs; results do not depend on them).
+// GLV halves or the plain folded scalar?  k256 only, below MSM_GLV_MAX_TERMS terms (see MsmSplit).  Round 2 put the crossover above
+// 2^21 terms (GLV / plain = 3.58 / 3.74 ms at 2^21, 6.46 / 6.16 at 2^22); since then the Horner chain — what the halves shorten —
+// became three times cheaper (rows of a wave, round 5) while the halves still double prepare and sort, and the round-6 sweep with
+// HEAD's kernels (tools/gpu_msm_crossover.py, profiles/r06/msm_glv_crossover_*.txt) reads, best GLV (c = 15) / best plain (c = 16):
+// 1.467 / 1.547 ms at 2^20 terms, 2.528 / 2.468 at 2^21, 5.00 / 4.38 at 2^22 — the lines cross at about 1.6 x 2^20 terms.
+// ECGPU_MSM_GLV = 0 / 1 forces it off / on, ECGPU_MSM_GLV_MAX_LOG2 moves the threshold to a power of two (tuning knobs of the tool
+// build; results do not depend on them).
 template <class C>
 bool msm_use_glv(size_t n) {
     if (!MsmHasGlv<C>::value) return false;
-    int max_log2 = 21;
-    if (const char* e = getenv("ECGPU_MSM_GLV")) {
+    if (const char* e = knob("ECGPU_MSM_GLV")) {
         if (e[0] == '0') return false;
         if (e[0] == '1') return true;
     }
-    if (const char* e = getenv("ECGPU_MSM_GLV_MAX_LOG2")) max_log2 = atoi(e);
-    return max_log2 >= 0 && max_log2 < 40 && n <= ((size_t)1 << max_log2);
+    if (const char* e = knob("ECGPU_MSM_GLV_MAX_LOG2")) {
+        const int max_log2 = atoi(e);
+        return max_log2 >= 0 && max_log2 < 40 && n <= ((size_t)1 << max_log2);
+    }
+    return n < MSM_GLV_MAX_TERMS;
 }
 
 // per-device launch facts (a context per GPU may plan concurrently: no unsynchronised function statics)
@@ -1292,7 +1303,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     p.nb = (size_t)1 << (p.c - 1);
     p.seg = 4;                                              // buckets per running-sum lane: 4 ... 8 measured best for
                                                             // small MSMs (more lanes), neutral at 2^24 (tuning knob)
-    if (const char* e = getenv("ECGPU_MSM_SEG")) {
+    if (const char* e = knob("ECGPU_MSM_SEG")) {
         int v = atoi(e);
         if (v >= 1 && v <= 1024 && (v & (v - 1)) == 0) p.seg = v;
     }
@@ -1304,7 +1315,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     int tile_log2 = 18;                                   // terms per counting-sort tile (tuning knob)
-    if (const char* e = getenv("ECGPU_MSM_TILE_LOG2")) {
+    if (const char* e = knob("ECGPU_MSM_TILE_LOG2")) {
         int v = atoi(e);
         if (v >= 12 && v <= 24) tile_log2 = v;
     }
@@ -1333,7 +1344,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
         if (p.chunk < 32) p.chunk = 32;
         // (no rounding to a multiple of four: the index stream starts anywhere inside a 16-byte quad, ecgpu_msm_chunk.h.  Round 4
         // rounded up — 57 -> 60 entries at 2^21 GLV terms, and the third round of waves was 16 % empty)
-        if (const char* e = getenv("ECGPU_MSM_CHUNK")) {
+        if (const char* e = knob("ECGPU_MSM_CHUNK")) {
             long v = atol(e);
             if (v >= 1 && v <= (1L << 30)) p.chunk = (size_t)v;
         }
@@ -1342,7 +1353,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
     }
     {
         bool two = ne >= ((size_t)1 << 17);      // measured: equal at 2^16, 12 % faster at 2^18, 14 % at 2^24
-        if (const char* e = getenv("ECGPU_MSM_SORT2")) two = atoi(e) != 0;
+        if (const char* e = knob("ECGPU_MSM_SORT2")) two = atoi(e) != 0;
         if (two && p.c - 1 > MSM_SORT2_BITS_A) {
             p.sort_bits_b = p.c - 1 - MSM_SORT2_BITS_A;
             // packed form: as many low bucket bits as fit beside the index and the sign (fewer low bits = more level-A keys)
@@ -1356,7 +1367,7 @@ MsmPlan msm_plan(size_t n, int force_c, bool glv) {
             // large-LDS attribute: with 9 level-A bits (more than 2^24 entries per window) the 33 windows of p521 would need 67.6 KB
             // — such a plan keeps the unpacked form with its 8 level-A bits
             packed = packed && (size_t)p.nwin * (p.nb >> bb) * 4 <= (size_t)64 * 1024;
-            if (const char* e = getenv("ECGPU_MSM_SORT_PACKED")) packed = packed && atoi(e) != 0;   // 0: the round-3 kernels (A/B runs)
+            if (const char* e = knob("ECGPU_MSM_SORT_PACKED")) packed = packed && atoi(e) != 0;   // 0: the round-3 kernels (A/B runs)
             if (packed) {
                 p.sort_packed = true;
                 p.idx_bits = idx_bits;
@@ -1410,7 +1421,7 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
         // (k_msm_find_big ran before the accumulation: launch_msm_parts)
         hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3(MSM_BIG_GRID), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
                            (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
-                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
+                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list, (uint32_t)p.max_big);
         hipLaunchKernelGGL((k_msm_finish_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
                            (const uint32_t*)partials, (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts,
                            (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, (const uint32_t*)buckets, p.seg, p.nseg,
@@ -1422,7 +1433,7 @@ void launch_msm_tail(const MsmPlan& p, hipStream_t stream, uint8_t* ws, uint32_t
                            (const uint32_t*)sorted, ne, p.nb, p.nwin, p.chunk, p.nchunks, buckets, big_list, (uint32_t)p.max_big);
         hipLaunchKernelGGL(k_msm_big_buckets<C>, dim3(MSM_BIG_GRID), dim3(BLOCK), 0, stream, (const uint32_t*)partials,
                            (const uint32_t*)counts, (const uint32_t*)offsets, (const uint32_t*)pts, (const uint32_t*)sorted, ne, p.nb,
-                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list);
+                           p.chunk, p.nchunks, buckets, (const uint32_t*)big_list, (uint32_t)p.max_big);
         hipLaunchKernelGGL((k_msm_reduce_segments<C>), dim3((unsigned)((nsg + 63) / 64)), dim3(64), 0, stream,
                            (const uint32_t*)buckets, p.nb, p.seg, p.nseg, p.nwin, msm_top_shift(p.kbits, p.c), segs);
     }
@@ -1503,7 +1514,7 @@ void launch_msm_parts(const MsmPlan& p, hipStream_t stream, const uint8_t* d_sca
                            (const unsigned long long*)vmask, ne, p.sort_bits_b, p.idx_bits, (uint32_t)p.npart, cursor, tmp);
         // level B: one workgroup per (partition, window); small partitions (small MSMs) get 256 lanes
         unsigned tb = ne / p.npart >= 4096 ? 1024u : 256u;
-        if (const char* e = getenv("ECGPU_MSM_SORTB_T")) {            // tuning knob: lanes per level-B workgroup
+        if (const char* e = knob("ECGPU_MSM_SORTB_T")) {            // tuning knob: lanes per level-B workgroup
             const int v = atoi(e);
             if (v == 256 || v == 512 || v == 1024) tb = (unsigned)v;
         }

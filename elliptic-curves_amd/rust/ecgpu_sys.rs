@@ -38,6 +38,8 @@ pub const ECGPU_ERR_OOM: c_int = -6;
 pub const ECGPU_ERR_ARG: c_int = -7;
 pub const ECGPU_TABLE_ADAPTIVE: c_int = 0;
 pub const ECGPU_TABLE_EAGER: c_int = 1;
+pub const ECGPU_EXCHANGE_PEER: c_int = 1;
+pub const ECGPU_EXCHANGE_RCCL: c_int = 2;
 
 #[link(name = "ecgpu")]
 unsafe extern "C" {
@@ -208,6 +210,7 @@ unsafe extern "C" {
         plan_terms: usize,
         d_parts: *mut c_void,
     ) -> c_int;
+    pub fn ecgpu_msm_parts_join_dev(ctx: *mut EcgpuCtx, d_parts: *const c_void) -> c_int;
     pub fn ecgpu_msm_finish_dev(
         ctx: *mut EcgpuCtx,
         curve: c_int,
@@ -224,6 +227,7 @@ unsafe extern "C" {
     pub fn ecgpu_group_last_error(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_exchange(group: *const EcgpuGroup) -> *const c_char;
     pub fn ecgpu_group_exchange_reason(group: *const EcgpuGroup) -> *const c_char;
+    pub fn ecgpu_group_set_exchange(group: *mut EcgpuGroup, mode: c_int) -> c_int;
     pub fn ecgpu_group_set_msm_window(group: *mut EcgpuGroup, window_bits: c_int) -> c_int;
     pub fn ecgpu_group_set_exchange_timeout(group: *mut EcgpuGroup, seconds: f64) -> c_int;
     pub fn ecgpu_group_msm(

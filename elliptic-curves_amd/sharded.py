@@ -119,7 +119,10 @@ class RecordExchange:
         self.mine = torch.zeros((pad,), dtype=torch.uint8, device=device)[:nbytes]
         self.all = torch.zeros((self.world * nbytes,), dtype=torch.uint8, device=device)
 
-    def gather(self):
+    def gather(self, consumer_on_current_stream=False):
+        """All-gathers `mine` into `all` and returns it.  consumer_on_current_stream: what reads `all` next is queued on torch's current
+        stream (an Engine after set_stream(torch.cuda.current_stream()), as bench.py's): the collective is ordered before it on the
+        device and the host does not wait; otherwise (an Engine on its own stream) the host waits for the gathered bytes."""
         if self.all.is_cuda and self.dist.get_backend(self.group) == "gloo":
             # dry runs on a one-GPU box (bench.py ECGPU_BENCH_BACKEND=gloo): the records travel through the host
             self.torch.cuda.current_stream(self.all.device).synchronize()
@@ -128,10 +131,24 @@ class RecordExchange:
             self.all.copy_(host)
         else:
             self.dist.all_gather_into_tensor(self.all, self.mine, group=self.group)
-        if self.all.is_cuda:
+        if self.all.is_cuda and not consumer_on_current_stream:
             # a consumer that enqueues on a stream of its own (an Engine without set_stream) is not ordered after the
             # collective: wait for the gathered bytes
             self.torch.cuda.current_stream(self.all.device).synchronize()
+        return self.all
+
+
+class LocalRecord:
+    """RecordExchange's shape for ONE rank: the record is its own gathered form (`all` is `mine`), gather() moves nothing.  What
+    bench.py uses to time a single GPU's share of a sharded MSM in the sharded form (parts / join / finish) without a process group."""
+
+    def __init__(self, torch, nbytes, device):
+        pad = (nbytes + 255) // 256 * 256
+        self.nbytes, self.world = nbytes, 1
+        self.mine = torch.zeros((pad,), dtype=torch.uint8, device=device)[:nbytes]
+        self.all = self.mine
+
+    def gather(self, consumer_on_current_stream=False):
         return self.all
 
 

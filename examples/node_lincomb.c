@@ -2,7 +2,8 @@
  * of include/ecgpu.h; what the Rust caller of `LinearCombination::lincomb_vartime` would do through ecgpu_shim.rs).
  *
  *     make -C examples
- *     ./examples/node_lincomb [ndev] [log2 terms]        # default: every visible GPU (at most 8), 2^18 terms
+ *     ./examples/node_lincomb [ndev] [log2 terms] [peer|rccl]    # default: every visible GPU (at most 8), 2^18 terms, RCCL when it
+ *                                                                # can be had (rccl: or fail; peer: peer copies) — ecgpu_group_set_exchange
  *
  * The terms are k_i * P_i with P_i = s_i * G made on the GPUs themselves; the check is the group identity
  *     lincomb over the whole node  ==  lincomb on GPU 0 alone,
@@ -53,6 +54,10 @@ int main(int argc, char **argv) {
             for (int i = 0; i < ndev; i++) devices[i] = 0;
             if (ecgpu_group_init(&grp, devices, ndev) != ECGPU_OK) { fprintf(stderr, "no gfx950 device\n"); return 1; }
         }
+    }
+    if (argc > 3 && ecgpu_group_set_exchange(grp, strcmp(argv[3], "peer") == 0 ? ECGPU_EXCHANGE_PEER : ECGPU_EXCHANGE_RCCL) != ECGPU_OK) {
+        fprintf(stderr, "no gfx950 device with that exchange: %s\n", ecgpu_group_last_error(grp));
+        return 1;
     }
     printf("group of %d member(s), exchange by %s, %zu terms\n", ecgpu_group_size(grp), ecgpu_group_exchange(grp), n);
     uint8_t *k = malloc(n * 32), *s = malloc(n * 32), *pts = malloc(n * 64);

@@ -138,7 +138,10 @@ int ecgpu_copy_to_host(ecgpu_ctx *ctx, void *h_dst, const void *d_src, size_t by
  * the call being served included: 16 bits below 2^26, 22 bits below 2^29, then the curve's widest (k256 26, p256 / sm2 / the
  * other 256- and 224- / 192-bit sets 24, p384 / p521 / bp384 20) — each step where the time lost to the narrower table so far equals
  * the build time of the next one, so a caller never pays more than twice the best fixed choice and a 1,024-scalar call never
- * allocates gigabytes.  A step up costs the calling thread the build once; the narrower table is freed when its last user lets go.
+ * allocates gigabytes.  A step up costs the calling thread the build once — the call that crosses a tier waits for its stream and
+ * builds the next table before it returns (k256: 1 / 6 / 55 ms), on an asynchronous context too —; the narrower table is freed when
+ * its last user lets go.  Until a tier is reached the rate is the narrower table's (k256, per 2^20 scalars: ~0.83 ms at 16 bits,
+ * ~0.68 at 22, ~0.61 at 26; bench.py prints the three as `fixed_k256_tier_ms`, its headline uses ECGPU_TABLE_EAGER).
  * ECGPU_TABLE_EAGER: the widest table at the first call (a long-lived service: pay ~55 ms once at start-up).
  * A table that does not fit is replaced by one two bits narrower, down to 16 bits, before ECGPU_ERR_OOM is returned. */
 enum { ECGPU_TABLE_ADAPTIVE = 0, ECGPU_TABLE_EAGER = 1 };
@@ -276,7 +279,7 @@ int ecgpu_point_sum_dev(ecgpu_ctx *ctx, int curve, const void *d_points_xy,
  * torch.distributed job, peer copies inside ecgpu_group_msm), and ONE combining step — window sums over all GPUs, then the
  * chain of doublings over the windows — produces the result.  The serial tail of the method runs once, not once per GPU
  * plus a point sum.  `plan_terms` is the term count the window width is chosen from and must be the same on every GPU
- * (at least the largest shard); so must ecgpu_set_msm_window and the ECGPU_MSM_* environment knobs.  `lincomb` semantics as for ecgpu_msm_dev. */
+ * (at least the largest shard); so must ecgpu_set_msm_window.  `lincomb` semantics as for ecgpu_msm_dev. */
 size_t ecgpu_msm_parts_bytes(ecgpu_ctx *ctx, int curve, size_t plan_terms);
 /* The Pippenger window width (bits) the two halves use for `plan_terms` on this context — ecgpu_set_msm_window's override
  * or the measured default; every GPU of a sharded MSM must report the same value (ecgpu_group_msm_dev checks it).
@@ -284,6 +287,16 @@ size_t ecgpu_msm_parts_bytes(ecgpu_ctx *ctx, int curve, size_t plan_terms);
 int ecgpu_msm_plan_window(ecgpu_ctx *ctx, int curve, size_t plan_terms);
 int ecgpu_msm_parts_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const void *d_points_xy, const void *d_points_inf,
                         size_t n, size_t plan_terms, void *d_parts);
+/* Throughput form for back-to-back sharded MSMs: on an asynchronous context (ecgpu_set_async) with ecgpu_set_msm_lanes(L > 1),
+ * ecgpu_msm_parts_dev runs on one of L rotating internal streams + workspaces, ordered after what the context's stream holds at
+ * the call (the inputs) — so the exchange and the combining half of MSM i - 1, which the caller keeps on the context's stream,
+ * run beside the accumulation of MSM i:
+ *     ecgpu_msm_parts_dev(i, d_parts[i % L]);
+ *     ecgpu_msm_parts_join_dev(d_parts[(i - 1) % L]);  all-gather(i - 1);  ecgpu_msm_finish_dev(i - 1);
+ * ecgpu_msm_parts_join_dev makes the context's stream wait (on the device; the host does not) for the local half that wrote
+ * `d_parts`; until then the record belongs to its lane.  A no-op for a record written on the context's own stream.
+ * ecgpu_msm_finish_dev does not wait for local halves in flight.  One MSM alone gains nothing from lanes. */
+int ecgpu_msm_parts_join_dev(ecgpu_ctx *ctx, const void *d_parts);
 /* d_parts_all: nranks consecutive parts records (the all-gather's output). */
 int ecgpu_msm_finish_dev(ecgpu_ctx *ctx, int curve, const void *d_parts_all, int nranks, size_t plan_terms, void *d_out_xy,
                          void *d_out_inf);
@@ -296,7 +309,7 @@ int ecgpu_msm_finish_dev(ecgpu_ctx *ctx, int curve, const void *d_parts_all, int
  * on a one-GPU box).  Batch calls cut the index range into one contiguous slice per GPU and need no exchange; the MSM
  * cuts the terms the same way, runs ecgpu_msm_parts_dev per GPU and has ONE exchange step: RCCL ncclAllGather of the
  * per-window partial sums over xGMI when librccl can be dlopen()ed and the devices are distinct, a peer copy into
- * GPU 0 otherwise or with ECGPU_GROUP_EXCHANGE=peer (=rccl: fail instead of falling back); then ecgpu_msm_finish_dev once.
+ * GPU 0 otherwise or after ecgpu_group_set_exchange(ECGPU_EXCHANGE_PEER); then ecgpu_msm_finish_dev once.
  * Results are identical to the single-GPU calls.  Not thread-safe: one call at a time per group. */
 typedef struct ecgpu_group ecgpu_group;
 int ecgpu_group_init(ecgpu_group **group, const int *devices, int ndev);
@@ -305,10 +318,15 @@ int ecgpu_group_size(const ecgpu_group *group);
 ecgpu_ctx *ecgpu_group_ctx(ecgpu_group *group, int i);              /* borrowed: member i's context */
 const char *ecgpu_group_last_error(const ecgpu_group *group);
 const char *ecgpu_group_exchange(const ecgpu_group *group);         /* "rccl" or "peer" */
-/* why: "rccl: ncclCommInitAll over 8 devices", "peer: ECGPU_GROUP_EXCHANGE=peer", "peer: duplicate devices in the group",
+/* why: "rccl: ncclCommInitAll over 8 devices", "peer: ecgpu_group_set_exchange(ECGPU_EXCHANGE_PEER)", "peer: duplicate devices in the group",
  * "peer: librccl could not be loaded (...)", "peer: ncclCommInitAll failed (...)", "peer: ncclAllGather failed (...)": a
  * group whose RCCL exchange fails at run time falls back to peer copies for that call and all later ones */
 const char *ecgpu_group_exchange_reason(const ecgpu_group *group);
+/* Choose the exchange of an initialised group.  ECGPU_EXCHANGE_PEER: peer copies from now on (the communicators are released);
+ * ECGPU_EXCHANGE_RCCL: ECGPU_OK if the group exchanges over RCCL, ECGPU_ERR_HIP if it does not (a caller who wants "RCCL or
+ * nothing" instead of the silent fallback; the reason is in ecgpu_group_last_error).  The library reads no environment variable. */
+enum { ECGPU_EXCHANGE_PEER = 1, ECGPU_EXCHANGE_RCCL = 2 };
+int ecgpu_group_set_exchange(ecgpu_group *group, int mode);
 int ecgpu_group_set_msm_window(ecgpu_group *group, int window_bits);
 /* The exchange step of ecgpu_group_msm* never waits longer than this (default 10 s; seconds > 0): every member polls its exchange
  * stream against the deadline instead of blocking on it.  A collective that fails on any member, or has not completed by then

@@ -68,6 +68,64 @@ def batch_mul_base(curve, scalars):
     return out, inf
 
 
+def _host_threads():
+    """threads worth starting: the affinity mask capped by the container's cgroup CPU quota"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def _threaded(n, unit_fn, threads=None):
+    """unit_fn(lo, hi) over [0, n) in contiguous slices on all host cores (ctypes releases the GIL inside the C call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or _host_threads()
+    per = max(1, -(-n // (threads * 4)))
+    spans = [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(lambda sp: unit_fn(*sp), spans))
+
+
+def batch_mul_base_mt(curve, scalars, threads=None):
+    """batch_mul_base on every host core: the whole of a BASELINE-sized batch against the oracle in seconds."""
+    L = FIELD_BYTES[curve]
+    s = _arr(scalars)
+    n = s.size // L
+    out = np.zeros(n * 2 * L, np.uint8)
+    inf = np.zeros(n, np.uint8)
+    fn = lib().ecref_batch_mul_base
+
+    def unit(lo, hi):
+        _chk(fn(curve, _buf(s[lo * L: hi * L]), ctypes.c_size_t(hi - lo), _buf(out[lo * 2 * L: hi * 2 * L]), _buf(inf[lo:hi])))
+
+    _threaded(n, unit, threads)
+    return out, inf
+
+
+def batch_mul_mt(curve, scalars, points_xy, threads=None):
+    """batch_mul (no identity flags) on every host core."""
+    L = FIELD_BYTES[curve]
+    s, p = _arr(scalars), _arr(points_xy)
+    n = s.size // L
+    out = np.zeros(n * 2 * L, np.uint8)
+    inf = np.zeros(n, np.uint8)
+    fn = lib().ecref_batch_mul
+
+    def unit(lo, hi):
+        _chk(fn(curve, _buf(s[lo * L: hi * L]), _buf(p[lo * 2 * L: hi * 2 * L]), None, ctypes.c_size_t(hi - lo),
+                _buf(out[lo * 2 * L: hi * 2 * L]), _buf(inf[lo:hi])))
+
+    _threaded(n, unit, threads)
+    return out, inf
+
+
 def batch_mul(curve, scalars, points_xy, points_inf=None, vartime=False):
     L = FIELD_BYTES[curve]
     s, p = _arr(scalars), _arr(points_xy)

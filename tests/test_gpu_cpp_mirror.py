@@ -67,8 +67,7 @@ def test_c_node_lincomb_example_runs(ndev, mode):
     device is listed ndev times (independent contexts, worker threads, peer-copy exchange) or once over RCCL."""
     ex = os.path.join(os.path.dirname(HERE), "examples")
     subprocess.check_call(["make", "-s", "-C", ex])
-    env = dict(os.environ, ECGPU_GROUP_EXCHANGE=mode)
-    out = subprocess.run([os.path.join(ex, "node_lincomb"), str(ndev), "17"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([os.path.join(ex, "node_lincomb"), str(ndev), "17", mode], capture_output=True, text=True, timeout=600)
     if mode == "rccl" and out.returncode != 0 and "no gfx950 device" in out.stderr:
         pytest.skip("librccl could not be loaded")
     assert out.returncode == 0, out.stdout + out.stderr

@@ -108,8 +108,8 @@ def test_full_size_msm_k256_2p24_one_plan(eng):
 @pytest.mark.parametrize("curve", ["p256", "p384"])
 def test_full_size_variable_base_2p20(eng, curve):
     """configs[2] / configs[4]: 2^20 (scalar, point) pairs, device-resident.  k_i (s_i G) == (k_i s_i) G for EVERY
-    element (variable-base kernel against the fixed-base kernel, two different algorithms), plus the oracle on a strided
-    sample of 64 elements and on the edge elements forced into the head of the batch."""
+    element (variable-base kernel against the fixed-base kernel, two different algorithms), plus the oracle on the edge elements forced into the head of the batch
+    and on a strided sample of 2^16 elements (every host core)."""
     c = pyec.CURVES[curve]
     L, n = c.L, 1 << 20
     k = fast_scalars(c, n, 0xEC000003 + c.cid)
@@ -135,6 +135,10 @@ def test_full_size_variable_base_2p20(eng, curve):
     pts = eng.to_host(d_p).reshape(n, 2 * L)
     idx = np.concatenate([np.arange(8), np.arange(8, n, n // 56)])
     w, wf = oracle_lib.batch_mul(c.cid, k[idx].reshape(-1), pts[idx].reshape(-1))
+    assert bytes(out.reshape(n, 2 * L)[idx].reshape(-1)) == bytes(w) and bytes(inf[idx]) == bytes(wf)
+    # and one element in sixteen (2^16 of them) against the oracle's `ProjectivePoint * Scalar` on all host cores
+    idx = np.arange(5, n, 16)
+    w, wf = oracle_lib.batch_mul_mt(c.cid, k[idx].reshape(-1), pts[idx].reshape(-1))
     assert bytes(out.reshape(n, 2 * L)[idx].reshape(-1)) == bytes(w) and bytes(inf[idx]) == bytes(wf)
     for b in (d_k, d_s, d_p, d_o, d_f):
         b.free()

@@ -97,10 +97,9 @@ def test_group_on_distinct_devices(eng, mode, monkeypatch):
     == the oracle."""
     ndev = need_gpus(2)
     ecgpu = ecgpu_module()
-    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", mode)
     for devices in ([0, 1], list(range(ndev)), list(range(ndev))[::-1]):
         try:
-            grp = ecgpu.Group(devices)
+            grp = ecgpu.Group(devices, exchange=mode)
         except ecgpu.EcgpuError:
             if mode == "rccl":
                 pytest.skip("librccl could not be loaded / initialised in this process")
@@ -152,9 +151,8 @@ def test_group_rejects_diverging_member_plans(eng, monkeypatch):
     device 0)."""
     import ctypes
     ecgpu = ecgpu_module()
-    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", "peer")
     ndev = device_count()
-    grp = ecgpu.Group([0, 1] if ndev >= 2 else [0, 0])
+    grp = ecgpu.Group([0, 1] if ndev >= 2 else [0, 0], exchange="peer")
     try:
         lib = ecgpu.load_library()
         lib.ecgpu_group_ctx.restype = ctypes.c_void_p

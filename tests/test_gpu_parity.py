@@ -22,6 +22,17 @@ def eng():
     e.close()
 
 
+@pytest.fixture(scope="module")
+def keng():
+    """An engine on the TOOL build of the library (lib/libecgpu_knobs.so, csrc/ecgpu_knobs.h): the same kernel objects, but the ECGPU_*
+    tuning knobs are read from the environment — the product library never reads it.  The tests that force a code path the planner
+    would not pick at their sizes (two-level sort at small n, chunk sizes, the chunked host-pointer MSM, the fused tail) run on it."""
+    ecgpu = ecgpu_module()
+    e = ecgpu.Engine(0, variant="knobs")
+    yield e
+    e.close()
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _oracle_built():
     oracle_lib.build()
@@ -172,7 +183,7 @@ def test_variable_base_vs_oracle(eng, curve):
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 257, 4000])
-def test_msm_vs_oracle(eng, curve, n, monkeypatch):
+def test_msm_vs_oracle(eng, keng, curve, n, monkeypatch):
     c = pyec.CURVES[curve]
     if n == 0:
         o, f = eng.lincomb(c.cid, b"", b"")
@@ -192,21 +203,26 @@ def test_msm_vs_oracle(eng, curve, n, monkeypatch):
         pts[15 * 2 * c.L: 16 * 2 * c.L] = np.frombuffer(pyec.enc_point(c, neg)[0], np.uint8)
         scal[15 * c.L: 16 * c.L] = scal[14 * c.L: 15 * c.L]
     want, winf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=True)
-    for sort2 in ("0", "1"):                  # single-level / two-level (partition, then buckets) counting sort
+    for cbits in ((0, 5) if n < 257 else (0, 4, 9, 12, 16)):           # the product library: its own plan for every window width
+        eng.set_msm_window(cbits)
+        o, f = eng.lincomb(c.cid, scal, pts, inf)
+        assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits)
+    eng.set_msm_window(0)
+    for sort2 in ("0", "1"):                  # single-level / two-level (partition, then buckets) counting sort, forced (tool build)
         monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)
         for cbits in ((0, 5) if n < 257 else (0, 4, 9, 12, 16)):       # 0: automatic (small n: per-term products + tree sum)
-            eng.set_msm_window(cbits)
-            o, f = eng.lincomb(c.cid, scal, pts, inf)
+            keng.set_msm_window(cbits)
+            o, f = keng.lincomb(c.cid, scal, pts, inf)
             assert bytes(o) == bytes(want) and f == winf, (curve, n, cbits, sort2)
     monkeypatch.delenv("ECGPU_MSM_SORT2")
-    eng.set_msm_window(0)
+    keng.set_msm_window(0)
     if n == 17:
         want_ct, wf = oracle_lib.msm(c.cid, scal, pts, inf, vartime=False)
         assert bytes(want_ct) == bytes(want) and wf == winf
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
-def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
+def test_msm_chunk_sizes_and_skewed_scalars(eng, keng, curve, monkeypatch):
     """The accumulation lanes own fixed-size chunks of the sorted run, not buckets.  Sweep the chunk size (1 entry
     per lane .. everything in one lane) against the oracle, then feed scalar sets that put every term of a window
     into ONE bucket (all scalars equal / all ones): sum_i k P_i = k * sum_i P_i."""
@@ -219,11 +235,11 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
     for chunk in ("1", "33", "100000"):
         monkeypatch.setenv("ECGPU_MSM_CHUNK", chunk)
         for cbits in (0, 9):
-            eng.set_msm_window(cbits)
-            o, f = eng.lincomb(c.cid, scal, pts)
+            keng.set_msm_window(cbits)
+            o, f = keng.lincomb(c.cid, scal, pts)
             assert bytes(o) == bytes(want) and f == winf, (chunk, cbits)
     monkeypatch.delenv("ECGPU_MSM_CHUNK")
-    eng.set_msm_window(0)
+    keng.set_msm_window(0)
     n = 1 << 18
     pts, _ = eng.mul_by_generator(c.cid, rand_scalars(c.cid, n, 0xEC000016 + c.cid))
     total, tf = eng.point_sum(c.cid, pts)
@@ -232,7 +248,7 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
     for k, sort2 in ((k0, "0"), (k0, "1"), (pyec.enc_scalar(c, 1), "1"), (pyec.enc_scalar(c, c.n - 1), "0")):
         monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)          # "1": the two-level sort, whatever n is
         t0 = time.time()
-        o, f = eng.lincomb(c.cid, np.tile(np.frombuffer(k, np.uint8), n), pts)
+        o, f = keng.lincomb(c.cid, np.tile(np.frombuffer(k, np.uint8), n), pts)
         dt = time.time() - t0
         w, wf = eng.mul(c.cid, k, total)
         assert bytes(o) == bytes(w) and f == int(wf[0])
@@ -241,7 +257,7 @@ def test_msm_chunk_sizes_and_skewed_scalars(eng, curve, monkeypatch):
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
-def test_msm_exceptional_additions(eng, curve, monkeypatch):
+def test_msm_exceptional_additions(eng, keng, curve, monkeypatch):
     """Bucket runs with duplicates, P + Q next to P and Q, cancelling sums: the stretches whose incomplete XYZZ sum
     fails the exactness test are redone with the complete formulas (ecgpu_msm_chunk.h)."""
     import random
@@ -256,14 +272,14 @@ def test_msm_exceptional_additions(eng, curve, monkeypatch):
         else:
             monkeypatch.setenv("ECGPU_MSM_CHUNK", chunk)
         for cbits in (0, 4, 9):
-            eng.set_msm_window(cbits)
-            o, f = eng.lincomb(c.cid, scal, pxy)
+            keng.set_msm_window(cbits)
+            o, f = keng.lincomb(c.cid, scal, pxy)
             assert bytes(o) == bytes(want) and f == winf, (chunk, cbits)
     monkeypatch.delenv("ECGPU_MSM_CHUNK", raising=False)
-    eng.set_msm_window(0)
+    keng.set_msm_window(0)
     # a whole run of one repeated term: every stretch takes the complete path
     n = 5000
-    o, f = eng.lincomb(c.cid, scal[: c.L] * n, pxy[: 2 * c.L] * n)
+    o, f = keng.lincomb(c.cid, scal[: c.L] * n, pxy[: 2 * c.L] * n)
     w, wf = eng.mul(c.cid, pyec.enc_scalar(c, ks[0] * n % c.n), pxy[: 2 * c.L])
     assert bytes(o) == bytes(w) and f == int(wf[0])
 
@@ -348,19 +364,18 @@ def test_error_behaviour(eng, curve):
 # ---------------------------------------------------------------------------------------------------
 
 def test_full_size_fixed_base_k256(eng):
-    """config 2: 2^20 random k256 scalars.  (a) a strided sample is compared with the oracle bit for
-    bit; (b) checksum of checksums: sum_i (k_i G) == (sum_i k_i) G with the left side summed on the GPU
-    over ALL 2^20 outputs."""
+    """config 2: 2^20 random k256 scalars.  (a) EVERY output against the oracle, byte for byte (the oracle's `mul_by_generator` on all
+    host cores: a second or two); (b) checksum of checksums: sum_i (k_i G) == (sum_i k_i) G with the left side summed on the GPU
+    over all 2^20 outputs; (c) the constant-time form (ecgpu_batch_mul_base_ct) returns the same bytes."""
     c = pyec.K256
     n = 1 << 20
     scal = rand_scalars(0, n, 0xEC000002)
     out, inf = eng.mul_by_generator(0, scal)
     assert not inf.any()
-    idx = np.arange(0, n, 4099)
-    sample = np.concatenate([scal[32 * i: 32 * i + 32] for i in idx])
-    want, _ = oracle_lib.batch_mul_base(0, sample)
-    got = np.concatenate([out[64 * i: 64 * i + 64] for i in idx])
-    assert bytes(got) == bytes(want)
+    want, winf = oracle_lib.batch_mul_base_mt(0, scal)
+    assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+    out_ct, inf_ct = eng.mul_by_generator(0, scal, constant_time=True)
+    assert bytes(out_ct) == bytes(want) and bytes(inf_ct) == bytes(winf)
     total = scalars_to_int_sum(scal, 32, c.n)
     o, f = eng.point_sum(0, out)
     w, wf = oracle_lib.batch_mul_base(0, pyec.enc_scalar(c, total))
@@ -386,7 +401,7 @@ def test_full_size_variable_base_p256_sample(eng):
 
 
 @pytest.mark.parametrize("curve", ["k256", "p256"])
-def test_msm_multi_tile_ragged(eng, curve, monkeypatch):
+def test_msm_multi_tile_ragged(eng, keng, curve, monkeypatch):
     """More than one counting-sort tile with a ragged tail (n = 2^19 + 12345), identities sprinkled in, both
     the automatic window and c = 16: split linearity + all-G checksum."""
     c = pyec.CURVES[curve]
@@ -401,21 +416,21 @@ def test_msm_multi_tile_ragged(eng, curve, monkeypatch):
     h = (1 << 19) - 7
     for cbits, sort2 in ((0, "0"), (16, "0"), (16, "1"), (11, "1")):
         monkeypatch.setenv("ECGPU_MSM_SORT2", sort2)
-        eng.set_msm_window(cbits)
-        full, ff = eng.lincomb(c.cid, k, pts, inf)
-        a, af = eng.lincomb(c.cid, k[: c.L * h], pts[: 2 * c.L * h], inf[:h])
-        b, bf = eng.lincomb(c.cid, k[c.L * h:], pts[2 * c.L * h:], inf[h:])
+        keng.set_msm_window(cbits)
+        full, ff = keng.lincomb(c.cid, k, pts, inf)
+        a, af = keng.lincomb(c.cid, k[: c.L * h], pts[: 2 * c.L * h], inf[:h])
+        b, bf = keng.lincomb(c.cid, k[c.L * h:], pts[2 * c.L * h:], inf[h:])
         sm, sf = eng.point_sum(c.cid, np.concatenate([a, b]), np.array([af, bf], np.uint8))
         assert bytes(sm) == bytes(full) and sf == ff
         gxy = np.frombuffer(pyec.enc_point(c, pyec.G(c))[0], np.uint8)
-        o, f = eng.lincomb(c.cid, k, np.tile(gxy, n))
+        o, f = keng.lincomb(c.cid, k, np.tile(gxy, n))
         w, wf = oracle_lib.batch_mul_base(c.cid, pyec.enc_scalar(c, scalars_to_int_sum(k, c.L, c.n)))
         assert bytes(o) == bytes(w) and f == int(wf[0])
     monkeypatch.delenv("ECGPU_MSM_SORT2")
-    eng.set_msm_window(0)
+    keng.set_msm_window(0)
     # oracle on a sample of the same data
     m = 3000
-    o, f = eng.lincomb(c.cid, k[: c.L * m], pts[: 2 * c.L * m], inf[:m])
+    o, f = keng.lincomb(c.cid, k[: c.L * m], pts[: 2 * c.L * m], inf[:m])
     w, wf = oracle_lib.msm(c.cid, k[: c.L * m], pts[: 2 * c.L * m], inf[:m], vartime=True)
     assert bytes(o) == bytes(w) and f == wf
 
@@ -1395,9 +1410,8 @@ def test_group_multi_device_entry_points(eng, devices, mode, monkeypatch):
     one-member communicator, which is what can be exercised here), one combining step.  lincomb, mul_by_generator and mul
     must give the bytes of the single-context calls, for a GLV-sized and a tiny MSM, with identities mixed in."""
     ecgpu = ecgpu_module()
-    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", mode)
     try:
-        grp = ecgpu.Group(devices)
+        grp = ecgpu.Group(devices, exchange=mode)          # ecgpu_group_set_exchange: "rccl" = RCCL or an error, "peer" = peer copies
     except ecgpu.EcgpuError:
         if mode == "rccl":
             pytest.skip("librccl could not be loaded in this process")
@@ -1445,7 +1459,7 @@ def test_group_multi_device_entry_points(eng, devices, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("curve", ALL_CURVES)
-def test_host_pointer_msm_chunked_path_every_curve(eng, curve, monkeypatch):
+def test_host_pointer_msm_chunked_path_every_curve(eng, keng, curve, monkeypatch):
     """The chunked host-pointer ecgpu_msm on every parameter set, with the chunk size lowered to 2^10 terms
     (ECGPU_MSM_PIPE_LOG2) so that 2^11 + 37 terms take it: the partial-sum records sit at a pitch of 2L bytes, which is not a
     multiple of 16 for p224 (56) and p521 (132).  Result == the unchunked call == the oracle; identities mixed in."""
@@ -1460,7 +1474,7 @@ def test_host_pointer_msm_chunked_path_every_curve(eng, curve, monkeypatch):
     pts.reshape(n, 2 * c.L)[inf == 1] = 0
     plain, pf = eng.lincomb(c.cid, k, pts, inf)
     monkeypatch.setenv("ECGPU_MSM_PIPE_LOG2", "10")
-    o, f = eng.lincomb(c.cid, k, pts, inf)
+    o, f = keng.lincomb(c.cid, k, pts, inf)
     monkeypatch.delenv("ECGPU_MSM_PIPE_LOG2")
     assert bytes(o) == bytes(plain) and f == pf
     w, wf = oracle_lib.msm(c.cid, k, pts, inf, vartime=True)
@@ -1647,7 +1661,7 @@ def test_generator_table_policy_budget_and_pinning():
 
 
 @pytest.mark.parametrize("curve", ["k256", "p256", "p384"])
-def test_msm_fused_tail_form(eng, curve, monkeypatch):
+def test_msm_fused_tail_form(eng, keng, curve, monkeypatch):
     """ECGPU_MSM_FUSED_TAIL=1: the bucket finish inside the running sums (k_msm_finish_segments, with the degenerate buckets listed
     by k_msm_find_big before the accumulation and summed by k_msm_big_buckets) — not the default form, kept
     correct: random scalars, and a scalar set that puts thousands of terms into single buckets, against the default form and the
@@ -1662,7 +1676,7 @@ def test_msm_fused_tail_form(eng, curve, monkeypatch):
             k = np.tile(k[: 3 * c.L], n // 3 + 1)[: n * c.L].copy()          # three scalars: every window has three huge buckets
         want, wf = eng.lincomb(c.cid, k, pts)
         monkeypatch.setenv("ECGPU_MSM_FUSED_TAIL", "1")
-        got, gf = eng.lincomb(c.cid, k, pts)
+        got, gf = keng.lincomb(c.cid, k, pts)
         monkeypatch.delenv("ECGPU_MSM_FUSED_TAIL")
         assert bytes(got) == bytes(want) and gf == wf, (curve, case)
         ki = [int.from_bytes(bytes(k[i * c.L:(i + 1) * c.L]), "big") for i in range(n)]

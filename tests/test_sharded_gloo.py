@@ -144,6 +144,34 @@ for step in range(2):                                          # the buffers are
     got, gi = oracle_lib.msm(curve, ones, np.ascontiguousarray(rec[:, : 2 * L]).reshape(-1), np.ascontiguousarray(rec[:, 2 * L]))
     want, wi = oracle_lib.msm(curve, scal, pts)
     assert bytes(got) == bytes(want) and gi == wi, "rank %d mismatch" % rank
+# bench.py's throughput form (msm_k256_sharded_lanes): local half of step i, THEN exchange + combining half of step i - 1, on two
+# records that take turns; gather(consumer_on_current_stream=True) as the engine on torch's stream uses it
+exs = [ecgpu.RecordExchange(torch, dist, nbytes, "cpu") for _ in range(2)]
+pend, results = [], []
+def combine():
+    b, j = pend.pop(0)
+    rec = exs[b].gather(consumer_on_current_stream=True).numpy().reshape(world, nbytes)
+    got, gi = oracle_lib.msm(curve, ones, np.ascontiguousarray(rec[:, : 2 * L]).reshape(-1), np.ascontiguousarray(rec[:, 2 * L]))
+    results.append((j, bytes(got), gi))
+for i in range(5):
+    k_i = oracle_lib.scalar_reduce(curve, np.random.default_rng(100 + i).integers(0, 256, n * L, dtype=np.uint8))
+    xy, inf = oracle_lib.msm(curve, k_i[lo * L: hi * L], pts[lo * 2 * L: hi * 2 * L])
+    b = i % 2
+    exs[b].mine[: 2 * L] = torch.from_numpy(np.asarray(xy, np.uint8).copy()); exs[b].mine[2 * L] = int(inf)
+    pend.append((b, i))
+    if len(pend) > 1:
+        combine()
+while pend:
+    combine()
+assert [j for j, _, _ in results] == list(range(5))
+for j, got, gi in results:
+    k_j = oracle_lib.scalar_reduce(curve, np.random.default_rng(100 + j).integers(0, 256, n * L, dtype=np.uint8))
+    want, wi = oracle_lib.msm(curve, k_j, pts)
+    assert got == bytes(want) and gi == wi, "rank %d, pipelined step %d" % (rank, j)
+# one rank's form of the record (bench.py at N = 1): its own gathered form
+lr = ecgpu.LocalRecord(torch, nbytes, "cpu")
+lr.mine[:] = 7
+assert lr.gather(consumer_on_current_stream=True).data_ptr() == lr.mine.data_ptr() and lr.world == 1 and int(lr.all[nbytes - 1]) == 7
 print("rank", rank, "ok")
 dist.destroy_process_group()
 '''

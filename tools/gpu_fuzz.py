@@ -21,7 +21,7 @@ import pyec  # noqa: E402
 from gpu_common import rand_scalars, scalars_to_int_sum  # noqa: E402
 
 oracle_lib.build()
-e = ec.Engine(0)
+e = ec.Engine(0, variant="knobs")   # the tool build: the ECGPU_* knobs below are read there only (csrc/ecgpu_knobs.h)
 rng = random.Random(int(os.environ.get("FUZZ_SEED", "20260924")))
 budget = float(os.environ.get("FUZZ_SECONDS", "150"))
 t_end = time.time() + budget

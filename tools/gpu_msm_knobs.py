@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ec = importlib.import_module("elliptic-curves_amd")
-e = ec.Engine(0)
+e = ec.Engine(0, variant="knobs")   # the tool build: the ECGPU_* knobs below are read there only (csrc/ecgpu_knobs.h)
 e.set_stream(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator(device="cuda")
 g.manual_seed(12)

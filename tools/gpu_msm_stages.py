@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The k256 MSM at one GPU's share (2^21 terms) and at the full size (2^24): step time without a profiler, then the
 per-kernel times under rocprofv3 --kernel-trace.  Every size runs in a process of its own; extra environment settings
-(tuning knobs such as ECGPU_MSM_CHUNK, ECGPU_MSM_SEG) are inherited.    python tools/gpu_msm_stages.py [log2 sizes ...]"""
+(tuning knobs such as ECGPU_MSM_CHUNK, ECGPU_MSM_SEG: with ECGPU_TOOL_LIB=.../lib/libecgpu_knobs.so, the build that reads them) are inherited.    python tools/gpu_msm_stages.py [log2 sizes ...]"""
 import json
 import os
 import subprocess

@@ -14,7 +14,7 @@ curve = sys.argv[1] if len(sys.argv) > 1 else "k256"
 maxlg = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 cid = ec.CURVE_IDS[curve]
 L = ec.FIELD_BYTES[cid]
-e = ec.Engine(0)
+e = ec.Engine(0, variant="knobs")   # the tool build: the ECGPU_* knobs below are read there only (csrc/ecgpu_knobs.h)
 e.set_stream(torch.cuda.current_stream().cuda_stream)
 g = torch.Generator(device="cuda")
 g.manual_seed(11)

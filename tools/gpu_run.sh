@@ -83,7 +83,8 @@ print('== $w ${lg:-} $v', round(r['ms_per_step'], 4), r.get('check_vs_oracle'), 
       IFS=: read -r kv w lg <<< "$arg"
       nflag=""; [ -n "${lg:-}" ] && nflag="--n $((1 << lg))"
       for v in default knob default knob; do
-        pre=""; [ "$v" = knob ] && pre="env ${kv//,/ }"
+        # (the knobs are read by the tool build only, csrc/ecgpu_knobs.h: both legs load it, one with the variables set)
+        pre="env ECGPU_TOOL_LIB=$ROOT/elliptic-curves_amd/lib/libecgpu_knobs.so"; [ "$v" = knob ] && pre="$pre ${kv//,/ }"
         timeout 600 $pre python bench.py --only "$w" $nflag --steps "${AB_STEPS:-10}" --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 r = json.loads(sys.stdin.read().strip().splitlines()[-1])

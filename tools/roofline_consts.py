@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builds profiles/roofline_consts.json — the executed-work constants bench.py prices its kernels with.
 
-    python tools/roofline_consts.py <dir>        (<dir>/pmc_<workload>.json as written by `tools/gpu_run.sh <tag>
+    python tools/roofline_consts.py <dir> [<dir> ...]   (<dir>/pmc_<workload>.json as written by `tools/gpu_run.sh <tag>
                                                   pmc:<workload>`; a kernel's counters are taken from its OWN workload's file —
                                                   the same kernel also runs at other sizes in the setup of other workloads)
 
@@ -27,13 +27,16 @@ CSRC = os.path.join(ROOT, "elliptic-curves_amd", "csrc")
 
 # bench kernel name -> (instantiation group, curve struct, mangled-name substring, units per launch, workload)
 KERNELS = {
-    "k_fixed_base<K256Params>": ("base", "K256Params", "k_fixed_base", 1 << 20, "fixed_k256"),
-    "k_normalize<K256Params, 0>": ("base", "K256Params", "k_normalizeINS_10K256ParamsELi0E", 1 << 20, "fixed_k256"),
+    # (<C, true> / <C, 0, true>: the quad-major hand-over between the two, the default since round 6; tools/pmc_summary.py drops the flag)
+    "k_fixed_base<K256Params>": ("base", "K256Params", "k_fixed_baseINS_10K256ParamsELb1E", 1 << 20, "fixed_k256"),
+    "k_normalize<K256Params, 0>": ("base", "K256Params", "k_normalizeINS_10K256ParamsELi0ELb1E", 1 << 20, "fixed_k256"),
     "k_var_base<P256Params>": ("var", "P256Params", "k_var_baseINS_10P256ParamsELb0E", 1 << 20, "var_p256"),     # <C, false>: the plain ladder
     "k_var_base<P384Params>": ("var", "P384Params", "k_var_baseINS_10P384ParamsELb0E", 1 << 20, "var_p384"),
     "k_var_base<K256Params>": ("var", "K256Params", "k_var_baseINS_10K256ParamsELb1E", 1 << 20, "recover_k256"),   # <C, true>: adds its product to a G;   # b R of a G + b R: 2^20 launches per call
     "k_msm_accumulate<K256Params>": ("msm", "K256Params", "k_msm_accumulate", 1 << 24, "msm_k256"),
     "k_var_base_ct<P256Params>": ("ct", "P256Params", "k_var_base_ct", 1 << 20, "var_p256_ct"),
+    "k_fixed_base_ct<K256Params>": ("ct", "K256Params", "k_fixed_base_ct", 1 << 20, "fixed_k256_ct"),
+    "k_var_base_ct<K256Params>": ("ct", "K256Params", "k_var_base_ct", 1 << 20, "lincomb_ct_k256"),
 }
 # per-group compile flags of elliptic-curves_amd/Makefile (FLAGS_<group>: none at present)
 GROUP_FLAGS = {}
@@ -63,12 +66,13 @@ def isa_histogram(group, curve, substr):
 
 
 def main():
-    d = sys.argv[1]
+    dirs = sys.argv[1:]          # several directories: a workload's counters come from the LAST one that holds its file
     out = {}
     for name, (group, curve, substr, units, workload) in KERNELS.items():
-        path = os.path.join(d, "pmc_%s.json" % workload)
-        if not os.path.exists(path):
+        found = [os.path.join(d, "pmc_%s.json" % workload) for d in dirs if os.path.exists(os.path.join(d, "pmc_%s.json" % workload))]
+        if not found:
             continue
+        path = found[-1]
         with open(path) as f:
             rec = json.load(f).get(name)
         if not rec or "SQ_INSTS_VALU" not in rec:
