@@ -1451,8 +1451,14 @@ int ecgpu_synchronize(ecgpu_ctx* ctx) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return ECGPU_OK;
     }
-    int rc = drain(ctx);
-    if (rc != ECGPU_OK) return rc;
+    // (nothing queued since the last drain: the status word on the device is clear and there is nothing to wait for — a caller that
+    // switches the mode around every call, like ecgpu_group_msm_dev, pays for one round trip per call, not two)
+    if (ctx->pending || ctx->lanes_pending) {
+        int rc = drain(ctx);
+        if (rc != ECGPU_OK) return rc;
+    } else {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     const int st = ctx->deferred;
     ctx->deferred = 0;
     return status_error(ctx, st);

@@ -66,7 +66,7 @@ struct Member {
     int device = 0;
     ecgpu_ctx* ctx = nullptr;
     hipStream_t work = nullptr;        // the context's stream for the life of the group (ecgpu_set_stream): local half, combining half
-    hipStream_t stream = nullptr;      // exchange stream: waits for ev_parts on the device, then the RCCL collective or the peer copy
+    hipStream_t stream = nullptr;      // exchange stream: the RCCL collective or the peer copy, queued when the local half has ended
     hipEvent_t ev_parts = nullptr;     // recorded on `work` behind the local half
     bool leak_parts = false;           // a collective that could not be ended may still read d_parts: that allocation is never freed
     nccl_comm_t comm = nullptr;
@@ -141,9 +141,11 @@ void shard(size_t n, int r, int world, size_t* lo, size_t* hi) {      // contigu
     *hi = *lo + base + ((size_t)r < rem ? 1 : 0);
 }
 
-void worker_main(ecgpu_group* g, int r) {
-    Worker& w = *g->workers[r - 1];
-    (void)hipSetDevice(g->m[r].device);
+constexpr int RELEASED = -1000;          // internal: a member's job stopped because another member had failed
+
+void worker_main(Worker* wp, int r, int device) {
+    Worker& w = *wp;
+    (void)hipSetDevice(device);
     std::unique_lock<std::mutex> lk(w.mu);
     for (;;) {
         w.cv.wait(lk, [&] { return w.job != nullptr || w.quit; });
@@ -185,11 +187,14 @@ int for_each_member(ecgpu_group* g, F&& f) {
         w.cv.wait(lk, [&] { return w.done; });
         rc[r] = w.rc;
     }
-    for (int r = 0; r < nd; r++)           // (every worker is parked again: no concurrent writer of g->err any more)
-        if (rc[r] != ECGPU_OK) {
-            const char* ce = ecgpu_last_error(g->m[r].ctx);
-            return fail(g, rc[r], std::string("device ") + std::to_string(g->m[r].device) + ": " + (ce ? ce : ""));
-        }
+    // (every worker is parked again: no concurrent writer of g->err any more.)  A member that only stopped because another one had
+    // failed (RELEASED) does not decide the call's result: the member with the real error does.
+    for (int pass = 0; pass < 2; pass++)
+        for (int r = 0; r < nd; r++)
+            if (rc[r] != ECGPU_OK && (pass == 1 || rc[r] != RELEASED)) {
+                const char* ce = ecgpu_last_error(g->m[r].ctx);
+                return fail(g, rc[r] == RELEASED ? ECGPU_ERR_HIP : rc[r], std::string("device ") + std::to_string(g->m[r].device) + ": " + (ce ? ce : ""));
+            }
     return ECGPU_OK;
 }
 
@@ -223,9 +228,11 @@ int ecgpu_group_init(ecgpu_group** out, const int* devices, int ndev) {
         }
     }
     try {
+        g->workers.reserve(ndev);                       // (no reallocation once a worker runs; a worker only ever sees its own Worker)
         for (int r = 1; r < ndev; r++) {
             g->workers.emplace_back(new Worker());
-            g->workers.back()->th = std::thread(worker_main, g, r);
+            Worker* w = g->workers.back().get();
+            w->th = std::thread(worker_main, w, r, devices[r]);
         }
     } catch (...) {
         ecgpu_group_destroy(g);
@@ -384,18 +391,23 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
     void* d_o = m0.d_in2;
     void* d_f = (uint8_t*)m0.d_in2 + flag_off;
 
-    // One pass over the members, each on its own thread, and the host waits ONCE per member:
-    //   local half (ecgpu_msm_parts_dev, queued on the member's work stream; the context is asynchronous for the length of the call)
-    //   -> ev_parts -> the exchange stream waits for it ON THE DEVICE -> the collective / the peer copy is queued behind it
-    //   -> the host waits for the local half (hipEventSynchronize: compute, it ends), then for the exchange stream against the group's
-    //      deadline — spinning on hipStreamQuery for the first 200 us (a 41 KiB exchange takes tens of microseconds), then in 50 us naps.
-    // The exchange has a stream of its own so that one that never ENDS — how RCCL has failed on this pool — leaves the contexts' work
-    // streams clean: every member stops waiting at the deadline, or at once when another member's enqueue has failed (its own
-    // collective then has no partner), the communicators are aborted, the exchange streams replaced by fresh ones, the parts — still
-    // in every GPU's d_parts — travel by peer copies, and the group stays on peer copies (ecgpu_group_exchange_reason says why).
+    // One pass over the members, each on its own (parked) thread:
+    //   local half (ecgpu_msm_parts_dev, queued on the member's work stream; the context is asynchronous for that long), waited for
+    //   with hipEventSynchronize — compute, it ends — and its input errors collected;
+    //   THEN the collective / the peer copy is queued on the exchange stream, and the host waits for that stream against the group's
+    //   deadline: spinning on hipStreamQuery for the first 200 us (a 41 KiB exchange takes tens of microseconds), then in 50 us naps.
+    // The exchange is queued only when nothing else of this call is outstanding on the device, and on a stream of its own: one that
+    // never ENDS — how RCCL has failed on this pool — must not be able to hold anything the call still waits for.  (Round 6 first
+    // queued it BEHIND the local half with an event, to save the host round trip: HIP streams share a handful of hardware queues, and
+    // a collective that waits for its partners then sat in front of another member's local half in the same queue — with the test
+    // hook's stand-in, for ever.)  Every member stops waiting at the deadline, or at once when another member's enqueue has failed
+    // (its own collective then has no partner); the communicators are then aborted, the exchange streams replaced by fresh ones,
+    // the parts — still in every GPU's d_parts — travel by peer copies, and the group stays on peer copies
+    // (ecgpu_group_exchange_reason says why).
     const int fault = g_test_exchange_fault.load();
     struct Shared {
         std::atomic<bool> enqueue_failed{false};
+        std::atomic<int> parts_ended{0};       // members whose local half has ended (the exchange is queued when ALL have)
         std::mutex mu;
         int nrc_seen = 0;
         bool timed_out = false;
@@ -431,9 +443,19 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
                 e = ecgpu_msm_parts_dev(mb.ctx, curve, d_scalars[r], d_points_xy[r], d_points_inf ? d_points_inf[r] : nullptr, n_per_device[r],
                                         plan_terms, mb.d_parts);
                 if (e == ECGPU_OK && hipEventRecord(mb.ev_parts, mb.work) != hipSuccess) e = ECGPU_ERR_HIP;
+                // the local half: compute, it ends; its input errors (a scalar >= n, a point off the curve) are the call's result
+                if (e == ECGPU_OK) e = hipEventSynchronize(mb.ev_parts) == hipSuccess ? ecgpu_synchronize(mb.ctx) : ECGPU_ERR_HIP;
+                scope.ctx = nullptr;
+                const int e2 = ecgpu_set_async(mb.ctx, 0);
+                if (e == ECGPU_OK) e = e2;
                 if (e != ECGPU_OK) return bail(e);
+                // Nobody queues its exchange before EVERY member's local half has ended: a collective that waits for its partners in
+                // a hardware queue another member's local half is still queued in (members on one device share queues) would wait
+                // for ever.  A member that failed releases the others (enqueue_failed).
+                sh.parts_ended.fetch_add(1);
+                while (sh.parts_ended.load() < nd && !sh.enqueue_failed.load()) std::this_thread::yield();
+                if (sh.enqueue_failed.load()) return RELEASED;
             }
-            if (hipStreamWaitEvent(mb.stream, mb.ev_parts, 0) != hipSuccess) return bail(ECGPU_ERR_HIP);
             bool coll_failed = false;
             if (use_coll) {
                 int nrc = 0;
@@ -446,8 +468,8 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
                 } else {
                     nrc = g->rccl.all_gather(mb.d_parts, mb.d_all, bytes, NCCL_UINT8, mb.comm, mb.stream);
                 }
-                if (nrc != 0) {                                          // the others stop waiting at once; this member still ends its local
-                    std::lock_guard<std::mutex> lock(sh.mu);             // half properly below (its input errors are the call's result)
+                if (nrc != 0) {                                          // the others stop waiting at once
+                    std::lock_guard<std::mutex> lock(sh.mu);
                     sh.nrc_seen = nrc;
                     sh.enqueue_failed.store(true);
                     coll_failed = true;
@@ -458,14 +480,6 @@ int ecgpu_group_msm_dev(ecgpu_group* g, int curve, const void* const* d_scalars,
                                           ? hipMemcpyAsync(dst, mb.d_parts, bytes, hipMemcpyDeviceToDevice, mb.stream)
                                           : hipMemcpyPeerAsync(dst, m0.device, mb.d_parts, mb.device, bytes, mb.stream);
                 if (he != hipSuccess) return bail(ECGPU_ERR_HIP);
-            }
-            if (with_parts) {
-                // the local half: compute, it ends; its input errors (a scalar >= n, a point off the curve) are reported here
-                e = hipEventSynchronize(mb.ev_parts) == hipSuccess ? ecgpu_synchronize(mb.ctx) : ECGPU_ERR_HIP;
-                scope.ctx = nullptr;
-                const int e2 = ecgpu_set_async(mb.ctx, 0);
-                if (e == ECGPU_OK) e = e2;
-                if (e != ECGPU_OK) return bail(e);
             }
             if (coll_failed) return ECGPU_ERR_HIP;
             const int w = wait_exchange(mb, use_coll ? &sh.enqueue_failed : nullptr);

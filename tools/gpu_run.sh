@@ -35,8 +35,8 @@ for recipe in "$@"; do
   case "$name" in
     smoke) timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.txt" ;;
     pytest)
-      if [ -n "$arg" ]; then timeout 1700 python -m pytest tests -m gpu -q -x -k "${arg//+/ }" --durations=8 > "$OUT/pytest_${arg}.txt" 2>&1; tail -15 "$OUT/pytest_${arg}.txt"
-      else timeout 1700 python -m pytest tests -m gpu -q -x --durations=12 > "$OUT/pytest_gpu.txt" 2>&1; tail -20 "$OUT/pytest_gpu.txt"; fi ;;
+      if [ -n "$arg" ]; then timeout 1700 python -m pytest tests -m gpu -q -x --timeout=${TEST_TIMEOUT:-600} -k "${arg//+/ }" --durations=8 > "$OUT/pytest_${arg}.txt" 2>&1; tail -15 "$OUT/pytest_${arg}.txt"
+      else timeout 1700 python -m pytest tests -m gpu -q -x --timeout=${TEST_TIMEOUT:-900} --durations=12 > "$OUT/pytest_gpu.txt" 2>&1; tail -20 "$OUT/pytest_gpu.txt"; fi ;;
     bench)
       w=${arg:-fixed_k256}
       timeout 900 python bench.py --workload "$w" --steps "$STEPS" --warmup 2 --check > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"; tail -c 3000 "$OUT/bench_$w.json"; tail -3 "$OUT/bench_$w.err" ;;
