@@ -612,7 +612,7 @@ class Bench:
             t = torch.tensor([elapsed], dtype=torch.float64)           # (the control plane is gloo: a host tensor)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        per_rank = self.per_rank_stages(cid, sets[0], n, plan_terms, exchanges[0], d_out, d_inf) if sharded and world > 1 else None
+        per_rank = self.per_rank_stages(cid, sets[0], n, plan_terms, exchanges[0], d_out, d_inf) if sharded and world > 1 and lanes == 1 else None
 
         units_per_step = n_total if kind == "msm" else n * world
         value = units_per_step * args.steps / elapsed
@@ -1039,6 +1039,9 @@ def main():
                 # in a child process with a deadline: the library's own RCCL communicator (ncclCommInitAll over all GPUs from
                 # one process) meets this hardware for the first time here, and a hang must not cost the line above
                 group = group_msm_in_child(args, b.world)
+            # the other ranks wait on the HOST (gloo) while the child has the GPUs: an RCCL barrier here would leave a spinning collective
+            # kernel on every other GPU for as long as the child runs (and inside the nccl group's watchdog timeout)
+            b.dist.barrier()
             b.fence()
     if rec is not None and single:
         print(json.dumps(rec), flush=True)                       # profiling / sweep runs: the full record of one workload

@@ -189,7 +189,12 @@ def run_nccl_probe(local_device, port_offset=1, timeout=None):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["ECGPU_PROBE_DEVICE"] = str(local_device)
     env["ECGPU_PROBE_TIMEOUT"] = str(int(max(20, timeout - 30)))
-    for k in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCH_NCCL_ASYNC_ERROR_HANDLING"):
+    # The canary makes a rendezvous of its own on MASTER_PORT + port_offset, where rank 0's child must HOST the store.  Under
+    # `python -m torch.distributed.run` — the driver's launch — the workers inherit TORCHELASTIC_USE_AGENT_STORE=True, which makes
+    # every rank a CLIENT of the agent's store: with it left in place nobody listens on the canary's port, every canary times out in
+    # its rendezvous ("The client socket has timed out ... (127.0.0.1, 29542)", the reason on record in profiles/r04 and r05's
+    # N-rank dry runs) and a healthy 8-GPU node would have been sent to the gloo fallback without RCCL ever being tried.
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")] + ["TORCH_NCCL_ASYNC_ERROR_HANDLING"]:
         env.pop(k, None)
     if os.environ.get("ECGPU_NCCL_PROBE_FAIL"):            # fault injection for the dry runs / tests: crash | hang
         mode = os.environ["ECGPU_NCCL_PROBE_FAIL"]

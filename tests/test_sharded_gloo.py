@@ -234,3 +234,35 @@ def test_init_exchange_falls_back_to_gloo_world2(tmp_path, prefer, fault, kind):
         assert "exchange " + kind in o, o
         if fault == "hang":
             assert "killed" in o, o
+
+
+def test_canary_hosts_its_own_rendezvous_under_torchrun(monkeypatch):
+    """Under `python -m torch.distributed.run` (the driver's launch) every worker inherits TORCHELASTIC_USE_AGENT_STORE=True, which
+    makes torch connect to the AGENT's store as a client.  The RCCL canary has a rendezvous of its own on MASTER_PORT + 1: with that
+    variable left in its environment nobody hosts the store there and every canary times out — a healthy 8-GPU node would be sent to
+    the gloo fallback (the reason on record in the round-4 / round-5 dry runs).  The child's environment must carry no TORCHELASTIC_*
+    variable, its own port and the device it probes."""
+    ecgpu = importlib.import_module("elliptic-curves_amd")
+    sharded = sys.modules[ecgpu.__name__ + ".sharded"]
+    seen = {}
+
+    class FakeProc:
+        returncode = 0
+
+        def __init__(self, cmd, env=None, **kw):
+            seen["cmd"], seen["env"] = cmd, dict(env)
+
+        def communicate(self, timeout=None):
+            return "NCCL_PROBE_OK\n", ""
+
+    monkeypatch.setattr(sharded.subprocess, "Popen", FakeProc)
+    for k, v in {"TORCHELASTIC_USE_AGENT_STORE": "True", "TORCHELASTIC_RUN_ID": "x", "TORCHELASTIC_RESTART_COUNT": "0",
+                 "TORCHELASTIC_MAX_RESTARTS": "0", "MASTER_PORT": "29541", "MASTER_ADDR": "127.0.0.1", "RANK": "1", "WORLD_SIZE": "2"}.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("ECGPU_NCCL_PROBE_FAIL", raising=False)
+    ok, reason = sharded.run_nccl_probe(3, timeout=50)
+    assert ok and "healthy" in reason
+    env = seen["env"]
+    assert not [k for k in env if k.startswith("TORCHELASTIC_")], sorted(k for k in env if k.startswith("TORCHELASTIC_"))
+    assert env["MASTER_PORT"] == "29542" and env["ECGPU_PROBE_DEVICE"] == "3" and env["RANK"] == "1" and env["WORLD_SIZE"] == "2"
+    assert seen["cmd"][-1] == "--nccl-probe"
