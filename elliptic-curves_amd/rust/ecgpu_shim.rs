@@ -62,7 +62,7 @@ pub static ENGINE: LazyLock<Option<Mutex<Engine>>> = LazyLock::new(|| {
     // The generator tables follow the library's default footprint policy (ECGPU_TABLE_ADAPTIVE: 34 MB until the device has
     // multiplied 2^26 scalars by G, 21.5 GB only from 2^29 on — the reference's own table is 30-60 KB and lazily built,
     // primeorder/src/tables/basepoint.rs:29-76).  Until a tier is reached the rate is the narrower table's — per 2^20 k256 scalars
-    // about 0.83 ms at 16 bits and 0.68 ms at 22 against 0.61 ms at 26 (bench.py prints all three: `fixed_k256_tier_ms`; its
+    // about 0.93 ms at 16 bits and 0.74 ms at 22 against 0.59 ms at 26 (bench.py prints all three: `fixed_k256_tier_ms`; its
     // headline runs on the widest, policy eager) — and the ONE call that crosses a tier builds the next table before it returns
     // (1 / 6 / 55 ms on the calling thread, also on an asynchronous context).  A service that wants the steady-state rate from
     // its first batch sets ECGPU_TABLE_POLICY=eager; ECGPU_TABLE_BUDGET_MB caps a table whatever the policy.

@@ -140,8 +140,8 @@ int ecgpu_copy_to_host(ecgpu_ctx *ctx, void *h_dst, const void *d_src, size_t by
  * the build time of the next one, so a caller never pays more than twice the best fixed choice and a 1,024-scalar call never
  * allocates gigabytes.  A step up costs the calling thread the build once — the call that crosses a tier waits for its stream and
  * builds the next table before it returns (k256: 1 / 6 / 55 ms), on an asynchronous context too —; the narrower table is freed when
- * its last user lets go.  Until a tier is reached the rate is the narrower table's (k256, per 2^20 scalars: ~0.83 ms at 16 bits,
- * ~0.68 at 22, ~0.61 at 26; bench.py prints the three as `fixed_k256_tier_ms`, its headline uses ECGPU_TABLE_EAGER).
+ * its last user lets go.  Until a tier is reached the rate is the narrower table's (k256, per 2^20 scalars: ~0.93 ms at 16 bits,
+ * ~0.74 at 22, ~0.59 at 26; bench.py prints the three as `fixed_k256_tier_ms`, its headline uses ECGPU_TABLE_EAGER).
  * ECGPU_TABLE_EAGER: the widest table at the first call (a long-lived service: pay ~55 ms once at start-up).
  * A table that does not fit is replaced by one two bits narrower, down to 16 bits, before ECGPU_ERR_OOM is returned. */
 enum { ECGPU_TABLE_ADAPTIVE = 0, ECGPU_TABLE_EAGER = 1 };

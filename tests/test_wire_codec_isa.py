@@ -1,6 +1,6 @@
 """The wire-record codecs of the odd-sized parameter sets on the gfx950 ISA (tools/wire_codec_isa_check.py): whole words
 (p521: one halfword + sixteen words) in, whole words out — no byte-wise loads for the compiler to merge and re-extract,
-the code shape that once decoded p521 operands wrongly on the GPU.  Compiles to assembly; no GPU needed.
+the code shape that once decoded p521 operands wrongly on the GPU (docs/DESIGN_long_form_r01-r05.md §4).  Compiles to assembly; no GPU needed.
 The variable-base group of p224 and p521 (scalar and point records in, raw projective out) is checked here (half a minute);
 the tool covers all four kernel groups and p192."""
 import os

@@ -1,4 +1,4 @@
-// p521_byte_loads.hip — stand-alone probe for the wire-record load fault of DESIGN.md §4 (round 2).
+// p521_byte_loads.hip — stand-alone probe for the wire-record load fault of docs/DESIGN_long_form_r01-r05.md §4 (round 2).
 //
 // History: p521's 66-byte big-endian records were first decoded byte by byte (`words[j] |= bytes[k] << s`).  hipcc merges such
 // loads into wide unaligned ones (8 + 2 + 16 + 16 + 16 + 8 bytes) and re-extracts the bytes with v_perm_b32 / SDWA sequences;

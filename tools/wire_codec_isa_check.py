@@ -2,7 +2,7 @@
 """Build-time check of the wire-record codecs of the parameter sets whose records are not whole 16-byte vectors — p224
 (28 / 56 bytes), p192 (24 / 48) and p521 (66 / 132) — on the gfx950 ISA.
 
-Background: p521's records were once decoded byte by byte; the compiler merged those loads into wide unaligned
+Background (docs/DESIGN_long_form_r01-r05.md §4): p521's records were once decoded byte by byte; the compiler merged those loads into wide unaligned
 ones and re-extracted the bytes with v_perm_b32 / SDWA sequences, and inside two large kernels the decoded operand had wrong
 bits on gfx950.  load_wire / store_wire (csrc/ecgpu_kernels.h) now move whole 32-bit words (p521: one halfword + sixteen
 words), which leaves nothing to extract.  This tool keeps it that way: it compiles the kernel groups to assembly (no GPU
