@@ -263,7 +263,7 @@ while time.time() < t_end:
         assert bytes(v) == bytes(oracle_lib.bign_verify(bytes(hs), bytes(sigs), Q)), ("bign", n)
         vm = e.bign_verify_msg(Q, msgs, msg_len, bytes(sigs))
         assert bytes(vm) == bytes(v) == bytes(oracle_lib.bign_verify_msg(Q, msgs, msg_len, bytes(sigs))), ("bign_msg", n, msg_len)
-        assert 0 < int(v.sum()) or n < 4
+        assert 0 < int(v.sum()) or n < 12        # (a sanity check of the CASE, not of the engine: a third of the signatures are disturbed, so twelve disturbed ones in a row are a 2e-6 event)
         stats["bign_verify"] += 1
     elif kind == "fixed":
         n = rng.randrange(1, 3000)
