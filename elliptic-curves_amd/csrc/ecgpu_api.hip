@@ -100,6 +100,7 @@ struct ecgpu_ctx {
     int msm_c = 0;   // 0 = choose from n
     DevBuf proj, prefix, vtab, bases, in0, in1, in2, in3, out0, out1, msm_ws;
     DevBuf ec_u1, ec_u2, ec_q, ec_valid, ec_xy, ec_inf, ec_r, ec_e, ec_s, ec_id;   // signature verification scratch
+    DevBuf ec_winv;                    // the batch's s^-1 / r^-1 modulo the group order (k_scalar_batch_inv; its prefix products use `prefix`)
     DevBuf ct_flags;             // one verdict byte per element of a uniform-schedule batch
     DevBuf cx_xy, cx_inf;        // x || y + flag records decoded from compressed input (ecgpu_msm_compressed, ecgpu_batch_mul_compressed)
     bool keep_status = false;    // the status word already holds the verdicts of a first stage of the call: do not clear it
@@ -1158,6 +1159,15 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
     if (mode != VERIFY_RECOVER && (rc = ensure(ctx, ctx->ec_xy, n * 2 * L)) != ECGPU_OK) return rc;
     if ((rc = ensure(ctx, ctx->ec_inf, n + 16)) != ECGPU_OK) return rc;
     if (mode == VERIFY_SCHNORR_RAW && (rc = ensure(ctx, ctx->ec_r, n * L)) != ECGPU_OK) return rc;
+    // ECDSA verification and recovery invert one scalar per signature: done for the whole batch by Montgomery's trick
+    const bool batch_inv = mode == VERIFY_RECOVER || mode == VERIFY_ECDSA;
+    if (batch_inv) {
+        if ((rc = ensure(ctx, ctx->ec_winv, n * L + 16)) != ECGPU_OK) return rc;
+        static_assert(Field<C>::NS >= C::N, "the normalisation's prefix array holds the inverses' prefix products too");
+        if ((rc = ensure(ctx, ctx->prefix, n * Field<C>::NS * 4)) != ECGPU_OK) return rc;      // (the size normalize_out asks for later)
+    }
+    uint32_t* inv_prefix = batch_inv ? (uint32_t*)ctx->prefix.p : nullptr;
+    uint8_t* inv_out = batch_inv ? (uint8_t*)ctx->ec_winv.p : nullptr;
     if ((rc = reset_status(ctx)) != ECGPU_OK) return rc;
     const Table& t = ctx->table[C::ID];
     uint32_t* pa = (uint32_t*)ctx->proj.p;
@@ -1170,7 +1180,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
         d_r = ctx->ec_r.p;
     } else if (mode == VERIFY_RECOVER)
         launch_ecdsa_recover_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
-                                        (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
+                                        (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid, inv_prefix, inv_out);
     else if (mode == VERIFY_SM2DSA)
         launch_sm2dsa_prepare<C>(ctx->stream, (const uint8_t*)d_r, (const uint8_t*)d_s, (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else if (mode == VERIFY_BIGN)
@@ -1180,7 +1190,7 @@ int verify_dev(ecgpu_ctx* ctx, int mode, const void* d_h, const void* d_r, const
                                   (const uint8_t*)d_q_xy, n, u1, u2, q, valid);
     else
         launch_ecdsa_prepare<C>(ctx->stream, (const uint8_t*)d_h, (const uint8_t*)d_r, (const uint8_t*)d_s,
-                                (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid);
+                                (const uint8_t*)d_q_xy, n, reject_high_s, u1, u2, q, valid, inv_prefix, inv_out);
     record(ctx, 3);
     launch_fixed_base<C>(ctx->stream, u1, n, (const uint32_t*)t.d, t.w, t.nwin, pa, ctx->d_status);
     launch_var_base<C>(ctx->stream, u2, q, nullptr, n, (uint32_t*)ctx->vtab.p, tstride, nullptr, ctx->d_status, pa);   // pa[i] += u2[i] Q[i]
@@ -1270,7 +1280,7 @@ void ecgpu_destroy(ecgpu_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3,
-                      &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
+                      &ctx->out0, &ctx->out1, &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_winv, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy,
                       &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e, &ctx->ec_s, &ctx->ec_id})
         if (b->p) (void)hipFree(b->p);
     for (DevBuf* b : {&ctx->ct_flags, &ctx->cx_xy, &ctx->cx_inf})
@@ -1469,7 +1479,7 @@ int ecgpu_wipe(ecgpu_ctx* ctx) {
     for (auto& l : ctx->lane)
         if (l.s) HIP_TRY(ctx, hipStreamSynchronize(l.s));
     for (DevBuf* b : {&ctx->proj, &ctx->prefix, &ctx->vtab, &ctx->bases, &ctx->in0, &ctx->in1, &ctx->in2, &ctx->in3, &ctx->out0, &ctx->out1,
-                      &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy, &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e,
+                      &ctx->msm_ws, &ctx->ec_u1, &ctx->ec_u2, &ctx->ec_winv, &ctx->ec_q, &ctx->ec_valid, &ctx->ec_xy, &ctx->ec_inf, &ctx->ec_r, &ctx->ec_e,
                       &ctx->ec_s, &ctx->ec_id, &ctx->ct_flags, &ctx->cx_xy, &ctx->cx_inf})
         if (b->p) HIP_TRY(ctx, hipMemsetAsync(b->p, 0, b->cap, ctx->stream));
     for (auto& l : ctx->lane)

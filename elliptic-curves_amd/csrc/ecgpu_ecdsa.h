@@ -21,24 +21,91 @@
 
 namespace ecgpu {
 
+// ---- inverses modulo the group order for a whole batch: Montgomery's trick, one division-step inversion per LANE instead of one per
+// signature.  `Scalar::invert` (k256/src/arithmetic/scalar.rs:139-143; primefield/src/monty.rs:373-375) is what verification
+// (s^-1) and recovery (r^-1) call once per signature: 21.5 k dependent instructions each, 90 % of k_ecdsa_prepare.  Lane t owns
+// elements t, t + T, t + 2T, ... (a wave touches consecutive records, like k_normalize): running products in the Montgomery domain
+// (one multiplication per product), the prefix products parked in `prefix` (N words per element), one inversion of the lane's
+// product, a backward pass that peels the inverses off.  An element outside [1, n - 1] is left out of the product and gets 0 —
+// the prepare kernels fail it on their range check and never use its inverse.
+template <class C>
+__global__ void __launch_bounds__(BLOCK)
+k_scalar_batch_inv(const uint8_t* __restrict__ in, size_t n, size_t nthreads, uint32_t* __restrict__ prefix, uint8_t* __restrict__ out) {
+    using S = ScalarN<C>;
+    constexpr int N = C::N, WB = WireBytes<C>::value;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nthreads || t >= n) return;
+    uint32_t acc[N], one_m[N];
+    {
+        uint32_t one[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) one[i] = i == 0 ? 1u : 0u;
+        S::to_mont(one_m, one);                                    // R mod n
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) acc[i] = one_m[i];
+    for (size_t j = t; j < n; j += nthreads) {
+        uint32_t a[N], am[N];
+        load_wire<C>(a, in + j * WB);
+        const bool ok = !S::is_zero(a) && S::in_range(a);
+        uint32_t* pj = prefix + j * N;
+#pragma unroll
+        for (int i = 0; i < N; i++) pj[i] = acc[i];                // the product of the lane's earlier elements (Montgomery form)
+        if (ok) {
+            S::to_mont(am, a);
+            S::mont_mul(acc, acc, am);
+        }
+    }
+    uint32_t inv[N];
+    {
+        // acc = P R as an integer; x = acc^-1 = P^-1 R^-1; x R2 / R = P^-1; P^-1 R2 / R = P^-1 R: the Montgomery form of P^-1
+        uint32_t x[N];
+        S::inv(x, acc);
+        S::to_mont(x, x);
+        S::to_mont(inv, x);
+    }
+    const size_t last = t + ((n - 1 - t) / nthreads) * nthreads;
+    for (size_t j = last;; j -= nthreads) {
+        uint32_t a[N], am[N], w[N];
+        load_wire<C>(a, in + j * WB);
+        const bool ok = !S::is_zero(a) && S::in_range(a);
+#pragma unroll
+        for (int i = 0; i < N; i++) w[i] = 0u;
+        if (ok) {
+            uint32_t pre[N], wm[N];
+            const uint32_t* pj = prefix + j * N;
+#pragma unroll
+            for (int i = 0; i < N; i++) pre[i] = pj[i];
+            S::mont_mul(wm, inv, pre);                             // (a_0 .. a_j)^-1 (a_0 .. a_(j-1)) = a_j^-1
+            S::to_mont(am, a);
+            S::mont_mul(inv, inv, am);                             // (a_0 .. a_(j-1))^-1
+            S::from_mont(w, wm);
+        }
+        store_wire<C>(out + j * WB, w);
+        if (j < nthreads) break;
+    }
+}
+
 // prepare: range checks, public-key validation, u1 / u2 as wire-format scalars for the scalar-mul kernels.
 // Elements that are already known to fail get u1 = u2 = 0 and Q = G so that the arithmetic kernels see valid input.
 template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_ecdsa_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                 const uint8_t* __restrict__ q_xy, size_t n, int reject_high_s, uint8_t* __restrict__ u1_out,
-                uint8_t* __restrict__ u2_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+                uint8_t* __restrict__ u2_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid,
+                const uint8_t* __restrict__ s_inv) {           // s_inv: the batch's s^-1 (k_scalar_batch_inv), or null
     constexpr int N = C::N, WB = WireBytes<C>::value;
     (void)N; (void)WB;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], u1[N], u2[N];
+    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], u1[N], u2[N], w[N];
     load_wire<C>(zw, z + i * WB);
     load_wire<C>(rw, r + i * WB);
     load_wire<C>(sw, s + i * WB);
     load_wire<C>(cx, q_xy + i * (2 * WB));
     load_wire<C>(cy, q_xy + i * (2 * WB) + WB);
-    const bool ok = ecdsa_prepare_words<C>(zw, rw, sw, cx, cy, reject_high_s, u1, u2);      // ecgpu_verify.h
+    if (s_inv) load_wire<C>(w, s_inv + i * WB);
+    const bool ok = ecdsa_prepare_words<C>(zw, rw, sw, cx, cy, reject_high_s, u1, u2, s_inv ? w : nullptr);      // ecgpu_verify.h
     store_wire<C>(u1_out + i * WB, u1);
     store_wire<C>(u2_out + i * WB, u2);
     store_wire<C>(q_out + i * (2 * WB), cx);
@@ -103,15 +170,17 @@ template <class C>
 __global__ void __launch_bounds__(BLOCK)
 k_ecdsa_recover_prepare(const uint8_t* __restrict__ z, const uint8_t* __restrict__ r, const uint8_t* __restrict__ s,
                         const uint8_t* __restrict__ recid, size_t n, int reject_high_s, uint8_t* __restrict__ a_out,
-                        uint8_t* __restrict__ b_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid) {
+                        uint8_t* __restrict__ b_out, uint8_t* __restrict__ q_out, uint8_t* __restrict__ valid,
+                        const uint8_t* __restrict__ r_inv) {       // r_inv: the batch's r^-1 (k_scalar_batch_inv), or null
     constexpr int N = C::N, WB = WireBytes<C>::value;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], a[N], b[N];
+    uint32_t zw[N], rw[N], sw[N], cx[N], cy[N], a[N], b[N], w[N];
     load_wire<C>(zw, z + i * WB);
     load_wire<C>(rw, r + i * WB);
     load_wire<C>(sw, s + i * WB);
-    const bool ok = ecdsa_recover_prepare_words<C>(zw, rw, sw, recid[i], reject_high_s, a, b, cx, cy);   // ecgpu_verify.h
+    if (r_inv) load_wire<C>(w, r_inv + i * WB);
+    const bool ok = ecdsa_recover_prepare_words<C>(zw, rw, sw, recid[i], reject_high_s, a, b, cx, cy, r_inv ? w : nullptr);   // ecgpu_verify.h
     store_wire<C>(a_out + i * WB, a);
     store_wire<C>(b_out + i * WB, b);
     store_wire<C>(q_out + i * (2 * WB), cx);

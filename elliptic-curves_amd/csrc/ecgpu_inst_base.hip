@@ -79,11 +79,21 @@ template <> void launch_proj_sum<CurveT>(hipStream_t s, uint32_t* a, size_t n, u
     }
     if (src != a) (void)hipMemcpyAsync(a, src, 3 * Field<CurveT>::NS * 4, hipMemcpyDeviceToDevice, s);
 }
+// the batch's inverses modulo the group order: like the normalisation, about one wave per SIMD (one inversion per lane)
+static void launch_scalar_batch_inv(hipStream_t s, const uint8_t* in, size_t n, uint32_t* prefix, uint8_t* out) {
+    if (n == 0) return;
+    size_t k = (n + 65535) / 65536;
+    if (k > 64) k = 64;
+    const size_t nthreads = (n + k - 1) / k;
+    hipLaunchKernelGGL(k_scalar_batch_inv<CurveT>, dim3(grid_for(nthreads)), dim3(BLOCK), 0, s, in, n, nthreads, prefix, out);
+}
 template <> void launch_ecdsa_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                               const uint8_t* q_xy, size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2,
-                                              uint8_t* q_out, uint8_t* valid) {
+                                              uint8_t* q_out, uint8_t* valid, uint32_t* inv_prefix, uint8_t* inv_out) {
+    const bool batch = inv_prefix && inv_out;
+    if (batch) launch_scalar_batch_inv(s, sig_s, n, inv_prefix, inv_out);
     hipLaunchKernelGGL(k_ecdsa_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, z, r, sig_s, q_xy, n, reject_high_s, u1, u2,
-                       q_out, valid);
+                       q_out, valid, batch ? (const uint8_t*)inv_out : (const uint8_t*)nullptr);
 }
 template <> void launch_schnorr_prepare<CurveT>(hipStream_t s, const uint8_t* e, const uint8_t* r, const uint8_t* sig_s,
                                                 const uint8_t* p_xy, size_t n, uint8_t* a, uint8_t* b, uint8_t* q_out,
@@ -117,9 +127,11 @@ template <> void launch_ecdsa_hash_msg<CurveT>(hipStream_t s, const uint8_t* msg
 }
 template <> void launch_ecdsa_recover_prepare<CurveT>(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                                       const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
-                                                      uint8_t* q_out, uint8_t* valid) {
+                                                      uint8_t* q_out, uint8_t* valid, uint32_t* inv_prefix, uint8_t* inv_out) {
+    const bool batch = inv_prefix && inv_out;
+    if (batch) launch_scalar_batch_inv(s, r, n, inv_prefix, inv_out);
     hipLaunchKernelGGL(k_ecdsa_recover_prepare<CurveT>, dim3(grid_for(n)), dim3(BLOCK), 0, s, z, r, sig_s, recid, n, reject_high_s,
-                       a, b, q_out, valid);
+                       a, b, q_out, valid, batch ? (const uint8_t*)inv_out : (const uint8_t*)nullptr);
 }
 template <> void launch_ecdsa_recover_finish<CurveT>(hipStream_t s, uint8_t* xy, const uint8_t* inf, const uint8_t* valid, size_t n,
                                                      uint8_t* ok) {

@@ -58,13 +58,17 @@ template <class C> void launch_point_sum(hipStream_t s, const uint8_t* xy, const
                                          int* status);
 // a[0] = sum of the n projective points a[0..n) (a is clobbered; tmp holds ceil(n / 256) points)
 template <class C> void launch_proj_sum(hipStream_t s, uint32_t* a, size_t n, uint32_t* tmp);
+// inv_prefix (n x N words) / inv_out (n wire scalars): scratch for the batch's inverses modulo the group order — s^-1 here, r^-1 in
+// the recovery — by Montgomery's trick (k_scalar_batch_inv); both null: every lane inverts for itself
 template <class C> void launch_ecdsa_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy,
-                                             size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid);
+                                             size_t n, int reject_high_s, uint8_t* u1, uint8_t* u2, uint8_t* q_out, uint8_t* valid,
+                                             uint32_t* inv_prefix = nullptr, uint8_t* inv_out = nullptr);
 template <class C> void launch_ecdsa_hash_msg(hipStream_t s, const uint8_t* msgs, size_t msg_len, const uint8_t* sigs, size_t n, uint8_t* z_out,
                                               uint8_t* r_out, uint8_t* s_out);
 template <class C> void launch_ecdsa_recover_prepare(hipStream_t s, const uint8_t* z, const uint8_t* r, const uint8_t* sig_s,
                                                      const uint8_t* recid, size_t n, int reject_high_s, uint8_t* a, uint8_t* b,
-                                                     uint8_t* q_out, uint8_t* valid);
+                                                     uint8_t* q_out, uint8_t* valid, uint32_t* inv_prefix = nullptr,
+                                                     uint8_t* inv_out = nullptr);
 template <class C> void launch_ecdsa_recover_finish(hipStream_t s, uint8_t* xy, const uint8_t* inf, const uint8_t* valid, size_t n,
                                                     uint8_t* ok);
 template <class C> void launch_sm2dsa_prepare(hipStream_t s, const uint8_t* r, const uint8_t* sig_s, const uint8_t* q_xy, size_t n, uint8_t* a,

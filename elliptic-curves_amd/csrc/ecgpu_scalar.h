@@ -74,6 +74,14 @@ struct ScalarN {
         mont_mul(t, a, b);
         mont_mul(r, t, C::ORDER_R2);
     }
+    // a R mod n (the Montgomery form of a < n), and back
+    static ECGPU_HD void to_mont(uint32_t* r, const uint32_t* a) { mont_mul(r, a, C::ORDER_R2); }
+    static ECGPU_HD void from_mont(uint32_t* r, const uint32_t* a) {
+        uint32_t one[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) one[i] = i == 0 ? 1u : 0u;
+        mont_mul(r, a, one);
+    }
     // 1 / a mod n (0 -> 0), division steps like the reference's Scalar::invert (k256 scalar.rs:139-143)
     static ECGPU_HD void inv(uint32_t* r, const uint32_t* a) { ModInv<N>::invert(r, a, C::ORDER); }
     // a > (n - 1) / 2   (k256 scalar.rs:419-423 IsHigh; ecdsa NORMALIZE_S)

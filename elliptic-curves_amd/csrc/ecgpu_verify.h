@@ -33,8 +33,10 @@ ECGPU_HD void verify_blank(bool ok, uint32_t* a, uint32_t* b, uint32_t* cx, uint
 
 // ECDSA (verify_prehashed): range checks, key validation, u1 = z / s, u2 = r / s.  Returns the element's validity.
 template <class C>
+// w_in: s^-1 mod n computed elsewhere (k_scalar_batch_inv: Montgomery's trick over the batch; 0 for an s outside [1, n - 1], which
+// fails the range check here anyway), or nullptr: the inversion happens here.
 ECGPU_HD bool ecdsa_prepare_words(const uint32_t* zw, const uint32_t* rw, const uint32_t* sw, uint32_t* cx, uint32_t* cy,
-                                  int reject_high_s, uint32_t* u1, uint32_t* u2) {
+                                  int reject_high_s, uint32_t* u1, uint32_t* u2, const uint32_t* w_in = nullptr) {
     using S = ScalarN<C>;
     constexpr int N = C::N;
     bool ok = !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
@@ -42,7 +44,12 @@ ECGPU_HD bool ecdsa_prepare_words(const uint32_t* zw, const uint32_t* rw, const 
     ok = verify_point_ok<C>(cx, cy) && ok;
     uint32_t zr[N], w[N];
     S::reduce_wire(zr, zw);
-    S::inv(w, sw);
+    if (w_in) {
+#pragma unroll
+        for (int j = 0; j < N; j++) w[j] = w_in[j];
+    } else {
+        S::inv(w, sw);
+    }
     S::mul(u1, zr, w);
     S::mul(u2, rw, w);
     verify_blank<C>(ok, u1, u2, cx, cy);
@@ -223,7 +230,8 @@ ECGPU_HD bool decompress_words(uint32_t* cx, bool y_is_odd, uint32_t* cy) {
 // holds by construction: (z / s) G + (r / s) (a G + b R) = R, whose x is r mod n, and R is a finite point.
 template <class C>
 ECGPU_HD bool ecdsa_recover_prepare_words(const uint32_t* zw, const uint32_t* rw, const uint32_t* sw, uint32_t recid,
-                                          int reject_high_s, uint32_t* a, uint32_t* b, uint32_t* cx, uint32_t* cy) {
+                                          int reject_high_s, uint32_t* a, uint32_t* b, uint32_t* cx, uint32_t* cy,
+                                          const uint32_t* rinv_in = nullptr) {      // (r^-1 from k_scalar_batch_inv, or nullptr)
     using S = ScalarN<C>;
     constexpr int N = C::N;
     bool ok = recid <= 3u && !S::is_zero(rw) && S::in_range(rw) && !S::is_zero(sw) && S::in_range(sw);
@@ -237,7 +245,12 @@ ECGPU_HD bool ecdsa_recover_prepare_words(const uint32_t* zw, const uint32_t* rw
     ok = decompress_words<C>(cx, (recid & 1u) != 0, cy) && ok;
     uint32_t zr[N], rinv[N], t[N], d[N];
     S::reduce_wire(zr, zw);
-    S::inv(rinv, rw);
+    if (rinv_in) {
+#pragma unroll
+        for (int j = 0; j < N; j++) rinv[j] = rinv_in[j];
+    } else {
+        S::inv(rinv, rw);
+    }
     S::mul(t, rinv, zr);
     const bool tz = S::is_zero(t);
     mp_sub<N>(d, C::ORDER, t);

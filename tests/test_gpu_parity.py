@@ -1684,3 +1684,31 @@ def test_msm_fused_tail_form(eng, keng, curve, monkeypatch):
         dot = sum(a * b for a, b in zip(ki, si)) % c.n
         o, oi = oracle_lib.batch_mul_base(c.cid, np.frombuffer(dot.to_bytes(c.L, "big"), np.uint8))
         assert bytes(got) == bytes(o) and gf == int(oi[0]), (curve, case)
+
+
+@pytest.mark.parametrize("curve", ["k256", "p256", "p384"])
+def test_signature_batches_share_their_scalar_inversions(eng, curve):
+    """ECDSA verification and public-key recovery invert one scalar per signature modulo the group order (`Scalar::invert`,
+    k256/src/arithmetic/scalar.rs:139-143); k_scalar_batch_inv does it for the whole batch by Montgomery's trick, several signatures per
+    lane from 65,537 signatures on.  200,000 signatures (a tile of model-made cases of prime length, so that the signatures of one lane
+    are different cases; range failures — s = 0, r = 0, s = n — among them, which must drop out of the lane's product): every verdict
+    and every recovered key must equal the small-batch result (one inversion per lane), which the other tests pin to the oracle."""
+    from gpu_common import recover_cases, recover_pack
+    c = pyec.CURVES[curve]
+    L = c.L
+    z, r, s, q, exp = ecdsa_pack(ecdsa_cases(c, 0x1B1 + c.cid, nvalid=24))
+    m = len(exp)
+    small = eng.ecdsa_verify(c.cid, z, r, s, q)
+    assert bytes(small) == bytes(exp)
+    n = 200003                                        # (prime: the lane stride ceil(n / 4) is no multiple of the tile length)
+    reps = n // m + 1
+    big = eng.ecdsa_verify(c.cid, (z * reps)[: n * L], (r * reps)[: n * L], (s * reps)[: n * L], (q * reps)[: n * 2 * L])
+    assert bytes(big) == bytes(np.tile(exp, reps)[:n])
+    rz, rr, rs, rid, rxy, rok = recover_pack(recover_cases(c, 0x1B2 + c.cid, nvalid=12), L)
+    m2 = len(rok)
+    k_small, ok_small = eng.ecdsa_recover(c.cid, rz, rr, rs, rid)
+    assert bytes(k_small) == rxy and bytes(ok_small) == bytes(rok)
+    n = 140009
+    reps = n // m2 + 1
+    k_big, ok_big = eng.ecdsa_recover(c.cid, (rz * reps)[: n * L], (rr * reps)[: n * L], (rs * reps)[: n * L], (bytes(rid) * reps)[:n])
+    assert bytes(k_big) == (rxy * reps)[: n * 2 * L] and bytes(ok_big) == (bytes(rok) * reps)[:n]
