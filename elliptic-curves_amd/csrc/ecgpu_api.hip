@@ -926,6 +926,10 @@ int msm_parts_dev(ecgpu_ctx* ctx, const void* d_scalars, const void* d_xy, const
         ecgpu_ctx::MsmLane* lp = nullptr;
         if ((rc = next_lane(ctx, plan.workspace_bytes, &lp)) != ECGPU_OK) return rc;
         ecgpu_ctx::MsmLane& l = *lp;
+        // A lane remembers ONE record.  If the record of its previous local half was never joined (more local halves in flight than
+        // lanes), that half is joined now — the context's stream waits for it before anything queued later —, so that whatever the
+        // caller does with the old record afterwards is still ordered behind the kernels that wrote it.
+        if (l.parts_out) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, l.ev_done, 0));
         HIP_TRY(ctx, hipEventRecord(l.ev_in, ctx->stream));
         HIP_TRY(ctx, hipStreamWaitEvent(l.s, l.ev_in, 0));
         launch_msm_parts<C>(plan, l.s, (const uint8_t*)d_scalars, (const uint8_t*)d_xy, (const uint8_t*)d_inf, n, l.ws.p, (uint32_t*)d_parts,

@@ -294,7 +294,9 @@ int ecgpu_msm_parts_dev(ecgpu_ctx *ctx, int curve, const void *d_scalars, const 
  *     ecgpu_msm_parts_dev(i, d_parts[i % L]);
  *     ecgpu_msm_parts_join_dev(d_parts[(i - 1) % L]);  all-gather(i - 1);  ecgpu_msm_finish_dev(i - 1);
  * ecgpu_msm_parts_join_dev makes the context's stream wait (on the device; the host does not) for the local half that wrote
- * `d_parts`; until then the record belongs to its lane.  A no-op for a record written on the context's own stream.
+ * `d_parts`; until then the record belongs to its lane.  A no-op for a record written on the context's own stream.  A lane keeps
+ * track of ONE record: a local half that is still un-joined when its lane comes around again (more halves in flight than lanes) is
+ * joined by that call — correct, but the context's stream then waits for it.
  * ecgpu_msm_finish_dev does not wait for local halves in flight.  One MSM alone gains nothing from lanes. */
 int ecgpu_msm_parts_join_dev(ecgpu_ctx *ctx, const void *d_parts);
 /* d_parts_all: nranks consecutive parts records (the all-gather's output). */

@@ -1712,3 +1712,96 @@ def test_signature_batches_share_their_scalar_inversions(eng, curve):
     reps = n // m2 + 1
     k_big, ok_big = eng.ecdsa_recover(c.cid, (rz * reps)[: n * L], (rr * reps)[: n * L], (rs * reps)[: n * L], (bytes(rid) * reps)[:n])
     assert bytes(k_big) == (rxy * reps)[: n * 2 * L] and bytes(ok_big) == (bytes(rok) * reps)[:n]
+
+
+@pytest.mark.parametrize("curve,n", [("k256", (1 << 17) + 11), ("k256", 1 << 21), ("p256", (1 << 16) + 3)])
+def test_sharded_msm_steps_on_rotating_lanes(curve, n):
+    """The throughput form of the sharded MSM (include/ecgpu.h, ecgpu_msm_parts_join_dev): on an asynchronous context with two MSM
+    lanes the local halves of consecutive MSMs run on rotating internal streams; the caller joins the record it is about to exchange
+    and queues the combining half on the context's stream, beside the next local half.  Five different MSMs in a software pipeline
+    (local half of i, THEN join + combining half of i - 1; two "ranks" = two shards per MSM, both computed here) must give the bytes
+    of five one-call MSMs; a bad point in step 3 surfaces at ecgpu_synchronize.  k256 at 2^21 terms: the plain-scalar plan."""
+    ecgpu = ecgpu_module()
+    e = ecgpu.Engine(0)
+    try:
+        c = pyec.CURVES[curve]
+        L = c.L
+        steps, shards, lanes = 5, 2, 2
+        s = rand_scalars(c.cid, n, 0xEC0071F7 + c.cid)
+        pts, _ = e.mul_by_generator(c.cid, s)
+        ks = [rand_scalars(c.cid, n, 0xEC0072F7 + c.cid + i) for i in range(steps)]
+        want = [e.lincomb(c.cid, k, pts) for k in ks]
+        bounds = [ecgpu.shard_range(n, r, shards) for r in range(shards)]
+        plan_terms = max(hi - lo for lo, hi in bounds)
+        nbytes = e.msm_parts_bytes(c.cid, plan_terms)
+        d_p = [e.to_device(pts[lo * 2 * L: hi * 2 * L]) for lo, hi in bounds]
+        d_k = [[e.to_device(k[lo * L: hi * L]) for lo, hi in bounds] for k in ks]
+        # one gathered record (shards * nbytes) per lane SLOT; an MSM's shards are local halves of their own, so an MSM takes `shards`
+        # consecutive lanes turns: with two lanes and two shards, shard r of every MSM runs on lane r
+        d_all = [e.dev_alloc(shards * nbytes) for _ in range(lanes)]
+        d_o = [e.dev_alloc(2 * L + 32) for _ in range(steps)]
+        e.set_async(True)
+        e.set_msm_lanes(lanes)
+        pend = []
+
+        def combine():
+            i = pend.pop(0)
+            buf = d_all[i % lanes]
+            for r in range(shards):
+                e.msm_parts_join_dev(buf.at(r * nbytes))
+            e.msm_finish_dev(c.cid, buf, shards, plan_terms, d_o[i].at(0), d_o[i].at((2 * L + 15) // 16 * 16))
+
+        for i in range(steps):
+            buf = d_all[i % lanes]
+            for r, (lo, hi) in enumerate(bounds):
+                e.msm_parts_dev(c.cid, d_k[i][r], d_p[r], None, hi - lo, plan_terms, buf.at(r * nbytes))
+            pend.append(i)
+            if len(pend) > 1:
+                combine()
+        while pend:
+            combine()
+        e.synchronize()
+        for i in range(steps):
+            rec = e.to_host(d_o[i], 2 * L + 32)
+            assert bytes(rec[: 2 * L]) == bytes(want[i][0]) and int(rec[(2 * L + 15) // 16 * 16]) == want[i][1], (curve, n, i)
+        # an input error in a queued local half: deferred to ecgpu_synchronize, exactly once
+        bad = pts[: 2 * L * (bounds[0][1] - bounds[0][0])].copy()
+        bad[2 * L - 1] ^= 1
+        d_bad = e.to_device(bad)
+        e.msm_parts_dev(c.cid, d_k[0][0], d_bad, None, bounds[0][1] - bounds[0][0], plan_terms, d_all[0].at(0))
+        with pytest.raises(ecgpu.EcgpuError) as ei:
+            e.synchronize()
+        assert ei.value.code == ecgpu.ERR_POINT
+        e.synchronize()
+        e.set_msm_lanes(1)
+        e.set_async(False)
+    finally:
+        e.close()
+
+
+def test_group_exchange_choice_is_an_api_call_not_an_environment_variable(monkeypatch):
+    """ecgpu_group_set_exchange: a group of duplicate devices has no RCCL exchange — asking for "RCCL or nothing" is an error that says
+    why, asking for peer copies is fine; and the product library ignores ECGPU_GROUP_EXCHANGE (round 5 read it)."""
+    ecgpu = ecgpu_module()
+    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", "rccl")
+    grp = ecgpu.Group([0, 0])                        # (round 5: ECGPU_ERR_HIP with this variable set)
+    try:
+        assert grp.exchange == "peer" and "duplicate devices" in grp.exchange_reason
+        with pytest.raises(ecgpu.EcgpuError) as ei:
+            grp.set_exchange("rccl")
+        assert ei.value.code == ecgpu.ERR_HIP and "no RCCL exchange" in str(ei.value)
+        grp.set_exchange("peer")
+        assert grp.exchange == "peer"
+    finally:
+        grp.close()
+    monkeypatch.setenv("ECGPU_GROUP_EXCHANGE", "peer")
+    try:
+        grp = ecgpu.Group([0])
+    except ecgpu.EcgpuError:
+        pytest.skip("no group on this box")
+    try:
+        if grp.exchange == "rccl":                   # (librccl loadable: the variable did not turn it off)
+            grp.set_exchange("peer")
+            assert grp.exchange == "peer" and "ecgpu_group_set_exchange" in grp.exchange_reason
+    finally:
+        grp.close()
