@@ -243,3 +243,16 @@ def test_comb_table_falls_back_to_a_narrower_window_when_it_does_not_fit(monkeyp
     finally:
         hook(0)
         e.close()
+
+
+def test_one_rank_rccl_exchange_is_ordered_between_the_halves_on_the_device():
+    """tests/gpu_rccl_one_rank_check.py: bench.py's N > 1 MSM step with a REAL RCCL all-gather (a world of one rank: the one-GPU box
+    can show this), queued back to back without a host wait — every step must combine ITS record — and the same on two lanes."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_rccl_one_rank_check.py")],
+                       capture_output=True, text=True, timeout=600)
+    if "SKIP:" in r.stdout:
+        pytest.skip(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
