@@ -21,6 +21,11 @@
 
 #include "ecgpu_params.h"
 
+// -DECGPU_DIVSTEPS_MAD=0: the division steps with masks and additions as until round 5 (A/B: profiles/r06/)
+#ifndef ECGPU_DIVSTEPS_MAD
+#define ECGPU_DIVSTEPS_MAD 1
+#endif
+
 namespace ecgpu {
 
 template <int NW>          // modulus size in 32-bit words: 6, 7, 8, 12 or 17
@@ -70,7 +75,75 @@ struct ModInv {
     }
 
     // 30 half-delta division steps on the low bits; zeta = -(delta + 1/2)
+    //
+    // Round 6: the conditional additions of a step as MULTIPLY-ADDS by a multiplier in {-1, 0, +1} resp. {0, 1} — g += (+-f) & c2 is
+    // g += f * m1 with m1 = sign(zeta) restricted to "g odd", f += g & c1 is f += g * m2 — on 64-bit accumulators whose upper halves are
+    // never read (the product of a 32-bit value by 0xFFFFFFFF is its negative modulo 2^32: only the lower half of a pair carries the
+    // value, the carry into the upper half is garbage and stays there).  One v_mad_u64_u32 replaces xor + sub + and + add: 16
+    // instructions per step instead of 23 (ISA of k_normalize<K256Params, 0>, tools/isa_loops.py).  A division-step inversion is a lone
+    // wave's instruction COUNT wherever it matters (k_normalize, k_msm_combine, k_scalar_batch_inv: one wave per SIMD issues an
+    // instruction every ~7 cycles whatever it is), so the six full-rate multiply-adds cost nothing there; where the SIMD is shared
+    // (the table build of the ladders) six 4-cycle and ten 2-cycle instructions replace twenty-three 2-cycle ones: equal.
+    // Same branch-free schedule, same matrices: the g++ host twin runs this very code (tests/hostcheck).
+    // Device: the six multiply-adds and the three shifts of a step are two assembly statements (the compiler, left to itself, proves
+    // that only the lower halves are read, takes the pairs apart again and ends up with MORE instructions than the masked form — 142
+    // for five steps; and it separates single-instruction asm statements by s_nop).  The shifts take the whole pair along.  Left: the
+    // lower half is exact modulo 2^32, which is all u and v are.  Right (g): garbage from the upper half enters at bit 31 and moves
+    // down one bit per step — a step only looks at bit 0, and the 30 steps of a batch only depend on the low 30 bits of f and g (the
+    // reason a batch can work on one limb at all): it never reaches a bit that is read.
+    static ECGPU_HD void step_a(uint64_t& g, uint64_t& q, uint64_t& r, uint32_t fl, uint32_t ul, uint32_t vl, uint32_t m1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t carry;
+        asm("v_mad_u64_u32 %0, %3, %4, %7, %0\n\t"
+            "v_mad_u64_u32 %1, %3, %5, %7, %1\n\t"
+            "v_mad_u64_u32 %2, %3, %6, %7, %2"
+            : "+v"(g), "+v"(q), "+v"(r), "=&s"(carry)
+            : "v"(fl), "v"(ul), "v"(vl), "v"(m1));
+#else
+        g += (uint64_t)fl * m1;
+        q += (uint64_t)ul * m1;
+        r += (uint64_t)vl * m1;
+#endif
+    }
+    static ECGPU_HD void step_b(uint64_t& f, uint64_t& u, uint64_t& v, uint64_t& g, uint32_t gl, uint32_t ql, uint32_t rl, uint32_t m2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t carry;
+        asm("v_mad_u64_u32 %0, %4, %5, %8, %0\n\t"
+            "v_mad_u64_u32 %1, %4, %6, %8, %1\n\t"
+            "v_mad_u64_u32 %2, %4, %7, %8, %2\n\t"
+            "v_lshrrev_b64 %3, 1, %3\n\t"
+            "v_lshlrev_b64 %1, 1, %1\n\t"
+            "v_lshlrev_b64 %2, 1, %2"
+            : "+v"(f), "+v"(u), "+v"(v), "+v"(g), "=&s"(carry)
+            : "v"(gl), "v"(ql), "v"(rl), "v"(m2));
+#else
+        f += (uint64_t)gl * m2;
+        u += (uint64_t)ql * m2;
+        v += (uint64_t)rl * m2;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+#endif
+    }
     static ECGPU_HD int32_t divsteps_30(int32_t zeta, uint32_t f0, uint32_t g0, Trans* t) {
+#if ECGPU_DIVSTEPS_MAD
+        uint64_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;           // the values are the LOWER halves
+#pragma unroll 5
+        for (int i = 0; i < 30; i++) {
+            const uint32_t neg = (uint32_t)(zeta >> 31);                   // all ones iff zeta < 0  (delta > 0)
+            const uint32_t c2 = 0u - ((uint32_t)g & 1u);                   // all ones iff g odd
+            const uint32_t m1 = (neg | 1u) & c2;                           // g odd: -1 if delta > 0 else +1; g even: 0
+            step_a(g, q, r, (uint32_t)f, (uint32_t)u, (uint32_t)v, m1);    // g += (+-f) if g odd; the same on the matrix rows
+            const uint32_t c1 = neg & c2;                                  // swap iff delta > 0 and g odd
+            zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
+            step_b(f, u, v, g, (uint32_t)g, (uint32_t)q, (uint32_t)r, c1 & 1u);    // f += g (the new g) if swapping; g >>= 1, u <<= 1, v <<= 1
+        }
+        t->u = (int32_t)(uint32_t)u;
+        t->v = (int32_t)(uint32_t)v;
+        t->q = (int32_t)(uint32_t)q;
+        t->r = (int32_t)(uint32_t)r;
+        return zeta;
+#else
         uint32_t u = 1, v = 0, q = 0, r = 1;
         uint32_t f = f0, g = g0;
 #pragma unroll 5
@@ -95,6 +168,7 @@ struct ModInv {
         t->q = (int32_t)q;
         t->r = (int32_t)r;
         return zeta;
+#endif
     }
 
     // acc + a b on signed 32-bit factors.  On the device as v_mad_i64_i32 by hand: the limbs are known to be non-negative, the
@@ -110,6 +184,41 @@ struct ModInv {
         return r;
 #else
         return acc + (int64_t)a * b;
+#endif
+    }
+
+    // cx += a1 b1 + a2 b2 and cy += a3 b1 + a4 b2: the four products of one limb of the matrix update as ONE assembly statement (the
+    // compiler separates single-instruction statements by s_nop: 55 of them per batch of 30 steps until round 6)
+    static ECGPU_HD void smad4(int64_t& cx, int64_t& cy, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t b1, int32_t b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t carry;
+        asm("v_mad_i64_i32 %0, %2, %3, %7, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %5, %7, %1\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %8, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %6, %8, %1"
+            : "+v"(cx), "+v"(cy), "=&s"(carry)
+            : "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(b1), "v"(b2));
+#else
+        cx += (int64_t)a1 * b1 + (int64_t)a2 * b2;
+        cy += (int64_t)a3 * b1 + (int64_t)a4 * b2;
+#endif
+    }
+    // the same + the multiples of the modulus limb pl (wave-uniform: a scalar register): cx += pl mx, cy += pl my
+    static ECGPU_HD void smad6(int64_t& cx, int64_t& cy, int32_t a1, int32_t a2, int32_t a3, int32_t a4, int32_t b1, int32_t b2,
+                               int32_t pl, int32_t mx, int32_t my) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t carry;
+        asm("v_mad_i64_i32 %0, %2, %3, %7, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %5, %7, %1\n\t"
+            "v_mad_i64_i32 %0, %2, %4, %8, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %6, %8, %1\n\t"
+            "v_mad_i64_i32 %0, %2, %9, %10, %0\n\t"
+            "v_mad_i64_i32 %1, %2, %9, %11, %1"
+            : "+v"(cx), "+v"(cy), "=&s"(carry)
+            : "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(b1), "v"(b2), "s"(pl), "v"(mx), "v"(my));
+#else
+        cx += (int64_t)a1 * b1 + (int64_t)a2 * b2 + (int64_t)pl * mx;
+        cy += (int64_t)a3 * b1 + (int64_t)a4 * b2 + (int64_t)pl * my;
 #endif
     }
 
@@ -132,10 +241,7 @@ struct ModInv {
         for (int i = 1; i < NL; i++) {
             di = d.v[i];
             ei = e.v[i];
-            cd = smad(u, di, smad(v, ei, cd));
-            ce = smad(q, di, smad(r, ei, ce));
-            cd = smad<true>(p.v[i], md, cd);
-            ce = smad<true>(p.v[i], me, ce);
+            smad6(cd, ce, u, v, q, r, di, ei, p.v[i], md, me);
             d.v[i - 1] = (int32_t)cd & M30;
             cd >>= 30;
             e.v[i - 1] = (int32_t)ce & M30;
@@ -156,8 +262,7 @@ struct ModInv {
         for (int i = 1; i < NL; i++) {
             fi = f.v[i];
             gi = g.v[i];
-            cf = smad(u, fi, smad(v, gi, cf));
-            cg = smad(q, fi, smad(r, gi, cg));
+            smad4(cf, cg, u, v, q, r, fi, gi);
             f.v[i - 1] = (int32_t)cf & M30;
             cf >>= 30;
             g.v[i - 1] = (int32_t)cg & M30;

@@ -17,7 +17,7 @@ for tu in "$@"; do
   SKIP="$SKIP|inst_${group}_$curve.o"
 done
 wait
-OBJS=$(ls build/*.o | grep -Ev "${SKIP#|}")
+OBJS=$(ls build/*.o | grep -Ev "${SKIP#|}|misc_knobs.o")      # (misc_knobs.o belongs to the tool build lib/libecgpu_knobs.so only)
 ALT=$(for tu in "$@"; do echo "build_alt/inst_${tu%%_*}_${tu#*_}.o"; done)
 hipcc --offload-arch=gfx950 -shared -fPIC -o "lib/libecgpu_$SUFFIX.so" $OBJS $ALT -ldl -lpthread
 echo "lib/libecgpu_$SUFFIX.so"
