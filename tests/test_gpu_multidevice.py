@@ -245,6 +245,37 @@ def test_comb_table_falls_back_to_a_narrower_window_when_it_does_not_fit(monkeyp
         e.close()
 
 
+def test_a_context_on_a_narrower_table_gets_the_wide_one_when_the_refusal_expires():
+    """include/ecgpu.h: "a table that does not fit is replaced by one two bits narrower" — and that refusal is not for ever.  A
+    context that fell back keeps asking: while the refusal stands (here: the test hook's cap; 64 calls per attempt) it stays on
+    the narrow table — a second refusal costs one failed allocation and nothing else —, and once the memory is there the wide
+    table is built BEFORE the narrow one is let go and the context moves over.  Results never change."""
+    import ctypes
+    ecgpu = ecgpu_module()
+    hook = ecgpu.load_library().ecgpu_testhook_table_max_mb
+    hook.restype, hook.argtypes = None, [ctypes.c_size_t]
+    c = pyec.CURVES["p192"]
+    k = rand_scalars(c.cid, 300, 0xEC0013F7)
+    want, winf = oracle_lib.batch_mul_base(c.cid, k)
+    e = ecgpu.Engine(0)
+    try:
+        e.set_base_window(c.cid, 22)          # 906 MB; the cap lets 16 bits (19 MB) through
+        hook(64)
+        out, inf = e.mul_by_generator(c.cid, k)
+        assert bytes(out) == bytes(want) and e.base_table_info(c.cid)["window_bits"] == 16
+        for _ in range(150):                  # two expiries of the refusal with the cap still in place: retried, refused again
+            out, inf = e.mul_by_generator(c.cid, k)
+        assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf) and e.base_table_info(c.cid)["window_bits"] == 16
+        hook(0)                               # the memory is there now
+        for _ in range(70):
+            out, inf = e.mul_by_generator(c.cid, k)
+        assert bytes(out) == bytes(want) and bytes(inf) == bytes(winf)
+        assert e.base_table_info(c.cid)["window_bits"] == 22, e.base_table_info(c.cid)
+    finally:
+        hook(0)
+        e.close()
+
+
 def test_one_rank_rccl_exchange_is_ordered_between_the_halves_on_the_device():
     """tests/gpu_rccl_one_rank_check.py: bench.py's N > 1 MSM step with a REAL RCCL all-gather (a world of one rank: the one-GPU box
     can show this), queued back to back without a host wait — every step must combine ITS record — and the same on two lanes."""
