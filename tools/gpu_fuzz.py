@@ -73,7 +73,7 @@ kind = c = n = None
 while time.time() < t_end:
     c = pyec.CURVES[rng.choice(NAMES)]
     L = c.L
-    kind = rng.choice(["msm", "msm", "msm", "shards", "fixed", "var", "sig", "lanes"])
+    kind = rng.choice(["msm", "msm", "msm", "shards", "shard_lanes", "fixed", "var", "sig", "lanes"])
     if kind == "sig" and c.name == "bign256":
         kind = "bign"
     if kind == "sig" and c.name == "sm2":
@@ -183,6 +183,57 @@ while time.time() < t_end:
         for b in (d_all, d_o, d_f):
             b.free()
         stats["msm_shards"] += 1
+    elif kind == "shard_lanes":
+        # sharded MSM steps in a software pipeline on rotating lanes (ecgpu_msm_parts_join_dev): several MSMs, each cut into random
+        # shards whose local halves take the lanes in turn, the combining half of MSM i queued after the local halves of MSM i + 1 ==
+        # the one-call MSMs (more local halves in flight than lanes: the implicit join when a lane comes around again)
+        msm_knobs(c)
+        e.set_msm_window(0)
+        P = pool(c)
+        nj, nsh = rng.randrange(2, 6), rng.randrange(1, 4)
+        n = rng.choice([rng.randrange(1, 300), rng.randrange(300, 1 << 14), rng.randrange(1 << 14, 1 << 17)])
+        cuts = sorted(rng.randrange(n + 1) for _ in range(nsh - 1))
+        bounds = list(zip([0] + cuts, cuts + [n]))
+        plan_terms = max(hi - lo for lo, hi in bounds) or 1
+        pts = P[np.array([rng.randrange(1 << 16) for _ in range(n)])].copy().reshape(-1)
+        ks = [rand_scalars(c.cid, n, rng.randrange(1 << 30)) for _ in range(nj)]
+        want = [e.lincomb(c.cid, k, pts) for k in ks]
+        nbytes = e.msm_parts_bytes(c.cid, plan_terms)
+        lanes = rng.randrange(2, 5)
+        nbuf = rng.randrange(2, 4)                           # gathered-record buffers in rotation (>= 2: the pipeline is two deep)
+        d_p = [e.to_device(pts[lo * 2 * L: hi * 2 * L]) if hi > lo else None for lo, hi in bounds]
+        d_k = [[e.to_device(k[lo * L: hi * L]) if hi > lo else None for lo, hi in bounds] for k in ks]
+        d_all = [e.dev_alloc(nsh * nbytes) for _ in range(nbuf)]
+        d_o = [e.dev_alloc((2 * L + 15) // 16 * 16 + 16) for _ in range(nj)]
+        e.set_async(True)
+        e.set_msm_lanes(lanes)
+        pend = []
+
+        def combine():
+            i = pend.pop(0)
+            buf = d_all[i % nbuf]
+            for r_ in range(nsh):
+                e.msm_parts_join_dev(buf.at(r_ * nbytes))
+            e.msm_finish_dev(c.cid, buf, nsh, plan_terms, d_o[i].at(0), d_o[i].at((2 * L + 15) // 16 * 16))
+
+        for i in range(nj):
+            for r_, (lo, hi) in enumerate(bounds):
+                e.msm_parts_dev(c.cid, d_k[i][r_], d_p[r_], None, hi - lo, plan_terms, d_all[i % nbuf].at(r_ * nbytes))
+            pend.append(i)
+            if len(pend) > 1:
+                combine()
+        while pend:
+            combine()
+        e.synchronize()
+        e.set_msm_lanes(1)
+        e.set_async(False)
+        for i in range(nj):
+            rec = e.to_host(d_o[i], (2 * L + 15) // 16 * 16 + 1)
+            assert (bytes(rec[: 2 * L]), int(rec[(2 * L + 15) // 16 * 16])) == (bytes(want[i][0]), want[i][1]), \
+                ("shard_lanes", c.name, n, bounds, lanes, nbuf, i, dict(os.environ))
+        for b in d_all + d_o + [x for x in d_p if x is not None] + [x for row in d_k for x in row if x is not None]:
+            b.free()
+        stats["msm_shard_lanes"] += 1
     elif kind == "sig":
         # signatures made from engine-computed nonce points (valid ones), some disturbed: verification, public-key recovery
         # and message-level verification against the oracle, verdict for verdict and key for key
